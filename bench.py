@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rays/s of the IntrinsicNeRF render path at 64+128 samples per ray.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+One "step" renders one synthetic 800x800 Blender-chair frame (BASELINE.json configs[2]: 640,000 rays,
+64 coarse + 128 importance samples, separate coarse/fine networks, white background, eval mode)
+through the product front-end ``intrinsicnerf_amd.object_level.render``.  With N GPUs the frame's rays
+are split into N row bands (one process per GPU) and the rendered maps are all-gathered over RCCL, so
+the total work is fixed: "scaling": "strong".  Inputs are resident in HBM before the timed region.
+
+Prints ONE JSON line (rank 0) with the bench contract's fields plus
+  "roofline"     : achieved fp32-MFMA TFLOP/s of the dominant kernel (k_encode_mlp) from HIP-event
+                   timings of that kernel at this workload's sizes, vs the 157.3 TFLOP/s dense peak;
+  "cpu_baseline" : the CPU oracle (PyTorch-CPU restatement == reference, see oracle/) timed on this
+                   box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+H = W = 800
+N_SAMPLES, N_IMPORTANCE = 64, 128
+CAMERA_ANGLE_X = 0.6911112070083618          # NeRF-synthetic transforms_*.json
+NEAR, FAR = 2.0, 6.0                         # run_nerf.py:705-706
+FLOP_PER_POINT = 2 * 659456                  # BASELINE.md section 2 (GEMM MACs of one NeRF evaluation)
+PEAK_F32_MFMA_TFLOPS = 157.3                 # MI355X_MICROARCH.md: dense fp32 matrix peak
+
+
+def chair_pose(theta_deg=40.0, phi_deg=-30.0, radius=4.0):
+    """pose_spherical of the NeRF-synthetic orbit (load_blender.py:29-34 convention)."""
+    th, ph = np.deg2rad(theta_deg), np.deg2rad(phi_deg)
+    t = np.eye(4); t[2, 3] = radius
+    rp = np.array([[1, 0, 0, 0], [0, np.cos(ph), -np.sin(ph), 0], [0, np.sin(ph), np.cos(ph), 0], [0, 0, 0, 1.0]])
+    rt = np.array([[np.cos(th), 0, -np.sin(th), 0], [0, 1, 0, 0], [np.sin(th), 0, np.cos(th), 0], [0, 0, 0, 1.0]])
+    flip = np.array([[-1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1.0]])
+    return torch.tensor((flip @ rt @ rp @ t)[:3, :4], dtype=torch.float32)
+
+
+def cpu_baseline(budget_s=12.0):
+    """Time the CPU oracle on rays of the same frame with the same networks (all host cores)."""
+    import oracle
+    from intrinsicnerf_amd import object_level as ol
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    focal = 0.5 * W / np.tan(0.5 * CAMERA_ANGLE_X)
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+    ro, rd = ol.get_rays(H, W, K, chair_pose())
+    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    sel = torch.arange(0, H * W, 157)[:2048]                   # rays spread over the frame
+    ro, rd = ro[sel], rd[sel]
+    rays = torch.cat([ro, rd, NEAR * torch.ones_like(rd[:, :1]), FAR * torch.ones_like(rd[:, :1]),
+                      rd / rd.norm(dim=-1, keepdim=True)], -1)
+    sd_c, sd_f = oracle.make_state_dict("object", seed=0), oracle.make_state_dict("object", seed=1)
+    cfg = oracle.RenderConfig(variant="object", n_samples=N_SAMPLES, n_importance=N_IMPORTANCE, white_bkgd=True)
+    chunk = 512
+    with torch.no_grad():
+        oracle.render_rays(rays[:chunk], sd_c, sd_f, cfg)      # warm-up (thread pool, allocator)
+        done, t0 = 0, time.perf_counter()
+        while True:
+            lo = done % rays.shape[0]
+            oracle.render_rays(rays[lo:lo + chunk], sd_c, sd_f, cfg)
+            done += chunk
+            dt = time.perf_counter() - t0
+            if dt >= budget_s:
+                break
+    return {"value": done / dt, "unit": "rays/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"{done} rays of the same 800x800 frame, 64+128 samples, PyTorch-CPU oracle "
+                      f"(oracle/intrinsic_render.py == reference, see tests/golden), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    import __graft_entry__
+    __graft_entry__.build()
+    import oracle                                      # only for make_state_dict (seeded default init) + cpu_baseline
+    from intrinsicnerf_amd import _capi, distributed as idist, kernels, object_level as ol, packing
+
+    # ---- synthetic workload: configs[2], resident in HBM ----
+    focal = 0.5 * W / np.tan(0.5 * CAMERA_ANGLE_X)
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+    ro, rd = ol.get_rays(H, W, K, chair_pose().to(dev))
+    ro, rd = ro.reshape(-1, 3).contiguous(), rd.reshape(-1, 3).contiguous()
+    n_total = H * W
+    b, e = idist.shard_bounds(n_total, rank, world)
+    ro_l, rd_l = ro[b:e].contiguous(), rd[b:e].contiguous()
+    n_local = e - b
+    embed, ch = ol.get_embedder(10, 0)
+    embed_d, ch_d = ol.get_embedder(4, 0)
+    mk = lambda: ol.NeRF(D=8, W=256, input_ch=ch, output_ch=5, skips=[4], input_ch_views=ch_d, use_viewdirs=True).to(dev)
+    net_c, net_f = mk(), mk()
+    net_c.load_state_dict(oracle.make_state_dict("object", seed=0))      # random-init weights, seeds 0 / 1
+    net_f.load_state_dict(oracle.make_state_dict("object", seed=1))
+    kw = dict(network_fn=net_c, network_fine=net_f, network_query_fn=ol.NetworkQuery(embed, embed_d), N_samples=N_SAMPLES,
+              N_importance=N_IMPORTANCE, white_bkgd=True, perturb=False, raw_noise_std=0., use_viewdirs=True, ndc=False,
+              lindisp=False)
+
+    def step():
+        with torch.no_grad():
+            r = ol.render(H, W, K, chunk=n_local, rays=(ro_l, rd_l), near=NEAR, far=FAR, **kw)
+            maps = dict(zip(("rgb_map", "disp_map", "acc_map", "albedo_map", "shading_map", "residual_map"), r[:6]))
+            return idist.gather_maps(maps, n_total) if world > 1 else maps
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert frame["rgb_map"].shape[0] == n_total and torch.isfinite(frame["rgb_map"]).all()
+    rays_per_s = n_total * args.steps / dt
+
+    # ---- roofline of the dominant kernel (k_encode_mlp): HIP events around its launches, same sizes ----
+    desc = _capi.net_desc(_capi.VARIANT_OBJECT, 0, 10, 4, 1.0)
+    pc, pf = packing.packed_for_module(net_c, desc, dev), packing.packed_for_module(net_f, desc, dev)
+    vd = rd_l / rd_l.norm(dim=-1, keepdim=True)
+    rays_l = torch.cat([ro_l, rd_l, NEAR * torch.ones_like(rd_l[:, :1]), FAR * torch.ones_like(rd_l[:, :1]), vd], -1)
+    t_vals = torch.linspace(0., 1., N_SAMPLES, device=dev)
+    u = torch.linspace(0., 1., N_IMPORTANCE, device=dev)
+    st = kernels.render_rays_fused(desc, pc, pf, rays_l, N_SAMPLES, N_IMPORTANCE, t_vals, u, white_bkgd=True, want_stages=True)
+    z_c, z_f = st["z_coarse"], st["z_fine"]
+    del st
+    torch.cuda.synchronize()
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    durs = []                                                  # one entry per k_encode_mlp launch [ms]
+    for _ in range(max(1, args.steps)):
+        for packed, z in ((pc, z_c), (pf, z_f)):
+            a, bb = ev(), ev()
+            a.record()
+            kernels.encode_mlp(desc, packed, rays_l, z)
+            bb.record()
+            bb.synchronize()
+            durs.append(a.elapsed_time(bb))
+    avg_ms = sum(durs) / len(durs)
+    flop_per_launch = FLOP_PER_POINT * n_local * (N_SAMPLES + (N_SAMPLES + N_IMPORTANCE)) / 2.0   # mean of the two launches
+    achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "kernel": "k_encode_mlp", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                "avg_launch_ms": avg_ms, "launches_timed": len(durs),
+                "flop_per_launch": flop_per_launch}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        print(json.dumps({
+            "metric": "rays/sec (64+128 samples/ray)", "value": rays_per_s, "unit": "rays/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Blender chair 800x800 frame (640000 rays), 64 coarse + 128 importance samples, "
+                                   "coarse+fine intrinsic NeRF (D=8, W=256), white_bkgd, eval mode, random-init weights "
+                                   "(seeds 0/1)", "rays_per_step": n_total, "parallelism": f"ray-sharded x{world}",
+                       "gather": "all_gather of 12 floats/ray" if world > 1 else "none"},
+            "roofline": roofline, "cpu_baseline": cpu}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,193 @@
+/*
+ * inerf.h - C ABI of libinerf.so: the MI355X (gfx950) implementation of IntrinsicNeRF's volumetric
+ * render_rays hot path.
+ *
+ * The reference (zju3dv/IntrinsicNeRF) is pure Python on PyTorch and has no FFI of its own: the
+ * "operator interface" of this path is the set of Python functions listed below.  Each entry point
+ * of this header replaces the ATen op sequence of one of them and is what a ctypes / cffi / pybind
+ * binding on the reference side would bind (INTEGRATION.md shows the ctypes stub).  Citations are
+ * relative to the reference repository root.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 unless the parameter is marked [host];
+ *   - the library never allocates device memory: outputs and scratch are caller-owned;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - return value: 0 = success, negative = INERF_E_* (never throws, never aborts);
+ *   - thread-safe as long as concurrent calls use distinct streams and distinct output/workspace
+ *     buffers; packed weights are read-only and may be shared.
+ */
+#ifndef INERF_H
+#define INERF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define INERF_VERSION_MAJOR 0
+#define INERF_VERSION_MINOR 1
+
+/* error codes */
+#define INERF_OK              0
+#define INERF_E_INVALID      -1   /* bad argument (null pointer, non-positive size, unknown variant ...) */
+#define INERF_E_UNSUPPORTED  -2   /* configuration outside what the kernels implement (see each call)    */
+#define INERF_E_WORKSPACE    -3   /* workspace pointer null or too small                                  */
+#define INERF_E_HIP          -4   /* a HIP runtime call failed; inerf_last_hip_error() has the code       */
+
+/* network variants */
+#define INERF_VARIANT_OBJECT  0   /* object_level/run_nerf_helpers.py:247 NeRF (11 raw channels)          */
+#define INERF_VARIANT_SSR     1   /* SSR/models/semantic_nerf.py:74 Semantic_NeRF (11 + C [+128] channels) */
+
+/* render flags */
+#define INERF_FLAG_WHITE_BKGD   1u   /* run_nerf.py:407-410 / model_utils.py:109-114                      */
+#define INERF_FLAG_LINDISP      2u   /* run_nerf.py:467-468 (object-level only)                           */
+#define INERF_FLAG_ENDPOINT     4u   /* SSR endpoint_feat: fine raw carries the 128-d views activation    */
+#define INERF_FLAG_U_PER_RAY    8u   /* `u` is [N, n_importance] (random) instead of a shared [n_importance] */
+
+#define INERF_BASE_CHANNELS   11   /* rgb3 sigma albedo3 shading residual3 (run_nerf_helpers.py:321)       */
+#define INERF_ENDPOINT_DIM    128
+#define INERF_RAY_FLOATS      11   /* o3 d3 near far viewdir3 (run_nerf.py:122-128, rays.py:251-255)       */
+#define INERF_MAX_CLASSES     240  /* semantic classes supported by the packed layout                     */
+
+const char* inerf_version(void);
+int inerf_last_hip_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Network description and weight packing.
+ * Replaces: the nn.Module parameter storage of NeRF (run_nerf_helpers.py:259-279) and Semantic_NeRF
+ * (semantic_nerf.py:98-118) as seen by forward().  Fixed architecture D=8, W=256, skips=[4],
+ * use_viewdirs=True - every shipped config (run_nerf.py:545-552, every SSR/configs yaml).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct inerf_net_desc {
+    int32_t variant;      /* INERF_VARIANT_*                                                       */
+    int32_t n_classes;    /* SSR: semantic classes C (0 = semantic head absent); object: must be 0 */
+    int32_t l_xyz;        /* multires       (0..10)  -> 3+6*l_xyz encoded position channels        */
+    int32_t l_dir;        /* multires_views (0..4)   -> 3+6*l_dir encoded direction channels       */
+    float   xyz_div;      /* encoder input divisor: 1 (object) / 10 (SSR, semantic_nerf.py:64)     */
+} inerf_net_desc;
+
+/* Number of state-dict tensors the packer expects, and the canonical order/shape of tensor i:
+ * pts_linears.{0..7}.{weight,bias}, views_linears.0, feature_linear, alpha_linear, then
+ *   object: shading_linear (=residual head), albedo_linear1, albedo_linear2, test_linear1, test_linear2
+ *   ssr   : [semantic_linear.0.0, semantic_linear.1,] residual_linear, albedo_linear1, albedo_linear2,
+ *           shading_linear1, shading_linear2
+ * (weight then bias for each).  inerf_tensor_info lets a binding verify a state dict; the returned
+ * name pointer stays valid until the next inerf_tensor_info call on the same thread. */
+int inerf_num_tensors(const inerf_net_desc* net);
+int inerf_tensor_info(const inerf_net_desc* net, int index, const char** name /*[host] out*/,
+                      int64_t* rows /*out*/, int64_t* cols /*out; 0 for a bias*/);
+
+/* Size in floats of the packed blob for this network. */
+int64_t inerf_packed_floats(const inerf_net_desc* net);
+
+/* Pack the [host] fp32 state-dict tensors (row-major [out,in], canonical order above) into the
+ * MFMA-fragment-ordered blob the kernels stream ([host] packed_out, inerf_packed_floats() floats).
+ * The caller uploads the blob to the device once per weight update. */
+int inerf_pack_weights(const inerf_net_desc* net, const float* const* tensors /*[host]*/, int n_tensors,
+                       float* packed_out /*[host]*/, int64_t packed_capacity_floats);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stage kernels (each is also a parity-test boundary).
+ * ------------------------------------------------------------------------------------------- */
+
+/* z_vals[N,S]: stratified depths.  Replaces run_nerf.py:464-486 / trainer.py:730-746.
+ * rays[N,11]; t_vals[S] = linspace(0,1,S) supplied by the caller (so its rounding is the host
+ * framework's); t_rand[N,S] or NULL (perturb == 0); lindisp via flags. */
+int inerf_sample_coarse(const float* rays, const float* t_vals, const float* t_rand, int64_t n_rays, int n_samples,
+                        uint32_t flags, float* z_out, void* stream);
+
+/* raw[N,S,CH] = MLP(encode(o + d*z), encode(viewdir)).  Replaces run_network + NeRF.forward:
+ * run_nerf.py:42-56 + run_nerf_helpers.py:195-243,284-321 / model_utils.py:19-35 +
+ * semantic_nerf.py:14-65,123-181.  CH = 11 + n_classes (+128 if INERF_FLAG_ENDPOINT).
+ * packed_weights: device copy of the inerf_pack_weights() blob. */
+int inerf_encode_mlp(const inerf_net_desc* net, const float* packed_weights, const float* rays, const float* z_vals,
+                     int64_t n_rays, int n_samples, uint32_t flags, float* raw_out, void* stream);
+
+/* Alpha compositing.  Replaces raw2outputs: run_nerf.py:359-412 / model_utils.py:39-116.
+ * raw[N,S,CH]; z[N,S]; rays_d: pointer to the first direction, consecutive rays `rays_d_stride`
+ * floats apart (3 for a [N,3] tensor, 11 for the d-part of a packed ray batch);
+ * noise[N,S] (already scaled by raw_noise_std) or NULL.  n_classes / feat_dim select the optional
+ * semantic (raw[...,11:11+C]) and endpoint-feature (the LAST feat_dim channels) sums.
+ * Any output pointer may be NULL to skip it.  disp is NaN where acc == 0, as in the reference. */
+typedef struct inerf_composite_out {
+    float* rgb;       /* [N,3] */
+    float* disp;      /* [N]   */
+    float* acc;       /* [N]   */
+    float* depth;     /* [N]   */
+    float* albedo;    /* [N,3] */
+    float* shading;   /* [N]   */
+    float* residual;  /* [N,3] */
+    float* sem;       /* [N,C]        or NULL */
+    float* feat;      /* [N,feat_dim] or NULL */
+    float* weights;   /* [N,S]        or NULL */
+} inerf_composite_out;
+
+int inerf_composite(const float* raw, const float* z_vals, const float* rays_d, int rays_d_stride, const float* noise,
+                    int64_t n_rays, int n_samples, int channels, int n_classes, int feat_dim, uint32_t flags,
+                    const inerf_composite_out* out, void* stream);
+
+/* Hierarchical resampling + merge.  Replaces z_vals_mid + sample_pdf + sort(cat(...)) + std:
+ * run_nerf.py:499-503,519 + run_nerf_helpers.py:402-445 / trainer.py:758-766,799 + rays.py:176-220.
+ * z_coarse[N,Sc], weights[N,Sc] (the full coarse weights; the kernel takes [1:-1] itself);
+ * u: [n_importance] shared, or [N,n_importance] with INERF_FLAG_U_PER_RAY.
+ * Outputs (any may be NULL): z_samples[N,n_importance], z_merged[N,Sc+n_importance] ascending,
+ * z_std[N] (population std of the new samples).  Limits: 3 <= Sc <= 256, 1 <= n_importance <= 512. */
+int inerf_sample_fine(const float* z_coarse, const float* weights, const float* u, int64_t n_rays, int n_coarse,
+                      int n_importance, uint32_t flags, float* z_samples, float* z_merged, float* z_std, void* stream);
+
+/* Stand-alone inverse-CDF sampler with the reference's own signature sample_pdf(bins, weights, N):
+ * run_nerf_helpers.py:402-445 / rays.py:176-220.  bins[N,n_bins], weights[N,n_bins-1],
+ * u as above -> samples[N,n_samples].  Limits: 2 <= n_bins <= 256, 1 <= n_samples <= 512. */
+int inerf_sample_pdf(const float* bins, const float* weights, const float* u, int64_t n_rays, int n_bins, int n_samples,
+                     uint32_t flags, float* samples, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Whole path.  Replaces render_rays (run_nerf.py:415-528) / SSRTrainer.volumetric_rendering
+ * (trainer.py:717-808) for one ray batch: coarse sampling -> coarse MLP -> compositing ->
+ * resampling -> fine MLP -> compositing, all enqueued on `stream` with no host synchronisation.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct inerf_render_args {
+    /* networks */
+    inerf_net_desc net;
+    const float* packed_coarse;   /* device blob                                                   */
+    const float* packed_fine;     /* device blob; NULL = reuse coarse (network_fine is None)        */
+    /* inputs */
+    const float* rays;            /* [N,11]                                                        */
+    int64_t      n_rays;
+    int32_t      n_samples;       /* coarse samples per ray                                        */
+    int32_t      n_importance;    /* 0 = coarse pass only                                          */
+    uint32_t     flags;           /* INERF_FLAG_*                                                  */
+    const float* t_vals;          /* [n_samples] linspace(0,1,n_samples)                           */
+    const float* t_rand;          /* [N,n_samples] or NULL                                         */
+    const float* u;               /* [n_importance] or [N,n_importance] (INERF_FLAG_U_PER_RAY)     */
+    const float* noise_coarse;    /* [N,n_samples] or NULL                                         */
+    const float* noise_fine;      /* [N,n_samples+n_importance] or NULL                            */
+    /* outputs (any pointer may be NULL) */
+    inerf_composite_out coarse;
+    inerf_composite_out fine;
+    float* z_std;                 /* [N]                                                           */
+    float* raw_coarse;            /* [N,n_samples,CHc]; NULL = keep in workspace                   */
+    float* raw_fine;              /* [N,n_samples+n_importance,CHf]; NULL = keep in workspace      */
+    float* z_coarse;              /* [N,n_samples]          optional copy-out of stage tensors     */
+    float* z_samples;             /* [N,n_importance]                                               */
+    float* z_fine;                /* [N,n_samples+n_importance]                                     */
+    /* scratch */
+    void*   workspace;
+    int64_t workspace_bytes;
+} inerf_render_args;
+
+/* Bytes of workspace inerf_render_rays needs for these sizes (independent of which optional
+ * outputs are requested). */
+int64_t inerf_workspace_bytes(const inerf_net_desc* net, int64_t n_rays, int n_samples, int n_importance, uint32_t flags);
+
+int inerf_render_rays(const inerf_render_args* args, void* stream);
+
+/* Raw channel counts for this network. */
+int inerf_raw_channels(const inerf_net_desc* net, uint32_t flags, int fine);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INERF_H */

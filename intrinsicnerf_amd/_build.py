@@ -1,0 +1,49 @@
+"""Build recipe for ``libinerf.so`` (hand-written HIP for gfx950 + the C ABI of include/inerf.h).
+
+Plain ``hipcc`` - no cmake, no torch extension machinery: the library has no torch types in its
+interface.  ``hipcc`` cross-compiles for gfx950 without a GPU, so this runs in the build container;
+the resulting ``.so`` is git-ignored but travels to the GPU box with the working tree.
+"""
+import os
+import shutil
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(PKG_DIR, "libinerf.so")
+SOURCES = ["pack.cpp", "api.cpp", "mlp.hip", "ray_ops.hip"]
+HEADERS = [os.path.join(CSRC, "layout.h"), os.path.join(os.path.dirname(PKG_DIR), "include", "inerf.h")]
+# -ffp-contract=off: the reference rounds o + d*z, albedo*shading + residual, near*(1-t) + far*t ... as
+# separate multiplies and adds; fused multiply-adds would move sample positions by an ulp, which the
+# 2^9 frequency encoding amplifies.  MFMA accumulation is unaffected (it is an explicit builtin).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+         "-Wno-comment", "-Wno-unused-result"]
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force=False, verbose=False):
+    """Compile ``libinerf.so`` in-tree if it is missing or older than its sources.  Returns its path."""
+    if not force and not _stale():
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libinerf.so (ROCm toolchain required)")
+    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + proc.stdout + proc.stderr)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_library(force=True, verbose=True))

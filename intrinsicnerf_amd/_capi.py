@@ -1,0 +1,90 @@
+"""ctypes binding of the C ABI declared in ``include/inerf.h``.
+
+There is deliberately NO fallback: if ``libinerf.so`` is missing or does not load, importing the
+render front-ends raises.  Tensors cross the boundary as raw device pointers (``Tensor.data_ptr()``)
+and the current HIP stream handle; torch only owns memory and streams.
+"""
+import ctypes as C
+import os
+
+from ._build import LIB_PATH
+
+OK, E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_HIP = 0, -1, -2, -3, -4
+VARIANT_OBJECT, VARIANT_SSR = 0, 1
+FLAG_WHITE_BKGD, FLAG_LINDISP, FLAG_ENDPOINT, FLAG_U_PER_RAY, FLAG_BINS_DIRECT = 1, 2, 4, 8, 16
+BASE_CHANNELS, ENDPOINT_DIM, RAY_FLOATS, MAX_CLASSES = 11, 128, 11, 240
+
+_ERR = {E_INVALID: "invalid argument", E_UNSUPPORTED: "unsupported configuration",
+        E_WORKSPACE: "workspace missing or too small", E_HIP: "HIP runtime error"}
+
+
+class NetDesc(C.Structure):
+    _fields_ = [("variant", C.c_int32), ("n_classes", C.c_int32), ("l_xyz", C.c_int32), ("l_dir", C.c_int32),
+                ("xyz_div", C.c_float)]
+
+
+class CompositeOut(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in
+                ("rgb", "disp", "acc", "depth", "albedo", "shading", "residual", "sem", "feat", "weights")]
+
+
+class RenderArgs(C.Structure):
+    _fields_ = [("net", NetDesc), ("packed_coarse", C.c_void_p), ("packed_fine", C.c_void_p),
+                ("rays", C.c_void_p), ("n_rays", C.c_int64), ("n_samples", C.c_int32), ("n_importance", C.c_int32),
+                ("flags", C.c_uint32), ("t_vals", C.c_void_p), ("t_rand", C.c_void_p), ("u", C.c_void_p),
+                ("noise_coarse", C.c_void_p), ("noise_fine", C.c_void_p),
+                ("coarse", CompositeOut), ("fine", CompositeOut), ("z_std", C.c_void_p),
+                ("raw_coarse", C.c_void_p), ("raw_fine", C.c_void_p), ("z_coarse", C.c_void_p),
+                ("z_samples", C.c_void_p), ("z_fine", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
+
+
+# every symbol include/inerf.h declares: (restype, argtypes)
+_P, _I, _L, _U = C.c_void_p, C.c_int, C.c_int64, C.c_uint32
+SYMBOLS = {
+    "inerf_version": (C.c_char_p, []),
+    "inerf_last_hip_error": (_I, []),
+    "inerf_num_tensors": (_I, [C.POINTER(NetDesc)]),
+    "inerf_tensor_info": (_I, [C.POINTER(NetDesc), _I, C.POINTER(C.c_char_p), C.POINTER(_L), C.POINTER(_L)]),
+    "inerf_packed_floats": (_L, [C.POINTER(NetDesc)]),
+    "inerf_raw_channels": (_I, [C.POINTER(NetDesc), _U, _I]),
+    "inerf_pack_weights": (_I, [C.POINTER(NetDesc), C.POINTER(_P), _I, _P, _L]),
+    "inerf_sample_coarse": (_I, [_P, _P, _P, _L, _I, _U, _P, _P]),
+    "inerf_encode_mlp": (_I, [C.POINTER(NetDesc), _P, _P, _P, _L, _I, _U, _P, _P]),
+    "inerf_composite": (_I, [_P, _P, _P, _I, _P, _L, _I, _I, _I, _I, _U, C.POINTER(CompositeOut), _P]),
+    "inerf_sample_fine": (_I, [_P, _P, _P, _L, _I, _I, _U, _P, _P, _P, _P]),
+    "inerf_sample_pdf": (_I, [_P, _P, _P, _L, _I, _I, _U, _P, _P]),
+    "inerf_workspace_bytes": (_L, [C.POINTER(NetDesc), _L, _I, _I, _U]),
+    "inerf_render_rays": (_I, [C.POINTER(RenderArgs), _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library (loads on first use; raises if it is not built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is not built.  Run `python -c 'import __graft_entry__ as g; g.build()'` (or "
+                "`python -m intrinsicnerf_amd._build`).  intrinsicnerf_amd has no CPU or eager fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)          # AttributeError here = header/library mismatch
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc == OK:
+        return
+    msg = _ERR.get(rc, f"error {rc}")
+    if rc == E_HIP:
+        msg += f" (hipError_t {lib().inerf_last_hip_error()})"
+    raise RuntimeError(f"{what}: {msg}")
+
+
+def net_desc(variant, n_classes=0, l_xyz=10, l_dir=4, xyz_div=1.0):
+    return NetDesc(int(variant), int(n_classes), int(l_xyz), int(l_dir), float(xyz_div))

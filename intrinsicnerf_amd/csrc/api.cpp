@@ -1,0 +1,91 @@
+// api.cpp - whole-path entry point of the C ABI: enqueues the stage kernels for one ray batch.
+// Replaces render_rays (object_level/run_nerf.py:415-528) / SSRTrainer.volumetric_rendering
+// (SSR/training/trainer.py:717-808).  No host synchronisation, no allocation: all scratch lives in
+// the caller's workspace.
+#include <cstdint>
+
+#include "layout.h"
+
+namespace {
+
+constexpr int64_t kAlign = 256;
+inline int64_t up(int64_t b) { return (b + kAlign - 1) / kAlign * kAlign; }
+
+struct Plan {
+    int64_t z_c, w_c, raw_c, z_s, z_f, raw_f, total;
+    int ch_c, ch_f, s_f;
+};
+
+Plan plan(const inerf_net_desc& net, int64_t n, int sc, int ni, uint32_t flags) {
+    Plan p{};
+    p.ch_c = inerf_raw_channels(&net, flags, 0);
+    p.ch_f = inerf_raw_channels(&net, flags, 1);
+    p.s_f = sc + ni;
+    int64_t off = 0;
+    auto take = [&](int64_t floats) { int64_t o = off; off += up(floats * 4); return o; };
+    p.z_c = take(n * sc);
+    p.w_c = take(n * sc);
+    p.raw_c = take(n * sc * p.ch_c);
+    if (ni > 0) {
+        p.z_s = take(n * ni);
+        p.z_f = take(n * p.s_f);
+        p.raw_f = take(n * p.s_f * p.ch_f);
+    }
+    p.total = off;
+    return p;
+}
+
+}  // namespace
+
+extern "C" int64_t inerf_workspace_bytes(const inerf_net_desc* net, int64_t n_rays, int n_samples, int n_importance,
+                                         uint32_t flags) {
+    if (!net || !inerf::net_supported(*net) || n_rays < 0 || n_samples < 1 || n_importance < 0) return INERF_E_INVALID;
+    return plan(*net, n_rays, n_samples, n_importance, flags).total;
+}
+
+extern "C" int inerf_render_rays(const inerf_render_args* a, void* stream) {
+    if (!a || !a->packed_coarse || !a->rays || !a->t_vals || a->n_rays < 0 || a->n_samples < 1 || a->n_importance < 0)
+        return INERF_E_INVALID;
+    if (!inerf::net_supported(a->net)) return INERF_E_UNSUPPORTED;
+    if (a->n_importance > 0 && !a->u) return INERF_E_INVALID;
+    if (a->n_rays == 0) return INERF_OK;
+    const Plan p = plan(a->net, a->n_rays, a->n_samples, a->n_importance, a->flags);
+    if (!a->workspace || a->workspace_bytes < p.total) return INERF_E_WORKSPACE;
+    char* ws = static_cast<char*>(a->workspace);
+    auto f = [&](int64_t off) { return reinterpret_cast<float*>(ws + off); };
+    const bool ssr = a->net.variant == INERF_VARIANT_SSR;
+    const int n_cls = ssr ? a->net.n_classes : 0;
+    const int64_t n = a->n_rays;
+    const int sc = a->n_samples, ni = a->n_importance;
+    int rc;
+
+    // ---- coarse pass ----
+    float* z_c = a->z_coarse ? a->z_coarse : f(p.z_c);
+    rc = inerf_sample_coarse(a->rays, a->t_vals, a->t_rand, n, sc, a->flags, z_c, stream);
+    if (rc) return rc;
+    float* raw_c = a->raw_coarse ? a->raw_coarse : f(p.raw_c);
+    // the coarse net never emits the endpoint feature (trainer.py:751-755: endpoint_feat=False)
+    rc = inerf_encode_mlp(&a->net, a->packed_coarse, a->rays, z_c, n, sc, a->flags & ~INERF_FLAG_ENDPOINT, raw_c, stream);
+    if (rc) return rc;
+    inerf_composite_out oc = a->coarse;
+    oc.feat = nullptr;
+    if (ni > 0 && !oc.weights) oc.weights = f(p.w_c);
+    rc = inerf_composite(raw_c, z_c, a->rays + 3, INERF_RAY_FLOATS, a->noise_coarse, n, sc, p.ch_c, oc.sem ? n_cls : 0, 0,
+                         a->flags, &oc, stream);
+    if (rc || ni == 0) return rc;
+
+    // ---- resample, fine pass ----
+    float* z_s = a->z_samples ? a->z_samples : f(p.z_s);
+    float* z_f = a->z_fine ? a->z_fine : f(p.z_f);
+    rc = inerf_sample_fine(z_c, oc.weights, a->u, n, sc, ni, a->flags, z_s, z_f, a->z_std, stream);
+    if (rc) return rc;
+    float* raw_f = a->raw_fine ? a->raw_fine : f(p.raw_f);
+    const float* w_fine = a->packed_fine ? a->packed_fine : a->packed_coarse;   // run_nerf.py:506
+    rc = inerf_encode_mlp(&a->net, w_fine, a->rays, z_f, n, p.s_f, a->flags, raw_f, stream);
+    if (rc) return rc;
+    const bool ep = ssr && (a->flags & INERF_FLAG_ENDPOINT);
+    inerf_composite_out of = a->fine;
+    if (!ep) of.feat = nullptr;
+    return inerf_composite(raw_f, z_f, a->rays + 3, INERF_RAY_FLOATS, a->noise_fine, n, p.s_f, p.ch_f, of.sem ? n_cls : 0,
+                           (ep && of.feat) ? INERF_ENDPOINT_DIM : 0, a->flags, &of, stream);
+}

@@ -1,0 +1,98 @@
+// layout.h - geometry of a work tile in LDS and of the packed weight blob.  Shared by the host
+// packer (pack.cpp) and the encode+MLP kernel (mlp.hip); plain C++, no HIP types.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/inerf.h"
+
+namespace inerf {
+
+// ---- architecture constants (run_nerf.py:545-552: netdepth 8, netwidth 256; skips=[4], :285) ----
+constexpr int kWidth = 256;        // W
+constexpr int kDepth = 8;          // D
+constexpr int kSkipInput = 5;      // pts_linears[5] consumes cat([pts, h]) (run_nerf_helpers.py:290-291)
+constexpr int kHalf = 128;         // W/2
+constexpr int kMaxLxyz = 10;
+constexpr int kMaxLdir = 4;
+
+// ---- tile geometry ----
+// One workgroup = 4 waves = one tile of 64 sample points.  Activations live in LDS as
+// X[point][column] (column = channel, contiguous), so both MFMA operands are read along k with one
+// ds_read_b128 per 4 k-values.  The row stride is 4*odd floats: rows 0..15 then start on 16
+// distinct 16-byte bank slots, which makes every ds_read_b128 / ds_write_b128 used here
+// conflict-free (bank = (36*row + const) mod 64 dwords).
+constexpr int kTilePoints = 64;
+constexpr int kWaves = 4;
+constexpr int kEncCols = 64;       // 3 + 6*10 = 63 encoded xyz channels + 1 zero pad
+constexpr int kDirCols = 32;       // 3 + 6*4  = 27 encoded dir channels + 5 zero pad
+constexpr int kColEnc = 0;
+constexpr int kColDir = kColEnc + kEncCols;     // 64
+constexpr int kColA = kColDir + kDirCols;       // 96   activation buffer A (256 wide)
+constexpr int kColB = kColA + kWidth;           // 352  activation buffer B (256 wide)
+constexpr int kLdsStride = kColB + kWidth + 4;  // 612 = 4 * 153
+constexpr int kLdsBytes = kTilePoints * kLdsStride * 4;   // 156,672 B of the CU's 160 KiB
+
+// ---- packed blob ----
+// "Wide" GEMMs (32x32x2 MFMA): the output channels are split evenly over the 4 waves; wave w owns
+// RB = n_out/128 blocks of 32 channels.  For k-block kb (8 consecutive virtual k) and row block rb,
+// the 64 lanes of the wave load one float4 each, contiguous:
+//     blob[off + (((w*KB + kb)*RB + rb)*64 + lane)*4 + c] = W[w*32*RB + 32*rb + (lane&31)][8*kb + 4*(lane>>5) + c]
+// i.e. exactly the A-operand fragments of four consecutive v_mfma_f32_32x32x2_f32 (c = 0..3).
+// "Skinny" GEMMs (16x16x4 MFMA, <= 16*RBS output rows, every wave reads the same weights):
+//     blob[off + ((rb*KB16 + kb)*64 + lane)*4 + c] = W[16*rb + (lane&15)][16*kb + 4*(lane>>4) + c]
+// Virtual k runs over the concatenation of the layer's LDS source segments (e.g. [enc64 | h256] for
+// pts_linears[5]); padded columns/rows hold zeros.  Biases are stored unpermuted (padded with zeros).
+struct GemmSlot {
+    int32_t w;      // float offset of the packed weights
+    int32_t b;      // float offset of the bias vector
+};
+
+struct NetLayout {
+    GemmSlot trunk[kDepth];   // pts_linears.0-7                       wide, 256 out
+    GemmSlot alpha;           // alpha_linear                          skinny, 1 row block, K=256
+    GemmSlot sem1;            // semantic_linear.0.0 (ssr, C>0)        wide, 128 out, K=256
+    GemmSlot sem2;            // semantic_linear.1                     skinny, sem_rbs row blocks, K=128
+    GemmSlot as1;             // albedo_linear1 (rows 0-127) + shading hidden (rows 128-255)   wide, K=256
+    GemmSlot as2;             // rows 0-2 albedo_linear2 (k<128), row 3 shading out (k>=128)   skinny, K=256
+    GemmSlot feat;            // feature_linear                        wide, 256 out, K=256
+    GemmSlot views;           // views_linears.0 over [feature256 | dir32]   wide, 128 out, K=288
+    GemmSlot res;             // residual head                         skinny, K=128
+    int32_t sem_rbs;          // ceil(C/16), 0 when the semantic head is absent
+    int32_t total_floats;
+};
+
+inline int trunk_k(int layer) { return layer == 0 ? kEncCols : (layer == kSkipInput ? kEncCols + kWidth : kWidth); }
+
+inline NetLayout make_layout(const inerf_net_desc& net) {
+    NetLayout L{};
+    int32_t off = 0;
+    auto take = [&](int32_t n) { int32_t o = off; off += (n + 3) & ~3; return o; };
+    auto wide = [&](GemmSlot& s, int n_out, int k) { s.w = take(n_out * k); s.b = take(n_out); };
+    auto skinny = [&](GemmSlot& s, int rbs, int k) { s.w = take(rbs * 16 * k); s.b = take(rbs * 16); };
+    for (int i = 0; i < kDepth; ++i) wide(L.trunk[i], kWidth, trunk_k(i));
+    skinny(L.alpha, 1, kWidth);
+    L.sem_rbs = 0;
+    if (net.variant == INERF_VARIANT_SSR && net.n_classes > 0) {
+        L.sem_rbs = (net.n_classes + 15) / 16;
+        wide(L.sem1, kHalf, kWidth);
+        skinny(L.sem2, L.sem_rbs, kHalf);
+    }
+    wide(L.as1, kWidth, kWidth);
+    skinny(L.as2, 1, kWidth);
+    wide(L.feat, kWidth, kWidth);
+    wide(L.views, kHalf, kWidth + kDirCols);
+    skinny(L.res, 1, kHalf);
+    L.total_floats = off;
+    return L;
+}
+
+inline bool net_supported(const inerf_net_desc& n) {
+    if (n.variant != INERF_VARIANT_OBJECT && n.variant != INERF_VARIANT_SSR) return false;
+    if (n.l_xyz < 0 || n.l_xyz > kMaxLxyz || n.l_dir < 0 || n.l_dir > kMaxLdir) return false;
+    if (n.n_classes < 0 || n.n_classes > INERF_MAX_CLASSES) return false;
+    if (n.variant == INERF_VARIANT_OBJECT && n.n_classes != 0) return false;
+    if (!(n.xyz_div > 0.0f)) return false;
+    return true;
+}
+
+}  // namespace inerf

@@ -1,0 +1,223 @@
+// pack.cpp - host side of the C ABI: network description, canonical tensor order, weight packer.
+// Replaces (as seen by forward()) the nn.Module parameter storage of
+//   object_level/run_nerf_helpers.py:259-279 (NeRF)  and  SSR/models/semantic_nerf.py:98-118 (Semantic_NeRF).
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "layout.h"
+
+namespace {
+
+struct TensorSpec {
+    std::string name;
+    int64_t rows, cols;   // cols == 0 for a bias
+};
+
+struct Net {
+    inerf_net_desc d;
+    int e, dv;            // real encoded widths
+    std::vector<TensorSpec> spec;
+};
+
+void add_linear(std::vector<TensorSpec>& s, const std::string& n, int64_t out, int64_t in) {
+    s.push_back({n + ".weight", out, in});
+    s.push_back({n + ".bias", out, 0});
+}
+
+Net describe(const inerf_net_desc& d) {
+    using namespace inerf;
+    Net n{d, 3 + 6 * d.l_xyz, 3 + 6 * d.l_dir, {}};
+    for (int i = 0; i < kDepth; ++i) {
+        int in = i == 0 ? n.e : (i == kSkipInput ? n.e + kWidth : kWidth);
+        add_linear(n.spec, "pts_linears." + std::to_string(i), kWidth, in);
+    }
+    add_linear(n.spec, "views_linears.0", kHalf, kWidth + n.dv);
+    add_linear(n.spec, "feature_linear", kWidth, kWidth);
+    add_linear(n.spec, "alpha_linear", 1, kWidth);
+    if (d.variant == INERF_VARIANT_OBJECT) {
+        add_linear(n.spec, "shading_linear", 3, kHalf);      // residual head (run_nerf_helpers.py:314)
+        add_linear(n.spec, "albedo_linear1", kHalf, kWidth);
+        add_linear(n.spec, "albedo_linear2", 3, kHalf);
+        add_linear(n.spec, "test_linear1", kHalf, kWidth);   // shading head (run_nerf_helpers.py:302)
+        add_linear(n.spec, "test_linear2", 1, kHalf);
+    } else {
+        if (d.n_classes > 0) {
+            add_linear(n.spec, "semantic_linear.0.0", kHalf, kWidth);
+            add_linear(n.spec, "semantic_linear.1", d.n_classes, kHalf);
+        }
+        add_linear(n.spec, "residual_linear", 3, kHalf);
+        add_linear(n.spec, "albedo_linear1", kHalf, kWidth);
+        add_linear(n.spec, "albedo_linear2", 3, kHalf);
+        add_linear(n.spec, "shading_linear1", kHalf, kWidth);
+        add_linear(n.spec, "shading_linear2", 1, kHalf);
+    }
+    return n;
+}
+
+using Elem = std::function<float(int /*row*/, int /*virtual k*/)>;
+
+// wide GEMM: fragments of v_mfma_f32_32x32x2_f32's A operand, four k-steps per float4 (layout.h)
+void pack_wide(float* dst, int n_out, int k_total, const Elem& w) {
+    const int rb_per_wave = n_out / (32 * inerf::kWaves), kb_count = k_total / 8;
+    for (int wave = 0; wave < inerf::kWaves; ++wave)
+        for (int kb = 0; kb < kb_count; ++kb)
+            for (int rb = 0; rb < rb_per_wave; ++rb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int c = 0; c < 4; ++c) {
+                        int row = wave * 32 * rb_per_wave + 32 * rb + (lane & 31);
+                        int kv = 8 * kb + 4 * (lane >> 5) + c;
+                        dst[((((int64_t)wave * kb_count + kb) * rb_per_wave + rb) * 64 + lane) * 4 + c] = w(row, kv);
+                    }
+}
+
+// skinny GEMM: fragments of v_mfma_f32_16x16x4_f32's A operand
+void pack_skinny(float* dst, int rbs, int k_total, const Elem& w) {
+    const int kb_count = k_total / 16;
+    for (int rb = 0; rb < rbs; ++rb)
+        for (int kb = 0; kb < kb_count; ++kb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int c = 0; c < 4; ++c) {
+                    int row = 16 * rb + (lane & 15);
+                    int kv = 16 * kb + 4 * (lane >> 4) + c;
+                    dst[(((int64_t)rb * kb_count + kb) * 64 + lane) * 4 + c] = w(row, kv);
+                }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* inerf_version(void) { return "inerf 0.1 (gfx950)"; }
+
+int inerf_num_tensors(const inerf_net_desc* net) {
+    if (!net || !inerf::net_supported(*net)) return INERF_E_INVALID;
+    return (int)describe(*net).spec.size();
+}
+
+int inerf_tensor_info(const inerf_net_desc* net, int index, const char** name, int64_t* rows, int64_t* cols) {
+    if (!net || !inerf::net_supported(*net)) return INERF_E_INVALID;
+    // names are kept alive for the life of the process (one small table per distinct description)
+    static thread_local std::vector<TensorSpec> table;
+    table = describe(*net).spec;
+    if (index < 0 || index >= (int)table.size()) return INERF_E_INVALID;
+    if (name) *name = table[index].name.c_str();
+    if (rows) *rows = table[index].rows;
+    if (cols) *cols = table[index].cols;
+    return INERF_OK;
+}
+
+int64_t inerf_packed_floats(const inerf_net_desc* net) {
+    if (!net || !inerf::net_supported(*net)) return INERF_E_INVALID;
+    return inerf::make_layout(*net).total_floats;
+}
+
+int inerf_raw_channels(const inerf_net_desc* net, uint32_t flags, int fine) {
+    if (!net || !inerf::net_supported(*net)) return INERF_E_INVALID;
+    int ch = INERF_BASE_CHANNELS + (net->variant == INERF_VARIANT_SSR ? net->n_classes : 0);
+    if (fine && net->variant == INERF_VARIANT_SSR && (flags & INERF_FLAG_ENDPOINT)) ch += INERF_ENDPOINT_DIM;
+    return ch;
+}
+
+int inerf_pack_weights(const inerf_net_desc* net, const float* const* tensors, int n_tensors, float* out,
+                       int64_t capacity) {
+    using namespace inerf;
+    if (!net || !tensors || !out || !net_supported(*net)) return INERF_E_INVALID;
+    const Net n = describe(*net);
+    if (n_tensors != (int)n.spec.size()) return INERF_E_INVALID;
+    for (int i = 0; i < n_tensors; ++i)
+        if (!tensors[i]) return INERF_E_INVALID;
+    const NetLayout L = make_layout(*net);
+    if (capacity < L.total_floats) return INERF_E_INVALID;
+    std::memset(out, 0, sizeof(float) * (size_t)L.total_floats);
+
+    auto find = [&](const char* key) -> int {
+        for (int i = 0; i < n_tensors; ++i)
+            if (n.spec[i].name == key) return i;
+        return -1;
+    };
+    auto W = [&](const std::string& lin) { return tensors[find((lin + ".weight").c_str())]; };
+    auto B = [&](const std::string& lin) { return tensors[find((lin + ".bias").c_str())]; };
+    auto copy_bias = [&](int32_t off, const float* b, int count) { std::memcpy(out + off, b, sizeof(float) * count); };
+    const int e = n.e, dv = n.dv;
+
+    // ---- trunk ----
+    for (int i = 0; i < kDepth; ++i) {
+        const std::string lin = "pts_linears." + std::to_string(i);
+        const float* w = W(lin);
+        const int in = (int)n.spec[find((lin + ".weight").c_str())].cols;
+        Elem el;
+        if (i == 0)                       // virtual k = encoded xyz column (64 wide, zero padded)
+            el = [=](int r, int kv) { return kv < e ? w[(int64_t)r * in + kv] : 0.0f; };
+        else if (i == kSkipInput)         // virtual k = [enc64 | h256]; reference order is cat([pts, h])
+            el = [=](int r, int kv) {
+                if (kv < kEncCols) return kv < e ? w[(int64_t)r * in + kv] : 0.0f;
+                return w[(int64_t)r * in + e + (kv - kEncCols)];
+            };
+        else
+            el = [=](int r, int kv) { return w[(int64_t)r * in + kv]; };
+        pack_wide(out + L.trunk[i].w, kWidth, trunk_k(i), el);
+        copy_bias(L.trunk[i].b, B(lin), kWidth);
+    }
+    // ---- sigma ----
+    {
+        const float* w = W("alpha_linear");
+        pack_skinny(out + L.alpha.w, 1, kWidth, [=](int r, int kv) { return r == 0 ? w[kv] : 0.0f; });
+        out[L.alpha.b] = B("alpha_linear")[0];
+    }
+    // ---- semantic head (ssr) ----
+    if (L.sem_rbs > 0) {
+        const float* w1 = W("semantic_linear.0.0");
+        pack_wide(out + L.sem1.w, kHalf, kWidth, [=](int r, int kv) { return w1[(int64_t)r * kWidth + kv]; });
+        copy_bias(L.sem1.b, B("semantic_linear.0.0"), kHalf);
+        const float* w2 = W("semantic_linear.1");
+        const int c = net->n_classes;
+        pack_skinny(out + L.sem2.w, L.sem_rbs, kHalf,
+                    [=](int r, int kv) { return r < c ? w2[(int64_t)r * kHalf + kv] : 0.0f; });
+        copy_bias(L.sem2.b, B("semantic_linear.1"), c);
+    }
+    // ---- albedo + shading hidden layers fused into one 256-row GEMM, then one skinny output GEMM ----
+    const bool obj = net->variant == INERF_VARIANT_OBJECT;
+    const std::string sh1 = obj ? "test_linear1" : "shading_linear1";
+    const std::string sh2 = obj ? "test_linear2" : "shading_linear2";
+    const std::string rs = obj ? "shading_linear" : "residual_linear";
+    {
+        const float* wa = W("albedo_linear1");
+        const float* ws = W(sh1);
+        pack_wide(out + L.as1.w, kWidth, kWidth, [=](int r, int kv) {
+            return r < kHalf ? wa[(int64_t)r * kWidth + kv] : ws[(int64_t)(r - kHalf) * kWidth + kv];
+        });
+        copy_bias(L.as1.b, B("albedo_linear1"), kHalf);
+        copy_bias(L.as1.b + kHalf, B(sh1), kHalf);
+        const float* wa2 = W("albedo_linear2");
+        const float* ws2 = W(sh2);
+        pack_skinny(out + L.as2.w, 1, kWidth, [=](int r, int kv) {
+            if (r < 3) return kv < kHalf ? wa2[(int64_t)r * kHalf + kv] : 0.0f;
+            if (r == 3) return kv >= kHalf ? ws2[kv - kHalf] : 0.0f;
+            return 0.0f;
+        });
+        copy_bias(L.as2.b, B("albedo_linear2"), 3);
+        out[L.as2.b + 3] = B(sh2)[0];
+    }
+    // ---- feature, views, residual ----
+    {
+        const float* wf = W("feature_linear");
+        pack_wide(out + L.feat.w, kWidth, kWidth, [=](int r, int kv) { return wf[(int64_t)r * kWidth + kv]; });
+        copy_bias(L.feat.b, B("feature_linear"), kWidth);
+        const float* wv = W("views_linears.0");
+        const int in = kWidth + dv;
+        pack_wide(out + L.views.w, kHalf, kWidth + kDirCols, [=](int r, int kv) {
+            if (kv < kWidth) return wv[(int64_t)r * in + kv];
+            const int dc = kv - kWidth;
+            return dc < dv ? wv[(int64_t)r * in + kWidth + dc] : 0.0f;
+        });
+        copy_bias(L.views.b, B("views_linears.0"), kHalf);
+        const float* wr = W(rs);
+        pack_skinny(out + L.res.w, 1, kHalf, [=](int r, int kv) { return r < 3 ? wr[(int64_t)r * kHalf + kv] : 0.0f; });
+        copy_bias(L.res.b, B(rs), 3);
+    }
+    return INERF_OK;
+}
+
+}  // extern "C"

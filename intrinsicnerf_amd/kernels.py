@@ -1,0 +1,227 @@
+"""Tensor-level launchers for the C ABI (``include/inerf.h``): validate, allocate, pass raw pointers.
+
+torch is plumbing here - it owns device memory and the HIP stream; all arithmetic happens in
+``libinerf.so``.  Every function requires fp32 tensors on a HIP device and raises otherwise: there is
+no CPU or eager fallback.
+"""
+import ctypes as C
+
+import torch
+
+from . import _capi
+from ._capi import (BASE_CHANNELS, ENDPOINT_DIM, FLAG_ENDPOINT, FLAG_LINDISP, FLAG_U_PER_RAY, FLAG_WHITE_BKGD,
+                    RAY_FLOATS, CompositeOut, RenderArgs)
+
+MAX_POINTS_PER_LAUNCH = (1 << 31) - 1
+
+
+def _dev(t, name, shape=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} lives on {t.device}: intrinsicnerf_amd runs only on a HIP device "
+                           "(no CPU / eager fallback exists)")
+    if t.dtype != torch.float32:
+        raise ValueError(f"{name} must be float32, got {t.dtype}")
+    if shape is not None:
+        if t.dim() != len(shape) or any(s is not None and int(t.shape[i]) != s for i, s in enumerate(shape)):
+            raise ValueError(f"{name} has shape {tuple(t.shape)}, expected {tuple('*' if s is None else s for s in shape)}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _opt(t, name, shape, like):
+    if t is None:
+        return None
+    t = _dev(t, name, shape)
+    if t.device != like.device:
+        raise ValueError(f"{name} is on {t.device}, expected {like.device}")
+    return t
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(t):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _new(like, *shape):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+def sample_coarse(rays, t_vals, t_rand=None, lindisp=False):
+    """z_vals[N,S] (run_nerf.py:464-486 / trainer.py:730-746)."""
+    rays = _dev(rays, "rays", (None, RAY_FLOATS))
+    t_vals = _dev(t_vals, "t_vals", (None,))
+    n, s = rays.shape[0], t_vals.shape[0]
+    t_rand = _opt(t_rand, "t_rand", (n, s), rays)
+    z = _new(rays, n, s)
+    with torch.cuda.device(rays.device):
+        rc = _capi.lib().inerf_sample_coarse(_ptr(rays), _ptr(t_vals), _ptr(t_rand), n, s,
+                                             FLAG_LINDISP if lindisp else 0, _ptr(z), _stream(rays))
+    _capi.check(rc, "inerf_sample_coarse")
+    return z
+
+
+def encode_mlp(desc, packed, rays, z_vals, endpoint=False):
+    """raw[N,S,CH]: fused encoding + MLP (run_network + NeRF.forward)."""
+    rays = _dev(rays, "rays", (None, RAY_FLOATS))
+    z_vals = _dev(z_vals, "z_vals", (rays.shape[0], None))
+    packed = _dev(packed, "packed weights", (None,))
+    n, s = z_vals.shape
+    flags = FLAG_ENDPOINT if endpoint else 0
+    ch = _capi.lib().inerf_raw_channels(desc, flags, 1)
+    raw = _new(rays, n, s, ch)
+    with torch.cuda.device(rays.device):
+        rc = _capi.lib().inerf_encode_mlp(desc, _ptr(packed), _ptr(rays), _ptr(z_vals), n, s, flags, _ptr(raw),
+                                          _stream(rays))
+    _capi.check(rc, "inerf_encode_mlp")
+    return raw
+
+
+def composite(raw, z_vals, rays_d, noise=None, white_bkgd=False, n_classes=0, feat_dim=0, want_weights=True):
+    """raw2outputs (run_nerf.py:359-412 / model_utils.py:39-116) -> dict of maps."""
+    raw = _dev(raw, "raw", (None, None, None))
+    n, s, ch = raw.shape
+    z_vals = _dev(z_vals, "z_vals", (n, s))
+    rays_d = _dev(rays_d, "rays_d", (n, 3))
+    noise = _opt(noise, "noise", (n, s), raw)
+    out = {k: _new(raw, n, 3) for k in ("rgb", "albedo", "residual")}
+    out.update({k: _new(raw, n) for k in ("disp", "acc", "depth", "shading")})
+    if n_classes > 0:
+        out["sem"] = _new(raw, n, n_classes)
+    if feat_dim > 0:
+        out["feat"] = _new(raw, n, feat_dim)
+    if want_weights:
+        out["weights"] = _new(raw, n, s)
+    co = CompositeOut(**{k: t.data_ptr() for k, t in out.items()})
+    with torch.cuda.device(raw.device):
+        rc = _capi.lib().inerf_composite(_ptr(raw), _ptr(z_vals), _ptr(rays_d), 3, _ptr(noise), n, s, ch, n_classes,
+                                         feat_dim, FLAG_WHITE_BKGD if white_bkgd else 0, C.byref(co), _stream(raw))
+    _capi.check(rc, "inerf_composite")
+    return out
+
+
+def _u_arg(u, n, n_imp, like):
+    u = _dev(u, "u")
+    if u.dim() == 1 and u.shape[0] == n_imp:
+        return u, 0
+    if u.dim() == 2 and tuple(u.shape) == (n, n_imp):
+        return u, FLAG_U_PER_RAY
+    raise ValueError(f"u has shape {tuple(u.shape)}, expected ({n_imp},) or ({n}, {n_imp})")
+
+
+def sample_fine(z_coarse, weights, u, n_importance):
+    """z_mid + sample_pdf + sort(cat) + std (run_nerf.py:499-503,519) -> (z_samples, z_merged, z_std)."""
+    z_coarse = _dev(z_coarse, "z_coarse", (None, None))
+    n, sc = z_coarse.shape
+    weights = _dev(weights, "weights", (n, sc))
+    u, flags = _u_arg(u, n, n_importance, z_coarse)
+    z_s, z_m, z_std = _new(z_coarse, n, n_importance), _new(z_coarse, n, sc + n_importance), _new(z_coarse, n)
+    with torch.cuda.device(z_coarse.device):
+        rc = _capi.lib().inerf_sample_fine(_ptr(z_coarse), _ptr(weights), _ptr(u), n, sc, n_importance, flags,
+                                           _ptr(z_s), _ptr(z_m), _ptr(z_std), _stream(z_coarse))
+    _capi.check(rc, "inerf_sample_fine")
+    return z_s, z_m, z_std
+
+
+def sample_pdf(bins, weights, u, n_samples):
+    """Stand-alone sample_pdf(bins, weights, N) (run_nerf_helpers.py:402-445)."""
+    bins = _dev(bins, "bins", (None, None))
+    n, nb = bins.shape
+    weights = _dev(weights, "weights", (n, nb - 1))
+    u, flags = _u_arg(u, n, n_samples, bins)
+    out = _new(bins, n, n_samples)
+    with torch.cuda.device(bins.device):
+        rc = _capi.lib().inerf_sample_pdf(_ptr(bins), _ptr(weights), _ptr(u), n, nb, n_samples, flags, _ptr(out),
+                                          _stream(bins))
+    _capi.check(rc, "inerf_sample_pdf")
+    return out
+
+
+_MAP_KEYS = ("rgb", "disp", "acc", "depth", "albedo", "shading", "residual")
+
+
+def render_rays_fused(desc, packed_coarse, packed_fine, rays, n_samples, n_importance, t_vals, u=None, t_rand=None,
+                      noise_coarse=None, noise_fine=None, white_bkgd=False, lindisp=False, endpoint=False,
+                      want_raw_coarse=False, want_raw_fine=False, want_stages=False, want_sem=True):
+    """Whole render_rays path for one ray batch through ``inerf_render_rays``.
+
+    Returns a dict with ``{rgb,disp,acc,depth,albedo,shading,residual[,sem]}_{coarse,fine}``, ``z_std``
+    and, on request, ``raw_*`` / stage tensors (``z_coarse, weights_coarse, z_samples, z_fine,
+    weights_fine``).  Everything is enqueued on the current stream; nothing synchronises.
+    """
+    L = _capi.lib()
+    rays = _dev(rays, "rays", (None, RAY_FLOATS))
+    n = rays.shape[0]
+    if n * (n_samples + n_importance) > MAX_POINTS_PER_LAUNCH:
+        raise ValueError("ray batch too large for one launch; chunk it (the render() front-ends do)")
+    packed_coarse = _dev(packed_coarse, "packed_coarse", (None,))
+    packed_fine = _opt(packed_fine, "packed_fine", (None,), rays)
+    t_vals = _dev(t_vals, "t_vals", (n_samples,))
+    t_rand = _opt(t_rand, "t_rand", (n, n_samples), rays)
+    noise_coarse = _opt(noise_coarse, "noise_coarse", (n, n_samples), rays)
+    s_f = n_samples + n_importance
+    noise_fine = _opt(noise_fine, "noise_fine", (n, s_f), rays) if n_importance > 0 else None
+    flags = (FLAG_WHITE_BKGD if white_bkgd else 0) | (FLAG_LINDISP if lindisp else 0) | (FLAG_ENDPOINT if endpoint else 0)
+    if n_importance > 0:
+        if u is None:
+            raise ValueError("u is required when n_importance > 0")
+        u, uf = _u_arg(u, n, n_importance, rays)
+        flags |= uf
+    n_cls = desc.n_classes if (desc.variant == _capi.VARIANT_SSR and want_sem) else 0
+    ch_c, ch_f = L.inerf_raw_channels(desc, flags, 0), L.inerf_raw_channels(desc, flags, 1)
+
+    out = {}
+
+    def maps(level, s_count, with_feat):
+        d = {k: _new(rays, n, 3) for k in ("rgb", "albedo", "residual")}
+        d.update({k: _new(rays, n) for k in ("disp", "acc", "depth", "shading")})
+        if n_cls > 0:
+            d["sem"] = _new(rays, n, n_cls)
+        if with_feat:
+            d["feat"] = _new(rays, n, ENDPOINT_DIM)
+        if want_stages:
+            d["weights"] = _new(rays, n, s_count)
+        for k, t in d.items():
+            out[f"{k}_{level}"] = t
+        return CompositeOut(**{k: t.data_ptr() for k, t in d.items()})
+
+    args = RenderArgs()
+    args.net = desc
+    args.packed_coarse, args.packed_fine = packed_coarse.data_ptr(), (packed_fine.data_ptr() if packed_fine is not None else None)
+    args.rays, args.n_rays, args.n_samples, args.n_importance, args.flags = rays.data_ptr(), n, n_samples, n_importance, flags
+    args.t_vals = t_vals.data_ptr()
+    args.t_rand = t_rand.data_ptr() if t_rand is not None else None
+    args.u = u.data_ptr() if n_importance > 0 else None
+    args.noise_coarse = noise_coarse.data_ptr() if noise_coarse is not None else None
+    args.noise_fine = noise_fine.data_ptr() if noise_fine is not None else None
+    args.coarse = maps("coarse", n_samples, False)
+    if n_importance > 0:
+        args.fine = maps("fine", s_f, bool(endpoint and desc.variant == _capi.VARIANT_SSR))
+        out["z_std"] = _new(rays, n)
+        args.z_std = out["z_std"].data_ptr()
+    if want_raw_coarse:
+        out["raw_coarse"] = _new(rays, n, n_samples, ch_c)
+        args.raw_coarse = out["raw_coarse"].data_ptr()
+    if want_raw_fine and n_importance > 0:
+        out["raw_fine"] = _new(rays, n, s_f, ch_f)
+        args.raw_fine = out["raw_fine"].data_ptr()
+    if want_stages:
+        out["z_coarse"] = _new(rays, n, n_samples)
+        args.z_coarse = out["z_coarse"].data_ptr()
+        if n_importance > 0:
+            out["z_samples"], out["z_fine"] = _new(rays, n, n_importance), _new(rays, n, s_f)
+            args.z_samples, args.z_fine = out["z_samples"].data_ptr(), out["z_fine"].data_ptr()
+    ws_bytes = L.inerf_workspace_bytes(desc, n, n_samples, n_importance, flags)
+    if ws_bytes < 0:
+        _capi.check(int(ws_bytes), "inerf_workspace_bytes")
+    ws = torch.empty(max(int(ws_bytes), 1), dtype=torch.uint8, device=rays.device)
+    args.workspace, args.workspace_bytes = ws.data_ptr(), int(ws_bytes)
+    with torch.cuda.device(rays.device):
+        rc = L.inerf_render_rays(C.byref(args), _stream(rays))
+    _capi.check(rc, "inerf_render_rays")
+    # `ws` and the input tensors are kept alive by the caching allocator's stream semantics: they are
+    # released on the same stream the kernels were enqueued on.
+    return out

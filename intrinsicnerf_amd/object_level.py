@@ -1,0 +1,410 @@
+"""Drop-in front-end for the object-level code base (``object_level/run_nerf.py`` + ``run_nerf_helpers.py``).
+
+Same function names, argument meaning, return structure and error behaviour as the reference, so
+that ``run_nerf.py`` keeps working when it imports these instead of its own definitions
+(INTEGRATION.md).  The arithmetic is done by ``libinerf.so`` (hand-written HIP for gfx950); this
+file is plumbing: shape handling, RNG draws in the reference's order, chunk loops, dict assembly.
+
+Reference lines (relative to ``/root/reference/object_level``):
+  render          run_nerf.py:74-139        batchify_rays   run_nerf.py:59-71
+  render_rays     run_nerf.py:415-528       run_network     run_nerf.py:42-56
+  raw2outputs     run_nerf.py:359-412       sample_pdf      run_nerf_helpers.py:402-445
+  NeRF            run_nerf_helpers.py:247   get_embedder    run_nerf_helpers.py:228-243
+  get_rays        run_nerf_helpers.py:359   ndc_rays        run_nerf_helpers.py:381-399
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _capi, kernels, packing
+
+__all__ = ["Embedder", "get_embedder", "NeRF", "NetworkQuery", "run_network", "raw2outputs", "sample_pdf",
+           "render_rays", "batchify_rays", "render", "get_rays", "get_rays_np", "ndc_rays", "create_nerf"]
+
+
+# ----------------------------------------------------------------------------------------------
+# encoder + model (host-side mirrors; the hot path reads only their hyper-parameters and weights)
+# ----------------------------------------------------------------------------------------------
+class Embedder:
+    """Frequency encoder description (run_nerf_helpers.py:195-225).
+
+    In the fused path only ``n_freqs`` / ``scalar_factor`` are read - the encoding itself happens
+    inside the MLP kernel.  Calling the object evaluates the same encoding with torch ops (used by
+    code that wants the embedding itself, e.g. a user-supplied network).
+    """
+
+    def __init__(self, n_freqs, input_dims=3, scalar_factor=1.0):
+        self.n_freqs = int(n_freqs)
+        self.input_dims = input_dims
+        self.scalar_factor = float(scalar_factor)
+        self.out_dim = input_dims * (1 + 2 * self.n_freqs)
+
+    def __call__(self, x):
+        if self.scalar_factor != 1.0:
+            x = x / self.scalar_factor
+        bands = [x]
+        for k in range(self.n_freqs):
+            bands += [torch.sin(x * float(2 ** k)), torch.cos(x * float(2 ** k))]
+        return torch.cat(bands, -1)
+
+    embed = __call__
+
+
+def get_embedder(multires, i=0):
+    """(embed_fn, out_dim) - run_nerf_helpers.py:228-243.  ``i == -1`` means no encoding."""
+    if i == -1:
+        return nn.Identity(), 3
+    e = Embedder(multires)
+    return e, e.out_dim
+
+
+class NeRF(nn.Module):
+    """Intrinsic NeRF MLP with the reference's parameter names and shapes (run_nerf_helpers.py:247-325).
+
+    ``pts_linears.0-7``, ``views_linears.0``, ``feature_linear``, ``alpha_linear``, ``shading_linear``
+    (the RESIDUAL head), ``albedo_linear1/2``, ``test_linear1/2`` (the SHADING head): checkpoints
+    written by the reference load unchanged.  ``forward`` is the definition of the network in torch
+    ops for callers that hold an already-embedded tensor; ``render_rays`` / ``run_network`` never call
+    it - they hand the module's weights to the fused HIP kernel.
+    """
+
+    def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, output_ch=4, skips=[4], use_viewdirs=False):
+        super().__init__()
+        self.D, self.W = D, W
+        self.input_ch, self.input_ch_views = input_ch, input_ch_views
+        self.skips = list(skips)
+        self.use_viewdirs = use_viewdirs
+        self.pts_linears = nn.ModuleList(
+            [nn.Linear(input_ch, W)] +
+            [nn.Linear(W + input_ch, W) if i in self.skips else nn.Linear(W, W) for i in range(D - 1)])
+        self.views_linears = nn.ModuleList([nn.Linear(input_ch_views + W, W // 2)])
+        if use_viewdirs:
+            self.feature_linear = nn.Linear(W, W)
+            self.alpha_linear = nn.Linear(W, 1)
+            self.shading_linear = nn.Linear(W // 2, 3)
+            self.albedo_linear1 = nn.Linear(W, W // 2)
+            self.albedo_linear2 = nn.Linear(W // 2, 3)
+            self.test_linear1 = nn.Linear(W, W // 2)
+            self.test_linear2 = nn.Linear(W // 2, 1)
+        else:
+            self.output_linear = nn.Linear(W, output_ch)
+
+    def fused_desc(self):
+        """C-ABI description if the fused kernel supports this architecture, else None."""
+        if not (self.use_viewdirs and self.D == 8 and self.W == 256 and self.skips == [4]):
+            return None
+        l_xyz, rx = divmod(self.input_ch - 3, 6)
+        l_dir, rd = divmod(self.input_ch_views - 3, 6)
+        if rx or rd or not (0 <= l_xyz <= 10 and 0 <= l_dir <= 4):
+            return None
+        return _capi.net_desc(_capi.VARIANT_OBJECT, 0, l_xyz, l_dir, 1.0)
+
+    def forward(self, x):
+        pts, views = torch.split(x, [self.input_ch, self.input_ch_views], dim=-1)
+        h = pts
+        for i, layer in enumerate(self.pts_linears):
+            h = F.relu(layer(h))
+            if i in self.skips:
+                h = torch.cat([pts, h], -1)
+        if not self.use_viewdirs:
+            return self.output_linear(h)
+        sigma = self.alpha_linear(h)
+        albedo = torch.sigmoid(self.albedo_linear2(F.relu(self.albedo_linear1(h))))
+        shading = torch.sigmoid(self.test_linear2(F.relu(self.test_linear1(h))))
+        v = torch.cat([self.feature_linear(h), views], -1)
+        for layer in self.views_linears:
+            v = F.relu(layer(v))
+        residual = torch.sigmoid(self.shading_linear(v))
+        rgb = albedo * shading + residual
+        return torch.cat([rgb, sigma, albedo, shading, residual], -1)
+
+
+class NetworkQuery:
+    """The ``network_query_fn`` closure of create_nerf (run_nerf.py:298-301) as an inspectable object."""
+
+    def __init__(self, embed_fn, embeddirs_fn, netchunk=1024 * 64):
+        self.embed_fn, self.embeddirs_fn, self.netchunk = embed_fn, embeddirs_fn, netchunk
+
+    def __call__(self, inputs, viewdirs, network_fn):
+        return run_network(inputs, viewdirs, network_fn, self.embed_fn, self.embeddirs_fn, self.netchunk)
+
+
+def _fusable(network_fn, embed_fn, embeddirs_fn):
+    """Descriptor if (network, encoders) is a combination the fused kernel implements, else None."""
+    if not hasattr(network_fn, "fused_desc"):
+        return None
+    desc = network_fn.fused_desc()
+    if desc is None or not isinstance(embed_fn, Embedder) or not isinstance(embeddirs_fn, Embedder):
+        return None
+    if embed_fn.n_freqs != desc.l_xyz or embeddirs_fn.n_freqs != desc.l_dir or embeddirs_fn.scalar_factor != 1.0:
+        return None
+    desc.xyz_div = embed_fn.scalar_factor
+    return desc
+
+
+def _no_grad_guard(what, *modules):
+    if torch.is_grad_enabled() and any(p.requires_grad for m in modules if m is not None for p in m.parameters()):
+        raise NotImplementedError(
+            f"{what}: gradients were requested, but the HIP path is forward-only in this release (the "
+            "backward kernels are SURVEY.md section 8(f) row 1).  Call under torch.no_grad().")
+
+
+def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64):
+    """Encode ``inputs[..., 3]`` (+ ``viewdirs[N, 3]``) and apply network ``fn`` - run_nerf.py:42-56.
+
+    With this package's NeRF + Embedder the whole thing is one fused HIP launch (``netchunk`` only
+    bounded the reference's activation memory and does not affect results).  Any other ``fn`` is
+    called like the reference does, on the torch-evaluated embedding.
+    """
+    desc = _fusable(fn, embed_fn, embeddirs_fn) if viewdirs is not None else None
+    if desc is None:
+        flat = torch.reshape(inputs, [-1, inputs.shape[-1]])
+        emb = embed_fn(flat)
+        if viewdirs is not None:
+            dirs = viewdirs[:, None].expand(inputs.shape)
+            emb = torch.cat([emb, embeddirs_fn(torch.reshape(dirs, [-1, dirs.shape[-1]]))], -1)
+        out = torch.cat([fn(emb[i:i + netchunk]) for i in range(0, emb.shape[0], netchunk)], 0) if netchunk else fn(emb)
+        return torch.reshape(out, list(inputs.shape[:-1]) + [out.shape[-1]])
+    _no_grad_guard("run_network", fn)
+    # arbitrary points: one "ray" per point with origin = point, direction = 0, depth 0 -> o + 0*0 = o
+    pts = torch.reshape(inputs, [-1, 3]).float()
+    dirs = torch.reshape(viewdirs[:, None].expand(inputs.shape), [-1, 3]).float()
+    rays = torch.zeros(pts.shape[0], _capi.RAY_FLOATS, dtype=torch.float32, device=pts.device)
+    rays[:, 0:3], rays[:, 8:11] = pts, dirs
+    z = torch.zeros(pts.shape[0], 1, dtype=torch.float32, device=pts.device)
+    raw = kernels.encode_mlp(desc, packing.packed_for_module(fn, desc, pts.device), rays, z)
+    return torch.reshape(raw, list(inputs.shape[:-1]) + [raw.shape[-1]])
+
+
+def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False):
+    """Alpha compositing - run_nerf.py:359-412.
+
+    Returns ``(rgb_map, disp_map, acc_map, weights, depth_map, albedo_map, shading_map, residual_map)``.
+    """
+    noise = None
+    if raw_noise_std > 0.:
+        noise = torch.randn(raw[..., 3].shape, device=raw.device) * raw_noise_std
+        if pytest:
+            np.random.seed(0)
+            noise = torch.Tensor(np.random.rand(*list(raw[..., 3].shape)) * raw_noise_std).to(raw.device)
+    o = kernels.composite(raw.float(), z_vals.float(), rays_d.float(), noise, white_bkgd)
+    return o["rgb"], o["disp"], o["acc"], o["weights"], o["depth"], o["albedo"], o["shading"], o["residual"]
+
+
+def _draw_u(n_rays, n_samples, det, pytest, device):
+    """The ``u`` of sample_pdf (run_nerf_helpers.py:409-425): shared linspace when deterministic."""
+    if pytest:
+        np.random.seed(0)
+        if det:
+            return torch.Tensor(np.linspace(0., 1., n_samples)).to(device)
+        return torch.Tensor(np.random.rand(n_rays, n_samples)).to(device)
+    if det:
+        return torch.linspace(0., 1., steps=n_samples, device=device)
+    return torch.rand(n_rays, n_samples, device=device)
+
+
+def sample_pdf(bins, weights, N_samples, det=False, pytest=False):
+    """Hierarchical sampling - run_nerf_helpers.py:402-445.  ``bins[N,B]``, ``weights[N,B-1]`` -> ``[N,N_samples]``."""
+    lead = bins.shape[:-1]
+    b2 = torch.reshape(bins, [-1, bins.shape[-1]]).float()
+    w2 = torch.reshape(weights, [-1, weights.shape[-1]]).float()
+    u = _draw_u(b2.shape[0], N_samples, det, pytest, bins.device)
+    return torch.reshape(kernels.sample_pdf(b2, w2, u, N_samples), list(lead) + [N_samples])
+
+
+_RET_MAP = (("rgb_map", "rgb"), ("disp_map", "disp"), ("acc_map", "acc"), ("albedo_map", "albedo"),
+            ("shading_map", "shading"), ("residual_map", "residual"))
+_RET_0 = (("rgb0", "rgb"), ("disp0", "disp"), ("acc0", "acc"), ("albedo0", "albedo"), ("shading0", "shading"),
+          ("residual0", "residual"))
+
+
+def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False, lindisp=False, perturb=0.,
+                N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0., verbose=False, pytest=False):
+    """Volumetric rendering of one ray batch - run_nerf.py:415-528 (same dict keys, same RNG draw order)."""
+    ray_batch = ray_batch.float()
+    n = ray_batch.shape[0]
+    dev = ray_batch.device
+    if ray_batch.shape[-1] <= 8:
+        raise NotImplementedError("render_rays without view directions: the 11-channel intrinsic network needs "
+                                  "use_viewdirs=True (run_nerf_helpers.py:281-282 is unused by every config)")
+    desc = None
+    if isinstance(network_query_fn, NetworkQuery):
+        desc = _fusable(network_fn, network_query_fn.embed_fn, network_query_fn.embeddirs_fn)
+        if desc is not None and network_fine is not None and _fusable(
+                network_fine, network_query_fn.embed_fn, network_query_fn.embeddirs_fn) is None:
+            desc = None
+    # random inputs, drawn in the reference's order: t_rand (:478), coarse noise (:387), u (helpers:414), fine noise
+    t_vals = torch.linspace(0., 1., steps=N_samples, device=dev)
+    t_rand = None
+    if perturb > 0.:
+        t_rand = torch.rand(n, N_samples, device=dev)
+        if pytest:
+            np.random.seed(0)
+            t_rand = torch.Tensor(np.random.rand(n, N_samples)).to(dev)
+
+    def noise(s):
+        if not raw_noise_std > 0.:
+            return None
+        nz = torch.randn(n, s, device=dev) * raw_noise_std
+        if pytest:
+            np.random.seed(0)
+            nz = torch.Tensor(np.random.rand(n, s) * raw_noise_std).to(dev)
+        return nz
+
+    if desc is not None:
+        _no_grad_guard("render_rays", network_fn, network_fine)
+        noise_c = noise(N_samples)
+        u = _draw_u(n, N_importance, perturb == 0., pytest, dev) if N_importance > 0 else None
+        noise_f = noise(N_samples + N_importance) if N_importance > 0 else None
+        fine_net = network_fine if network_fine is not None else network_fn
+        o = kernels.render_rays_fused(
+            desc, packing.packed_for_module(network_fn, desc, dev),
+            packing.packed_for_module(fine_net, desc, dev) if N_importance > 0 else None,
+            ray_batch, N_samples, N_importance, t_vals, u, t_rand, noise_c, noise_f, white_bkgd, lindisp,
+            want_raw_coarse=retraw and N_importance == 0, want_raw_fine=retraw)
+        lvl = "fine" if N_importance > 0 else "coarse"
+        ret = {rk: o[f"{ok}_{lvl}"] for rk, ok in _RET_MAP}
+        if retraw:
+            ret["raw"] = o["raw_" + lvl]
+        if N_importance > 0:
+            for rk, ok in _RET_0:
+                ret[rk] = o[ok + "_coarse"]
+            ret["z_std"] = o["z_std"]
+    else:
+        # user-supplied network: the stages still run on the HIP kernels, the network is called as given
+        rays_o, rays_d, viewdirs = ray_batch[:, 0:3], ray_batch[:, 3:6].contiguous(), ray_batch[:, -3:]
+        z_vals = kernels.sample_coarse(ray_batch, t_vals, t_rand, lindisp)
+        pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
+        raw = network_query_fn(pts, viewdirs, network_fn)
+        c = kernels.composite(raw.float(), z_vals, rays_d, noise(N_samples), white_bkgd)
+        ret = {rk: c[ok] for rk, ok in _RET_MAP}
+        if N_importance > 0:
+            c0 = c
+            u = _draw_u(n, N_importance, perturb == 0., pytest, dev)
+            z_samples, z_vals, z_std = kernels.sample_fine(z_vals, c0["weights"], u, N_importance)
+            pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
+            raw = network_query_fn(pts, viewdirs, network_fn if network_fine is None else network_fine)
+            c = kernels.composite(raw.float(), z_vals, rays_d, noise(N_samples + N_importance), white_bkgd)
+            ret = {rk: c[ok] for rk, ok in _RET_MAP}
+            for rk, ok in _RET_0:
+                ret[rk] = c0[ok]
+            ret["z_std"] = z_std
+        if retraw:
+            ret["raw"] = raw
+    if verbose:   # the reference's DEBUG nan/inf scan (run_nerf.py:524-526); each check is a device sync
+        for k in ret:
+            if torch.isnan(ret[k]).any() or torch.isinf(ret[k]).any():
+                print(f"! [Numerical Error] {k} contains nan or inf.")
+    return ret
+
+
+def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
+    """Render rays in chunks - run_nerf.py:59-71.  Results do not depend on ``chunk``."""
+    all_ret = {}
+    for i in range(0, rays_flat.shape[0], chunk):
+        ret = render_rays(rays_flat[i:i + chunk], **kwargs)
+        for k in ret:
+            all_ret.setdefault(k, []).append(ret[k])
+    return {k: torch.cat(all_ret[k], 0) for k in all_ret}
+
+
+def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
+           c2w_staticcam=None, **kwargs):
+    """Render an image or a ray batch - run_nerf.py:74-139.
+
+    Returns ``[rgb_map, disp_map, acc_map, albedo_map, shading_map, residual_map, extras]``.
+    """
+    if c2w is not None:
+        rays_o, rays_d = get_rays(H, W, K, c2w)
+    else:
+        rays_o, rays_d = rays
+    if use_viewdirs:
+        viewdirs = rays_d
+        if c2w_staticcam is not None:
+            rays_o, rays_d = get_rays(H, W, K, c2w_staticcam)
+        viewdirs = viewdirs / torch.norm(viewdirs, dim=-1, keepdim=True)
+        viewdirs = torch.reshape(viewdirs, [-1, 3]).float()
+    sh = rays_d.shape
+    if ndc:
+        rays_o, rays_d = ndc_rays(H, W, K[0][0], 1., rays_o, rays_d)
+    rays_o = torch.reshape(rays_o, [-1, 3]).float()
+    rays_d = torch.reshape(rays_d, [-1, 3]).float()
+    near, far = near * torch.ones_like(rays_d[..., :1]), far * torch.ones_like(rays_d[..., :1])
+    rays = torch.cat([rays_o, rays_d, near, far], -1)
+    if use_viewdirs:
+        rays = torch.cat([rays, viewdirs], -1)
+    all_ret = batchify_rays(rays, chunk, **kwargs)
+    for k in all_ret:
+        all_ret[k] = torch.reshape(all_ret[k], list(sh[:-1]) + list(all_ret[k].shape[1:]))
+    k_extract = ["rgb_map", "disp_map", "acc_map", "albedo_map", "shading_map", "residual_map"]
+    return [all_ret[k] for k in k_extract] + [{k: all_ret[k] for k in all_ret if k not in k_extract}]
+
+
+# ----------------------------------------------------------------------------------------------
+# ray generation (input producers of the path)
+# ----------------------------------------------------------------------------------------------
+def get_rays(H, W, K, c2w):
+    """Pinhole rays in the OpenGL (-z forward) convention - run_nerf_helpers.py:359-368."""
+    dev = c2w.device if isinstance(c2w, torch.Tensor) else None
+    c2w = torch.as_tensor(c2w, dtype=torch.float32, device=dev)
+    j, i = torch.meshgrid(torch.linspace(0, H - 1, H, device=c2w.device), torch.linspace(0, W - 1, W, device=c2w.device),
+                          indexing="ij")
+    dirs = torch.stack([(i - K[0][2]) / K[0][0], -(j - K[1][2]) / K[1][1], -torch.ones_like(i)], -1)
+    rays_d = torch.sum(dirs[..., None, :] * c2w[:3, :3], -1)
+    rays_o = c2w[:3, -1].expand(rays_d.shape)
+    return rays_o, rays_d
+
+
+def get_rays_np(H, W, K, c2w):
+    """NumPy twin of get_rays - run_nerf_helpers.py:371-378."""
+    i, j = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32), indexing="xy")
+    dirs = np.stack([(i - K[0][2]) / K[0][0], -(j - K[1][2]) / K[1][1], -np.ones_like(i)], -1)
+    rays_d = np.sum(dirs[..., np.newaxis, :] * c2w[:3, :3], -1)
+    return np.broadcast_to(c2w[:3, -1], np.shape(rays_d)), rays_d
+
+
+def ndc_rays(H, W, focal, near, rays_o, rays_d):
+    """Normalised-device-coordinate rays for forward-facing scenes - run_nerf_helpers.py:381-399."""
+    t = -(near + rays_o[..., 2]) / rays_d[..., 2]
+    rays_o = rays_o + t[..., None] * rays_d
+    sx, sy = -1. / (W / (2. * focal)), -1. / (H / (2. * focal))
+    o = torch.stack([sx * rays_o[..., 0] / rays_o[..., 2], sy * rays_o[..., 1] / rays_o[..., 2],
+                     1. + 2. * near / rays_o[..., 2]], -1)
+    d = torch.stack([sx * (rays_d[..., 0] / rays_d[..., 2] - rays_o[..., 0] / rays_o[..., 2]),
+                     sy * (rays_d[..., 1] / rays_d[..., 2] - rays_o[..., 1] / rays_o[..., 2]),
+                     -2. * near / rays_o[..., 2]], -1)
+    return o, d
+
+
+def create_nerf(args, device=None):
+    """Instantiate coarse + fine networks and the render kwargs - run_nerf.py:275-356 (without the
+    optimiser / checkpoint bookkeeping, which stays in the caller's training script).
+
+    ``args`` needs: multires, multires_views, i_embed, use_viewdirs, N_importance, N_samples, netdepth,
+    netwidth, netdepth_fine, netwidth_fine, netchunk, perturb, white_bkgd, raw_noise_std, lindisp,
+    dataset_type, no_ndc.  Returns ``(render_kwargs_train, render_kwargs_test, grad_vars)``.
+    """
+    device = device or torch.device("cuda")
+    embed_fn, input_ch = get_embedder(args.multires, args.i_embed)
+    embeddirs_fn, input_ch_views = (get_embedder(args.multires_views, args.i_embed) if args.use_viewdirs else (None, 0))
+    output_ch = 5 if args.N_importance > 0 else 4
+    model = NeRF(D=args.netdepth, W=args.netwidth, input_ch=input_ch, output_ch=output_ch, skips=[4],
+                 input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs).to(device)
+    grad_vars = list(model.parameters())
+    model_fine = None
+    if args.N_importance > 0:
+        model_fine = NeRF(D=args.netdepth_fine, W=args.netwidth_fine, input_ch=input_ch, output_ch=output_ch, skips=[4],
+                          input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs).to(device)
+        grad_vars += list(model_fine.parameters())
+    train = {"network_query_fn": NetworkQuery(embed_fn, embeddirs_fn, args.netchunk), "perturb": args.perturb,
+             "N_importance": args.N_importance, "network_fine": model_fine, "N_samples": args.N_samples,
+             "network_fn": model, "use_viewdirs": args.use_viewdirs, "white_bkgd": args.white_bkgd,
+             "raw_noise_std": args.raw_noise_std}
+    if args.dataset_type != "llff" or args.no_ndc:
+        train["ndc"] = False
+        train["lindisp"] = args.lindisp
+    test = dict(train)
+    test["perturb"] = False
+    test["raw_noise_std"] = 0.
+    return train, test, grad_vars

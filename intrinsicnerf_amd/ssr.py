@@ -1,0 +1,336 @@
+"""Drop-in front-end for the scene-level code base (``SSR/`` + ``train_SSR_main.py``).
+
+Mirrors, with identical names / argument meaning / returned keys (citations relative to
+``/root/reference/SSR``):
+  Semantic_NeRF            models/semantic_nerf.py:74-181     get_embedder   models/semantic_nerf.py:50-65
+  run_network              models/model_utils.py:19-35        raw2outputs    models/model_utils.py:39-116
+  sample_pdf               models/rays.py:176-220             create_rays    models/rays.py:223-256
+  batchify_rays            training/training_utils.py:5-17
+  SSRRenderMixin.render_rays / volumetric_rendering / create_ssr
+                           training/trainer.py:693-715 / 717-808 / 811-846
+``SSRTrainer`` keeps its data loading, losses and logging; it only has to inherit the mixin (or
+assign the three methods) - see INTEGRATION.md.  All arithmetic runs in ``libinerf.so``.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _capi, kernels, packing
+from .object_level import Embedder, _no_grad_guard
+
+__all__ = ["get_embedder", "Semantic_NeRF", "run_network", "raw2outputs", "sample_pdf", "create_rays",
+           "get_rays_camera", "get_rays_world", "batchify_rays", "SSRRenderMixin", "SSRRenderer"]
+
+
+def get_embedder(multires, i=0, scalar_factor=1):
+    """(embed_fn, out_dim); the input is divided by ``scalar_factor`` first - semantic_nerf.py:50-65."""
+    if i == -1:
+        return nn.Identity(), 3
+    e = Embedder(multires, scalar_factor=scalar_factor)
+    return e, e.out_dim
+
+
+def fc_block(in_f, out_f):
+    return nn.Sequential(nn.Linear(in_f, out_f), nn.ReLU(out_f))
+
+
+class Semantic_NeRF(nn.Module):
+    """Intrinsic NeRF + position-only semantic head, reference parameter names (semantic_nerf.py:98-118).
+
+    ``semantic_linear.0.0`` / ``semantic_linear.1``, ``residual_linear``, ``albedo_linear1/2``,
+    ``shading_linear1/2``.  As for the object-level module, ``forward`` defines the network in torch
+    ops for holders of an embedded tensor; the render path uses the fused kernel instead.
+    """
+
+    def __init__(self, enable_semantic, num_semantic_classes, D=8, W=256, input_ch=3, input_ch_views=3, output_ch=4,
+                 skips=[4], use_viewdirs=False):
+        super().__init__()
+        self.D, self.W = D, W
+        self.input_ch, self.input_ch_views = input_ch, input_ch_views
+        self.skips = list(skips)
+        self.use_viewdirs = use_viewdirs
+        self.enable_semantic = enable_semantic
+        self.num_semantic_classes = num_semantic_classes if enable_semantic else 0
+        self.pts_linears = nn.ModuleList(
+            [nn.Linear(input_ch, W)] +
+            [nn.Linear(W + input_ch, W) if i in self.skips else nn.Linear(W, W) for i in range(D - 1)])
+        self.views_linears = nn.ModuleList([nn.Linear(input_ch_views + W, W // 2)])
+        if use_viewdirs:
+            self.feature_linear = nn.Linear(W, W)
+            self.alpha_linear = nn.Linear(W, 1)
+            if enable_semantic:
+                self.semantic_linear = nn.Sequential(fc_block(W, W // 2), nn.Linear(W // 2, num_semantic_classes))
+            self.residual_linear = nn.Linear(W // 2, 3)
+            self.albedo_linear1 = nn.Linear(W, W // 2)
+            self.albedo_linear2 = nn.Linear(W // 2, 3)
+            self.shading_linear1 = nn.Linear(W, W // 2)
+            self.shading_linear2 = nn.Linear(W // 2, 1)
+        else:
+            self.output_linear = nn.Linear(W, output_ch)
+
+    def fused_desc(self):
+        if not (self.use_viewdirs and self.D == 8 and self.W == 256 and self.skips == [4]):
+            return None
+        l_xyz, rx = divmod(self.input_ch - 3, 6)
+        l_dir, rd = divmod(self.input_ch_views - 3, 6)
+        if rx or rd or not (0 <= l_xyz <= 10 and 0 <= l_dir <= 4) or self.num_semantic_classes > _capi.MAX_CLASSES:
+            return None
+        return _capi.net_desc(_capi.VARIANT_SSR, self.num_semantic_classes, l_xyz, l_dir, 1.0)
+
+    def forward(self, x, show_endpoint=False):
+        pts, views = torch.split(x, [self.input_ch, self.input_ch_views], dim=-1)
+        h = pts
+        for i, layer in enumerate(self.pts_linears):
+            h = F.relu(layer(h))
+            if i in self.skips:
+                h = torch.cat([pts, h], -1)
+        if not self.use_viewdirs:
+            out = self.output_linear(h)
+            return out
+        sigma = self.alpha_linear(h)
+        sem = self.semantic_linear(h) if self.enable_semantic else None
+        albedo = torch.sigmoid(self.albedo_linear2(F.relu(self.albedo_linear1(h))))
+        shading = torch.sigmoid(self.shading_linear2(F.relu(self.shading_linear1(h))))
+        v = torch.cat([self.feature_linear(h), views], -1)
+        for layer in self.views_linears:
+            v = F.relu(layer(v))
+        residual = torch.sigmoid(self.residual_linear(v))
+        rgb = albedo * shading + residual
+        parts = [rgb, sigma, albedo, shading, residual] + ([sem] if sem is not None else [])
+        if show_endpoint:
+            parts.append(v)
+        return torch.cat(parts, -1)
+
+
+def _fusable(fn, embed_fn, embeddirs_fn):
+    if not hasattr(fn, "fused_desc"):
+        return None
+    desc = fn.fused_desc()
+    if desc is None or not isinstance(embed_fn, Embedder) or not isinstance(embeddirs_fn, Embedder):
+        return None
+    if embed_fn.n_freqs != desc.l_xyz or embeddirs_fn.n_freqs != desc.l_dir or embeddirs_fn.scalar_factor != 1.0:
+        return None
+    desc.xyz_div = embed_fn.scalar_factor
+    return desc
+
+
+def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64, show_endpoint=False):
+    """Encode + apply the network - model_utils.py:19-35.  ``fn`` is a Semantic_NeRF (fused HIP launch) or
+    any callable on the embedded tensor (called as the reference does).  ``show_endpoint`` is what the
+    reference expresses as ``lambda x: net(x, self.endpoint_feat)`` (trainer.py:770)."""
+    desc = _fusable(fn, embed_fn, embeddirs_fn) if viewdirs is not None else None
+    if desc is None:
+        flat = torch.reshape(inputs, [-1, inputs.shape[-1]])
+        emb = embed_fn(flat)
+        if viewdirs is not None:
+            dirs = viewdirs[:, None].expand(inputs.shape)
+            emb = torch.cat([emb, embeddirs_fn(torch.reshape(dirs, [-1, dirs.shape[-1]]))], -1)
+        out = torch.cat([fn(emb[i:i + netchunk]) for i in range(0, emb.shape[0], netchunk)], 0) if netchunk else fn(emb)
+        return torch.reshape(out, list(inputs.shape[:-1]) + [out.shape[-1]])
+    _no_grad_guard("run_network", fn)
+    pts = torch.reshape(inputs, [-1, 3]).float()
+    dirs = torch.reshape(viewdirs[:, None].expand(inputs.shape), [-1, 3]).float()
+    rays = torch.zeros(pts.shape[0], _capi.RAY_FLOATS, dtype=torch.float32, device=pts.device)
+    rays[:, 0:3], rays[:, 8:11] = pts, dirs
+    z = torch.zeros(pts.shape[0], 1, dtype=torch.float32, device=pts.device)
+    raw = kernels.encode_mlp(desc, packing.packed_for_module(fn, desc, pts.device), rays, z, endpoint=show_endpoint)
+    return torch.reshape(raw, list(inputs.shape[:-1]) + [raw.shape[-1]])
+
+
+def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, enable_semantic=True, num_sem_class=0,
+                endpoint_feat=False):
+    """Compositing incl. semantic logits / endpoint feature - model_utils.py:39-116.
+
+    Returns ``(rgb, disp, acc, weights, depth, sem, feat, albedo, shading, residual)``; ``sem`` / ``feat``
+    are ``torch.tensor(0)`` when disabled, as in the reference.
+    """
+    if enable_semantic:
+        assert num_sem_class > 0
+    noise = torch.randn(raw[..., 3].shape, device=raw.device) * raw_noise_std if raw_noise_std > 0. else None
+    o = kernels.composite(raw.float(), z_vals.float(), rays_d.float(), noise, white_bkgd,
+                          n_classes=num_sem_class if enable_semantic else 0, feat_dim=128 if endpoint_feat else 0)
+    sem = o["sem"] if enable_semantic else torch.tensor(0)
+    feat = o["feat"] if endpoint_feat else torch.tensor(0)
+    return o["rgb"], o["disp"], o["acc"], o["weights"], o["depth"], sem, feat, o["albedo"], o["shading"], o["residual"]
+
+
+def sample_pdf(bins, weights, N_samples, det=False):
+    """Inverse-CDF sampling - rays.py:176-220."""
+    b2 = torch.reshape(bins, [-1, bins.shape[-1]]).float()
+    w2 = torch.reshape(weights, [-1, weights.shape[-1]]).float()
+    if det:
+        u = torch.linspace(0., 1., steps=N_samples, device=bins.device)
+    else:
+        u = torch.rand(b2.shape[0], N_samples, device=bins.device)
+    return torch.reshape(kernels.sample_pdf(b2, w2, u, N_samples), list(bins.shape[:-1]) + [N_samples])
+
+
+# ----------------------------------------------------------------------------------------------
+# ray generation (input producer; rays.py:27-67,223-256)
+# ----------------------------------------------------------------------------------------------
+def get_rays_camera(B, H, W, fx, fy, cx, cy, depth_type="z", convention="opencv"):
+    assert depth_type in ("z", "euclidean")
+    j, i = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    i = i.float()[None].expand(B, H, W)
+    j = j.float()[None].expand(B, H, W)
+    if convention == "opencv":
+        dirs = torch.stack(((i - cx) / fx, (j - cy) / fy, torch.ones(B, H, W)), dim=3)
+    elif convention == "opengl":
+        dirs = torch.stack(((i - cx) / fx, -(j - cy) / fy, -torch.ones(B, H, W)), dim=3)
+    else:
+        raise AssertionError(convention)
+    if depth_type == "euclidean":
+        dirs = dirs * (1. / torch.norm(dirs, dim=3, keepdim=True))
+    return dirs
+
+
+def get_rays_world(T_WC, dirs_C):
+    R_WC = T_WC[:, :3, :3]
+    dirs_W = torch.matmul(R_WC[:, None, ...], dirs_C[..., None]).squeeze(-1)
+    origins = torch.broadcast_tensors(T_WC[:, :3, -1][:, None, :], dirs_W)[0]
+    return origins, dirs_W
+
+
+def create_rays(num_rays, Ts_c2w, height, width, fx, fy, cx, cy, near, far, c2w_staticcam=None, depth_type="z",
+                use_viewdirs=True, convention="opencv"):
+    """[num_images, H*W, 11] ray batch ``[o3, d3, near, far, viewdir3]`` - rays.py:223-256."""
+    dirs_C = get_rays_camera(num_rays, height, width, fx, fy, cx, cy, depth_type=depth_type,
+                             convention=convention).view(num_rays, -1, 3)
+    rays_o, rays_d = get_rays_world(Ts_c2w, dirs_C)
+    if use_viewdirs:
+        viewdirs = rays_d
+        if c2w_staticcam is not None:
+            rays_o, rays_d = get_rays_world(c2w_staticcam, dirs_C)
+        viewdirs = viewdirs / torch.norm(viewdirs, dim=-1, keepdim=True).float()
+    near, far = near * torch.ones_like(rays_d[..., :1]), far * torch.ones_like(rays_d[..., :1])
+    rays = torch.cat([rays_o, rays_d, near, far], -1)
+    if use_viewdirs:
+        rays = torch.cat([rays, viewdirs], -1)
+    return rays
+
+
+def batchify_rays(render_fn, rays_flat, chunk=1024 * 32):
+    """training_utils.py:5-17."""
+    all_ret = {}
+    for i in range(0, rays_flat.shape[0], chunk):
+        ret = render_fn(rays_flat[i:i + chunk])
+        for k in ret:
+            all_ret.setdefault(k, []).append(ret[k])
+    return {k: torch.cat(all_ret[k], 0) for k in all_ret}
+
+
+# ----------------------------------------------------------------------------------------------
+# the trainer's render methods
+# ----------------------------------------------------------------------------------------------
+class SSRRenderMixin:
+    """``render_rays`` / ``volumetric_rendering`` / ``create_ssr`` of SSRTrainer (trainer.py:693-846).
+
+    Reads the same attributes the reference methods read: ``N_samples, N_importance, perturb,
+    training, raw_noise_std, white_bkgd, enable_semantic, num_valid_semantic_class, endpoint_feat,
+    netchunk, chunk, ssr_net_coarse, ssr_net_fine, embed_fn, embeddirs_fn``.  Two optional extras:
+    ``return_raw`` (default True, as the reference always returns raw_coarse / raw_fine - ~3 GB per
+    320x240 frame; set False to skip materialising them for the caller) and ``check_numerics``
+    (default True: the reference's ungated nan/inf print, trainer.py:803-806, one device sync per key).
+    """
+
+    return_raw = True
+    check_numerics = True
+
+    def render_rays(self, flat_rays):
+        ray_shape = flat_rays.shape
+        all_ret = batchify_rays(self.volumetric_rendering, flat_rays, self.chunk)
+        for k in all_ret:
+            all_ret[k] = torch.reshape(all_ret[k], list(ray_shape[:-1]) + list(all_ret[k].shape[1:]))
+        return all_ret
+
+    def volumetric_rendering(self, ray_batch):
+        ray_batch = ray_batch.float()
+        n, dev = ray_batch.shape[0], ray_batch.device
+        if ray_batch.shape[-1] <= 8:
+            raise NotImplementedError("volumetric_rendering needs view directions (use_viewdirs: true in every config)")
+        desc = _fusable(self.ssr_net_coarse, self.embed_fn, self.embeddirs_fn)
+        if desc is None or (self.N_importance > 0 and _fusable(self.ssr_net_fine, self.embed_fn, self.embeddirs_fn) is None):
+            raise NotImplementedError("networks / encoders outside the fused kernel's architecture (D=8, W=256, "
+                                      "skips=[4], multires<=10, multires_views<=4); there is no eager fallback")
+        _no_grad_guard("volumetric_rendering", self.ssr_net_coarse, self.ssr_net_fine)
+        training = bool(self.training)
+        t_vals = torch.linspace(0., 1., steps=self.N_samples, device=dev)
+        # RNG draws in the reference's order: t_rand (:744), coarse noise (model_utils.py:70), u (rays.py:197), fine noise
+        t_rand = torch.rand(n, self.N_samples, device=dev) if (self.perturb > 0. and training) else None
+        std = self.raw_noise_std if training else 0
+        noise_c = torch.randn(n, self.N_samples, device=dev) * std if std > 0. else None
+        u = noise_f = None
+        if self.N_importance > 0:
+            det = (self.perturb == 0.) or (not training)
+            u = (torch.linspace(0., 1., steps=self.N_importance, device=dev) if det
+                 else torch.rand(n, self.N_importance, device=dev))
+            noise_f = torch.randn(n, self.N_samples + self.N_importance, device=dev) * std if std > 0. else None
+        ep = bool(self.endpoint_feat) and self.N_importance > 0
+        o = kernels.render_rays_fused(
+            desc, packing.packed_for_module(self.ssr_net_coarse, desc, dev),
+            packing.packed_for_module(self.ssr_net_fine, desc, dev) if self.N_importance > 0 else None,
+            ray_batch, self.N_samples, self.N_importance, t_vals, u, t_rand, noise_c, noise_f,
+            white_bkgd=self.white_bkgd, endpoint=ep, want_raw_coarse=self.return_raw, want_raw_fine=self.return_raw,
+            want_sem=bool(self.enable_semantic))
+        ret = {}
+        if self.return_raw:
+            ret["raw_coarse"] = o["raw_coarse"]
+        for k in ("rgb", "disp", "acc", "depth", "albedo", "shading", "residual"):
+            ret[k + "_coarse"] = o[k + "_coarse"]
+        if self.enable_semantic:
+            ret["sem_logits_coarse"] = o["sem_coarse"]
+        if self.N_importance > 0:
+            for k in ("rgb", "disp", "acc", "depth", "albedo", "shading", "residual"):
+                ret[k + "_fine"] = o[k + "_fine"]
+            if self.enable_semantic:
+                ret["sem_logits_fine"] = o["sem_fine"]
+            ret["z_std"] = o["z_std"]
+            if self.return_raw:
+                ret["raw_fine"] = o["raw_fine"]
+            if ep:
+                ret["feat_map_fine"] = o["feat_fine"]
+        if self.check_numerics:
+            for k in ret:
+                if torch.isnan(ret[k]).any() or torch.isinf(ret[k]).any():
+                    print(f"! [Numerical Error] {k} contains nan or inf.")
+        return ret
+
+    def create_ssr(self):
+        """Build coarse + fine Semantic_NeRF and the encoders - trainer.py:811-846 (optimiser included)."""
+        r, m = self.config["render"], self.config["model"]
+        embed_fn, input_ch = get_embedder(r["multires"], r["i_embed"], scalar_factor=10)
+        embeddirs_fn, input_ch_views = (get_embedder(r["multires_views"], r["i_embed"], scalar_factor=1)
+                                        if r["use_viewdirs"] else (None, 0))
+        output_ch = 5 if self.N_importance > 0 else 4
+        mk = lambda d, w: Semantic_NeRF(enable_semantic=self.enable_semantic,
+                                        num_semantic_classes=self.num_valid_semantic_class, D=d, W=w, input_ch=input_ch,
+                                        output_ch=output_ch, skips=[4], input_ch_views=input_ch_views,
+                                        use_viewdirs=r["use_viewdirs"]).cuda()
+        model = mk(m["netdepth"], m["netwidth"])
+        grad_vars = list(model.parameters())
+        model_fine = None
+        if self.N_importance > 0:
+            model_fine = mk(m["netdepth_fine"], m["netwidth_fine"])
+            grad_vars += list(model_fine.parameters())
+        self.ssr_net_coarse, self.ssr_net_fine = model, model_fine
+        self.embed_fn, self.embeddirs_fn = embed_fn, embeddirs_fn
+        self.optimizer = torch.optim.Adam(params=grad_vars, lr=getattr(self, "lrate", 5e-4))
+
+
+class SSRRenderer(SSRRenderMixin):
+    """Stand-alone holder of the attributes the mixin reads (for rendering without the trainer)."""
+
+    def __init__(self, num_classes, N_samples=64, N_importance=128, multires=10, multires_views=4, white_bkgd=False,
+                 enable_semantic=True, endpoint_feat=False, chunk=1024 * 32, netchunk=1024 * 32, perturb=1.,
+                 raw_noise_std=1., device="cuda"):
+        self.N_samples, self.N_importance = N_samples, N_importance
+        self.perturb, self.raw_noise_std, self.white_bkgd = perturb, raw_noise_std, white_bkgd
+        self.enable_semantic, self.num_valid_semantic_class = enable_semantic, num_classes
+        self.endpoint_feat, self.chunk, self.netchunk = endpoint_feat, chunk, netchunk
+        self.training = False
+        self.embed_fn, ch = get_embedder(multires, 0, scalar_factor=10)
+        self.embeddirs_fn, chv = get_embedder(multires_views, 0, scalar_factor=1)
+        mk = lambda: Semantic_NeRF(enable_semantic, num_classes, D=8, W=256, input_ch=ch, output_ch=5, skips=[4],
+                                   input_ch_views=chv, use_viewdirs=True).to(device)
+        self.ssr_net_coarse = mk()
+        self.ssr_net_fine = mk() if N_importance > 0 else None

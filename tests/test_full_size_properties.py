@@ -1,0 +1,61 @@
+"""GPU: size-independent properties at BASELINE.json's full chunk size (32768 rays x (64+128) samples),
+where running the CPU oracle would take minutes."""
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def test_full_chunk_properties():
+    from intrinsicnerf_amd import _capi, kernels, packing
+    dev = torch.device("cuda:0")
+    n = 32768                                                  # the reference's chunk (run_nerf.py:559)
+    g = torch.Generator().manual_seed(0)
+    o = torch.tensor([[2.5, 1.5, 2.0]]).expand(n, 3)
+    d = -o / o.norm(dim=-1, keepdim=True) + 0.2 * torch.randn(n, 3, generator=g)
+    rays = torch.cat([o, d, 2 * torch.ones(n, 1), 6 * torch.ones(n, 1), d / d.norm(dim=-1, keepdim=True)], -1).to(dev)
+    kw = dict(sigma_gain_log2=5, sigma_bias=-6.0, weight_gain_log2=1)
+    desc = _capi.net_desc(_capi.VARIANT_OBJECT, 0, 10, 4, 1.0)
+    pc = packing.pack_state_dict(desc, oracle.lcg_state_dict("object", seed=30, **kw)).to(dev)
+    pf = packing.pack_state_dict(desc, oracle.lcg_state_dict("object", seed=31, **kw)).to(dev)
+    t_vals, u = torch.linspace(0., 1., 64, device=dev), torch.linspace(0., 1., 128, device=dev)
+    run = lambda r: kernels.render_rays_fused(desc, pc, pf, r, 64, 128, t_vals, u, white_bkgd=True, want_stages=True)
+    out = run(rays)
+    torch.cuda.synchronize()
+    # 1. every output finite except disp where acc == 0
+    for k, v in out.items():
+        if not k.startswith("disp"):
+            assert torch.isfinite(v).all(), k
+    assert torch.equal(torch.isnan(out["disp_fine"]), out["acc_fine"] == 0)
+    # 2. merged depths: ascending, inside [near, far], a superset of the coarse depths
+    zf = out["z_fine"]
+    assert (zf[:, 1:] >= zf[:, :-1]).all() and zf.min() >= 2.0 and zf.max() <= 6.0
+    assert torch.equal(torch.sort(torch.cat([out["z_coarse"], out["z_samples"]], -1), -1)[0], zf)
+    # 3. compositing invariants: weights >= 0, sum == acc <= 1 (+ulps), depth/acc inside the ray segment
+    for lvl in ("coarse", "fine"):
+        w, acc = out["weights_" + lvl], out["acc_" + lvl]
+        assert (w >= 0).all() and (acc <= 1 + 1e-5).all()
+        assert torch.allclose(w.sum(-1), acc, rtol=1e-5, atol=1e-6)
+        hit = acc > 1e-3
+        ratio = out["depth_" + lvl][hit] / acc[hit]
+        assert (ratio >= 2.0 - 1e-3).all() and (ratio <= 6.0 + 1e-3).all()
+    # 4. rgb = albedo*shading + residual holds per sample, so white-bkgd maps stay in [0, 3]
+    assert out["rgb_fine"].min() >= 0 and out["rgb_fine"].max() <= 3.0
+    # 5. rays are independent: a permuted / re-chunked batch gives bit-identical rows
+    perm = torch.randperm(n, generator=g).to(dev)
+    out2 = run(rays[perm].contiguous())
+    for k in ("rgb_fine", "albedo_fine", "shading_fine", "residual_fine", "acc_fine", "z_std", "rgb_coarse"):
+        assert torch.equal(out[k][perm], out2[k]), k
+    out3 = run(rays[:1000].contiguous())
+    assert torch.equal(out3["rgb_fine"], out["rgb_fine"][:1000])
+    # 6. spot-check 48 rays of the big batch against the oracle
+    idx = torch.arange(0, n, n // 48)[:48]
+    sd_c, sd_f = oracle.lcg_state_dict("object", seed=30, **kw), oracle.lcg_state_dict("object", seed=31, **kw)
+    cfg = oracle.RenderConfig(variant="object", white_bkgd=True)
+    with torch.no_grad():
+        want = oracle.render_rays(rays[idx.to(dev)].cpu(), sd_c, sd_f, cfg, t_vals=t_vals.cpu(), u=u.cpu())
+    for k in ("rgb_fine", "albedo_fine", "shading_fine", "residual_fine", "acc_fine", "depth_fine"):
+        got = out[k][idx.to(dev)].cpu()
+        assert torch.allclose(got, want[k], rtol=1e-4, atol=1e-5), k

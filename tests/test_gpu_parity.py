@@ -1,0 +1,292 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden fixtures (= the real reference's
+outputs) and against the CPU oracle on seeded inputs.
+
+Tolerance (BASELINE.json north_star: "within 1e-4 rel fp32"): ``|got - want| <= 1e-5 + 1e-4 |want|``
+for every map, raw tensor and stage tensor.  ``disp`` is the one exception: it is 1/(depth/acc), which
+amplifies fp32 round-off - the reference's own fp32-vs-fp64 noise floor on it is 8.9e-5 (SURVEY.md
+section 6) - so it is held to 5e-4 relative, NaNs required at identical rays.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from _cases import assert_maps_close, case_config, case_random_inputs, case_weights
+from conftest import golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL, RTOL_DISP = 1e-4, 1e-5, 5e-4
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _desc(cfg):
+    from intrinsicnerf_amd import _capi
+    ssr = cfg.variant == "ssr"
+    return _capi.net_desc(_capi.VARIANT_SSR if ssr else _capi.VARIANT_OBJECT, cfg.n_classes if ssr else 0,
+                          cfg.l_xyz, cfg.l_dir, cfg.xyz_div)
+
+
+def _packed(cfg, sd):
+    from intrinsicnerf_amd import packing
+    return packing.pack_state_dict(_desc(cfg), sd).to(_dev())
+
+
+def _rtol(key):
+    return RTOL_DISP if key.startswith("disp") else RTOL
+
+
+# ------------------------------------------------------------------------------------------------
+# whole path vs the reference's outputs
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", golden_names("object_") + golden_names("ssr_"))
+def test_fused_path_matches_reference(name):
+    from intrinsicnerf_amd import kernels
+    fx = load_golden(name)
+    cfg = case_config(fx)
+    sd_c, sd_f = case_weights(fx)
+    dev = _dev()
+    rnd = case_random_inputs(fx, dev)
+    u = rnd.pop("u", None)
+    if u is None and cfg.n_importance > 0:
+        u = torch.linspace(0.0, 1.0, cfg.n_importance).to(dev)
+    out = kernels.render_rays_fused(
+        _desc(cfg), _packed(cfg, sd_c), _packed(cfg, sd_f), torch.from_numpy(fx["rays"]).to(dev), 64, cfg.n_importance,
+        torch.from_numpy(fx["t_vals"]).to(dev), u, rnd.get("t_rand"), rnd.get("noise_coarse"), rnd.get("noise_fine"),
+        white_bkgd=cfg.white_bkgd, lindisp=cfg.lindisp, endpoint=cfg.endpoint_feat,
+        want_raw_coarse=True, want_raw_fine=True, want_stages=True)
+    torch.cuda.synchronize()
+    checked = 0
+    for key, want in fx.items():
+        if key.startswith("ref_"):
+            k = key[4:]
+            got = out[k].cpu().numpy()
+            if k.startswith("raw"):
+                got = got[: want.shape[0]]
+            assert_maps_close(got, want, _rtol(k), ATOL, f"{name}:{k}")
+            checked += 1
+        elif key.startswith("stage_") and key != "stage_raw_coarse":
+            k = key[6:]
+            assert_maps_close(out[k].cpu().numpy(), want, RTOL, ATOL, f"{name}:stage {k}")
+            checked += 1
+    assert checked >= 10
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference-signature front-ends
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["object_chair_det", "object_chair_train_rng", "object_coarse_only_lindisp"])
+def test_object_level_render_rays_frontend(name):
+    from intrinsicnerf_amd import object_level as ol
+    fx = load_golden(name)
+    cfg = case_config(fx)
+    sd_c, sd_f = case_weights(fx)
+    dev = _dev()
+    embed, ch = ol.get_embedder(10, 0)
+    embed_d, ch_d = ol.get_embedder(4, 0)
+    mk = lambda: ol.NeRF(D=8, W=256, input_ch=ch, output_ch=5, skips=[4], input_ch_views=ch_d, use_viewdirs=True)
+    net_c, net_f = mk().to(dev), mk().to(dev)
+    net_c.load_state_dict(sd_c); net_f.load_state_dict(sd_f)
+    q = ol.NetworkQuery(embed, embed_d, 65536)
+    train = "in_t_rand" in fx
+    with torch.no_grad():
+        ret = ol.render_rays(torch.from_numpy(fx["rays"]).to(dev), net_c, q, 64, retraw=True, lindisp=cfg.lindisp,
+                             perturb=1.0 if train else 0.0, N_importance=cfg.n_importance, network_fine=net_f,
+                             white_bkgd=cfg.white_bkgd, raw_noise_std=1.0 if train else 0.0, pytest=train)
+    lvl = "fine" if cfg.n_importance > 0 else "coarse"
+    pairs = [("rgb_map", "rgb_" + lvl), ("disp_map", "disp_" + lvl), ("acc_map", "acc_" + lvl),
+             ("albedo_map", "albedo_" + lvl), ("shading_map", "shading_" + lvl), ("residual_map", "residual_" + lvl)]
+    expected_keys = {"rgb_map", "disp_map", "acc_map", "albedo_map", "shading_map", "residual_map", "raw"}
+    if cfg.n_importance > 0:
+        pairs += [("rgb0", "rgb_coarse"), ("disp0", "disp_coarse"), ("acc0", "acc_coarse"), ("albedo0", "albedo_coarse"),
+                  ("shading0", "shading_coarse"), ("residual0", "residual_coarse"), ("z_std", "z_std")]
+        expected_keys |= {"rgb0", "disp0", "acc0", "albedo0", "shading0", "residual0", "z_std"}
+    assert set(ret.keys()) == expected_keys            # run_nerf.py:512-522
+    for rk, ok in pairs:
+        assert_maps_close(ret[rk].cpu().numpy(), fx["ref_" + ok], _rtol(ok), ATOL, f"{name}:{rk}")
+    assert tuple(ret["raw"].shape) == (fx["rays"].shape[0], 64 + cfg.n_importance, 11)
+
+
+def test_object_level_render_image_api():
+    """render(H, W, K, c2w=...) returns the reference's 7-element list with image-shaped maps; chunking is invisible."""
+    from intrinsicnerf_amd import object_level as ol
+    dev = _dev()
+    H = W = 24
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112070083618)
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+    c2w = torch.tensor([[-0.7660, 0.3214, -0.5567, -2.2270], [-0.6428, -0.3830, 0.6634, 2.6537],
+                        [0.0, 0.8660, 0.5, 2.0]], device=dev)
+    sd_c = oracle.lcg_state_dict("object", seed=20, sigma_gain_log2=5, sigma_bias=-6.0, weight_gain_log2=1)
+    sd_f = oracle.lcg_state_dict("object", seed=21, sigma_gain_log2=5, sigma_bias=-6.0, weight_gain_log2=1)
+    embed, ch = ol.get_embedder(10, 0); embed_d, ch_d = ol.get_embedder(4, 0)
+    mk = lambda: ol.NeRF(D=8, W=256, input_ch=ch, output_ch=5, skips=[4], input_ch_views=ch_d, use_viewdirs=True).to(dev)
+    net_c, net_f = mk(), mk()
+    net_c.load_state_dict(sd_c); net_f.load_state_dict(sd_f)
+    kw = dict(network_fn=net_c, network_fine=net_f, network_query_fn=ol.NetworkQuery(embed, embed_d), N_samples=64,
+              N_importance=128, white_bkgd=True, perturb=False, raw_noise_std=0., use_viewdirs=True, ndc=False, lindisp=False)
+    with torch.no_grad():
+        full = ol.render(H, W, K, chunk=1 << 15, c2w=c2w, near=2., far=6., **kw)
+        small = ol.render(H, W, K, chunk=100, c2w=c2w, near=2., far=6., **kw)
+    assert len(full) == 7 and isinstance(full[6], dict)
+    assert tuple(full[0].shape) == (H, W, 3) and tuple(full[1].shape) == (H, W) and tuple(full[3].shape) == (H, W, 3)
+    for a, b in zip(full[:6], small[:6]):
+        assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))        # chunk-size invariance: bit-exact
+    # against the oracle on the same rays
+    ro, rd = ol.get_rays(H, W, K, c2w)
+    vd = rd / rd.norm(dim=-1, keepdim=True)
+    rays = torch.cat([ro, rd, 2 * torch.ones_like(rd[..., :1]), 6 * torch.ones_like(rd[..., :1]), vd], -1).reshape(-1, 11).cpu()
+    cfg = oracle.RenderConfig(variant="object", white_bkgd=True)
+    with torch.no_grad():
+        want = oracle.render_rays(rays, sd_c, sd_f, cfg, t_vals=torch.linspace(0., 1., 64))
+    assert_maps_close(full[0].reshape(-1, 3).cpu().numpy(), want["rgb_fine"].numpy(), RTOL, ATOL, "render rgb")
+    assert_maps_close(full[4].reshape(-1).cpu().numpy(), want["shading_fine"].numpy(), RTOL, ATOL, "render shading")
+
+
+@pytest.mark.parametrize("name", ["ssr_room_det_c28", "ssr_endpoint_c5_wb", "ssr_c101"])
+def test_ssr_trainer_render_rays_frontend(name):
+    from intrinsicnerf_amd import ssr
+    fx = load_golden(name)
+    cfg = case_config(fx)
+    sd_c, sd_f = case_weights(fx)
+    r = ssr.SSRRenderer(cfg.n_classes, white_bkgd=cfg.white_bkgd, endpoint_feat=cfg.endpoint_feat, chunk=7, device=_dev())
+    r.ssr_net_coarse.load_state_dict(sd_c); r.ssr_net_fine.load_state_dict(sd_f)
+    r.check_numerics = False
+    with torch.no_grad():
+        ret = r.render_rays(torch.from_numpy(fx["rays"]).to(_dev()))
+    keys = {f"{k}_{l}" for l in ("coarse", "fine") for k in ("rgb", "disp", "acc", "depth", "albedo", "shading", "residual")}
+    keys |= {"raw_coarse", "raw_fine", "z_std", "sem_logits_coarse", "sem_logits_fine"}
+    if cfg.endpoint_feat:
+        keys.add("feat_map_fine")
+    assert set(ret.keys()) == keys                       # trainer.py:777-802
+    ren = {"sem_logits_coarse": "sem_coarse", "sem_logits_fine": "sem_fine", "feat_map_fine": "feat_fine"}
+    for k in keys:
+        want = fx["ref_" + ren.get(k, k)]
+        got = ret[k].cpu().numpy()
+        if k.startswith("raw"):
+            got = got[: want.shape[0]]
+        assert_maps_close(got, want, _rtol(k), ATOL, f"{name}:{k}")
+
+
+# ------------------------------------------------------------------------------------------------
+# stage kernels
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", golden_names("stage_composite_"))
+def test_composite_edge_cases(name):
+    from intrinsicnerf_amd import kernels
+    fx = load_golden(name)
+    ssr = "ssr" in name
+    dev = _dev()
+    out = kernels.composite(torch.from_numpy(fx["raw"]).to(dev), torch.from_numpy(fx["z"]).to(dev),
+                            torch.from_numpy(fx["rays_d"]).to(dev), None, bool(fx["white_bkgd"]),
+                            n_classes=int(fx["n_classes"]) if ssr else 0, feat_dim=128 if ssr else 0)
+    for key, want in fx.items():
+        if key.startswith("ref_"):
+            assert_maps_close(out[key[4:]].cpu().numpy(), want, _rtol(key[4:]), ATOL, f"{name}:{key}")
+    if not ssr:
+        assert torch.isnan(out["disp"][0]).item() and out["acc"][0].item() == 0.0       # empty ray
+        assert out["weights"][1, -1].item() == 1.0                                         # only the 1e10 interval
+        assert out["weights"][3, 0].item() == 1.0 and out["weights"][3, 1:].abs().max().item() < 1e-9
+
+
+def test_sample_pdf_edge_cases():
+    from intrinsicnerf_amd import kernels
+    fx = load_golden("stage_sample_pdf")
+    dev = _dev()
+    bins, w = torch.from_numpy(fx["bins"]).to(dev), torch.from_numpy(fx["weights"]).to(dev)
+    det = kernels.sample_pdf(bins, w, torch.linspace(0., 1., 128).to(dev), 128)
+    assert_maps_close(det.cpu().numpy(), fx["ref_det"], RTOL, ATOL, "sample_pdf det")
+    rnd = kernels.sample_pdf(bins, w, torch.from_numpy(fx["u_rnd"]).to(dev), 128)
+    # ray 4 has u values sitting exactly on cdf entries: a 1-ulp cdf difference legitimately moves a sample
+    # to the neighbouring bin edge, so that ray is compared on the sorted sample set with a bin-width tolerance
+    mask = fx["ref_rnd_mask"].astype(bool)
+    assert_maps_close(rnd.cpu().numpy()[mask], fx["ref_rnd"][mask], RTOL, ATOL, "sample_pdf rnd")
+    assert np.all(np.abs(np.sort(rnd.cpu().numpy()[4]) - np.sort(fx["ref_rnd"][4])) < 0.08)
+
+
+def test_sample_fine_merge_sorted_and_std():
+    from intrinsicnerf_amd import kernels
+    fx = load_golden("stage_sample_pdf")
+    dev = _dev()
+    z = torch.from_numpy(fx["z_coarse"]).to(dev)
+    n = z.shape[0]
+    g = torch.Generator().manual_seed(4)
+    wfull = torch.rand(n, 64, generator=g)
+    u = torch.rand(n, 128, generator=g)
+    zs, zm, zstd = kernels.sample_fine(z, wfull.to(dev), u.to(dev), 128)
+    bins = 0.5 * (z[:, 1:] + z[:, :-1]).cpu()
+    want = oracle.inverse_cdf_sample(bins, wfull[:, 1:-1], u)
+    assert_maps_close(zs.cpu().numpy(), want.numpy(), RTOL, ATOL, "z_samples")
+    merged = torch.sort(torch.cat([z.cpu(), zs.cpu()], -1), -1)[0]
+    assert torch.equal(zm.cpu(), merged)                    # a permutation of its own inputs, ascending: bit-exact
+    assert_maps_close(zstd.cpu().numpy(), torch.std(want, -1, unbiased=False).numpy(), RTOL, ATOL, "z_std")
+
+
+@pytest.mark.parametrize("variant,c,s", [("object", 0, 64), ("object", 0, 192), ("ssr", 28, 64), ("ssr", 3, 50)])
+def test_encode_mlp_raw(variant, c, s):
+    """Stage parity of the dominant kernel on default-init-like weights and awkward sizes (ragged last tile)."""
+    from intrinsicnerf_amd import kernels
+    dev = _dev()
+    cfg = oracle.RenderConfig(variant=variant, n_samples=s, n_importance=0, n_classes=c)
+    sd = oracle.make_state_dict(variant, c, seed=5)
+    g = torch.Generator().manual_seed(6)
+    n = 37                                                    # 37 * s is not a multiple of the 64-point tile
+    o = torch.randn(n, 3, generator=g)
+    d = torch.randn(n, 3, generator=g)
+    near, far = (2.0, 6.0) if variant == "object" else (0.1, 10.0)
+    rays = torch.cat([o, d, near * torch.ones(n, 1), far * torch.ones(n, 1), d / d.norm(dim=-1, keepdim=True)], -1)
+    z = torch.sort(torch.rand(n, s, generator=g) * (far - near) + near, -1)[0]
+    with torch.no_grad():
+        pts = rays[:, None, 0:3] + rays[:, None, 3:6] * z[:, :, None]
+        want = oracle.query_network(sd, pts, rays[:, 8:11], cfg)
+    raw = kernels.encode_mlp(_desc(cfg), _packed(cfg, sd), rays.to(dev), z.to(dev))
+    assert_maps_close(raw.cpu().numpy(), want.numpy(), RTOL, ATOL, f"raw {variant} C={c} S={s}")
+
+
+def test_run_network_arbitrary_points():
+    """run_network(pts, viewdirs, net, ...) on a point grid (what extract_colour_mesh.py:158-162 does)."""
+    from intrinsicnerf_amd import ssr
+    dev = _dev()
+    c = 6
+    sd = oracle.make_state_dict("ssr", c, seed=8)
+    embed, ch = ssr.get_embedder(10, 0, scalar_factor=10); embed_d, ch_d = ssr.get_embedder(4, 0, scalar_factor=1)
+    net = ssr.Semantic_NeRF(True, c, D=8, W=256, input_ch=ch, output_ch=5, skips=[4], input_ch_views=ch_d,
+                            use_viewdirs=True).to(dev)
+    net.load_state_dict(sd)
+    g = torch.Generator().manual_seed(9)
+    pts = torch.randn(50, 7, 3, generator=g) * 3
+    vd = torch.zeros(50, 3)
+    with torch.no_grad():
+        got = ssr.run_network(pts.to(dev), vd.to(dev), net, embed, embed_d, netchunk=1024)
+        cfg = oracle.RenderConfig(variant="ssr", n_classes=c)
+        want = oracle.query_network(sd, pts, vd, cfg)
+    assert_maps_close(got.cpu().numpy(), want.numpy(), RTOL, ATOL, "run_network grid")
+
+
+def test_sample_coarse_bit_exact():
+    from intrinsicnerf_amd import kernels
+    dev = _dev()
+    g = torch.Generator().manual_seed(1)
+    n = 33
+    rays = torch.randn(n, 11, generator=g)
+    rays[:, 6] = torch.rand(n, generator=g) + 0.5
+    rays[:, 7] = rays[:, 6] + torch.rand(n, generator=g) * 5 + 1
+    t = torch.linspace(0., 1., 64)
+    tr = torch.rand(n, 64, generator=g)
+    for lindisp in (False, True):
+        for t_rand in (None, tr):
+            want = oracle.coarse_depths(rays[:, 6:7], rays[:, 7:8], t, lindisp, t_rand)
+            got = kernels.sample_coarse(rays.to(dev), t.to(dev), None if t_rand is None else t_rand.to(dev), lindisp)
+            assert torch.equal(got.cpu(), want), f"lindisp={lindisp} perturb={t_rand is not None}"
+
+
+def test_gradients_fail_loudly():
+    from intrinsicnerf_amd import object_level as ol
+    dev = _dev()
+    embed, ch = ol.get_embedder(10, 0); embed_d, ch_d = ol.get_embedder(4, 0)
+    net = ol.NeRF(D=8, W=256, input_ch=ch, output_ch=5, skips=[4], input_ch_views=ch_d, use_viewdirs=True).to(dev)
+    rays = torch.rand(4, 11, device=dev)
+    with pytest.raises(NotImplementedError):
+        ol.render_rays(rays, net, ol.NetworkQuery(embed, embed_d), 64)
