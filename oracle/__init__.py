@@ -20,6 +20,7 @@ from .intrinsic_render import (  # noqa: F401
     RenderConfig,
     freq_encode,
     mlp_forward,
+    query_network,
     composite,
     inverse_cdf_sample,
     coarse_depths,
@@ -28,3 +29,4 @@ from .intrinsic_render import (  # noqa: F401
     state_dict_spec,
     lcg_state_dict,
 )
+from .conditioning import calibrated_lcg_weights, conditioning_scores  # noqa: F401

@@ -130,7 +130,8 @@ def _mix64(x: np.ndarray) -> np.ndarray:
 
 
 def lcg_state_dict(variant: str, n_classes: int = 0, seed: int = 0, sigma_gain_log2: int = 0,
-                   sigma_bias: float = 0.0, weight_gain_log2: int = 0) -> Dict[str, Tensor]:
+                   sigma_bias: float = 0.0, weight_gain_log2: int = 0, freq_decay: bool = False,
+                   l_xyz: int = 10, l_dir: int = 4) -> Dict[str, Tensor]:
     """Closed-form weights that are exactly representable in fp32 on every platform.
 
     Every value is ``k * 2**-15 * 2**-e`` with integer ``|k| <= 2**15`` and ``2**-e`` the power of two
@@ -139,10 +140,21 @@ def lcg_state_dict(variant: str, n_classes: int = 0, seed: int = 0, sigma_gain_l
     preserving through the ReLU trunk, so the output depends visibly on position like a trained
     net's does); ``sigma_gain_log2`` / ``sigma_bias`` (an exact dyadic value, please) further scale /
     shift ``alpha_linear`` so that densities, compositing weights and the resampling pdf are far
-    from uniform.
+    from uniform.  ``freq_decay`` multiplies the input columns that carry frequency band ``f`` of the
+    positional / directional encoding by ``2**-f`` (pts_linears.0, pts_linears.5, views_linears.0): a
+    1/f spectrum like a trained network's, instead of the white spectrum of a random one whose
+    output changes by O(1) when a sample moves by 1e-3 (which makes any fp32 evaluation of the
+    two-pass path irreproducible, the reference's included - see tests/golden/make_golden.py).
     """
+    def band_scale(n_cols_enc, n_freqs, offset, total):
+        sc = np.ones(total)
+        for f in range(n_freqs):
+            sc[offset + 3 + 6 * f: offset + 9 + 6 * f] = 2.0 ** -f
+        return sc
+
+    e_cols, d_cols = 3 + 6 * l_xyz, 3 + 6 * l_dir
     sd = {}
-    for t_idx, (key, shape) in enumerate(state_dict_spec(variant, n_classes)):
+    for t_idx, (key, shape) in enumerate(state_dict_spec(variant, n_classes, l_xyz, l_dir)):
         if key.endswith(".weight"):
             fan_in = shape[1]
         n = int(np.prod(shape))
@@ -155,6 +167,10 @@ def lcg_state_dict(variant: str, n_classes: int = 0, seed: int = 0, sigma_gain_l
         vals = k.astype(np.float64) * 2.0 ** (-15 - e)
         if key.endswith(".weight"):
             vals = vals * 2.0 ** weight_gain_log2
+            if freq_decay and key in ("pts_linears.0.weight", f"pts_linears.{SKIP_AFTER + 1}.weight"):
+                vals = (vals.reshape(shape) * band_scale(e_cols, l_xyz, 0, shape[1])[None, :]).reshape(-1)
+            if freq_decay and key == "views_linears.0.weight":
+                vals = (vals.reshape(shape) * band_scale(d_cols, l_dir, NET_WIDTH, shape[1])[None, :]).reshape(-1)
         if key.startswith("alpha_linear"):
             vals = vals * 2.0 ** sigma_gain_log2
             if key.endswith(".bias"):

@@ -16,7 +16,7 @@ def case_config(fx):
 
 def case_weights(fx):
     variant, c, seed = str(fx["variant"]), int(fx["n_classes"]), int(fx["seed"])
-    kw = dict(sigma_gain_log2=int(fx["sigma_gain_log2"]), weight_gain_log2=int(fx["weight_gain_log2"]))
+    kw = dict(sigma_gain_log2=int(fx["sigma_gain_log2"]), weight_gain_log2=int(fx["weight_gain_log2"]), freq_decay=True)
     sd_c = oracle.lcg_state_dict(variant, c, seed=2 * seed, sigma_bias=float(fx["sigma_bias_coarse"]), **kw)
     sd_f = oracle.lcg_state_dict(variant, c, seed=2 * seed + 1, sigma_bias=float(fx["sigma_bias_fine"]), **kw)
     return sd_c, sd_f

@@ -16,6 +16,18 @@ For every case the script
      (this is what pins the oracle - the reference ships no tests for this path),
   4. stores inputs + reference outputs as a fixture.
 
+Conditioning.  With random (untrained) weights the path is numerically ill-conditioned on many rays:
+the 2^9 frequency band turns a 1e-6 depth change into an O(1) phase change, sample_pdf divides by
+cdf differences as small as 1e-5 in near-empty bins, and the 1e10 last interval makes alpha a step
+function of sigma.  On such rays the reference's own fp32 result is 1e-2 away from the same math in
+fp64, so no independent fp32 implementation can be expected within 1e-4 of it.  Each case therefore
+draws 6x more candidate rays than it keeps, evaluates the reference arithmetic (via the validated
+oracle) in fp32 AND fp64, and keeps rays on which the two agree 5x better than the parity tolerance
+(|d| <= 0.2 * (1e-5 + 1e-4 |x|) on every map and stage tensor).  The kept rays are stored in the
+fixture; nothing else is hand-tuned.  For the same reason the closed-form test weights carry a 1/f
+spectrum over the encoding's frequency bands (``lcg_state_dict(freq_decay=True)``), like a trained
+network; with a white spectrum no ray at all passes the filter.
+
 The reference import recipe (stubs for absent third-party modules, no-op ``.cuda()``) is the one
 recorded in SURVEY.md Appendix A.  Fixtures are data only - no reference source is copied.
 """
@@ -147,55 +159,92 @@ def check_same(tag, ref, mine, tol=2e-6):
 
 
 def calibrated_weights(variant, n_classes, seed, rays, cfg, sigma_gain_log2, weight_gain_log2, quantile):
-    """Closed-form weights whose density straddles zero on these rays.
+    return oracle.calibrated_lcg_weights(variant, n_classes, seed, rays, sigma_gain_log2, quantile, weight_gain_log2,
+                                         netchunk=cfg.netchunk)
 
-    ``sigma_bias`` := -(the ``quantile`` of the un-biased coarse-sample densities), rounded to 1/16 so
-    it stays a dyadic rational; it is stored in the fixture next to the seed, which is all a test needs
-    to rebuild the exact same weights.  ``quantile=None`` keeps the bias at 0.
+
+class injected_rng:
+    """Feed prepared tensors to the reference's RNG calls, in call order.
+
+    The reference draws t_rand / noise / u from np.random.rand (its pytest hooks) or torch.rand /
+    torch.randn; to run it on hand-selected rays with the random inputs stored in the fixture, those
+    functions are replaced for the duration of the call.  Random numbers are inputs, not algorithm.
     """
-    wp = dict(sigma_gain_log2=sigma_gain_log2, weight_gain_log2=weight_gain_log2)
-    if quantile is None:
-        return oracle.lcg_state_dict(variant, n_classes, seed=seed, sigma_bias=0.0, **wp), 0.0
-    sd0 = oracle.lcg_state_dict(variant, n_classes, seed=seed, sigma_bias=0.0, **wp)
-    with torch.no_grad():
-        probe = oracle.render_rays(rays, sd0, None, oracle.RenderConfig(
-            variant=variant, n_samples=64, n_importance=0, n_classes=n_classes, netchunk=cfg.netchunk), stages=True)
-    b = -float(torch.quantile(probe["raw_coarse"][..., 3].flatten(), min(quantile, 1.0)))
-    b = round(b * 16.0) / 16.0 - (1.0 if quantile > 1.0 else 0.0)      # quantile > 1: density < 0 everywhere
-    return oracle.lcg_state_dict(variant, n_classes, seed=seed, sigma_bias=b, **wp), b
+
+    def __init__(self, np_rand=(), torch_rand=(), torch_randn=()):
+        self.q = {"np": list(np_rand), "rand": list(torch_rand), "randn": list(torch_randn)}
+
+    def _pop(self, kind, shape):
+        t = self.q[kind].pop(0)
+        assert tuple(t.shape) == tuple(shape), (kind, tuple(t.shape), tuple(shape))
+        return t
+
+    def __enter__(self):
+        self.saved = (np.random.rand, torch.rand, torch.randn)
+        o_np, o_rand, o_randn = self.saved
+        def shape_of(a):
+            return tuple(a[0]) if len(a) == 1 and not isinstance(a[0], int) else tuple(a)
+        # an exhausted queue falls through to the real generator (the reference draws torch.rand even when
+        # its pytest hook then overwrites the result with np.random.rand, run_nerf.py:478-484)
+        np.random.rand = lambda *shape: self._pop("np", shape).double().numpy() if self.q["np"] else o_np(*shape)
+        torch.rand = lambda *a, **k: self._pop("rand", shape_of(a)).clone() if self.q["rand"] else o_rand(*a, **k)
+        torch.randn = lambda *a, **k: self._pop("randn", shape_of(a)).clone() if self.q["randn"] else o_randn(*a, **k)
+        return self
+
+    def __exit__(self, *exc):
+        np.random.rand, torch.rand, torch.randn = self.saved
+        assert not any(self.q.values()) or exc[0] is not None, "unused injected random tensors"
+
+
+def keep_well_conditioned(name, rays, n, sd_c, sd_f, cfg, t_vals, draw_extra):
+    """First n candidate rays whose fp32 evaluation is within a tenth of the parity tolerance of fp64."""
+    extra = draw_extra(rays.shape[0])
+    score = oracle.conditioning_scores(rays, sd_c, sd_f, cfg, t_vals, extra)
+    ok = torch.nonzero(score <= 0.2).flatten()
+    print(f"{name}: {ok.numel()}/{rays.shape[0]} candidate rays are well-conditioned "
+          f"(median score {float(score[torch.isfinite(score)].median()):.2g})")
+    assert ok.numel() >= n, f"{name}: only {ok.numel()} well-conditioned rays, need {n}"
+    sel = ok[:n]
+    return rays[sel].contiguous(), {k: v[sel].contiguous() for k, v in extra.items()}
 
 # ------------------------------------------------------------------------------------------
 # object-level cases
 # ------------------------------------------------------------------------------------------
 def object_case(run_nerf, H_ref, name, n, seed, n_importance, white_bkgd, lindisp, train_rng,
-                sigma_gain_log2, quantile, weight_gain_log2=1, keep_raw=4):
+                sigma_gain_log2, quantile, weight_gain_log2=0, keep_raw=4):
     cfg = oracle.RenderConfig(variant="object", n_samples=64, n_importance=n_importance,
                               white_bkgd=white_bkgd, lindisp=lindisp)
-    rays = chair_rays(H_ref, n, seed)
-    sd_c, b_c = calibrated_weights("object", 0, 2 * seed, rays, cfg, sigma_gain_log2, weight_gain_log2, quantile)
-    sd_f, b_f = calibrated_weights("object", 0, 2 * seed + 1, rays, cfg, sigma_gain_log2, weight_gain_log2, quantile)
+    cand = chair_rays(H_ref, 6 * n, seed)
+    sd_c, b_c = calibrated_weights("object", 0, 2 * seed, cand, cfg, sigma_gain_log2, weight_gain_log2, quantile)
+    sd_f, b_f = calibrated_weights("object", 0, 2 * seed + 1, cand, cfg, sigma_gain_log2, weight_gain_log2, quantile)
     wp = dict(sigma_gain_log2=sigma_gain_log2, weight_gain_log2=weight_gain_log2, sigma_bias_coarse=b_c, sigma_bias_fine=b_f)
+    t_vals = torch.linspace(0.0, 1.0, 64)
+    std = 1.0 if train_rng else 0.0
+
+    def draw_extra(m):
+        if not train_rng:
+            return {}
+        g = torch.Generator().manual_seed(500 + seed)
+        ex = dict(t_rand=torch.rand(m, 64, generator=g), noise_coarse=torch.rand(m, 64, generator=g) * std)
+        if n_importance > 0:
+            ex.update(u=torch.rand(m, n_importance, generator=g), noise_fine=torch.rand(m, 64 + n_importance, generator=g) * std)
+        return ex
+
+    rays, extra = keep_well_conditioned(name, cand, n, sd_c, sd_f, cfg, t_vals, draw_extra)
     embed, ch = H_ref.get_embedder(10, 0)
     embed_d, ch_d = H_ref.get_embedder(4, 0)
     mk = lambda: H_ref.NeRF(D=8, W=256, input_ch=ch, output_ch=5, skips=[4], input_ch_views=ch_d, use_viewdirs=True)
     net_c, net_f = mk(), mk()
     net_c.load_state_dict(sd_c); net_f.load_state_dict(sd_f)
     q = lambda x, v, fn: run_nerf.run_network(x, v, fn, embed_fn=embed, embeddirs_fn=embed_d, netchunk=65536)
-    std = 1.0 if train_rng else 0.0
-    with torch.no_grad():
+    # the reference's pytest hooks call np.random.rand once per draw (run_nerf.py:389-393,480-484; helpers:416-425),
+    # in this order: t_rand, coarse noise, u, fine noise
+    feed = [extra[k] for k in ("t_rand", "noise_coarse", "u", "noise_fine") if k in extra]
+    with torch.no_grad(), injected_rng(np_rand=feed):
         ref = run_nerf.render_rays(rays, net_c, q, 64, retraw=True, lindisp=lindisp,
                                    perturb=1.0 if train_rng else 0.0, N_importance=n_importance,
                                    network_fine=net_f, white_bkgd=white_bkgd, raw_noise_std=std,
                                    pytest=train_rng)
-    t_vals = torch.linspace(0.0, 1.0, 64)
-    extra = {}
-    if train_rng:  # the reference's pytest hooks: np.random.seed(0) before EVERY draw (run_nerf.py:389-393,480-484; helpers:416-425)
-        def draw(*shape):
-            np.random.seed(0)
-            return torch.Tensor(np.random.rand(*shape))
-        extra = dict(t_rand=draw(n, 64), noise_coarse=draw(n, 64) * std)
-        if n_importance > 0:
-            extra.update(u=draw(n, n_importance), noise_fine=draw(n, 64 + n_importance) * std)
     with torch.no_grad():
         mine = oracle.render_rays(rays, sd_c, sd_f, cfg, t_vals=t_vals, stages=True, **extra)
     suffix = "fine" if n_importance > 0 else "coarse"
@@ -250,27 +299,32 @@ def ssr_trainer(SSRTrainer, n_classes, endpoint_feat, white_bkgd, training, n_im
 
 
 def ssr_case(SSRTrainer, ssr_rays, name, n, seed, n_classes, endpoint_feat, white_bkgd, training,
-             sigma_gain_log2, quantile, weight_gain_log2=1, keep_raw=4):
+             sigma_gain_log2, quantile, weight_gain_log2=0, keep_raw=4):
     import contextlib, io
     cfg = oracle.RenderConfig(variant="ssr", n_samples=64, n_importance=128, white_bkgd=white_bkgd,
                               n_classes=n_classes, endpoint_feat=endpoint_feat, netchunk=32768)
-    rays = room_rays(ssr_rays, n, seed)
-    sd_c, b_c = calibrated_weights("ssr", n_classes, 2 * seed, rays, cfg, sigma_gain_log2, weight_gain_log2, quantile)
-    sd_f, b_f = calibrated_weights("ssr", n_classes, 2 * seed + 1, rays, cfg, sigma_gain_log2, weight_gain_log2, quantile)
+    cand = room_rays(ssr_rays, 6 * n, seed)
+    sd_c, b_c = calibrated_weights("ssr", n_classes, 2 * seed, cand, cfg, sigma_gain_log2, weight_gain_log2, quantile)
+    sd_f, b_f = calibrated_weights("ssr", n_classes, 2 * seed + 1, cand, cfg, sigma_gain_log2, weight_gain_log2, quantile)
     wp = dict(sigma_gain_log2=sigma_gain_log2, weight_gain_log2=weight_gain_log2, sigma_bias_coarse=b_c, sigma_bias_fine=b_f)
+    t_vals = torch.linspace(0.0, 1.0, 64)
+
+    def draw_extra(m):
+        if not training:
+            return {}
+        g = torch.Generator().manual_seed(700 + seed)
+        return dict(t_rand=torch.rand(m, 64, generator=g), noise_coarse=torch.randn(m, 64, generator=g) * 1.0,
+                    u=torch.rand(m, 128, generator=g), noise_fine=torch.randn(m, 192, generator=g) * 1.0)
+
+    rays, extra = keep_well_conditioned(name, cand, n, sd_c, sd_f, cfg, t_vals, draw_extra)
     tr = ssr_trainer(SSRTrainer, n_classes, endpoint_feat, white_bkgd, training)
     tr.ssr_net_coarse.load_state_dict(sd_c); tr.ssr_net_fine.load_state_dict(sd_f)
-    extra = {}
-    torch.manual_seed(77 + seed)
-    if training:   # draw in the reference's order: trainer.py:744, model_utils.py:70, rays.py:197, model_utils.py:70
-        extra["t_rand"] = torch.rand(n, 64)
-        extra["noise_coarse"] = torch.randn(n, 64) * 1.0
-        extra["u"] = torch.rand(n, 128)
-        extra["noise_fine"] = torch.randn(n, 192) * 1.0
-        torch.manual_seed(77 + seed)
-    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+    # training mode draws, in order: torch.rand t_rand (trainer.py:744), torch.randn coarse noise (model_utils.py:70),
+    # torch.rand u (rays.py:197), torch.randn fine noise (model_utils.py:70)
+    feed = injected_rng(torch_rand=[extra[k] for k in ("t_rand", "u") if k in extra],
+                        torch_randn=[extra[k] for k in ("noise_coarse", "noise_fine") if k in extra])
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()), feed:
         ref = tr.render_rays(rays)
-    t_vals = torch.linspace(0.0, 1.0, 64)
     with torch.no_grad():
         mine = oracle.render_rays(rays, sd_c, sd_f, cfg, t_vals=t_vals, stages=True, **extra)
     keys = ["rgb", "disp", "acc", "depth", "albedo", "shading", "residual"]
@@ -379,28 +433,28 @@ def main():
     run_nerf, H_ref, SSRTrainer, ssr_rays, ssr_mu = import_reference()
     # ---- object-level: BASELINE configs 1-3 in miniature
     object_case(run_nerf, H_ref, "object_chair_det", n=24, seed=0, n_importance=128, white_bkgd=True,
-                lindisp=False, train_rng=False, sigma_gain_log2=6, quantile=0.7)
-    object_case(run_nerf, H_ref, "object_chair_soft", n=12, seed=1, n_importance=128, white_bkgd=True,
-                lindisp=False, train_rng=False, sigma_gain_log2=3, quantile=0.7)
+                lindisp=False, train_rng=False, sigma_gain_log2=5, quantile=0.7)
+    object_case(run_nerf, H_ref, "object_chair_dense", n=12, seed=1, n_importance=128, white_bkgd=True,
+                lindisp=False, train_rng=False, sigma_gain_log2=5, quantile=0.1)
     object_case(run_nerf, H_ref, "object_chair_train_rng", n=12, seed=2, n_importance=128, white_bkgd=True,
-                lindisp=False, train_rng=True, sigma_gain_log2=5, quantile=0.7)
+                lindisp=False, train_rng=True, sigma_gain_log2=5, quantile=0.5)
     object_case(run_nerf, H_ref, "object_coarse_only_lindisp", n=12, seed=3, n_importance=0, white_bkgd=False,
-                lindisp=True, train_rng=False, sigma_gain_log2=5, quantile=0.7)
-    object_case(run_nerf, H_ref, "object_default_init", n=8, seed=4, n_importance=128, white_bkgd=False,
-                lindisp=False, train_rng=False, sigma_gain_log2=0, quantile=None, weight_gain_log2=0)
+                lindisp=True, train_rng=False, sigma_gain_log2=5, quantile=0.5)
+    object_case(run_nerf, H_ref, "object_strong_weights", n=8, seed=4, n_importance=128, white_bkgd=False,
+                lindisp=False, train_rng=False, sigma_gain_log2=3, quantile=0.5, weight_gain_log2=1)
     object_case(run_nerf, H_ref, "object_empty_space", n=8, seed=5, n_importance=128, white_bkgd=True,
                 lindisp=False, train_rng=False, sigma_gain_log2=3, quantile=2.0)   # sigma < 0 everywhere: acc = 0, disp NaN
     # ---- SSR: BASELINE config 4 in miniature
     ssr_case(SSRTrainer, ssr_rays, "ssr_room_det_c28", n=24, seed=0, n_classes=28, endpoint_feat=False,
-             white_bkgd=False, training=False, sigma_gain_log2=3, quantile=0.7)
+             white_bkgd=False, training=False, sigma_gain_log2=4, quantile=0.7)
     ssr_case(SSRTrainer, ssr_rays, "ssr_room_train_rng_c28", n=12, seed=1, n_classes=28, endpoint_feat=False,
-             white_bkgd=False, training=True, sigma_gain_log2=3, quantile=0.7)
+             white_bkgd=False, training=True, sigma_gain_log2=4, quantile=0.5)
     ssr_case(SSRTrainer, ssr_rays, "ssr_endpoint_c5_wb", n=8, seed=2, n_classes=5, endpoint_feat=True,
-             white_bkgd=True, training=False, sigma_gain_log2=4, quantile=0.7)
+             white_bkgd=True, training=False, sigma_gain_log2=4, quantile=0.5)
     ssr_case(SSRTrainer, ssr_rays, "ssr_c101", n=6, seed=3, n_classes=101, endpoint_feat=False,
-             white_bkgd=False, training=False, sigma_gain_log2=3, quantile=0.7)
+             white_bkgd=False, training=False, sigma_gain_log2=4, quantile=0.3)
     ssr_case(SSRTrainer, ssr_rays, "ssr_c1", n=6, seed=4, n_classes=1, endpoint_feat=False,
-             white_bkgd=False, training=False, sigma_gain_log2=2, quantile=0.7)
+             white_bkgd=False, training=False, sigma_gain_log2=3, quantile=0.5)
     # ---- stage-level edge cases
     stage_composite_cases(run_nerf, ssr_mu)
     stage_sample_pdf_cases(H_ref, ssr_rays)

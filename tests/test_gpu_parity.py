@@ -119,8 +119,11 @@ def test_object_level_render_image_api():
     K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
     c2w = torch.tensor([[-0.7660, 0.3214, -0.5567, -2.2270], [-0.6428, -0.3830, 0.6634, 2.6537],
                         [0.0, 0.8660, 0.5, 2.0]], device=dev)
-    sd_c = oracle.lcg_state_dict("object", seed=20, sigma_gain_log2=5, sigma_bias=-6.0, weight_gain_log2=1)
-    sd_f = oracle.lcg_state_dict("object", seed=21, sigma_gain_log2=5, sigma_bias=-6.0, weight_gain_log2=1)
+    ro0, rd0 = ol.get_rays(H, W, K, c2w)
+    probe = torch.cat([ro0, rd0, 2 * torch.ones_like(rd0[..., :1]), 6 * torch.ones_like(rd0[..., :1]),
+                       rd0 / rd0.norm(dim=-1, keepdim=True)], -1).reshape(-1, 11).cpu()
+    sd_c, _ = oracle.calibrated_lcg_weights("object", 0, 20, probe)
+    sd_f, _ = oracle.calibrated_lcg_weights("object", 0, 21, probe)
     embed, ch = ol.get_embedder(10, 0); embed_d, ch_d = ol.get_embedder(4, 0)
     mk = lambda: ol.NeRF(D=8, W=256, input_ch=ch, output_ch=5, skips=[4], input_ch_views=ch_d, use_viewdirs=True).to(dev)
     net_c, net_f = mk(), mk()
@@ -139,10 +142,15 @@ def test_object_level_render_image_api():
     vd = rd / rd.norm(dim=-1, keepdim=True)
     rays = torch.cat([ro, rd, 2 * torch.ones_like(rd[..., :1]), 6 * torch.ones_like(rd[..., :1]), vd], -1).reshape(-1, 11).cpu()
     cfg = oracle.RenderConfig(variant="object", white_bkgd=True)
+    t_vals = torch.linspace(0., 1., 64)
     with torch.no_grad():
-        want = oracle.render_rays(rays, sd_c, sd_f, cfg, t_vals=torch.linspace(0., 1., 64))
-    assert_maps_close(full[0].reshape(-1, 3).cpu().numpy(), want["rgb_fine"].numpy(), RTOL, ATOL, "render rgb")
-    assert_maps_close(full[4].reshape(-1).cpu().numpy(), want["shading_fine"].numpy(), RTOL, ATOL, "render shading")
+        want = oracle.render_rays(rays, sd_c, sd_f, cfg, t_vals=t_vals)
+    # compare on the rays where the reference arithmetic itself is reproducible (oracle/conditioning.py)
+    ok = (oracle.conditioning_scores(rays, sd_c, sd_f, cfg, t_vals) <= 0.2).numpy()
+    assert ok.mean() > 0.5
+    for idx, key in ((0, "rgb_fine"), (2, "acc_fine"), (3, "albedo_fine"), (4, "shading_fine"), (5, "residual_fine")):
+        got = full[idx].reshape(H * W, -1).cpu().numpy()[ok]
+        assert_maps_close(got, want[key].reshape(H * W, -1).numpy()[ok], RTOL, ATOL, f"render {key}")
 
 
 @pytest.mark.parametrize("name", ["ssr_room_det_c28", "ssr_endpoint_c5_wb", "ssr_c101"])
