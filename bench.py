@@ -45,36 +45,60 @@ def chair_pose(theta_deg=40.0, phi_deg=-30.0, radius=4.0):
     return torch.tensor((flip @ rt @ rp @ t)[:3, :4], dtype=torch.float32)
 
 
-def cpu_baseline(budget_s=12.0):
-    """Time the CPU oracle on rays of the same frame with the same networks (all host cores)."""
+def cpu_baseline(budget_s=14.0):
+    """Time the CPU oracle on rays of the same frame with the same networks.
+
+    torch's intra-op pool is not monotone in thread count on many-core hosts (256 threads on a 512-ray
+    chunk is ~60x slower than 32), so the thread count is probed first and the remaining budget is
+    spent at the best one; "cores" reports the threads actually used.
+    """
     import oracle
     from intrinsicnerf_amd import object_level as ol
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
     focal = 0.5 * W / np.tan(0.5 * CAMERA_ANGLE_X)
     K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
     ro, rd = ol.get_rays(H, W, K, chair_pose())
     ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
-    sel = torch.arange(0, H * W, 157)[:2048]                   # rays spread over the frame
+    sel = torch.arange(0, H * W, 39)[:16384]                   # rays spread over the frame
     ro, rd = ro[sel], rd[sel]
     rays = torch.cat([ro, rd, NEAR * torch.ones_like(rd[:, :1]), FAR * torch.ones_like(rd[:, :1]),
                       rd / rd.norm(dim=-1, keepdim=True)], -1)
     sd_c, sd_f = oracle.make_state_dict("object", seed=0), oracle.make_state_dict("object", seed=1)
     cfg = oracle.RenderConfig(variant="object", n_samples=N_SAMPLES, n_importance=N_IMPORTANCE, white_bkgd=True)
-    chunk = 512
-    with torch.no_grad():
-        oracle.render_rays(rays[:chunk], sd_c, sd_f, cfg)      # warm-up (thread pool, allocator)
-        done, t0 = 0, time.perf_counter()
-        while True:
-            lo = done % rays.shape[0]
+    chunk = 1024
+
+    def run(lo):
+        with torch.no_grad():
             oracle.render_rays(rays[lo:lo + chunk], sd_c, sd_f, cfg)
-            done += chunk
-            dt = time.perf_counter() - t0
-            if dt >= budget_s:
-                break
-    return {"value": done / dt, "unit": "rays/s", "cores": int(torch.get_num_threads()), "kind": "port",
+
+    t_start = time.perf_counter()
+    best_t, best_rate = 1, 0.0
+    for t in sorted({min(avail, c) for c in (8, 16, 32, 64, 128)}):
+        torch.set_num_threads(t)
+        run(0)                                                  # warm the pool at this width
+        t0 = time.perf_counter()
+        run(chunk)
+        rate = chunk / (time.perf_counter() - t0)
+        if rate > best_rate:
+            best_t, best_rate = t, rate
+        if time.perf_counter() - t_start > 0.5 * budget_s:
+            break
+    torch.set_num_threads(best_t)
+    run(0)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        run((done + 2 * chunk) % (rays.shape[0] - chunk))
+        done += chunk
+        dt = time.perf_counter() - t0
+        if dt >= 0.5 * budget_s:
+            break
+    return {"value": done / dt, "unit": "rays/s", "cores": int(best_t), "kind": "port",
             "sample": f"{done} rays of the same 800x800 frame, 64+128 samples, PyTorch-CPU oracle "
-                      f"(oracle/intrinsic_render.py == reference, see tests/golden), {dt:.1f} s"}
+                      f"(oracle/intrinsic_render.py == reference, see tests/golden) in {dt:.1f} s at {best_t} threads "
+                      f"(best of a thread-count probe; host exposes {avail} logical CPUs)"}
 
 
 def main():

@@ -46,3 +46,28 @@ def assert_maps_close(got, want, rtol, atol, tag=""):
         i = int(np.argmax(err - bound))
         raise AssertionError(f"{tag}: max violation err={err[i]:.3e} bound={bound[i]:.3e} "
                              f"(want {want[ok][i]:.6g}, got {got[ok][i]:.6g}); max err {err.max():.3e}")
+
+
+class injected_np_rand:
+    """Feed the fixture's random tensors to ``np.random.rand`` calls, in call order.
+
+    The object-level front-end keeps the reference's ``pytest=True`` hooks (np.random.seed(0) followed by
+    np.random.rand, run_nerf.py:389-393,480-484; run_nerf_helpers.py:416-425).  The golden generator
+    ran the reference with these same tensors injected the same way (tests/golden/make_golden.py).
+    """
+
+    def __init__(self, tensors):
+        self.q = list(tensors)
+
+    def __enter__(self):
+        self.saved = np.random.rand
+        def fake(*shape):
+            t = self.q.pop(0)
+            assert tuple(t.shape) == tuple(shape), (tuple(t.shape), shape)
+            return t.double().cpu().numpy()
+        np.random.rand = fake
+        return self
+
+    def __exit__(self, *exc):
+        np.random.rand = self.saved
+        assert exc[0] is not None or not self.q, "front-end made fewer RNG draws than the reference"

@@ -1,0 +1,208 @@
+"""CPU: the C-ABI library loads, exports every symbol include/inerf.h declares, validates its arguments,
+and the host-side weight packer produces exactly the fragment layout the kernel documents.
+No compute entry point is launched here (there is no GPU in this suite)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import REPO
+
+
+@pytest.fixture(scope="module")
+def capi():
+    import __graft_entry__
+    __graft_entry__.build()
+    from intrinsicnerf_amd import _capi
+    return _capi
+
+
+def test_header_and_binding_agree(capi):
+    """Every function declared in include/inerf.h is exported by libinerf.so and bound in _capi.SYMBOLS."""
+    text = open(os.path.join(REPO, "include", "inerf.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = set(re.findall(r"\b(inerf_[a-z_0-9]+)\s*\(", text))
+    assert declared == set(capi.SYMBOLS), declared ^ set(capi.SYMBOLS)
+    lib = capi.lib()
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.inerf_version().startswith(b"inerf")
+
+
+def test_struct_layouts_match_header(capi):
+    # field order of the ctypes mirrors = field order of the C structs (checked by name against the header)
+    text = open(os.path.join(REPO, "include", "inerf.h")).read()
+    body = text[text.index("typedef struct inerf_render_args"):text.index("} inerf_render_args;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = re.findall(r"([a-z_]+)\s*;", body)
+    assert names == [f[0] for f in capi.RenderArgs._fields_]
+    body = text[text.index("typedef struct inerf_composite_out"):text.index("} inerf_composite_out;")]
+    names = re.findall(r"float\*\s*([a-z]+);", body)
+    assert names == [f[0] for f in capi.CompositeOut._fields_]
+    assert C.sizeof(capi.NetDesc) == 20
+
+
+def test_tensor_table_matches_reference_state_dicts(capi):
+    from intrinsicnerf_amd import packing
+    for variant, c in (("object", 0), ("ssr", 28), ("ssr", 0)):
+        desc = capi.net_desc(capi.VARIANT_SSR if variant == "ssr" else capi.VARIANT_OBJECT, c, 10, 4, 1.0)
+        table = packing.tensor_table(desc)
+        spec = oracle.state_dict_spec(variant, c)
+        assert [n for n, _ in table] == [n for n, _ in spec]
+        for (_, (r, cc)), (_, shape) in zip(table, spec):
+            assert (r, cc) == (shape[0], shape[1] if len(shape) == 2 else 0)
+
+
+def test_argument_validation(capi):
+    lib = capi.lib()
+    bad = capi.net_desc(7)
+    assert lib.inerf_num_tensors(bad) == capi.E_INVALID
+    assert lib.inerf_packed_floats(capi.net_desc(capi.VARIANT_OBJECT, 3)) == capi.E_INVALID      # object net has no classes
+    assert lib.inerf_packed_floats(capi.net_desc(capi.VARIANT_SSR, 0, 11, 4, 10.0)) == capi.E_INVALID   # multires > 10
+    good = capi.net_desc(capi.VARIANT_OBJECT)
+    assert lib.inerf_encode_mlp(good, None, None, None, 4, 64, 0, None, None) == capi.E_INVALID
+    assert lib.inerf_sample_fine(None, None, None, 4, 64, 128, 0, None, None, None, None) == capi.E_INVALID
+    assert lib.inerf_workspace_bytes(good, 1024, 64, 128, 0) > 1024 * 192 * 11 * 4
+    assert lib.inerf_raw_channels(capi.net_desc(capi.VARIANT_SSR, 28, 10, 4, 10.0), capi.FLAG_ENDPOINT, 1) == 11 + 28 + 128
+    assert lib.inerf_raw_channels(capi.net_desc(capi.VARIANT_SSR, 28, 10, 4, 10.0), capi.FLAG_ENDPOINT, 0) == 11 + 28
+    with pytest.raises(RuntimeError):
+        capi.check(capi.E_UNSUPPORTED, "x")
+
+
+# ---- packer: rebuild each layer's (virtual-k) weight matrix from the blob with the documented formula ----
+def _unpack_wide(blob, off, n_out, k_total):
+    rb_per_wave, kb_count = n_out // 128, k_total // 8
+    w = np.zeros((n_out, k_total), np.float32)
+    frag = blob[off: off + n_out * k_total].reshape(4, kb_count, rb_per_wave, 64, 4)
+    for wave in range(4):
+        for rb in range(rb_per_wave):
+            for lane in range(64):
+                row = wave * 32 * rb_per_wave + 32 * rb + (lane & 31)
+                for kb in range(kb_count):
+                    k0 = 8 * kb + 4 * (lane >> 5)
+                    w[row, k0:k0 + 4] = frag[wave, kb, rb, lane]
+    return w
+
+
+def _unpack_skinny(blob, off, rbs, k_total):
+    kb_count = k_total // 16
+    w = np.zeros((16 * rbs, k_total), np.float32)
+    frag = blob[off: off + 16 * rbs * k_total].reshape(rbs, kb_count, 64, 4)
+    for rb in range(rbs):
+        for lane in range(64):
+            for kb in range(kb_count):
+                k0 = 16 * kb + 4 * (lane >> 4)
+                w[16 * rb + (lane & 15), k0:k0 + 4] = frag[rb, kb, lane]
+    return w
+
+
+def _layout(variant, c):
+    """Python twin of csrc/layout.h make_layout (float offsets)."""
+    off = 0
+    slots = {}
+
+    def take(n):
+        nonlocal off
+        o = off
+        off += (n + 3) & ~3
+        return o
+    def wide(name, n_out, k): slots[name] = ("wide", take(n_out * k), take(n_out), n_out, k)
+    def skinny(name, rbs, k): slots[name] = ("skinny", take(rbs * 16 * k), take(rbs * 16), rbs, k)
+    for i in range(8):
+        wide(f"trunk{i}", 256, 64 if i == 0 else (320 if i == 5 else 256))
+    skinny("alpha", 1, 256)
+    if variant == "ssr" and c > 0:
+        wide("sem1", 128, 256)
+        skinny("sem2", (c + 15) // 16, 128)
+    wide("as1", 256, 256); skinny("as2", 1, 256); wide("feat", 256, 256); wide("views", 128, 288); skinny("res", 1, 128)
+    return slots, off
+
+
+@pytest.mark.parametrize("variant,c", [("object", 0), ("ssr", 28), ("ssr", 101), ("ssr", 0)])
+def test_packer_layout(capi, variant, c):
+    from intrinsicnerf_amd import packing
+    desc = capi.net_desc(capi.VARIANT_SSR if variant == "ssr" else capi.VARIANT_OBJECT, c, 10, 4, 10.0 if variant == "ssr" else 1.0)
+    sd = oracle.make_state_dict(variant, c, seed=11)
+    blob = packing.pack_state_dict(desc, sd).numpy()
+    slots, total = _layout(variant, c)
+    assert total == capi.lib().inerf_packed_floats(desc) == blob.shape[0]
+    g = lambda k: sd[k].numpy()
+    # trunk
+    for i in range(8):
+        _, ow, ob, n_out, k = slots[f"trunk{i}"]
+        w = _unpack_wide(blob, ow, n_out, k)
+        ref = g(f"pts_linears.{i}.weight")
+        if i == 0:
+            assert np.array_equal(w[:, :63], ref) and not w[:, 63].any()
+        elif i == 5:      # virtual k = [enc64 | h256], reference columns = [pts63 | h256]
+            assert np.array_equal(w[:, :63], ref[:, :63]) and not w[:, 63].any() and np.array_equal(w[:, 64:], ref[:, 63:])
+        else:
+            assert np.array_equal(w, ref)
+        assert np.array_equal(blob[ob:ob + 256], g(f"pts_linears.{i}.bias"))
+    # sigma
+    _, ow, ob, rbs, k = slots["alpha"]
+    w = _unpack_skinny(blob, ow, rbs, k)
+    assert np.array_equal(w[0], g("alpha_linear.weight")[0]) and not w[1:].any()
+    assert blob[ob] == g("alpha_linear.bias")[0] and not blob[ob + 1: ob + 16].any()
+    # albedo/shading fused
+    sh1, sh2, rs = (("test_linear1", "test_linear2", "shading_linear") if variant == "object"
+                    else ("shading_linear1", "shading_linear2", "residual_linear"))
+    _, ow, ob, n_out, k = slots["as1"]
+    w = _unpack_wide(blob, ow, n_out, k)
+    assert np.array_equal(w[:128], g("albedo_linear1.weight")) and np.array_equal(w[128:], g(sh1 + ".weight"))
+    assert np.array_equal(blob[ob:ob + 128], g("albedo_linear1.bias")) and np.array_equal(blob[ob + 128:ob + 256], g(sh1 + ".bias"))
+    _, ow, ob, rbs, k = slots["as2"]
+    w = _unpack_skinny(blob, ow, rbs, k)
+    assert np.array_equal(w[:3, :128], g("albedo_linear2.weight")) and not w[:3, 128:].any()
+    assert np.array_equal(w[3, 128:], g(sh2 + ".weight")[0]) and not w[3, :128].any() and not w[4:].any()
+    assert np.array_equal(blob[ob:ob + 3], g("albedo_linear2.bias")) and blob[ob + 3] == g(sh2 + ".bias")[0]
+    # feature / views / residual
+    _, ow, ob, n_out, k = slots["feat"]
+    assert np.array_equal(_unpack_wide(blob, ow, n_out, k), g("feature_linear.weight"))
+    _, ow, ob, n_out, k = slots["views"]
+    w = _unpack_wide(blob, ow, n_out, k)
+    ref = g("views_linears.0.weight")
+    assert np.array_equal(w[:, :256], ref[:, :256]) and np.array_equal(w[:, 256:283], ref[:, 256:]) and not w[:, 283:].any()
+    _, ow, ob, rbs, k = slots["res"]
+    w = _unpack_skinny(blob, ow, rbs, k)
+    assert np.array_equal(w[:3], g(rs + ".weight")) and not w[3:].any()
+    if variant == "ssr" and c > 0:
+        _, ow, ob, n_out, k = slots["sem1"]
+        assert np.array_equal(_unpack_wide(blob, ow, n_out, k), g("semantic_linear.0.0.weight"))
+        _, ow, ob, rbs, k = slots["sem2"]
+        w = _unpack_skinny(blob, ow, rbs, k)
+        assert np.array_equal(w[:c], g("semantic_linear.1.weight")) and not w[c:].any()
+        assert np.array_equal(blob[ob:ob + c], g("semantic_linear.1.bias"))
+
+
+def test_packer_rejects_bad_state_dicts(capi):
+    from intrinsicnerf_amd import packing
+    desc = capi.net_desc(capi.VARIANT_OBJECT)
+    sd = oracle.make_state_dict("object", 0, seed=1)
+    bad = dict(sd); bad.pop("alpha_linear.bias")
+    with pytest.raises(KeyError):
+        packing.pack_state_dict(desc, bad)
+    bad = dict(sd); bad["pts_linears.5.weight"] = torch.zeros(256, 256)
+    with pytest.raises(ValueError):
+        packing.pack_state_dict(desc, bad)
+    with pytest.raises(KeyError):       # an SSR checkpoint is not an object-level one
+        packing.pack_state_dict(desc, oracle.make_state_dict("ssr", 5, seed=1))
+
+
+def test_reduced_encoding_widths_pack(capi):
+    """multires < 10 / multires_views < 4: narrower first-layer inputs land in the same padded columns."""
+    from intrinsicnerf_amd import packing
+    desc = capi.net_desc(capi.VARIANT_OBJECT, 0, 6, 2, 1.0)
+    table = dict(packing.tensor_table(desc))
+    assert table["pts_linears.0.weight"] == (256, 39) and table["pts_linears.5.weight"] == (256, 295)
+    assert table["views_linears.0.weight"] == (128, 271)
+    sd = {k: torch.randn(r, c) if c else torch.randn(r) for k, (r, c) in table.items()}
+    blob = packing.pack_state_dict(desc, sd).numpy()
+    slots, _ = _layout("object", 0)
+    w = _unpack_wide(blob, slots["trunk5"][1], 256, 320)
+    assert np.array_equal(w[:, :39], sd["pts_linears.5.weight"].numpy()[:, :39]) and not w[:, 39:64].any()
+    assert np.array_equal(w[:, 64:], sd["pts_linears.5.weight"].numpy()[:, 39:])

@@ -1,0 +1,55 @@
+"""CPU, world_size 2 over gloo: ray sharding + the all-gather of rendered maps (the N > 1 path of bench.py)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_total, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from intrinsicnerf_amd import distributed as idist
+    b, e = idist.shard_bounds(n_total, rank, world)
+    idx = torch.arange(b, e, dtype=torch.float32)
+    # a deterministic "render": map values are functions of the global ray index
+    maps = {"rgb_map": torch.stack([idx, idx + 0.25, idx + 0.5], 1), "disp_map": -idx, "acc_map": idx * 2,
+            "albedo_map": torch.stack([idx * 3, idx * 3 + 1, idx * 3 + 2], 1), "shading_map": idx + 100,
+            "residual_map": torch.stack([idx, idx, idx], 1) * 0.5}
+    full = idist.gather_maps(maps, n_total)
+    torch.save({k: v.clone() for k, v in full.items()}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [10, 11])       # even and ragged bands
+def test_two_rank_gather(tmp_path, n_total):
+    import __graft_entry__
+    __graft_entry__.build()
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), n_total, str(tmp_path)), nprocs=world, join=True)
+    idx = torch.arange(n_total, dtype=torch.float32)
+    for r in range(world):
+        full = torch.load(os.path.join(tmp_path, f"rank{r}.pt"))
+        assert torch.equal(full["rgb_map"], torch.stack([idx, idx + 0.25, idx + 0.5], 1))
+        assert torch.equal(full["disp_map"], -idx) and torch.equal(full["acc_map"], idx * 2)
+        assert torch.equal(full["shading_map"], idx + 100)
+        assert torch.equal(full["albedo_map"][:, 2], idx * 3 + 2) and torch.equal(full["residual_map"][:, 1], idx * 0.5)
+
+
+def test_shard_bounds_cover_everything():
+    from intrinsicnerf_amd.distributed import shard_bounds
+    for n in (0, 1, 7, 640000, 76800):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,105 @@
+"""CPU: host logic of the reference-signature front-ends - module/state-dict compatibility, ray
+generators, and loud failure (no silent CPU / eager fallback) when asked to render without a HIP device."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    import __graft_entry__
+    __graft_entry__.build()
+
+
+def test_modules_have_reference_state_dict_layout():
+    from intrinsicnerf_amd import object_level as ol, ssr
+    net = ol.NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+    spec = oracle.state_dict_spec("object")
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == dict(spec)
+    net.load_state_dict(oracle.make_state_dict("object", seed=2))          # a reference checkpoint loads unchanged
+    for c in (28, 1):
+        snet = ssr.Semantic_NeRF(True, c, D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+        assert {k: tuple(v.shape) for k, v in snet.state_dict().items()} == dict(oracle.state_dict_spec("ssr", c))
+    snet0 = ssr.Semantic_NeRF(False, 7, D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+    assert {k: tuple(v.shape) for k, v in snet0.state_dict().items()} == dict(oracle.state_dict_spec("ssr", 0))
+    assert net.fused_desc().l_xyz == 10 and snet.fused_desc().n_classes == 1 and snet0.fused_desc().n_classes == 0
+    assert ol.NeRF(D=6, W=256, input_ch=63, input_ch_views=27, use_viewdirs=True).fused_desc() is None
+
+
+def test_module_forward_matches_oracle_definition():
+    """The torch definition kept in the modules (for holders of an embedded tensor) is the same function as the oracle's."""
+    from intrinsicnerf_amd import object_level as ol, ssr
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(50, 90, generator=g)
+    sd = oracle.make_state_dict("object", seed=3)
+    net = ol.NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+    net.load_state_dict(sd)
+    with torch.no_grad():
+        assert torch.allclose(net(x), oracle.mlp_forward(sd, x, oracle.RenderConfig("object")), atol=1e-6)
+        sd = oracle.make_state_dict("ssr", 9, seed=4)
+        snet = ssr.Semantic_NeRF(True, 9, D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+        snet.load_state_dict(sd)
+        cfg = oracle.RenderConfig("ssr", n_classes=9)
+        assert torch.allclose(snet(x), oracle.mlp_forward(sd, x, cfg), atol=1e-6)
+        assert torch.allclose(snet(x, True), oracle.mlp_forward(sd, x, cfg, endpoint=True), atol=1e-6)
+        emb, dim = ssr.get_embedder(10, 0, scalar_factor=10)
+        p = torch.randn(20, 3, generator=g)
+        assert dim == 63 and torch.equal(emb(p), oracle.freq_encode(p, 10, 10.0))
+
+
+def test_ray_generators():
+    from intrinsicnerf_amd import object_level as ol, ssr
+    H, W = 6, 8
+    K = np.array([[10.0, 0, 4.0], [0, 10.0, 3.0], [0, 0, 1]])
+    c2w = torch.tensor([[1.0, 0, 0, 0.5], [0, 1, 0, -0.5], [0, 0, 1, 2.0]])
+    ro, rd = ol.get_rays(H, W, K, c2w)
+    assert ro.shape == rd.shape == (H, W, 3)
+    assert torch.allclose(rd[2, 5], torch.tensor([(5 - 4.0) / 10, -(2 - 3.0) / 10, -1.0]))     # OpenGL: -z forward, y up
+    assert torch.equal(ro[0, 0], c2w[:, 3])
+    ro_np, rd_np = ol.get_rays_np(H, W, K, c2w.numpy())
+    assert np.allclose(rd_np, rd.numpy()) and np.allclose(ro_np, ro.numpy())
+    rays = ssr.create_rays(2, torch.eye(4)[None].repeat(2, 1, 1), H, W, 10.0, 10.0, 3.5, 2.5, 0.1, 10.0)
+    assert rays.shape == (2, H * W, 11)
+    r = rays[0].reshape(H, W, 11)[2, 5]
+    assert torch.allclose(r[3:6], torch.tensor([(5 - 3.5) / 10, (2 - 2.5) / 10, 1.0]))          # OpenCV: +z forward, y down
+    assert torch.allclose(r[8:11].norm(), torch.tensor(1.0)) and r[6].item() == pytest.approx(0.1) and r[7].item() == 10.0
+    o2, d2 = ol.ndc_rays(H, W, 10.0, 1.0, ro + torch.tensor([0, 0, 5.0]), rd)
+    assert o2.shape == d2.shape == (H, W, 3) and torch.isfinite(o2).all()
+
+
+def test_render_on_cpu_fails_loudly():
+    """No HIP device -> RuntimeError naming the problem; never a silent torch fallback."""
+    from intrinsicnerf_amd import object_level as ol, ssr
+    embed, ch = ol.get_embedder(10, 0)
+    embed_d, ch_d = ol.get_embedder(4, 0)
+    net = ol.NeRF(D=8, W=256, input_ch=ch, output_ch=5, skips=[4], input_ch_views=ch_d, use_viewdirs=True)
+    rays = torch.rand(8, 11)
+    with torch.no_grad():
+        with pytest.raises(RuntimeError, match="HIP device"):
+            ol.render_rays(rays, net, ol.NetworkQuery(embed, embed_d), 64, N_importance=128, network_fine=net)
+        with pytest.raises(RuntimeError, match="HIP device"):
+            ol.raw2outputs(torch.rand(8, 64, 11), torch.rand(8, 64), torch.rand(8, 3))
+        with pytest.raises(RuntimeError, match="HIP device"):
+            ol.sample_pdf(torch.rand(8, 63), torch.rand(8, 62), 128, det=True)
+        with pytest.raises(RuntimeError, match="HIP device"):
+            ssr.raw2outputs(torch.rand(8, 64, 16), torch.rand(8, 64), torch.rand(8, 3), num_sem_class=5)
+        r = ssr.SSRRenderer(5, device="cpu")
+        with pytest.raises(RuntimeError, match="HIP device"):
+            r.render_rays(rays)
+    with pytest.raises(NotImplementedError, match="gradients"):           # grad mode: forward-only release
+        ol.render_rays(rays, net, ol.NetworkQuery(embed, embed_d), 64)
+
+
+def test_unknown_network_is_called_like_the_reference_does():
+    """run_network with a foreign callable keeps the reference's generic behaviour (embed -> chunked fn)."""
+    from intrinsicnerf_amd import object_level as ol
+    embed, _ = ol.get_embedder(2, 0)
+    embed_d, _ = ol.get_embedder(1, 0)
+    calls = []
+    def fn(e):
+        calls.append(e.shape)
+        return e[:, :4]
+    out = ol.run_network(torch.rand(5, 3, 3), torch.rand(5, 3), fn, embed, embed_d, netchunk=4)
+    assert out.shape == (5, 3, 4) and len(calls) == 4 and calls[0] == (4, 15 + 9)
