@@ -22,6 +22,8 @@
 // residual round exactly like the reference's separate mul/add.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "layout.h"
 
 namespace inerf {
@@ -46,63 +48,92 @@ struct MlpParams {
 };
 
 // ------------------------------------------------------------------------------------------------
-// wide GEMM: RB blocks of 32 output channels per wave, 64 points, K = 8 * (kb0 + kb1)
+// wide GEMM: RB blocks of 32 output channels per wave x PB blocks of 32 points, K = 8 * (kb0 + kb1)
 // ------------------------------------------------------------------------------------------------
+// Operands of the first two k-blocks and the bias are fetched by wide_prefetch(), which the caller
+// issues BEFORE the previous layer's epilogue + barrier, so a layer never starts with an exposed L2
+// round trip.  Inside the loop the weight fragments run two k-blocks ahead and the LDS activation
+// fragments one k-block ahead of the MFMAs that consume them.
 template <int RB>
-__device__ __forceinline__ void wide_gemm(const float* __restrict__ wfrag,  // wave's fragment stream
-                                          const float* __restrict__ bias,   // + first channel of this wave
-                                          const float* xl,                  // lds + (lane&31)*stride + 4*(lane>>5)
-                                          int col0, int kb0, int col1, int kb1, int lane,
-                                          f32x16 (&acc)[RB][2]) {
+struct WidePre {
+    f32x4 w0[RB], w1[RB];   // weight fragments of k-block 0 and 1
+    f32x4 b[RB][4];         // bias for this lane's 4-channel groups
+};
+
+template <int RB>
+__device__ __forceinline__ void wide_prefetch(WidePre<RB>& pre, const float* __restrict__ wfrag,
+                                              const float* __restrict__ bias, int lane) {
+    const f32x4* wv = reinterpret_cast<const f32x4*>(wfrag) + lane;
     const int h4 = 4 * (lane >> 5);
-    // accumulators start at the bias: channel of register r is 32*rb + (r&3) + 8*(r>>2) + h4
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
+        pre.w0[rb] = wv[rb * 64];
+        pre.w1[rb] = wv[(RB + rb) * 64];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(bias + 32 * rb + 8 * g + h4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc[rb][0][4 * g + i] = b[i];
-                acc[rb][1][4 * g + i] = b[i];
-            }
-        }
+        for (int g = 0; g < 4; ++g) pre.b[rb][g] = *reinterpret_cast<const f32x4*>(bias + 32 * rb + 8 * g + h4);
     }
+}
+
+template <int RB, int PB>
+__device__ __forceinline__ void wide_gemm(const WidePre<RB>& pre, const float* __restrict__ wfrag,
+                                          const float* xl,                  // lds + (lane&31)*stride + 4*(lane>>5)
+                                          int col0, int kb0, int col1, int kb1, int lane,
+                                          f32x16 (&acc)[RB][PB]) {
+    // accumulators start at the bias: channel of register r is 32*rb + (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) acc[rb][pb][4 * g + i] = pre.b[rb][g][i];
     const f32x4* wv = reinterpret_cast<const f32x4*>(wfrag) + lane;
     const int kbt = kb0 + kb1;
-    f32x4 wn[RB];
+    auto xoff = [&](int kb) { return kb < kb0 ? col0 + 8 * kb : col1 + 8 * (kb - kb0); };
+    // 4 rotating weight buffers (distance 2) and 2 activation buffers (distance 1), indexed by compile-time
+    // constants inside a 4x unrolled body, so no in-flight load is ever copied (a copy would force a wait).
+    // Every K here is a multiple of 32, i.e. kbt is a multiple of 4.
+    f32x4 w[4][RB], x[2][PB];
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb) wn[rb] = wv[rb * 64];
-#pragma unroll 2
-    for (int kb = 0; kb < kbt; ++kb) {
-        f32x4 wc[RB];
+    for (int rb = 0; rb < RB; ++rb) { w[0][rb] = pre.w0[rb]; w[1][rb] = pre.w1[rb]; }
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) wc[rb] = wn[rb];
-        const int kn = kb + 1 < kbt ? kb + 1 : kb;            // prefetch the next k-block's fragments
+    for (int pb = 0; pb < PB; ++pb) x[0][pb] = *reinterpret_cast<const f32x4*>(xl + xoff(0) + pb * 32 * kLdsStride);
+#pragma unroll 1
+    for (int kb = 0; kb < kbt; kb += 4) {
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) wn[rb] = wv[(kn * RB + rb) * 64];
-        const int xo = kb < kb0 ? col0 + 8 * kb : col1 + 8 * (kb - kb0);
-        const f32x4 x0 = *reinterpret_cast<const f32x4*>(xl + xo);
-        const f32x4 x1 = *reinterpret_cast<const f32x4*>(xl + xo + 32 * kLdsStride);
+        for (int i = 0; i < 4; ++i) {
+            // issue the loads for later k-blocks first ...
+            const int k1 = kb + i + 1 < kbt ? kb + i + 1 : kbt - 1;
+            const int k2 = kb + i + 2 < kbt ? kb + i + 2 : kbt - 1;
+            const int xo = xoff(k1);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+            for (int rb = 0; rb < RB; ++rb) w[(i + 2) & 3][rb] = wv[(k2 * RB + rb) * 64];
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) {
-                acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[rb][c], x0[c], acc[rb][0], 0, 0, 0);
-                acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[rb][c], x1[c], acc[rb][1], 0, 0, 0);
-            }
+            for (int pb = 0; pb < PB; ++pb)
+                x[(i + 1) & 1][pb] = *reinterpret_cast<const f32x4*>(xl + xo + pb * 32 * kLdsStride);
+            __builtin_amdgcn_sched_barrier(0);
+            // ... then 4*RB*PB MFMAs on operands requested two (weights) / one (activations) steps ago
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb)
+                        acc[rb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[i & 3][rb][c], x[i & 1][pb][c], acc[rb][pb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
 
 // write the wave's accumulators to LDS activation columns [dcol + 32*RB*wave, ...) (optionally ReLU)
-template <int RB>
-__device__ __forceinline__ void wide_store(const f32x16 (&acc)[RB][2], float* dl /* lds + (lane&31)*stride + 4*(lane>>5) + dcol + chan0 */,
-                                           bool relu) {
+template <int RB, int PB>
+__device__ __forceinline__ void wide_store(const f32x16 (&acc)[RB][PB],
+                                           float* dl /* lds + (lane&31)*stride + 4*(lane>>5) + dcol + chan0 */, bool relu) {
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
 #pragma unroll
-        for (int pb = 0; pb < 2; ++pb) {
+        for (int pb = 0; pb < PB; ++pb) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 v;
@@ -147,10 +178,16 @@ __device__ __forceinline__ float sigmoid_ref(float x) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// the kernel
+// the kernel.  PB = 32-point blocks per tile:
+//   PB = 2: 64-point tile, 153 KiB of LDS, one workgroup per CU (1 wave per SIMD);
+//   PB = 1: 32-point tile,  76.5 KiB of LDS, TWO workgroups per CU (2 waves per SIMD): while one
+//           workgroup sits in a barrier / epilogue / encode phase the other one keeps the matrix
+//           pipe busy.  Costs 2x the L2->CU weight stream (8.6 TB/s chip-wide, 25 % of L2 bandwidth).
 // ------------------------------------------------------------------------------------------------
-template <bool kSsr>
-__global__ __launch_bounds__(256) void k_encode_mlp(const MlpParams p) {
+template <bool kSsr, int PB>
+__global__ __launch_bounds__(256, 3 - PB) void k_encode_mlp(const MlpParams p) {
+    constexpr int kPts = 32 * PB;
+    constexpr int kParts = 256 / kPts;            // encode: thread = (point, part)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -160,13 +197,21 @@ __global__ __launch_bounds__(256) void k_encode_mlp(const MlpParams p) {
 
     // per-lane LDS bases
     float* const xw = lds + (lane & 31) * kLdsStride + 4 * (lane >> 5);               // wide operand / result rows
-    const float* const xs = lds + (16 * wave + (lane & 15)) * kLdsStride + 4 * (lane >> 4);   // skinny operand rows
+    const bool skinny_wave = 16 * wave < kPts;                                         // PB = 1: waves 0,1 only
+    const float* const xs = lds + (16 * (skinny_wave ? wave : 0) + (lane & 15)) * kLdsStride + 4 * (lane >> 4);
+
+    auto frag256 = [&](const GemmSlot& s, int kbt) { return wts + s.w + (size_t)wave * kbt * 2 * 256; };
+    auto frag128 = [&](const GemmSlot& s, int kbt) { return wts + s.w + (size_t)wave * kbt * 256; };
+
+    WidePre<2> pre2;
+    WidePre<1> pre1;
+    wide_prefetch<2>(pre2, frag256(L.trunk[0], 8), wts + L.trunk[0].b + 64 * wave, lane);
 
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         // ---------------- encode: X[:, enc | dir] ----------------
         {
-            const int pt = tid & 63;
-            int gp = tile * kTilePoints + pt;
+            const int pt = tid % kPts, part = tid / kPts;
+            int gp = tile * kPts + pt;
             gp = gp < p.n_points ? gp : p.n_points - 1;
             const int ray = gp / p.n_samples;
             const float* __restrict__ r = p.rays + (size_t)ray * INERF_RAY_FLOATS;
@@ -180,8 +225,8 @@ __global__ __launch_bounds__(256) void k_encode_mlp(const MlpParams p) {
                 if (p.xyz_div != 1.0f) x[c] = __fdiv_rn(x[c], p.xyz_div);   // semantic_nerf.py:64
                 v[c] = r[8 + c];
             }
-            // frequencies are spread over the 4 waves; 2^f scaling is exact (run_nerf_helpers.py:212)
-            for (int f = wave; f < p.l_xyz; f += kWaves) {
+            // frequency bands are spread over the parts; 2^f scaling is exact (run_nerf_helpers.py:212)
+            for (int f = part; f < p.l_xyz; f += kParts) {
                 const float s = (float)(1 << f);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
@@ -191,22 +236,23 @@ __global__ __launch_bounds__(256) void k_encode_mlp(const MlpParams p) {
                     row[kColEnc + 6 + 6 * f + c] = cs;
                 }
             }
-            if (wave < p.l_dir) {
-                const float s = (float)(1 << wave);
+            const int fd = kParts - 1 - part;                                   // direction bands: one per part, from the top
+            if (fd < p.l_dir) {
+                const float s = (float)(1 << fd);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     float sn, cs;
                     sincosf(v[c] * s, &sn, &cs);
-                    row[kColDir + 3 + 6 * wave + c] = sn;
-                    row[kColDir + 6 + 6 * wave + c] = cs;
+                    row[kColDir + 3 + 6 * fd + c] = sn;
+                    row[kColDir + 6 + 6 * fd + c] = cs;
                 }
             }
-            if (wave == 2) {
+            if (part == 2) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) row[kColEnc + c] = x[c];
                 for (int c = 3 + 6 * p.l_xyz; c < kEncCols; ++c) row[kColEnc + c] = 0.0f;
             }
-            if (wave == 3) {
+            if (part == 3) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) row[kColDir + c] = v[c];
                 for (int c = 3 + 6 * p.l_dir; c < kDirCols; ++c) row[kColDir + c] = 0.0f;
@@ -215,59 +261,73 @@ __global__ __launch_bounds__(256) void k_encode_mlp(const MlpParams p) {
         __syncthreads();
 
         // ---------------- trunk: 8 x (Linear + ReLU), ping-pong A/B ----------------
-        auto wide256 = [&](const GemmSlot& s, int c0, int kb0, int c1, int kb1, int dcol, bool relu) {
-            f32x16 acc[2][2];
-            wide_gemm<2>(wts + s.w + (size_t)wave * (kb0 + kb1) * 2 * 256, wts + s.b + 64 * wave, xw, c0, kb0, c1, kb1,
-                         lane, acc);
-            wide_store<2>(acc, xw + dcol + 64 * wave, relu);
+        // every step: GEMM on prefetched operands -> prefetch the NEXT step's first operands -> epilogue -> barrier
+        auto step256 = [&](const GemmSlot& s, int c0, int kb0, int c1, int kb1, int dcol, bool relu, auto&& prefetch_next) {
+            f32x16 acc[2][PB];
+            wide_gemm<2, PB>(pre2, frag256(s, kb0 + kb1), xw, c0, kb0, c1, kb1, lane, acc);
+            prefetch_next();
+            wide_store<2, PB>(acc, xw + dcol + 64 * wave, relu);
             __syncthreads();
         };
-        auto wide128 = [&](const GemmSlot& s, int c0, int kb0, int c1, int kb1, int dcol, bool relu) {
-            f32x16 acc[1][2];
-            wide_gemm<1>(wts + s.w + (size_t)wave * (kb0 + kb1) * 256, wts + s.b + 32 * wave, xw, c0, kb0, c1, kb1, lane,
-                         acc);
-            wide_store<1>(acc, xw + dcol + 32 * wave, relu);
+        auto step128 = [&](const GemmSlot& s, int c0, int kb0, int c1, int kb1, int dcol, bool relu, auto&& prefetch_next) {
+            f32x16 acc[1][PB];
+            wide_gemm<1, PB>(pre1, frag128(s, kb0 + kb1), xw, c0, kb0, c1, kb1, lane, acc);
+            prefetch_next();
+            wide_store<1, PB>(acc, xw + dcol + 32 * wave, relu);
             __syncthreads();
         };
-        wide256(L.trunk[0], kColEnc, 8, 0, 0, kColA, true);
-        wide256(L.trunk[1], kColA, 32, 0, 0, kColB, true);
-        wide256(L.trunk[2], kColB, 32, 0, 0, kColA, true);
-        wide256(L.trunk[3], kColA, 32, 0, 0, kColB, true);
-        wide256(L.trunk[4], kColB, 32, 0, 0, kColA, true);
-        wide256(L.trunk[5], kColEnc, 8, kColA, 32, kColB, true);     // cat([pts, h]) (run_nerf_helpers.py:290-291)
-        wide256(L.trunk[6], kColB, 32, 0, 0, kColA, true);
-        wide256(L.trunk[7], kColA, 32, 0, 0, kColB, true);           // h7 in B
+        auto pf256 = [&](const GemmSlot& s, int kbt) {
+            return [&, kbt]() { wide_prefetch<2>(pre2, frag256(s, kbt), wts + s.b + 64 * wave, lane); };
+        };
+        auto pf128 = [&](const GemmSlot& s, int kbt) {
+            return [&, kbt]() { wide_prefetch<1>(pre1, frag128(s, kbt), wts + s.b + 32 * wave, lane); };
+        };
+        const bool sem = kSsr && L.sem_rbs > 0;
+        step256(L.trunk[0], kColEnc, 8, 0, 0, kColA, true, pf256(L.trunk[1], 32));
+        step256(L.trunk[1], kColA, 32, 0, 0, kColB, true, pf256(L.trunk[2], 32));
+        step256(L.trunk[2], kColB, 32, 0, 0, kColA, true, pf256(L.trunk[3], 32));
+        step256(L.trunk[3], kColA, 32, 0, 0, kColB, true, pf256(L.trunk[4], 32));
+        step256(L.trunk[4], kColB, 32, 0, 0, kColA, true, pf256(L.trunk[5], 40));
+        step256(L.trunk[5], kColEnc, 8, kColA, 32, kColB, true, pf256(L.trunk[6], 32));   // cat([pts, h]) (run_nerf_helpers.py:290-291)
+        step256(L.trunk[6], kColB, 32, 0, 0, kColA, true, pf256(L.trunk[7], 32));
+        if (sem) step256(L.trunk[7], kColA, 32, 0, 0, kColB, true, pf128(L.sem1, 32));      // h7 in B
+        else     step256(L.trunk[7], kColA, 32, 0, 0, kColB, true, pf256(L.as1, 32));
 
         // ---------------- heads ----------------
-        const int my_pt = tile * kTilePoints + 16 * wave + (lane & 15);     // the point this lane reports in skinny results
-        const bool my_valid = my_pt < p.n_points;
+        const int my_pt = tile * kPts + 16 * wave + (lane & 15);     // the point this lane reports in skinny results
+        const bool my_valid = skinny_wave && my_pt < p.n_points;
         float* const out_row = p.raw + (size_t)(my_valid ? my_pt : 0) * p.channels;
 
         // sigma = alpha_linear(h7)  (run_nerf_helpers.py:294) - no activation here, ReLU happens in raw2outputs
-        const f32x4 sig4 = skinny_gemm<16>(wts + L.alpha.w, wts + L.alpha.b, xs + kColB, lane);
+        f32x4 sig4 = {0.f, 0.f, 0.f, 0.f};
+        if (skinny_wave) sig4 = skinny_gemm<16>(wts + L.alpha.w, wts + L.alpha.b, xs + kColB, lane);
 
-        if (kSsr && L.sem_rbs > 0) {
+        if (sem) {
             // semantic head: Linear(256,128)+ReLU then Linear(128,C), logits raw (semantic_nerf.py:110,142)
-            wide128(L.sem1, kColB, 32, 0, 0, kColA, true);
-            for (int rb = 0; rb < L.sem_rbs; ++rb) {
-                const f32x4 lg = skinny_gemm<8>(wts + L.sem2.w + rb * 8 * 256, wts + L.sem2.b + 16 * rb, xs + kColA, lane);
-                const int ch0 = 16 * rb + 4 * (lane >> 4);
+            step128(L.sem1, kColB, 32, 0, 0, kColA, true, pf256(L.as1, 32));
+            if (skinny_wave) {
+                for (int rb = 0; rb < L.sem_rbs; ++rb) {
+                    const f32x4 lg = skinny_gemm<8>(wts + L.sem2.w + rb * 8 * 256, wts + L.sem2.b + 16 * rb, xs + kColA, lane);
+                    const int ch0 = 16 * rb + 4 * (lane >> 4);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (my_valid && ch0 + i < p.n_classes) out_row[INERF_BASE_CHANNELS + ch0 + i] = lg[i];
+                    for (int i = 0; i < 4; ++i)
+                        if (my_valid && ch0 + i < p.n_classes) out_row[INERF_BASE_CHANNELS + ch0 + i] = lg[i];
+                }
             }
             __syncthreads();                                  // A is about to be overwritten
         }
 
         // albedo / shading hidden layers (one 256-row GEMM), then their 3+1 outputs (one skinny GEMM)
-        wide256(L.as1, kColB, 32, 0, 0, kColA, true);
-        const f32x4 as4 = skinny_gemm<16>(wts + L.as2.w, wts + L.as2.b, xs + kColA, lane);
+        step256(L.as1, kColB, 32, 0, 0, kColA, true, pf256(L.feat, 32));
+        f32x4 as4 = {0.f, 0.f, 0.f, 0.f};
+        if (skinny_wave) as4 = skinny_gemm<16>(wts + L.as2.w, wts + L.as2.b, xs + kColA, lane);
         __syncthreads();                                      // A is about to be overwritten
 
         // feature = feature_linear(h7) (no activation), views layer over cat([feature, dirs]), residual head
-        wide256(L.feat, kColB, 32, 0, 0, kColA, false);
-        wide128(L.views, kColA, 32, kColDir, 4, kColB, true);
-        const f32x4 res4 = skinny_gemm<8>(wts + L.res.w, wts + L.res.b, xs + kColB, lane);
+        step256(L.feat, kColB, 32, 0, 0, kColA, false, pf128(L.views, 36));
+        step128(L.views, kColA, 32, kColDir, 4, kColB, true, pf256(L.trunk[0], 8));          // next tile's first layer
+        f32x4 res4 = {0.f, 0.f, 0.f, 0.f};
+        if (skinny_wave) res4 = skinny_gemm<8>(wts + L.res.w, wts + L.res.b, xs + kColB, lane);
 
         if (lane < 16 && my_valid) {
             const float a0 = sigmoid_ref(as4[0]), a1 = sigmoid_ref(as4[1]), a2 = sigmoid_ref(as4[2]);
@@ -286,8 +346,8 @@ __global__ __launch_bounds__(256) void k_encode_mlp(const MlpParams p) {
             // show_endpoint: append the post-ReLU views activation (semantic_nerf.py:163-164,181)
             const int col = tid & 127;
             const int base = INERF_BASE_CHANNELS + p.n_classes;
-            for (int pt = tid >> 7; pt < kTilePoints; pt += 2) {
-                const int gp = tile * kTilePoints + pt;
+            for (int pt = tid >> 7; pt < kPts; pt += 2) {
+                const int gp = tile * kPts + pt;
                 if (gp < p.n_points) p.raw[(size_t)gp * p.channels + base + col] = lds[pt * kLdsStride + kColB + col];
             }
         }
@@ -308,6 +368,19 @@ int device_cus() {
         g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     return g_num_cus;
+}
+
+// Tile shape: 64-point tiles, one workgroup per CU (default; measured 129.2 TFLOP/s) or 32-point
+// tiles, two workgroups per CU (124.8 TFLOP/s: the second workgroup hides barriers/epilogues but
+// doubles the weight stream and halves the skinny-GEMM parallelism).  INERF_TILE_POINTS=64|32
+// selects for A/B measurements.
+int tile_blocks() {
+    static int pb = 0;
+    if (pb == 0) {
+        const char* e = getenv("INERF_TILE_POINTS");
+        pb = (e && atoi(e) == 32) ? 1 : 2;
+    }
+    return pb;
 }
 
 int record(hipError_t e) {
@@ -334,20 +407,25 @@ extern "C" int inerf_encode_mlp(const inerf_net_desc* net, const float* packed, 
     p.L = make_layout(*net);
     p.n_points = (int)n_points;
     p.n_samples = n_samples;
-    p.n_tiles = (int)((n_points + kTilePoints - 1) / kTilePoints);
     p.endpoint = (ssr && (flags & INERF_FLAG_ENDPOINT)) ? 1 : 0;
     p.n_classes = ssr ? net->n_classes : 0;
     p.channels = INERF_BASE_CHANNELS + p.n_classes + (p.endpoint ? INERF_ENDPOINT_DIM : 0);
     p.l_xyz = net->l_xyz; p.l_dir = net->l_dir; p.xyz_div = net->xyz_div;
-    const int grid = p.n_tiles < device_cus() ? p.n_tiles : device_cus();
-    auto kern = ssr ? k_encode_mlp<true> : k_encode_mlp<false>;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[ssr]) {
+    const int pb = tile_blocks();
+    const int tile_pts = 32 * pb;
+    p.n_tiles = (int)((n_points + tile_pts - 1) / tile_pts);
+    const int lds_bytes = tile_pts * kLdsStride * 4;
+    const int max_grid = device_cus() * (3 - pb);                 // PB=1: two workgroups per CU
+    const int grid = p.n_tiles < max_grid ? p.n_tiles : max_grid;
+    void (*kern)(const MlpParams) = pb == 2 ? (ssr ? k_encode_mlp<true, 2> : k_encode_mlp<false, 2>)
+                                            : (ssr ? k_encode_mlp<true, 1> : k_encode_mlp<false, 1>);
+    static bool attr_set[2][2] = {{false, false}, {false, false}};
+    if (!attr_set[ssr][pb - 1]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           kLdsBytes);
+                                           lds_bytes);
         if (e != hipSuccess) return record(e);
-        attr_set[ssr] = true;
+        attr_set[ssr][pb - 1] = true;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kLdsBytes, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, p);
     return record(hipGetLastError());
 }
