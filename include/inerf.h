@@ -46,6 +46,17 @@ extern "C" {
 #define INERF_FLAG_ENDPOINT     4u   /* SSR endpoint_feat: fine raw carries the 128-d views activation    */
 #define INERF_FLAG_U_PER_RAY    8u   /* `u` is [N, n_importance] (random) instead of a shared [n_importance] */
 
+/* arithmetic of the MLP GEMMs (inerf_net_desc.precision) */
+#define INERF_PREC_F32        0   /* v_mfma_f32_32x32x2_f32: exact fp32 products and accumulation             */
+#define INERF_PREC_F16X3      1   /* every fp32 operand split into f16 hi + f16 (lo * 2^11); three f16 MFMA
+                                     products hi*hi + 2^-11 (hi*lo + lo*hi), fp32 accumulation: 22-bit operands,
+                                     fp32-level accuracy at the 16x faster f16 matrix pipe.  Activations above
+                                     6e4 in magnitude cannot be represented: the kernel then raises
+                                     INERF_STATUS_F16_RANGE in the caller's status word (re-run with F32).     */
+
+/* bits of the device status word (inerf_encode_mlp / inerf_render_rays `status` argument) */
+#define INERF_STATUS_F16_RANGE  1
+
 #define INERF_BASE_CHANNELS   11   /* rgb3 sigma albedo3 shading residual3 (run_nerf_helpers.py:321)       */
 #define INERF_ENDPOINT_DIM    128
 #define INERF_RAY_FLOATS      11   /* o3 d3 near far viewdir3 (run_nerf.py:122-128, rays.py:251-255)       */
@@ -66,6 +77,7 @@ typedef struct inerf_net_desc {
     int32_t l_xyz;        /* multires       (0..10)  -> 3+6*l_xyz encoded position channels        */
     int32_t l_dir;        /* multires_views (0..4)   -> 3+6*l_dir encoded direction channels       */
     float   xyz_div;      /* encoder input divisor: 1 (object) / 10 (SSR, semantic_nerf.py:64)     */
+    int32_t precision;    /* INERF_PREC_*: selects the packed format AND the MLP kernel            */
 } inerf_net_desc;
 
 /* Number of state-dict tensors the packer expects, and the canonical order/shape of tensor i:
@@ -101,9 +113,10 @@ int inerf_sample_coarse(const float* rays, const float* t_vals, const float* t_r
 /* raw[N,S,CH] = MLP(encode(o + d*z), encode(viewdir)).  Replaces run_network + NeRF.forward:
  * run_nerf.py:42-56 + run_nerf_helpers.py:195-243,284-321 / model_utils.py:19-35 +
  * semantic_nerf.py:14-65,123-181.  CH = 11 + n_classes (+128 if INERF_FLAG_ENDPOINT).
- * packed_weights: device copy of the inerf_pack_weights() blob. */
+ * packed_weights: device copy of the inerf_pack_weights() blob.
+ * status: optional device int32 the kernel ORs INERF_STATUS_* bits into (caller zeroes it). */
 int inerf_encode_mlp(const inerf_net_desc* net, const float* packed_weights, const float* rays, const float* z_vals,
-                     int64_t n_rays, int n_samples, uint32_t flags, float* raw_out, void* stream);
+                     int64_t n_rays, int n_samples, uint32_t flags, float* raw_out, int32_t* status, void* stream);
 
 /* Alpha compositing.  Replaces raw2outputs: run_nerf.py:359-412 / model_utils.py:39-116.
  * raw[N,S,CH]; z[N,S]; rays_d: pointer to the first direction, consecutive rays `rays_d_stride`
@@ -173,6 +186,7 @@ typedef struct inerf_render_args {
     float* z_coarse;              /* [N,n_samples]          optional copy-out of stage tensors     */
     float* z_samples;             /* [N,n_importance]                                               */
     float* z_fine;                /* [N,n_samples+n_importance]                                     */
+    int32_t* status;              /* optional device word for INERF_STATUS_* bits (caller zeroes it) */
     /* scratch */
     void*   workspace;
     int64_t workspace_bytes;

@@ -11,6 +11,8 @@ from ._build import LIB_PATH
 
 OK, E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_HIP = 0, -1, -2, -3, -4
 VARIANT_OBJECT, VARIANT_SSR = 0, 1
+PREC_F32, PREC_F16X3 = 0, 1
+STATUS_F16_RANGE = 1
 FLAG_WHITE_BKGD, FLAG_LINDISP, FLAG_ENDPOINT, FLAG_U_PER_RAY, FLAG_BINS_DIRECT = 1, 2, 4, 8, 16
 BASE_CHANNELS, ENDPOINT_DIM, RAY_FLOATS, MAX_CLASSES = 11, 128, 11, 240
 
@@ -20,7 +22,7 @@ _ERR = {E_INVALID: "invalid argument", E_UNSUPPORTED: "unsupported configuration
 
 class NetDesc(C.Structure):
     _fields_ = [("variant", C.c_int32), ("n_classes", C.c_int32), ("l_xyz", C.c_int32), ("l_dir", C.c_int32),
-                ("xyz_div", C.c_float)]
+                ("xyz_div", C.c_float), ("precision", C.c_int32)]
 
 
 class CompositeOut(C.Structure):
@@ -35,7 +37,7 @@ class RenderArgs(C.Structure):
                 ("noise_coarse", C.c_void_p), ("noise_fine", C.c_void_p),
                 ("coarse", CompositeOut), ("fine", CompositeOut), ("z_std", C.c_void_p),
                 ("raw_coarse", C.c_void_p), ("raw_fine", C.c_void_p), ("z_coarse", C.c_void_p),
-                ("z_samples", C.c_void_p), ("z_fine", C.c_void_p),
+                ("z_samples", C.c_void_p), ("z_fine", C.c_void_p), ("status", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
 
 
@@ -50,7 +52,7 @@ SYMBOLS = {
     "inerf_raw_channels": (_I, [C.POINTER(NetDesc), _U, _I]),
     "inerf_pack_weights": (_I, [C.POINTER(NetDesc), C.POINTER(_P), _I, _P, _L]),
     "inerf_sample_coarse": (_I, [_P, _P, _P, _L, _I, _U, _P, _P]),
-    "inerf_encode_mlp": (_I, [C.POINTER(NetDesc), _P, _P, _P, _L, _I, _U, _P, _P]),
+    "inerf_encode_mlp": (_I, [C.POINTER(NetDesc), _P, _P, _P, _L, _I, _U, _P, _P, _P]),
     "inerf_composite": (_I, [_P, _P, _P, _I, _P, _L, _I, _I, _I, _I, _U, C.POINTER(CompositeOut), _P]),
     "inerf_sample_fine": (_I, [_P, _P, _P, _L, _I, _I, _U, _P, _P, _P, _P]),
     "inerf_sample_pdf": (_I, [_P, _P, _P, _L, _I, _I, _U, _P, _P]),
@@ -86,5 +88,14 @@ def check(rc, what):
     raise RuntimeError(f"{what}: {msg}")
 
 
-def net_desc(variant, n_classes=0, l_xyz=10, l_dir=4, xyz_div=1.0):
-    return NetDesc(int(variant), int(n_classes), int(l_xyz), int(l_dir), float(xyz_div))
+def default_precision():
+    """MLP arithmetic used when a caller does not choose: $INERF_PRECISION = f32 (default) | f16x3."""
+    name = os.environ.get("INERF_PRECISION", "f32").lower()
+    if name not in ("f32", "f16x3"):
+        raise ValueError(f"INERF_PRECISION={name!r}: expected 'f32' or 'f16x3'")
+    return PREC_F16X3 if name == "f16x3" else PREC_F32
+
+
+def net_desc(variant, n_classes=0, l_xyz=10, l_dir=4, xyz_div=1.0, precision=None):
+    prec = default_precision() if precision is None else int(precision)
+    return NetDesc(int(variant), int(n_classes), int(l_xyz), int(l_dir), float(xyz_div), prec)

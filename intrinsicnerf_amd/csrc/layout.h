@@ -40,6 +40,11 @@ constexpr int kLdsBytes = kTilePoints * kLdsStride * 4;   // 156,672 B of the CU
 // i.e. exactly the A-operand fragments of four consecutive v_mfma_f32_32x32x2_f32 (c = 0..3).
 // "Skinny" GEMMs (16x16x4 MFMA, <= 16*RBS output rows, every wave reads the same weights):
 //     blob[off + ((rb*KB16 + kb)*64 + lane)*4 + c] = W[16*rb + (lane&15)][16*kb + 4*(lane>>4) + c]
+// With precision INERF_PREC_F16X3 the same float-sized regions hold f16 fragments instead (see
+// pack.cpp): per wave and 16-wide k-block, for each row block a 1 KiB "hi" fragment followed by a
+// 1 KiB "lo" fragment, lane l holding 8 halfs W[..+(l&31)][16*kb + 8*(l>>5) .. +7]; skinny GEMMs per
+// 32-wide k-block, lane l holding W[16*rb + (l&15)][32*kb + 8*(l>>4) .. +7].  Region sizes are
+// identical (2 halfs per weight = 4 bytes), so NetLayout serves both formats.
 // Virtual k runs over the concatenation of the layer's LDS source segments (e.g. [enc64 | h256] for
 // pts_linears[5]); padded columns/rows hold zeros.  Biases are stored unpermuted (padded with zeros).
 struct GemmSlot {
@@ -92,6 +97,7 @@ inline bool net_supported(const inerf_net_desc& n) {
     if (n.n_classes < 0 || n.n_classes > INERF_MAX_CLASSES) return false;
     if (n.variant == INERF_VARIANT_OBJECT && n.n_classes != 0) return false;
     if (!(n.xyz_div > 0.0f)) return false;
+    if (n.precision != INERF_PREC_F32 && n.precision != INERF_PREC_F16X3) return false;
     return true;
 }
 

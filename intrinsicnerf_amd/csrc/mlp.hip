@@ -24,28 +24,12 @@
 
 #include <cstdlib>
 
-#include "layout.h"
+#include "mlp_common.h"
 
 namespace inerf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct MlpParams {
-    const float* wts;       // packed blob
-    const float* rays;      // [N,11]
-    const float* z;         // [N,S]
-    float* raw;             // [N*S, channels]
-    NetLayout L;
-    int n_points;           // N*S  (< 2^31, checked on the host)
-    int n_samples;
-    int n_tiles;
-    int channels;
-    int n_classes;
-    int endpoint;
-    int l_xyz, l_dir;
-    float xyz_div;
-};
 
 // ------------------------------------------------------------------------------------------------
 // wide GEMM: RB blocks of 32 output channels per wave x PB blocks of 32 points, K = 8 * (kb0 + kb1)
@@ -393,24 +377,9 @@ int record(hipError_t e) {
 
 extern "C" int inerf_last_hip_error(void) { return inerf::g_last_hip_error; }
 
-extern "C" int inerf_encode_mlp(const inerf_net_desc* net, const float* packed, const float* rays, const float* z,
-                                int64_t n_rays, int n_samples, uint32_t flags, float* raw_out, void* stream) {
-    using namespace inerf;
-    if (!net || !packed || !rays || !z || !raw_out || n_rays < 0 || n_samples < 1) return INERF_E_INVALID;
-    if (!net_supported(*net)) return INERF_E_UNSUPPORTED;
-    if (n_rays == 0) return INERF_OK;
-    const int64_t n_points = n_rays * (int64_t)n_samples;
-    if (n_points >= (int64_t)1 << 31) return INERF_E_UNSUPPORTED;     // caller chunks (the front-ends do)
-    const bool ssr = net->variant == INERF_VARIANT_SSR;
-    MlpParams p;
-    p.wts = packed; p.rays = rays; p.z = z; p.raw = raw_out;
-    p.L = make_layout(*net);
-    p.n_points = (int)n_points;
-    p.n_samples = n_samples;
-    p.endpoint = (ssr && (flags & INERF_FLAG_ENDPOINT)) ? 1 : 0;
-    p.n_classes = ssr ? net->n_classes : 0;
-    p.channels = INERF_BASE_CHANNELS + p.n_classes + (p.endpoint ? INERF_ENDPOINT_DIM : 0);
-    p.l_xyz = net->l_xyz; p.l_dir = net->l_dir; p.xyz_div = net->xyz_div;
+namespace inerf {
+
+int launch_mlp_f32(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream) {
     const int pb = tile_blocks();
     const int tile_pts = 32 * pb;
     p.n_tiles = (int)((n_points + tile_pts - 1) / tile_pts);
@@ -426,6 +395,32 @@ extern "C" int inerf_encode_mlp(const inerf_net_desc* net, const float* packed, 
         if (e != hipSuccess) return record(e);
         attr_set[ssr][pb - 1] = true;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, stream, p);
     return record(hipGetLastError());
+}
+
+}  // namespace inerf
+
+extern "C" int inerf_encode_mlp(const inerf_net_desc* net, const float* packed, const float* rays, const float* z,
+                                int64_t n_rays, int n_samples, uint32_t flags, float* raw_out, int32_t* status,
+                                void* stream) {
+    using namespace inerf;
+    if (!net || !packed || !rays || !z || !raw_out || n_rays < 0 || n_samples < 1) return INERF_E_INVALID;
+    if (!net_supported(*net)) return INERF_E_UNSUPPORTED;
+    if (n_rays == 0) return INERF_OK;
+    const int64_t n_points = n_rays * (int64_t)n_samples;
+    if (n_points >= (int64_t)1 << 31) return INERF_E_UNSUPPORTED;     // caller chunks (the front-ends do)
+    const bool ssr = net->variant == INERF_VARIANT_SSR;
+    MlpParams p;
+    p.wts = packed; p.rays = rays; p.z = z; p.raw = raw_out; p.status = status;
+    p.L = make_layout(*net);
+    p.n_points = (int)n_points;
+    p.n_samples = n_samples;
+    p.n_tiles = 0;
+    p.endpoint = (ssr && (flags & INERF_FLAG_ENDPOINT)) ? 1 : 0;
+    p.n_classes = ssr ? net->n_classes : 0;
+    p.channels = INERF_BASE_CHANNELS + p.n_classes + (p.endpoint ? INERF_ENDPOINT_DIM : 0);
+    p.l_xyz = net->l_xyz; p.l_dir = net->l_dir; p.xyz_div = net->xyz_div;
+    return net->precision == INERF_PREC_F16X3 ? launch_mlp_f16x3(p, n_points, ssr, (hipStream_t)stream)
+                                              : launch_mlp_f32(p, n_points, ssr, (hipStream_t)stream);
 }

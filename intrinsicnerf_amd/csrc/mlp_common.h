@@ -1,0 +1,33 @@
+// mlp_common.h - shared between the two encode+MLP kernels (mlp.hip: exact fp32 MFMA; mlp_f16.hip:
+// f16 hi/lo split operands) and their launcher.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "layout.h"
+
+namespace inerf {
+
+struct MlpParams {
+    const float* wts;       // packed blob
+    const float* rays;      // [N,11]
+    const float* z;         // [N,S]
+    float* raw;             // [N*S, channels]
+    int32_t* status;        // optional device word for INERF_STATUS_* bits
+    NetLayout L;
+    int n_points;           // N*S  (< 2^31, checked on the host)
+    int n_samples;
+    int n_tiles;
+    int channels;
+    int n_classes;
+    int endpoint;
+    int l_xyz, l_dir;
+    float xyz_div;
+};
+
+int device_cus();
+int tile_blocks();
+int record(hipError_t e);
+int launch_mlp_f32(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream);
+int launch_mlp_f16x3(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream);
+
+}  // namespace inerf

@@ -1,0 +1,389 @@
+// mlp_f16.hip - the encode+MLP kernel on the f16 matrix pipe with split fp32 operands
+// (INERF_PREC_F16X3).  Same tile walk, same layer list, same outputs as mlp.hip; only the GEMM
+// arithmetic differs:
+//
+//     every fp32 operand v (weight or activation) is carried as  hi = f16(v),  lo = f16((v - hi) * 2^11)
+//     so that v = hi + lo * 2^-11 to 22 bits, and each product  w * x  is evaluated as
+//         hi_w*hi_x                       -> accumulator "main"   (fp32)
+//         hi_w*lo_x + lo_w*hi_x           -> accumulator "cross"  (fp32),  result = main + 2^-11 * cross
+//     (the lo*lo term is 2^-22 relative and dropped).  f16 x f16 products are exact in fp32, so the
+//     only roundings are the fp32 accumulations - the error against an fp64 evaluation is the same
+//     as the all-fp32 kernel's (measured on the oracle: 5e-7 of the channel scale for both).
+//
+// Three v_mfma_f32_32x32x16_f16 (16x the fp32 MFMA rate each) replace eight v_mfma_f32_32x32x2_f32:
+// 5.3x fewer matrix-pipe cycles per point.  The scaled low part keeps lo inside f16's normal range
+// for any v in [2^-14, 6e4]; smaller v lose relative (not absolute) precision, larger v cannot be
+// represented: the kernel then sets INERF_STATUS_F16_RANGE and the caller re-runs in fp32.
+//
+// LDS: two planes (hi, lo) of X[64 points][616 halfs]; 616*2 B = 77*16 B, so the 16 rows a
+// ds_read_b128 lane group touches fall on 16 distinct bank slots.  Columns as in layout.h
+// (enc 64 | dir 32 | A 256 | B 256).  157,696 B per workgroup, one workgroup per CU.
+#include <type_traits>
+
+#include "mlp_common.h"
+
+namespace inerf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kRowH = kColB + kWidth + 8;      // 616 halfs per row
+constexpr int kPlaneH = kTilePoints * kRowH;   // halfs per plane
+constexpr int kLdsBytesH = 2 * kPlaneH * 2;    // 157,696
+constexpr float kLoScale = 2048.0f;            // 2^11
+constexpr float kLoInv = 1.0f / 2048.0f;
+constexpr float kF16Safe = 6.0e4f;
+
+// `amax` is a per-thread running maximum of |v| over everything that was split into f16; it is compared
+// with the representable range once, at the end of the kernel (a per-value compare-and-flag made the
+// compiler keep every |v| alive and spill).
+__device__ __forceinline__ void split_store(_Float16* hi_ptr, float v, float& amax) {
+    const _Float16 h = (_Float16)v;
+    hi_ptr[0] = h;
+    hi_ptr[kPlaneH] = (_Float16)((v - (float)h) * kLoScale);
+    amax = fmaxf(amax, fabsf(v));
+}
+
+// ------------------------------------------------------------------------------------------------
+// wide GEMM: RB blocks of 32 channels per wave x 2 blocks of 32 points, K = 16 * (KB0 + KB1)
+// ------------------------------------------------------------------------------------------------
+template <int RB>
+struct WidePreH {
+    f16x8 w[2][RB][2];      // k-block 0/1, row block, hi/lo
+    f32x4 b[RB][4];
+};
+
+template <int RB>
+__device__ __forceinline__ void wide_prefetch_h(WidePreH<RB>& pre, const float* __restrict__ wfrag,
+                                                const float* __restrict__ bias, int lane) {
+    const f16x8* wv = reinterpret_cast<const f16x8*>(wfrag) + lane;
+    const int h4 = 4 * (lane >> 5);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int part = 0; part < 2; ++part) pre.w[kb][rb][part] = wv[((kb * RB + rb) * 2 + part) * 64];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pre.b[rb][g] = *reinterpret_cast<const f32x4*>(bias + 32 * rb + 8 * g + h4);
+}
+
+template <int RB, int KB0, int KB1>
+__device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const float* __restrict__ wfrag,
+                                            const _Float16* xl,      // plane_hi + (lane&31)*kRowH + 8*(lane>>5)
+                                            int col0, int col1, int lane, f32x16 (&am)[RB][2], f32x16 (&ac)[RB][2]) {
+    constexpr int KBT = KB0 + KB1;
+    static_assert(KBT % 2 == 0 && KBT >= 4, "k-block count");
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb) {
+                    am[rb][pb][4 * g + i] = pre.b[rb][g][i];
+                    ac[rb][pb][4 * g + i] = 0.0f;
+                }
+    const f16x8* wv = reinterpret_cast<const f16x8*>(wfrag) + lane;
+    auto xoff = [&](int kb) { return kb < KB0 ? col0 + 16 * kb : col1 + 16 * (kb - KB0); };
+    // 4 rotating weight buffers (two k-blocks ahead), 2 activation buffers (one ahead); all indices static
+    f16x8 w[4][RB][2], x[2][2][2];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int part = 0; part < 2; ++part) { w[0][rb][part] = pre.w[0][rb][part]; w[1][rb][part] = pre.w[1][rb][part]; }
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+        for (int part = 0; part < 2; ++part)
+            x[0][pb][part] = *reinterpret_cast<const f16x8*>(xl + part * kPlaneH + xoff(0) + pb * 32 * kRowH);
+
+// one k-block: request operands for k+2 (weights) / k+1 (activations), then 3*RB*2 MFMAs on block k.
+// A macro, not a lambda: the buffer indices must stay compile-time constants for the arrays to live in registers.
+#define INERF_F16_STEP(K, I)                                                                                         \
+    {                                                                                                                \
+        const int k1_ = (K) + 1 < KBT ? (K) + 1 : KBT - 1;                                                           \
+        const int k2_ = (K) + 2 < KBT ? (K) + 2 : KBT - 1;                                                           \
+        const int xo_ = xoff(k1_);                                                                                   \
+        _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                                            \
+            _Pragma("unroll") for (int part = 0; part < 2; ++part)                                                   \
+                w[((I) + 2) & 3][rb][part] = wv[((k2_ * RB + rb) * 2 + part) * 64];                                  \
+        _Pragma("unroll") for (int pb = 0; pb < 2; ++pb)                                                             \
+            _Pragma("unroll") for (int part = 0; part < 2; ++part)                                                   \
+                x[((I) + 1) & 1][pb][part] =                                                                         \
+                    *reinterpret_cast<const f16x8*>(xl + part * kPlaneH + xo_ + pb * 32 * kRowH);                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        /* hi*hi -> main; hi*lo and lo*hi -> cross; product-major: an accumulator is touched every 4th MFMA */       \
+        _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                                            \
+            _Pragma("unroll") for (int pb = 0; pb < 2; ++pb)                                                         \
+                am[rb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[(I) & 3][rb][0], x[(I) & 1][pb][0], am[rb][pb], 0, 0, 0); \
+        _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                                            \
+            _Pragma("unroll") for (int pb = 0; pb < 2; ++pb)                                                         \
+                ac[rb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[(I) & 3][rb][0], x[(I) & 1][pb][1], ac[rb][pb], 0, 0, 0); \
+        _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                                            \
+            _Pragma("unroll") for (int pb = 0; pb < 2; ++pb)                                                         \
+                ac[rb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[(I) & 3][rb][1], x[(I) & 1][pb][0], ac[rb][pb], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+    }
+    constexpr int KB4 = KBT & ~3;
+#pragma unroll 1
+    for (int kb = 0; kb < KB4; kb += 4) {
+        INERF_F16_STEP(kb + 0, 0)
+        INERF_F16_STEP(kb + 1, 1)
+        INERF_F16_STEP(kb + 2, 2)
+        INERF_F16_STEP(kb + 3, 3)
+    }
+    if constexpr (KBT - KB4 == 2) {
+        INERF_F16_STEP(KB4 + 0, 0)
+        INERF_F16_STEP(KB4 + 1, 1)
+    }
+#undef INERF_F16_STEP
+}
+
+// epilogue: y = main + 2^-11 cross (optionally ReLU) -> hi/lo planes; optional fp32 copy to global
+template <int RB>
+__device__ __forceinline__ void wide_store_h(const f32x16 (&am)[RB][2], const f32x16 (&ac)[RB][2],
+                                             _Float16* dl,   // plane_hi + (lane&31)*kRowH + 4*(lane>>5) + dcol + chan0
+                                             bool relu, float& amax, float* gout /* or nullptr: + chan0 + 4*(lane>>5) */,
+                                             int gstride, int valid0, int valid1) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f16x4 hi4, lo4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float y = __builtin_fmaf(ac[rb][pb][4 * g + i], kLoInv, am[rb][pb][4 * g + i]);
+                    if (relu) y = fmaxf(y, 0.0f);
+                    const _Float16 h = (_Float16)y;
+                    hi4[i] = h;
+                    lo4[i] = (_Float16)((y - (float)h) * kLoScale);
+                    amax = fmaxf(amax, fabsf(y));
+                    if (gout && (pb == 0 ? valid0 : valid1)) gout[(size_t)pb * 32 * gstride + 32 * rb + 8 * g + i] = y;
+                }
+                _Float16* d = dl + pb * 32 * kRowH + 32 * rb + 8 * g;
+                *reinterpret_cast<f16x4*>(d) = hi4;
+                *reinterpret_cast<f16x4*>(d + kPlaneH) = lo4;
+            }
+            // keep the scheduler from converting all 8 blocks at once (it would need >256 live VGPRs and spill)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// skinny GEMM: 16 output rows x this wave's 16 points on v_mfma_f32_16x16x32_f16, K = 32*KB32
+// ------------------------------------------------------------------------------------------------
+template <int KB32>
+__device__ __forceinline__ f32x4 skinny_gemm_h(const float* __restrict__ wfrag, const float* __restrict__ bias16,
+                                               const _Float16* xs /* plane_hi + (16*wave + (lane&15))*kRowH + col + 8*(lane>>4) */,
+                                               int lane) {
+    f32x4 am = *reinterpret_cast<const f32x4*>(bias16 + 4 * (lane >> 4));
+    f32x4 ac = {0.0f, 0.0f, 0.0f, 0.0f};
+    const f16x8* wv = reinterpret_cast<const f16x8*>(wfrag) + lane;
+#pragma unroll
+    for (int kb = 0; kb < KB32; ++kb) {
+        const f16x8 wh = wv[(2 * kb) * 64], wl = wv[(2 * kb + 1) * 64];
+        const f16x8 xh = *reinterpret_cast<const f16x8*>(xs + 32 * kb);
+        const f16x8 xl = *reinterpret_cast<const f16x8*>(xs + kPlaneH + 32 * kb);
+        am = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, am, 0, 0, 0);
+        ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, ac, 0, 0, 0);
+        ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, ac, 0, 0, 0);
+    }
+    f32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = __builtin_fmaf(ac[i], kLoInv, am[i]);
+    return r;
+}
+
+__device__ __forceinline__ float sigmoid_ref_h(float x) { return __fdiv_rn(1.0f, 1.0f + expf(-x)); }
+
+// ------------------------------------------------------------------------------------------------
+template <bool kSsr>
+__global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) {
+    constexpr int kPts = kTilePoints;
+    constexpr int kParts = 256 / kPts;
+    extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* __restrict__ wts = p.wts;
+    const NetLayout& L = p.L;
+    float amax = 0.0f;
+
+    _Float16* const xw = ldsh + (lane & 31) * kRowH;                                   // + 8*(lane>>5) for reads, 4*(lane>>5) for writes
+    const _Float16* const xr = xw + 8 * (lane >> 5);
+    _Float16* const xd = xw + 4 * (lane >> 5);
+    const _Float16* const xs = ldsh + (16 * wave + (lane & 15)) * kRowH + 8 * (lane >> 4);
+
+    // fragment streams: a wide GEMM with KBT k-blocks stores per wave KBT*RB*2 fragments of 256 floats
+    auto frag256 = [&](const GemmSlot& s, int kbt) { return wts + s.w + (size_t)wave * kbt * 2 * 2 * 256; };
+    auto frag128 = [&](const GemmSlot& s, int kbt) { return wts + s.w + (size_t)wave * kbt * 1 * 2 * 256; };
+
+    WidePreH<2> pre2;
+    WidePreH<1> pre1;
+    wide_prefetch_h<2>(pre2, frag256(L.trunk[0], 4), wts + L.trunk[0].b + 64 * wave, lane);
+
+    for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+        // ---------------- encode -> hi/lo planes ----------------
+        {
+            const int pt = tid % kPts, part = tid / kPts;
+            int gp = tile * kPts + pt;
+            gp = gp < p.n_points ? gp : p.n_points - 1;
+            const int ray = gp / p.n_samples;
+            const float* __restrict__ r = p.rays + (size_t)ray * INERF_RAY_FLOATS;
+            const float zz = p.z[gp];
+            _Float16* row = ldsh + pt * kRowH;
+            float x[3], v[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                x[c] = __fadd_rn(r[c], __fmul_rn(r[3 + c], zz));                 // run_nerf.py:488
+                if (p.xyz_div != 1.0f) x[c] = __fdiv_rn(x[c], p.xyz_div);        // semantic_nerf.py:64
+                v[c] = r[8 + c];
+            }
+            for (int f = part; f < p.l_xyz; f += kParts) {
+                const float s = (float)(1 << f);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float sn, cs;
+                    sincosf(x[c] * s, &sn, &cs);
+                    split_store(row + kColEnc + 3 + 6 * f + c, sn, amax);
+                    split_store(row + kColEnc + 6 + 6 * f + c, cs, amax);
+                }
+            }
+            const int fd = kParts - 1 - part;
+            if (fd < p.l_dir) {
+                const float s = (float)(1 << fd);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float sn, cs;
+                    sincosf(v[c] * s, &sn, &cs);
+                    split_store(row + kColDir + 3 + 6 * fd + c, sn, amax);
+                    split_store(row + kColDir + 6 + 6 * fd + c, cs, amax);
+                }
+            }
+            if (part == 2) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) split_store(row + kColEnc + c, x[c], amax);
+                for (int c = 3 + 6 * p.l_xyz; c < kEncCols; ++c) { row[kColEnc + c] = (_Float16)0.0f; row[kPlaneH + kColEnc + c] = (_Float16)0.0f; }
+            }
+            if (part == 3) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) split_store(row + kColDir + c, v[c], amax);
+                for (int c = 3 + 6 * p.l_dir; c < kDirCols; ++c) { row[kColDir + c] = (_Float16)0.0f; row[kPlaneH + kColDir + c] = (_Float16)0.0f; }
+            }
+        }
+        __syncthreads();
+
+        const int pt0 = tile * kPts + (lane & 31);              // this lane's points in wide results
+        auto step256 = [&](const GemmSlot& s, auto kb0c, auto kb1c, int c0, int c1, int dcol, bool relu, auto&& prefetch_next) {
+            constexpr int KB0 = decltype(kb0c)::value, KB1 = decltype(kb1c)::value;
+            f32x16 am[2][2], ac[2][2];
+            wide_gemm_h<2, KB0, KB1>(pre2, frag256(s, KB0 + KB1), xr, c0, c1, lane, am, ac);
+            prefetch_next();
+            wide_store_h<2>(am, ac, xd + dcol + 64 * wave, relu, amax, nullptr, 0, 0, 0);
+            __syncthreads();
+        };
+        auto step128 = [&](const GemmSlot& s, auto kb0c, auto kb1c, int c0, int c1, int dcol, bool relu, float* gout,
+                           auto&& prefetch_next) {
+            constexpr int KB0 = decltype(kb0c)::value, KB1 = decltype(kb1c)::value;
+            f32x16 am[1][2], ac[1][2];
+            wide_gemm_h<1, KB0, KB1>(pre1, frag128(s, KB0 + KB1), xr, c0, c1, lane, am, ac);
+            prefetch_next();
+            wide_store_h<1>(am, ac, xd + dcol + 32 * wave, relu, amax, gout, p.channels, pt0 < p.n_points,
+                            pt0 + 32 < p.n_points);
+            __syncthreads();
+        };
+        auto pf256 = [&](const GemmSlot& s, int kbt) {
+            return [&, kbt]() { wide_prefetch_h<2>(pre2, frag256(s, kbt), wts + s.b + 64 * wave, lane); };
+        };
+        auto pf128 = [&](const GemmSlot& s, int kbt) {
+            return [&, kbt]() { wide_prefetch_h<1>(pre1, frag128(s, kbt), wts + s.b + 32 * wave, lane); };
+        };
+        using std::integral_constant;
+        constexpr integral_constant<int, 0> K0{};
+        constexpr integral_constant<int, 2> K2{};
+        constexpr integral_constant<int, 4> K4{};
+        constexpr integral_constant<int, 16> K16{};
+        const bool sem = kSsr && L.sem_rbs > 0;
+        // ---------------- trunk ----------------
+        step256(L.trunk[0], K4, K0, kColEnc, 0, kColA, true, pf256(L.trunk[1], 16));
+        step256(L.trunk[1], K16, K0, kColA, 0, kColB, true, pf256(L.trunk[2], 16));
+        step256(L.trunk[2], K16, K0, kColB, 0, kColA, true, pf256(L.trunk[3], 16));
+        step256(L.trunk[3], K16, K0, kColA, 0, kColB, true, pf256(L.trunk[4], 16));
+        step256(L.trunk[4], K16, K0, kColB, 0, kColA, true, pf256(L.trunk[5], 20));
+        step256(L.trunk[5], K4, K16, kColEnc, kColA, kColB, true, pf256(L.trunk[6], 16));
+        step256(L.trunk[6], K16, K0, kColB, 0, kColA, true, pf256(L.trunk[7], 16));
+        if (sem) step256(L.trunk[7], K16, K0, kColA, 0, kColB, true, pf128(L.sem1, 16));
+        else     step256(L.trunk[7], K16, K0, kColA, 0, kColB, true, pf256(L.as1, 16));
+
+        // ---------------- heads ----------------
+        const int my_pt = tile * kPts + 16 * wave + (lane & 15);
+        const bool my_valid = my_pt < p.n_points;
+        float* const out_row = p.raw + (size_t)(my_valid ? my_pt : 0) * p.channels;
+
+        const f32x4 sig4 = skinny_gemm_h<8>(wts + L.alpha.w, wts + L.alpha.b, xs + kColB, lane);
+
+        if (sem) {
+            step128(L.sem1, K16, K0, kColB, 0, kColA, true, nullptr, pf256(L.as1, 16));
+            for (int rb = 0; rb < L.sem_rbs; ++rb) {
+                const f32x4 lg = skinny_gemm_h<4>(wts + L.sem2.w + rb * 4 * 2 * 256, wts + L.sem2.b + 16 * rb, xs + kColA, lane);
+                const int ch0 = 16 * rb + 4 * (lane >> 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (my_valid && ch0 + i < p.n_classes) out_row[INERF_BASE_CHANNELS + ch0 + i] = lg[i];
+            }
+            __syncthreads();
+        }
+
+        step256(L.as1, K16, K0, kColB, 0, kColA, true, pf256(L.feat, 16));
+        const f32x4 as4 = skinny_gemm_h<8>(wts + L.as2.w, wts + L.as2.b, xs + kColA, lane);
+        __syncthreads();
+
+        step256(L.feat, K16, K0, kColB, 0, kColA, false, pf128(L.views, 18));
+        // endpoint feature (semantic_nerf.py:163-164): the fp32 views activation goes straight to raw
+        float* ep = nullptr;
+        if (kSsr && p.endpoint)
+            ep = p.raw + (size_t)pt0 * p.channels + INERF_BASE_CHANNELS + p.n_classes + 32 * wave + 4 * (lane >> 5);
+        step128(L.views, K16, K2, kColA, kColDir, kColB, true, ep, pf256(L.trunk[0], 4));
+        const f32x4 res4 = skinny_gemm_h<4>(wts + L.res.w, wts + L.res.b, xs + kColB, lane);
+
+        if (lane < 16 && my_valid) {
+            const float a0 = sigmoid_ref_h(as4[0]), a1 = sigmoid_ref_h(as4[1]), a2 = sigmoid_ref_h(as4[2]);
+            const float sh = sigmoid_ref_h(as4[3]);
+            const float r0 = sigmoid_ref_h(res4[0]), r1 = sigmoid_ref_h(res4[1]), r2 = sigmoid_ref_h(res4[2]);
+            out_row[0] = __fadd_rn(__fmul_rn(a0, sh), r0);          // run_nerf_helpers.py:320
+            out_row[1] = __fadd_rn(__fmul_rn(a1, sh), r1);
+            out_row[2] = __fadd_rn(__fmul_rn(a2, sh), r2);
+            out_row[3] = sig4[0];
+            out_row[4] = a0; out_row[5] = a1; out_row[6] = a2;
+            out_row[7] = sh;
+            out_row[8] = r0; out_row[9] = r1; out_row[10] = r2;
+        }
+    }
+    if (p.status && __any(!(amax <= kF16Safe)) && lane == 0) atomicOr(p.status, INERF_STATUS_F16_RANGE);
+}
+
+int launch_mlp_f16x3(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream) {
+    p.n_tiles = (int)((n_points + kTilePoints - 1) / kTilePoints);
+    const int grid = p.n_tiles < device_cus() ? p.n_tiles : device_cus();
+    void (*kern)(const MlpParams) = ssr ? k_encode_mlp_f16x3<true> : k_encode_mlp_f16x3<false>;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[ssr]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           kLdsBytesH);
+        if (e != hipSuccess) return record(e);
+        attr_set[ssr] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kLdsBytesH, stream, p);
+    return record(hipGetLastError());
+}
+
+}  // namespace inerf

@@ -59,7 +59,7 @@ Net describe(const inerf_net_desc& d) {
 using Elem = std::function<float(int /*row*/, int /*virtual k*/)>;
 
 // wide GEMM: fragments of v_mfma_f32_32x32x2_f32's A operand, four k-steps per float4 (layout.h)
-void pack_wide(float* dst, int n_out, int k_total, const Elem& w) {
+void pack_wide_f32(float* dst, int n_out, int k_total, const Elem& w) {
     const int rb_per_wave = n_out / (32 * inerf::kWaves), kb_count = k_total / 8;
     for (int wave = 0; wave < inerf::kWaves; ++wave)
         for (int kb = 0; kb < kb_count; ++kb)
@@ -73,7 +73,7 @@ void pack_wide(float* dst, int n_out, int k_total, const Elem& w) {
 }
 
 // skinny GEMM: fragments of v_mfma_f32_16x16x4_f32's A operand
-void pack_skinny(float* dst, int rbs, int k_total, const Elem& w) {
+void pack_skinny_f32(float* dst, int rbs, int k_total, const Elem& w) {
     const int kb_count = k_total / 16;
     for (int rb = 0; rb < rbs; ++rb)
         for (int kb = 0; kb < kb_count; ++kb)
@@ -82,6 +82,50 @@ void pack_skinny(float* dst, int rbs, int k_total, const Elem& w) {
                     int row = 16 * rb + (lane & 15);
                     int kv = 16 * kb + 4 * (lane >> 4) + c;
                     dst[(((int64_t)rb * kb_count + kb) * 64 + lane) * 4 + c] = w(row, kv);
+                }
+}
+
+// ---- INERF_PREC_F16X3: w = hi + lo * 2^-11 with hi = f16(w), lo = f16((w - hi) * 2^11) ----
+struct HalfPair { _Float16 hi, lo; };
+
+inline HalfPair split_f16(float w) {
+    const _Float16 hi = (_Float16)w;
+    const _Float16 lo = (_Float16)((w - (float)hi) * 2048.0f);
+    return {hi, lo};
+}
+
+// wide GEMM, A-operand fragments of v_mfma_f32_32x32x16_f16: [wave][kb16][rb][hi|lo][lane][8 halfs]
+void pack_wide_f16(float* dst_f, int n_out, int k_total, const Elem& w) {
+    _Float16* dst = reinterpret_cast<_Float16*>(dst_f);
+    const int rb_per_wave = n_out / (32 * inerf::kWaves), kb_count = k_total / 16;
+    for (int wave = 0; wave < inerf::kWaves; ++wave)
+        for (int kb = 0; kb < kb_count; ++kb)
+            for (int rb = 0; rb < rb_per_wave; ++rb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int c = 0; c < 8; ++c) {
+                        const int row = wave * 32 * rb_per_wave + 32 * rb + (lane & 31);
+                        const int kv = 16 * kb + 8 * (lane >> 5) + c;
+                        const HalfPair h = split_f16(w(row, kv));
+                        const int64_t frag = (((int64_t)wave * kb_count + kb) * rb_per_wave + rb) * 2;
+                        dst[(frag * 64 + lane) * 8 + c] = h.hi;
+                        dst[((frag + 1) * 64 + lane) * 8 + c] = h.lo;
+                    }
+}
+
+// skinny GEMM, A-operand fragments of v_mfma_f32_16x16x32_f16: [rb][kb32][hi|lo][lane][8 halfs]
+void pack_skinny_f16(float* dst_f, int rbs, int k_total, const Elem& w) {
+    _Float16* dst = reinterpret_cast<_Float16*>(dst_f);
+    const int kb_count = k_total / 32;
+    for (int rb = 0; rb < rbs; ++rb)
+        for (int kb = 0; kb < kb_count; ++kb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int c = 0; c < 8; ++c) {
+                    const int row = 16 * rb + (lane & 15);
+                    const int kv = 32 * kb + 8 * (lane >> 4) + c;
+                    const HalfPair h = split_f16(w(row, kv));
+                    const int64_t frag = ((int64_t)rb * kb_count + kb) * 2;
+                    dst[(frag * 64 + lane) * 8 + c] = h.hi;
+                    dst[((frag + 1) * 64 + lane) * 8 + c] = h.lo;
                 }
 }
 
@@ -132,6 +176,9 @@ int inerf_pack_weights(const inerf_net_desc* net, const float* const* tensors, i
     if (capacity < L.total_floats) return INERF_E_INVALID;
     std::memset(out, 0, sizeof(float) * (size_t)L.total_floats);
 
+    const bool f16 = net->precision == INERF_PREC_F16X3;
+    auto pack_wide = [&](float* dst, int n_out, int k, const Elem& el) { f16 ? pack_wide_f16(dst, n_out, k, el) : pack_wide_f32(dst, n_out, k, el); };
+    auto pack_skinny = [&](float* dst, int rbs, int k, const Elem& el) { f16 ? pack_skinny_f16(dst, rbs, k, el) : pack_skinny_f32(dst, rbs, k, el); };
     auto find = [&](const char* key) -> int {
         for (int i = 0; i < n_tensors; ++i)
             if (n.spec[i].name == key) return i;

@@ -64,8 +64,22 @@ def sample_coarse(rays, t_vals, t_rand=None, lindisp=False):
     return z
 
 
-def encode_mlp(desc, packed, rays, z_vals, endpoint=False):
-    """raw[N,S,CH]: fused encoding + MLP (run_network + NeRF.forward)."""
+def _new_status(like):
+    return torch.zeros(1, dtype=torch.int32, device=like.device)
+
+
+def check_f16_range(status, what):
+    """Raise if a PREC_F16X3 launch met an activation outside f16's range (one device sync)."""
+    if status is not None and int(status.item()) & _capi.STATUS_F16_RANGE:
+        raise FloatingPointError(
+            f"{what}: an activation exceeded the f16 range (|v| > 6e4) in the split-precision MLP kernel; "
+            "results are invalid - re-run with precision f32 (INERF_PRECISION=f32)")
+
+
+def encode_mlp(desc, packed, rays, z_vals, endpoint=False, status=None):
+    """raw[N,S,CH]: fused encoding + MLP (run_network + NeRF.forward).
+
+    ``status``: optional int32[1] device tensor that collects INERF_STATUS_* bits (PREC_F16X3 range check)."""
     rays = _dev(rays, "rays", (None, RAY_FLOATS))
     z_vals = _dev(z_vals, "z_vals", (rays.shape[0], None))
     packed = _dev(packed, "packed weights", (None,))
@@ -75,7 +89,7 @@ def encode_mlp(desc, packed, rays, z_vals, endpoint=False):
     raw = _new(rays, n, s, ch)
     with torch.cuda.device(rays.device):
         rc = _capi.lib().inerf_encode_mlp(desc, _ptr(packed), _ptr(rays), _ptr(z_vals), n, s, flags, _ptr(raw),
-                                          _stream(rays))
+                                          None if status is None else C.c_void_p(status.data_ptr()), _stream(rays))
     _capi.check(rc, "inerf_encode_mlp")
     return raw
 
@@ -219,6 +233,9 @@ def render_rays_fused(desc, packed_coarse, packed_fine, rays, n_samples, n_impor
         _capi.check(int(ws_bytes), "inerf_workspace_bytes")
     ws = torch.empty(max(int(ws_bytes), 1), dtype=torch.uint8, device=rays.device)
     args.workspace, args.workspace_bytes = ws.data_ptr(), int(ws_bytes)
+    if desc.precision == _capi.PREC_F16X3:
+        out["status"] = _new_status(rays)          # caller checks it (check_f16_range) when it next synchronises
+        args.status = out["status"].data_ptr()
     with torch.cuda.device(rays.device):
         rc = L.inerf_render_rays(C.byref(args), _stream(rays))
     _capi.check(rc, "inerf_render_rays")

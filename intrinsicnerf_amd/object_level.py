@@ -173,7 +173,9 @@ def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64
     rays = torch.zeros(pts.shape[0], _capi.RAY_FLOATS, dtype=torch.float32, device=pts.device)
     rays[:, 0:3], rays[:, 8:11] = pts, dirs
     z = torch.zeros(pts.shape[0], 1, dtype=torch.float32, device=pts.device)
-    raw = kernels.encode_mlp(desc, packing.packed_for_module(fn, desc, pts.device), rays, z)
+    status = kernels._new_status(pts) if desc.precision == _capi.PREC_F16X3 else None
+    raw = kernels.encode_mlp(desc, packing.packed_for_module(fn, desc, pts.device), rays, z, status=status)
+    kernels.check_f16_range(status, "run_network")
     return torch.reshape(raw, list(inputs.shape[:-1]) + [raw.shape[-1]])
 
 
@@ -263,6 +265,7 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
             packing.packed_for_module(fine_net, desc, dev) if N_importance > 0 else None,
             ray_batch, N_samples, N_importance, t_vals, u, t_rand, noise_c, noise_f, white_bkgd, lindisp,
             want_raw_coarse=retraw and N_importance == 0, want_raw_fine=retraw)
+        kernels.check_f16_range(o.pop("status", None), "render_rays")
         lvl = "fine" if N_importance > 0 else "coarse"
         ret = {rk: o[f"{ok}_{lvl}"] for rk, ok in _RET_MAP}
         if retraw:

@@ -53,17 +53,18 @@ class _Entry:
     __slots__ = ("versions", "blob")
 
 
-_cache = weakref.WeakKeyDictionary()
+_cache = weakref.WeakKeyDictionary()      # module -> {precision: _Entry}
 
 
 def packed_for_module(module, desc, device):
     """Device blob for ``module`` (an nn.Module with the reference's parameter names), cached."""
     params = list(module.parameters())
-    versions = tuple((p._version, p.data_ptr()) for p in params) + (str(device), desc.n_classes, desc.l_xyz, desc.l_dir)
-    ent = _cache.get(module)
+    versions = tuple((p._version, p.data_ptr()) for p in params) + (str(device), desc.n_classes, desc.l_xyz, desc.l_dir, desc.precision)
+    per_module = _cache.setdefault(module, {})
+    ent = per_module.get(desc.precision)
     if ent is None or ent.versions != versions:
         ent = _Entry()
         ent.versions = versions
         ent.blob = pack_state_dict(desc, module.state_dict()).to(device)
-        _cache[module] = ent
+        per_module[desc.precision] = ent
     return ent.blob

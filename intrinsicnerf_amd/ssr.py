@@ -133,7 +133,10 @@ def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64
     rays = torch.zeros(pts.shape[0], _capi.RAY_FLOATS, dtype=torch.float32, device=pts.device)
     rays[:, 0:3], rays[:, 8:11] = pts, dirs
     z = torch.zeros(pts.shape[0], 1, dtype=torch.float32, device=pts.device)
-    raw = kernels.encode_mlp(desc, packing.packed_for_module(fn, desc, pts.device), rays, z, endpoint=show_endpoint)
+    status = kernels._new_status(pts) if desc.precision == _capi.PREC_F16X3 else None
+    raw = kernels.encode_mlp(desc, packing.packed_for_module(fn, desc, pts.device), rays, z, endpoint=show_endpoint,
+                             status=status)
+    kernels.check_f16_range(status, "run_network")
     return torch.reshape(raw, list(inputs.shape[:-1]) + [raw.shape[-1]])
 
 
@@ -272,6 +275,7 @@ class SSRRenderMixin:
             ray_batch, self.N_samples, self.N_importance, t_vals, u, t_rand, noise_c, noise_f,
             white_bkgd=self.white_bkgd, endpoint=ep, want_raw_coarse=self.return_raw, want_raw_fine=self.return_raw,
             want_sem=bool(self.enable_semantic))
+        kernels.check_f16_range(o.pop("status", None), "volumetric_rendering")
         ret = {}
         if self.return_raw:
             ret["raw_coarse"] = o["raw_coarse"]

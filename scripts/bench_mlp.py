@@ -23,11 +23,13 @@ ap.add_argument("--rays", type=int, default=65536)
 ap.add_argument("--samples", type=int, default=192)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--ssr", type=int, default=-1)
+ap.add_argument("--precision", default=None, choices=[None, "f32", "f16x3"])
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 ssr = a.ssr >= 0
 c = max(a.ssr, 0)
-desc = _capi.net_desc(_capi.VARIANT_SSR if ssr else _capi.VARIANT_OBJECT, c, 10, 4, 10.0 if ssr else 1.0)
+prec = None if a.precision is None else (_capi.PREC_F16X3 if a.precision == "f16x3" else _capi.PREC_F32)
+desc = _capi.net_desc(_capi.VARIANT_SSR if ssr else _capi.VARIANT_OBJECT, c, 10, 4, 10.0 if ssr else 1.0, prec)
 sd = oracle.make_state_dict("ssr" if ssr else "object", c, seed=0)
 packed = packing.pack_state_dict(desc, sd).to(dev)
 g = torch.Generator().manual_seed(0)
@@ -48,6 +50,6 @@ for _ in range(a.iters):
     ts.append(e0.elapsed_time(e1))
 flop_pt = 2 * (659456 + (32768 + 128 * c if (ssr and c > 0) else 0))
 best, med = min(ts), sorted(ts)[len(ts) // 2]
-print(f"k_encode_mlp: {n} rays x {a.samples} samples, median {med:.2f} ms (best {best:.2f}) -> "
+print(f"k_encode_mlp[{'f16x3' if desc.precision else 'f32'}]: {n} rays x {a.samples} samples, median {med:.2f} ms (best {best:.2f}) -> "
       f"{flop_pt * n * a.samples / med / 1e9:.1f} TFLOP/s median, {flop_pt * n * a.samples / best / 1e9:.1f} best; "
       f"checksum {float(raw.double().sum()):.10e} absmax {float(raw.abs().max()):.6f}")

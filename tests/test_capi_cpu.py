@@ -43,7 +43,7 @@ def test_struct_layouts_match_header(capi):
     body = text[text.index("typedef struct inerf_composite_out"):text.index("} inerf_composite_out;")]
     names = re.findall(r"float\*\s*([a-z]+);", body)
     assert names == [f[0] for f in capi.CompositeOut._fields_]
-    assert C.sizeof(capi.NetDesc) == 20
+    assert C.sizeof(capi.NetDesc) == 24
 
 
 def test_tensor_table_matches_reference_state_dicts(capi):
@@ -64,11 +64,12 @@ def test_argument_validation(capi):
     assert lib.inerf_packed_floats(capi.net_desc(capi.VARIANT_OBJECT, 3)) == capi.E_INVALID      # object net has no classes
     assert lib.inerf_packed_floats(capi.net_desc(capi.VARIANT_SSR, 0, 11, 4, 10.0)) == capi.E_INVALID   # multires > 10
     good = capi.net_desc(capi.VARIANT_OBJECT)
-    assert lib.inerf_encode_mlp(good, None, None, None, 4, 64, 0, None, None) == capi.E_INVALID
+    assert lib.inerf_encode_mlp(good, None, None, None, 4, 64, 0, None, None, None) == capi.E_INVALID
     assert lib.inerf_sample_fine(None, None, None, 4, 64, 128, 0, None, None, None, None) == capi.E_INVALID
     assert lib.inerf_workspace_bytes(good, 1024, 64, 128, 0) > 1024 * 192 * 11 * 4
     assert lib.inerf_raw_channels(capi.net_desc(capi.VARIANT_SSR, 28, 10, 4, 10.0), capi.FLAG_ENDPOINT, 1) == 11 + 28 + 128
     assert lib.inerf_raw_channels(capi.net_desc(capi.VARIANT_SSR, 28, 10, 4, 10.0), capi.FLAG_ENDPOINT, 0) == 11 + 28
+    assert lib.inerf_packed_floats(capi.net_desc(capi.VARIANT_OBJECT, precision=7)) == capi.E_INVALID     # unknown precision
     with pytest.raises(RuntimeError):
         capi.check(capi.E_UNSUPPORTED, "x")
 
@@ -177,6 +178,71 @@ def test_packer_layout(capi, variant, c):
         w = _unpack_skinny(blob, ow, rbs, k)
         assert np.array_equal(w[:c], g("semantic_linear.1.weight")) and not w[c:].any()
         assert np.array_equal(blob[ob:ob + c], g("semantic_linear.1.bias"))
+
+
+def _unpack_wide_f16(blob, off, n_out, k_total):
+    """Rebuild (hi, lo) matrices from the INERF_PREC_F16X3 fragment layout documented in csrc/layout.h."""
+    rb_per_wave, kb_count = n_out // 128, k_total // 16
+    halfs = blob[off: off + n_out * k_total].view(np.float16).reshape(4, kb_count, rb_per_wave, 2, 64, 8)
+    hi = np.zeros((n_out, k_total), np.float32); lo = np.zeros_like(hi)
+    for wave in range(4):
+        for rb in range(rb_per_wave):
+            for lane in range(64):
+                row = wave * 32 * rb_per_wave + 32 * rb + (lane & 31)
+                for kb in range(kb_count):
+                    k0 = 16 * kb + 8 * (lane >> 5)
+                    hi[row, k0:k0 + 8] = halfs[wave, kb, rb, 0, lane]
+                    lo[row, k0:k0 + 8] = halfs[wave, kb, rb, 1, lane]
+    return hi, lo
+
+
+def _unpack_skinny_f16(blob, off, rbs, k_total):
+    kb_count = k_total // 32
+    halfs = blob[off: off + 16 * rbs * k_total].view(np.float16).reshape(rbs, kb_count, 2, 64, 8)
+    hi = np.zeros((16 * rbs, k_total), np.float32); lo = np.zeros_like(hi)
+    for rb in range(rbs):
+        for lane in range(64):
+            for kb in range(kb_count):
+                k0 = 32 * kb + 8 * (lane >> 4)
+                hi[16 * rb + (lane & 15), k0:k0 + 8] = halfs[rb, kb, 0, lane]
+                lo[16 * rb + (lane & 15), k0:k0 + 8] = halfs[rb, kb, 1, lane]
+    return hi, lo
+
+
+def test_packer_f16x3_split(capi):
+    """hi + lo * 2^-11 reproduces every fp32 weight to 22 bits, in the documented fragment order."""
+    from intrinsicnerf_amd import packing
+    desc = capi.net_desc(capi.VARIANT_SSR, 28, 10, 4, 10.0, precision=capi.PREC_F16X3)
+    sd = oracle.make_state_dict("ssr", 28, seed=12)
+    blob = packing.pack_state_dict(desc, sd).numpy()
+    slots, total = _layout("ssr", 28)
+    assert blob.shape[0] == total
+    def check(w_hi_lo, ref):
+        hi, lo = w_hi_lo
+        rec = hi.astype(np.float64) + lo.astype(np.float64) / 2048.0
+        assert np.array_equal(hi, ref.astype(np.float16).astype(np.float32))            # hi = round-to-nearest f16
+        assert np.max(np.abs(rec - ref)) <= 2.0 ** -22 * np.max(np.abs(ref)) + 2.0 ** -36
+    _, ow, ob, n_out, k = slots["trunk3"]
+    check(_unpack_wide_f16(blob, ow, n_out, k), sd["pts_linears.3.weight"].numpy())
+    assert np.array_equal(blob[ob:ob + 256], sd["pts_linears.3.bias"].numpy())            # biases stay fp32
+    _, ow, ob, n_out, k = slots["trunk5"]
+    hi, lo = _unpack_wide_f16(blob, ow, n_out, k)
+    ref = sd["pts_linears.5.weight"].numpy()
+    check((hi[:, 64:], lo[:, 64:]), ref[:, 63:])
+    check((hi[:, :63], lo[:, :63]), ref[:, :63])
+    assert not hi[:, 63].any() and not lo[:, 63].any()
+    _, ow, ob, n_out, k = slots["views"]
+    hi, lo = _unpack_wide_f16(blob, ow, n_out, k)
+    ref = sd["views_linears.0.weight"].numpy()
+    check((hi[:, :283], lo[:, :283]), ref)
+    assert not hi[:, 283:].any()
+    _, ow, ob, rbs, k = slots["sem2"]
+    hi, lo = _unpack_skinny_f16(blob, ow, rbs, k)
+    check((hi[:28], lo[:28]), sd["semantic_linear.1.weight"].numpy())
+    assert not hi[28:].any() and not lo[28:].any()
+    _, ow, ob, rbs, k = slots["alpha"]
+    hi, lo = _unpack_skinny_f16(blob, ow, rbs, k)
+    check((hi[:1], lo[:1]), sd["alpha_linear.weight"].numpy())
 
 
 def test_packer_rejects_bad_state_dicts(capi):

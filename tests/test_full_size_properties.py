@@ -8,6 +8,13 @@ import oracle
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["f32", "f16x3"])
+def precision(request, monkeypatch):
+    """Every GPU parity test runs against both MLP kernels: exact-fp32 MFMA and the f16 hi/lo split one."""
+    monkeypatch.setenv("INERF_PRECISION", request.param)
+    return request.param
+
+
 def test_full_chunk_properties():
     from intrinsicnerf_amd import _capi, kernels, packing
     dev = torch.device("cuda:0")

@@ -16,6 +16,13 @@ from conftest import golden_names, load_golden
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["f32", "f16x3"])
+def precision(request, monkeypatch):
+    """Every GPU parity test runs against both MLP kernels: exact-fp32 MFMA and the f16 hi/lo split one."""
+    monkeypatch.setenv("INERF_PRECISION", request.param)
+    return request.param
+
 RTOL, ATOL, RTOL_DISP = 1e-4, 1e-5, 5e-4
 
 
@@ -290,6 +297,30 @@ def test_sample_coarse_bit_exact():
             want = oracle.coarse_depths(rays[:, 6:7], rays[:, 7:8], t, lindisp, t_rand)
             got = kernels.sample_coarse(rays.to(dev), t.to(dev), None if t_rand is None else t_rand.to(dev), lindisp)
             assert torch.equal(got.cpu(), want), f"lindisp={lindisp} perturb={t_rand is not None}"
+
+
+def test_f16_range_guard(precision):
+    """Activations beyond f16's range: the split-precision kernel must say so (status word -> FloatingPointError),
+    the fp32 kernel must simply compute them."""
+    from intrinsicnerf_amd import _capi, kernels, packing
+    dev = _dev()
+    sd = oracle.make_state_dict("object", 0, seed=5)
+    sd["pts_linears.0.bias"] = sd["pts_linears.0.bias"] + 1.0e5          # h1 ~ 1e5 > 65504
+    cfg = oracle.RenderConfig(variant="object")
+    desc = _desc(cfg)
+    rays = torch.rand(8, 11)
+    z = torch.rand(8, 64) + 2
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    raw = kernels.encode_mlp(desc, packing.pack_state_dict(desc, sd).to(dev), rays.to(dev), z.to(dev), status=status)
+    if precision == "f16x3":
+        assert int(status.item()) & _capi.STATUS_F16_RANGE
+        with pytest.raises(FloatingPointError):
+            kernels.check_f16_range(status, "test")
+    else:
+        assert int(status.item()) == 0
+        pts = rays[:, None, 0:3] + rays[:, None, 3:6] * z[:, :, None]
+        want = oracle.query_network(sd, pts, rays[:, 8:11], cfg)
+        assert_maps_close(raw.cpu().numpy(), want.numpy(), RTOL, 1e-4 * float(want.abs().max()), "raw with huge activations")
 
 
 def test_gradients_fail_loudly():
