@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256, 3 - PB) void k_encode_mlp(const MlpParams p) {
             gp = gp < p.n_points ? gp : p.n_points - 1;
             const int ray = gp / p.n_samples;
             const float* __restrict__ r = p.rays + (size_t)ray * INERF_RAY_FLOATS;
-            const float zz = p.z[gp];
+            const float zz = __builtin_nontemporal_load(p.z + gp);     // streamed once: keep it out of the L2 the weights live in
             float* row = lds + pt * kLdsStride;
             float x[3], v[3];
 #pragma unroll
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256, 3 - PB) void k_encode_mlp(const MlpParams p) {
                     const int ch0 = 16 * rb + 4 * (lane >> 4);
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        if (my_valid && ch0 + i < p.n_classes) out_row[INERF_BASE_CHANNELS + ch0 + i] = lg[i];
+                        if (my_valid && ch0 + i < p.n_classes) __builtin_nontemporal_store(lg[i], out_row + INERF_BASE_CHANNELS + ch0 + i);
                 }
             }
             __syncthreads();                                  // A is about to be overwritten
@@ -318,13 +318,13 @@ __global__ __launch_bounds__(256, 3 - PB) void k_encode_mlp(const MlpParams p) {
             const float sh = sigmoid_ref(as4[3]);
             const float r0 = sigmoid_ref(res4[0]), r1 = sigmoid_ref(res4[1]), r2 = sigmoid_ref(res4[2]);
             // rgb = albedo * shading + residual (run_nerf_helpers.py:320): multiply, then add
-            out_row[0] = __fadd_rn(__fmul_rn(a0, sh), r0);
-            out_row[1] = __fadd_rn(__fmul_rn(a1, sh), r1);
-            out_row[2] = __fadd_rn(__fmul_rn(a2, sh), r2);
-            out_row[3] = sig4[0];
-            out_row[4] = a0; out_row[5] = a1; out_row[6] = a2;
-            out_row[7] = sh;
-            out_row[8] = r0; out_row[9] = r1; out_row[10] = r2;
+            __builtin_nontemporal_store(__fadd_rn(__fmul_rn(a0, sh), r0), out_row + 0);
+            __builtin_nontemporal_store(__fadd_rn(__fmul_rn(a1, sh), r1), out_row + 1);
+            __builtin_nontemporal_store(__fadd_rn(__fmul_rn(a2, sh), r2), out_row + 2);
+            __builtin_nontemporal_store(sig4[0], out_row + 3);
+            __builtin_nontemporal_store(a0, out_row + 4); __builtin_nontemporal_store(a1, out_row + 5); __builtin_nontemporal_store(a2, out_row + 6);
+            __builtin_nontemporal_store(sh, out_row + 7);
+            __builtin_nontemporal_store(r0, out_row + 8); __builtin_nontemporal_store(r1, out_row + 9); __builtin_nontemporal_store(r2, out_row + 10);
         }
         if (kSsr && p.endpoint) {
             // show_endpoint: append the post-ReLU views activation (semantic_nerf.py:163-164,181)

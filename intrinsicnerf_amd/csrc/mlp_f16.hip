@@ -28,6 +28,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Weight / bias fetches go through ONE buffer descriptor over the packed blob: the per-lane part of the
+// address (lane * 16 B) is a single VGPR shared by every layer and the layer / wave / k-block part is a
+// wave-uniform SGPR offset.  With plain 64-bit global addresses the compiler materialised a VGPR address
+// pair per layer, kept ~60 of them live across the tile loop and spilled them to scratch - whose 43 MB
+// footprint then thrashed the L2 the weights are supposed to stay in.
+struct WeightBuf {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff;                                     // lane * 16 bytes
+    __device__ __forceinline__ f16x8 frag(int byte_off) const {          // byte_off: wave-uniform
+        return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, byte_off, 0));
+    }
+    __device__ __forceinline__ f32x4 vec4(int byte_off, int lane_bytes) const {   // small per-lane offset on top
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_bytes, byte_off, 0));
+    }
+};
 
 constexpr int kRowH = kColB + kWidth + 8;      // 616 halfs per row
 constexpr int kPlaneH = kTilePoints * kRowH;   // halfs per plane
@@ -56,24 +73,23 @@ struct WidePreH {
 };
 
 template <int RB>
-__device__ __forceinline__ void wide_prefetch_h(WidePreH<RB>& pre, const float* __restrict__ wfrag,
-                                                const float* __restrict__ bias, int lane) {
-    const f16x8* wv = reinterpret_cast<const f16x8*>(wfrag) + lane;
-    const int h4 = 4 * (lane >> 5);
+__device__ __forceinline__ void wide_prefetch_h(WidePreH<RB>& pre, const WeightBuf& wb, int frag_bytes /* wave's stream */,
+                                                int bias_bytes /* wave's first channel */, int lane) {
+    const int h16 = 16 * (lane >> 5);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-            for (int part = 0; part < 2; ++part) pre.w[kb][rb][part] = wv[((kb * RB + rb) * 2 + part) * 64];
+            for (int part = 0; part < 2; ++part) pre.w[kb][rb][part] = wb.frag(frag_bytes + ((kb * RB + rb) * 2 + part) * 1024);
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) pre.b[rb][g] = *reinterpret_cast<const f32x4*>(bias + 32 * rb + 8 * g + h4);
+        for (int g = 0; g < 4; ++g) pre.b[rb][g] = wb.vec4(bias_bytes + (32 * rb + 8 * g) * 4, h16);
 }
 
 template <int RB, int KB0, int KB1>
-__device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const float* __restrict__ wfrag,
+__device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const WeightBuf& wb, int frag_bytes,
                                             const _Float16* xl,      // plane_hi + (lane&31)*kRowH + 8*(lane>>5)
                                             int col0, int col1, int lane, f32x16 (&am)[RB][2], f32x16 (&ac)[RB][2]) {
     constexpr int KBT = KB0 + KB1;
@@ -89,9 +105,9 @@ __device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const float
                     am[rb][pb][4 * g + i] = pre.b[rb][g][i];
                     ac[rb][pb][4 * g + i] = 0.0f;
                 }
-    const f16x8* wv = reinterpret_cast<const f16x8*>(wfrag) + lane;
     auto xoff = [&](int kb) { return kb < KB0 ? col0 + 16 * kb : col1 + 16 * (kb - KB0); };
-    // 4 rotating weight buffers (two k-blocks ahead), 2 activation buffers (one ahead); all indices static
+    // 4 rotating weight buffers (two k-blocks ahead; three measured slower), 2 activation buffers (one ahead);
+    // all indices static
     f16x8 w[4][RB][2], x[2][2][2];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
@@ -103,7 +119,9 @@ __device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const float
         for (int part = 0; part < 2; ++part)
             x[0][pb][part] = *reinterpret_cast<const f16x8*>(xl + part * kPlaneH + xoff(0) + pb * 32 * kRowH);
 
-// one k-block: request operands for k+2 (weights) / k+1 (activations), then 3*RB*2 MFMAs on block k.
+// one k-block: request operands for k+2 (weights) / k+1 (activations) and run 3*RB*2 MFMAs on block k, with the
+// 2*RB global loads and 4 LDS reads interleaved BETWEEN the MFMAs (an f16 MFMA occupies the pipe for only 32
+// cycles, so a burst of 8 memory instructions ahead of them is not hidden; measured +x % vs the burst form).
 // A macro, not a lambda: the buffer indices must stay compile-time constants for the arrays to live in registers.
 #define INERF_F16_STEP(K, I)                                                                                         \
     {                                                                                                                \
@@ -112,12 +130,11 @@ __device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const float
         const int xo_ = xoff(k1_);                                                                                   \
         _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                                            \
             _Pragma("unroll") for (int part = 0; part < 2; ++part)                                                   \
-                w[((I) + 2) & 3][rb][part] = wv[((k2_ * RB + rb) * 2 + part) * 64];                                  \
+                w[((I) + 2) & 3][rb][part] = wb.frag(frag_bytes + ((k2_ * RB + rb) * 2 + part) * 1024);              \
         _Pragma("unroll") for (int pb = 0; pb < 2; ++pb)                                                             \
             _Pragma("unroll") for (int part = 0; part < 2; ++part)                                                   \
                 x[((I) + 1) & 1][pb][part] =                                                                         \
                     *reinterpret_cast<const f16x8*>(xl + part * kPlaneH + xo_ + pb * 32 * kRowH);                    \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
         /* hi*hi -> main; hi*lo and lo*hi -> cross; product-major: an accumulator is touched every 4th MFMA */       \
         _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                                            \
             _Pragma("unroll") for (int pb = 0; pb < 2; ++pb)                                                         \
@@ -128,6 +145,14 @@ __device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const float
         _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                                            \
             _Pragma("unroll") for (int pb = 0; pb < 2; ++pb)                                                         \
                 ac[rb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[(I) & 3][rb][1], x[(I) & 1][pb][0], ac[rb][pb], 0, 0, 0); \
+        /* issue order: MFMA, global load, MFMA, LDS read, MFMA - 2*RB times (masks: 0x8 MFMA, 0x20 VMEM read, 0x100 DS read) */ \
+        _Pragma("unroll") for (int q = 0; q < 2 * RB; ++q) {                                                        \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                       \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                       \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                       \
+            __builtin_amdgcn_sched_group_barrier(0x100, 4 / (2 * RB), 0);                                            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                       \
+        }                                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
     }
     constexpr int KB4 = KBT & ~3;
@@ -182,15 +207,14 @@ __device__ __forceinline__ void wide_store_h(const f32x16 (&am)[RB][2], const f3
 // skinny GEMM: 16 output rows x this wave's 16 points on v_mfma_f32_16x16x32_f16, K = 32*KB32
 // ------------------------------------------------------------------------------------------------
 template <int KB32>
-__device__ __forceinline__ f32x4 skinny_gemm_h(const float* __restrict__ wfrag, const float* __restrict__ bias16,
+__device__ __forceinline__ f32x4 skinny_gemm_h(const WeightBuf& wb, int frag_bytes, int bias_bytes,
                                                const _Float16* xs /* plane_hi + (16*wave + (lane&15))*kRowH + col + 8*(lane>>4) */,
                                                int lane) {
-    f32x4 am = *reinterpret_cast<const f32x4*>(bias16 + 4 * (lane >> 4));
+    f32x4 am = wb.vec4(bias_bytes, 16 * (lane >> 4));
     f32x4 ac = {0.0f, 0.0f, 0.0f, 0.0f};
-    const f16x8* wv = reinterpret_cast<const f16x8*>(wfrag) + lane;
 #pragma unroll
     for (int kb = 0; kb < KB32; ++kb) {
-        const f16x8 wh = wv[(2 * kb) * 64], wl = wv[(2 * kb + 1) * 64];
+        const f16x8 wh = wb.frag(frag_bytes + (2 * kb) * 1024), wl = wb.frag(frag_bytes + (2 * kb + 1) * 1024);
         const f16x8 xh = *reinterpret_cast<const f16x8*>(xs + 32 * kb);
         const f16x8 xl = *reinterpret_cast<const f16x8*>(xs + kPlaneH + 32 * kb);
         am = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, am, 0, 0, 0);
@@ -223,13 +247,18 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
     _Float16* const xd = xw + 4 * (lane >> 5);
     const _Float16* const xs = ldsh + (16 * wave + (lane & 15)) * kRowH + 8 * (lane >> 4);
 
-    // fragment streams: a wide GEMM with KBT k-blocks stores per wave KBT*RB*2 fragments of 256 floats
-    auto frag256 = [&](const GemmSlot& s, int kbt) { return wts + s.w + (size_t)wave * kbt * 2 * 2 * 256; };
-    auto frag128 = [&](const GemmSlot& s, int kbt) { return wts + s.w + (size_t)wave * kbt * 1 * 2 * 256; };
+    WeightBuf wb;
+    wb.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wts), 0, L.total_floats * 4, 0x00020000);
+    wb.voff = lane * 16;
+    // fragment streams (byte offsets, wave-uniform): a wide GEMM with KBT k-blocks stores per wave KBT*RB*2 KiB
+    auto frag256 = [&](const GemmSlot& s, int kbt) { return (s.w + wave * kbt * 2 * 2 * 256) * 4; };
+    auto frag128 = [&](const GemmSlot& s, int kbt) { return (s.w + wave * kbt * 1 * 2 * 256) * 4; };
+    auto bias256 = [&](const GemmSlot& s) { return (s.b + 64 * wave) * 4; };
+    auto bias128 = [&](const GemmSlot& s) { return (s.b + 32 * wave) * 4; };
 
     WidePreH<2> pre2;
     WidePreH<1> pre1;
-    wide_prefetch_h<2>(pre2, frag256(L.trunk[0], 4), wts + L.trunk[0].b + 64 * wave, lane);
+    wide_prefetch_h<2>(pre2, wb, frag256(L.trunk[0], 4), bias256(L.trunk[0]), lane);
 
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         // ---------------- encode -> hi/lo planes ----------------
@@ -239,7 +268,7 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
             gp = gp < p.n_points ? gp : p.n_points - 1;
             const int ray = gp / p.n_samples;
             const float* __restrict__ r = p.rays + (size_t)ray * INERF_RAY_FLOATS;
-            const float zz = p.z[gp];
+            const float zz = __builtin_nontemporal_load(p.z + gp);     // streamed once: keep it out of the L2 the weights live in
             _Float16* row = ldsh + pt * kRowH;
             float x[3], v[3];
 #pragma unroll
@@ -286,7 +315,7 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
         auto step256 = [&](const GemmSlot& s, auto kb0c, auto kb1c, int c0, int c1, int dcol, bool relu, auto&& prefetch_next) {
             constexpr int KB0 = decltype(kb0c)::value, KB1 = decltype(kb1c)::value;
             f32x16 am[2][2], ac[2][2];
-            wide_gemm_h<2, KB0, KB1>(pre2, frag256(s, KB0 + KB1), xr, c0, c1, lane, am, ac);
+            wide_gemm_h<2, KB0, KB1>(pre2, wb, frag256(s, KB0 + KB1), xr, c0, c1, lane, am, ac);
             prefetch_next();
             wide_store_h<2>(am, ac, xd + dcol + 64 * wave, relu, amax, nullptr, 0, 0, 0);
             __syncthreads();
@@ -295,17 +324,17 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
                            auto&& prefetch_next) {
             constexpr int KB0 = decltype(kb0c)::value, KB1 = decltype(kb1c)::value;
             f32x16 am[1][2], ac[1][2];
-            wide_gemm_h<1, KB0, KB1>(pre1, frag128(s, KB0 + KB1), xr, c0, c1, lane, am, ac);
+            wide_gemm_h<1, KB0, KB1>(pre1, wb, frag128(s, KB0 + KB1), xr, c0, c1, lane, am, ac);
             prefetch_next();
             wide_store_h<1>(am, ac, xd + dcol + 32 * wave, relu, amax, gout, p.channels, pt0 < p.n_points,
                             pt0 + 32 < p.n_points);
             __syncthreads();
         };
         auto pf256 = [&](const GemmSlot& s, int kbt) {
-            return [&, kbt]() { wide_prefetch_h<2>(pre2, frag256(s, kbt), wts + s.b + 64 * wave, lane); };
+            return [&, kbt]() { wide_prefetch_h<2>(pre2, wb, frag256(s, kbt), bias256(s), lane); };
         };
         auto pf128 = [&](const GemmSlot& s, int kbt) {
-            return [&, kbt]() { wide_prefetch_h<1>(pre1, frag128(s, kbt), wts + s.b + 32 * wave, lane); };
+            return [&, kbt]() { wide_prefetch_h<1>(pre1, wb, frag128(s, kbt), bias128(s), lane); };
         };
         using std::integral_constant;
         constexpr integral_constant<int, 0> K0{};
@@ -329,22 +358,22 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
         const bool my_valid = my_pt < p.n_points;
         float* const out_row = p.raw + (size_t)(my_valid ? my_pt : 0) * p.channels;
 
-        const f32x4 sig4 = skinny_gemm_h<8>(wts + L.alpha.w, wts + L.alpha.b, xs + kColB, lane);
+        const f32x4 sig4 = skinny_gemm_h<8>(wb, L.alpha.w * 4, L.alpha.b * 4, xs + kColB, lane);
 
         if (sem) {
             step128(L.sem1, K16, K0, kColB, 0, kColA, true, nullptr, pf256(L.as1, 16));
             for (int rb = 0; rb < L.sem_rbs; ++rb) {
-                const f32x4 lg = skinny_gemm_h<4>(wts + L.sem2.w + rb * 4 * 2 * 256, wts + L.sem2.b + 16 * rb, xs + kColA, lane);
+                const f32x4 lg = skinny_gemm_h<4>(wb, (L.sem2.w + rb * 4 * 2 * 256) * 4, (L.sem2.b + 16 * rb) * 4, xs + kColA, lane);
                 const int ch0 = 16 * rb + 4 * (lane >> 4);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (my_valid && ch0 + i < p.n_classes) out_row[INERF_BASE_CHANNELS + ch0 + i] = lg[i];
+                    if (my_valid && ch0 + i < p.n_classes) __builtin_nontemporal_store(lg[i], out_row + INERF_BASE_CHANNELS + ch0 + i);
             }
             __syncthreads();
         }
 
         step256(L.as1, K16, K0, kColB, 0, kColA, true, pf256(L.feat, 16));
-        const f32x4 as4 = skinny_gemm_h<8>(wts + L.as2.w, wts + L.as2.b, xs + kColA, lane);
+        const f32x4 as4 = skinny_gemm_h<8>(wb, L.as2.w * 4, L.as2.b * 4, xs + kColA, lane);
         __syncthreads();
 
         step256(L.feat, K16, K0, kColB, 0, kColA, false, pf128(L.views, 18));
@@ -353,19 +382,19 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
         if (kSsr && p.endpoint)
             ep = p.raw + (size_t)pt0 * p.channels + INERF_BASE_CHANNELS + p.n_classes + 32 * wave + 4 * (lane >> 5);
         step128(L.views, K16, K2, kColA, kColDir, kColB, true, ep, pf256(L.trunk[0], 4));
-        const f32x4 res4 = skinny_gemm_h<4>(wts + L.res.w, wts + L.res.b, xs + kColB, lane);
+        const f32x4 res4 = skinny_gemm_h<4>(wb, L.res.w * 4, L.res.b * 4, xs + kColB, lane);
 
         if (lane < 16 && my_valid) {
             const float a0 = sigmoid_ref_h(as4[0]), a1 = sigmoid_ref_h(as4[1]), a2 = sigmoid_ref_h(as4[2]);
             const float sh = sigmoid_ref_h(as4[3]);
             const float r0 = sigmoid_ref_h(res4[0]), r1 = sigmoid_ref_h(res4[1]), r2 = sigmoid_ref_h(res4[2]);
-            out_row[0] = __fadd_rn(__fmul_rn(a0, sh), r0);          // run_nerf_helpers.py:320
-            out_row[1] = __fadd_rn(__fmul_rn(a1, sh), r1);
-            out_row[2] = __fadd_rn(__fmul_rn(a2, sh), r2);
-            out_row[3] = sig4[0];
-            out_row[4] = a0; out_row[5] = a1; out_row[6] = a2;
-            out_row[7] = sh;
-            out_row[8] = r0; out_row[9] = r1; out_row[10] = r2;
+            __builtin_nontemporal_store(__fadd_rn(__fmul_rn(a0, sh), r0), out_row + 0);          // run_nerf_helpers.py:320
+            __builtin_nontemporal_store(__fadd_rn(__fmul_rn(a1, sh), r1), out_row + 1);
+            __builtin_nontemporal_store(__fadd_rn(__fmul_rn(a2, sh), r2), out_row + 2);
+            __builtin_nontemporal_store(sig4[0], out_row + 3);
+            __builtin_nontemporal_store(a0, out_row + 4); __builtin_nontemporal_store(a1, out_row + 5); __builtin_nontemporal_store(a2, out_row + 6);
+            __builtin_nontemporal_store(sh, out_row + 7);
+            __builtin_nontemporal_store(r0, out_row + 8); __builtin_nontemporal_store(r1, out_row + 9); __builtin_nontemporal_store(r2, out_row + 10);
         }
     }
     if (p.status && __any(!(amax <= kF16Safe)) && lane == 0) atomicOr(p.status, INERF_STATUS_F16_RANGE);

@@ -6,4 +6,4 @@ export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-$PWD}
 mkdir -p $REPO/gpurun_out/prof
 cd /tmp
-rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $REPO/gpurun_out/prof/$tag -o p -- python $REPO/scripts/bench_mlp.py --rays 32768 --iters 2 > $REPO/gpurun_out/prof/$tag.log 2>&1
+rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $REPO/gpurun_out/prof/$tag -o p -- python $REPO/scripts/bench_mlp.py --rays 32768 --iters 2 $BENCH_ARGS > $REPO/gpurun_out/prof/$tag.log 2>&1
