@@ -42,11 +42,17 @@ constexpr int kLdsBytes = kTilePoints * kLdsStride * 4;   // 156,672 B of the CU
 //     blob[off + ((rb*KB16 + kb)*64 + lane)*4 + c] = W[16*rb + (lane&15)][16*kb + 4*(lane>>4) + c]
 // With precision INERF_PREC_F16X3 the same float-sized regions hold f16 fragments instead (see
 // pack.cpp): per wave and 16-wide k-block, for each row block a 1 KiB "hi" fragment followed by a
-// 1 KiB "lo" fragment, lane l holding 8 halfs W[..+(l&31)][16*kb + 8*(l>>5) .. +7]; skinny GEMMs per
-// 32-wide k-block, lane l holding W[16*rb + (l&15)][32*kb + 8*(l>>4) .. +7].  Region sizes are
-// identical (2 halfs per weight = 4 bytes), so NetLayout serves both formats.
+// 1 KiB "lo" fragment, lane l holding 8 halfs W'[..+(l&31)][16*kb + 8*(l>>5) .. +7]; skinny GEMMs per
+// 32-wide k-block, lane l holding W'[16*rb + (l&15)][32*kb + 8*(l>>4) .. +7].  W' = W * 2^kw with a
+// per-GEMM power of two kw that brings max|W'| into (2^13, 2^14]; hi = f16(W'), lo = f16(W' - hi).
+// Region sizes are identical (2 halfs per weight = 4 bytes), so NetLayout serves both formats.
+// Activations travel scaled by kActScale, so the float after a bias vector holds the factor that maps
+// the f16 kernel's accumulator back: 2^-kw for wide GEMMs (whose biases are stored pre-multiplied by
+// kActScale, the output staying in the scaled domain) and 2^-kw / kActScale for the skinny output heads.
 // Virtual k runs over the concatenation of the layer's LDS source segments (e.g. [enc64 | h256] for
 // pts_linears[5]); padded columns/rows hold zeros.  Biases are stored unpermuted (padded with zeros).
+constexpr float kActScale = 8.0f;   // INERF_PREC_F16X3: activations are split as f16 hi/lo of (8 * value)
+
 struct GemmSlot {
     int32_t w;      // float offset of the packed weights
     int32_t b;      // float offset of the bias vector
@@ -72,8 +78,9 @@ inline NetLayout make_layout(const inerf_net_desc& net) {
     NetLayout L{};
     int32_t off = 0;
     auto take = [&](int32_t n) { int32_t o = off; off += (n + 3) & ~3; return o; };
-    auto wide = [&](GemmSlot& s, int n_out, int k) { s.w = take(n_out * k); s.b = take(n_out); };
-    auto skinny = [&](GemmSlot& s, int rbs, int k) { s.w = take(rbs * 16 * k); s.b = take(rbs * 16); };
+    // each bias vector is followed by 4 floats of per-GEMM constants ([0] = output scale, see kScaleSlot)
+    auto wide = [&](GemmSlot& s, int n_out, int k) { s.w = take(n_out * k); s.b = take(n_out + 4); };
+    auto skinny = [&](GemmSlot& s, int rbs, int k) { s.w = take(rbs * 16 * k); s.b = take(rbs * 16 + 4); };
     for (int i = 0; i < kDepth; ++i) wide(L.trunk[i], kWidth, trunk_k(i));
     skinny(L.alpha, 1, kWidth);
     L.sem_rbs = 0;

@@ -2,18 +2,18 @@
 // (INERF_PREC_F16X3).  Same tile walk, same layer list, same outputs as mlp.hip; only the GEMM
 // arithmetic differs:
 //
-//     every fp32 operand v (weight or activation) is carried as  hi = f16(v),  lo = f16((v - hi) * 2^11)
-//     so that v = hi + lo * 2^-11 to 22 bits, and each product  w * x  is evaluated as
-//         hi_w*hi_x                       -> accumulator "main"   (fp32)
-//         hi_w*lo_x + lo_w*hi_x           -> accumulator "cross"  (fp32),  result = main + 2^-11 * cross
-//     (the lo*lo term is 2^-22 relative and dropped).  f16 x f16 products are exact in fp32, so the
-//     only roundings are the fp32 accumulations - the error against an fp64 evaluation is the same
-//     as the all-fp32 kernel's (measured on the oracle: 5e-7 of the channel scale for both).
+//     every fp32 operand v (weight or activation) is first multiplied by a power of two (weights: per GEMM,
+//     max|W'| in (2^13, 2^14]; activations: 8) and then carried as  hi = f16(v'),  lo = f16(v' - hi):
+//     v' = hi + lo to 22 bits (relative) / 2^-25 (absolute - far below fp32 round-off of the unscaled
+//     value).  Each product  w * x  is evaluated as  hi_w*hi_x + hi_w*lo_x + lo_w*hi_x  on the f16 matrix
+//     cores, all three accumulated in ONE fp32 accumulator (the lo*lo term is 2^-22 relative and dropped).
+//     f16 x f16 products are exact in fp32, so the only roundings are the fp32 accumulations: the error
+//     against an fp64 evaluation is the same as the all-fp32 kernel's (5e-7 of the channel scale for both,
+//     measured on the oracle), and the parity tests hold both kernels to the same 1e-4.
 //
 // Three v_mfma_f32_32x32x16_f16 (16x the fp32 MFMA rate each) replace eight v_mfma_f32_32x32x2_f32:
-// 5.3x fewer matrix-pipe cycles per point.  The scaled low part keeps lo inside f16's normal range
-// for any v in [2^-14, 6e4]; smaller v lose relative (not absolute) precision, larger v cannot be
-// represented: the kernel then sets INERF_STATUS_F16_RANGE and the caller re-runs in fp32.
+// 5.3x fewer matrix-pipe cycles per point.  |activation| must stay below 6e4 / 8: beyond that the
+// kernel raises INERF_STATUS_F16_RANGE in the caller's status word and the caller re-runs in fp32.
 //
 // LDS: two planes (hi, lo) of X[64 points][616 halfs]; 616*2 B = 77*16 B, so the 16 rows a
 // ds_read_b128 lane group touches fall on 16 distinct bank slots.  Columns as in layout.h
@@ -44,23 +44,25 @@ struct WeightBuf {
     __device__ __forceinline__ f32x4 vec4(int byte_off, int lane_bytes) const {   // small per-lane offset on top
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_bytes, byte_off, 0));
     }
+    __device__ __forceinline__ float scalar(int byte_off) const {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, 0, byte_off, 0));
+    }
 };
 
 constexpr int kRowH = kColB + kWidth + 8;      // 616 halfs per row
 constexpr int kPlaneH = kTilePoints * kRowH;   // halfs per plane
 constexpr int kLdsBytesH = 2 * kPlaneH * 2;    // 157,696
-constexpr float kLoScale = 2048.0f;            // 2^11
-constexpr float kLoInv = 1.0f / 2048.0f;
-constexpr float kF16Safe = 6.0e4f;
+constexpr float kF16Safe = 6.0e4f;             // on the scaled value (kActScale * activation)
 
 // `amax` is a per-thread running maximum of |v| over everything that was split into f16; it is compared
 // with the representable range once, at the end of the kernel (a per-value compare-and-flag made the
 // compiler keep every |v| alive and spill).
 __device__ __forceinline__ void split_store(_Float16* hi_ptr, float v, float& amax) {
-    const _Float16 h = (_Float16)v;
+    const float t = v * kActScale;
+    const _Float16 h = (_Float16)t;
     hi_ptr[0] = h;
-    hi_ptr[kPlaneH] = (_Float16)((v - (float)h) * kLoScale);
-    amax = fmaxf(amax, fabsf(v));
+    hi_ptr[kPlaneH] = (_Float16)(t - (float)h);
+    amax = fmaxf(amax, fabsf(t));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -69,12 +71,13 @@ __device__ __forceinline__ void split_store(_Float16* hi_ptr, float v, float& am
 template <int RB>
 struct WidePreH {
     f16x8 w[2][RB][2];      // k-block 0/1, row block, hi/lo
-    f32x4 b[RB][4];
+    f32x4 b[RB][4];         // bias (already in the scaled activation domain)
+    float inv;              // accumulator -> scaled output factor (2^-kw)
 };
 
 template <int RB>
 __device__ __forceinline__ void wide_prefetch_h(WidePreH<RB>& pre, const WeightBuf& wb, int frag_bytes /* wave's stream */,
-                                                int bias_bytes /* wave's first channel */, int lane) {
+                                                int bias_bytes /* wave's first channel */, int scale_bytes, int lane) {
     const int h16 = 16 * (lane >> 5);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -86,12 +89,13 @@ __device__ __forceinline__ void wide_prefetch_h(WidePreH<RB>& pre, const WeightB
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int g = 0; g < 4; ++g) pre.b[rb][g] = wb.vec4(bias_bytes + (32 * rb + 8 * g) * 4, h16);
+    pre.inv = wb.scalar(scale_bytes);
 }
 
 template <int RB, int KB0, int KB1>
 __device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const WeightBuf& wb, int frag_bytes,
                                             const _Float16* xl,      // plane_hi + (lane&31)*kRowH + 8*(lane>>5)
-                                            int col0, int col1, int lane, f32x16 (&am)[RB][2], f32x16 (&ac)[RB][2]) {
+                                            int col0, int col1, int lane, f32x16 (&am)[RB][2]) {
     constexpr int KBT = KB0 + KB1;
     static_assert(KBT % 2 == 0 && KBT >= 4, "k-block count");
 #pragma unroll
@@ -101,10 +105,7 @@ __device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const Weigh
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int pb = 0; pb < 2; ++pb) {
-                    am[rb][pb][4 * g + i] = pre.b[rb][g][i];
-                    ac[rb][pb][4 * g + i] = 0.0f;
-                }
+                for (int pb = 0; pb < 2; ++pb) am[rb][pb][4 * g + i] = 0.0f;
     auto xoff = [&](int kb) { return kb < KB0 ? col0 + 16 * kb : col1 + 16 * (kb - KB0); };
     // 4 rotating weight buffers (two k-blocks ahead; three measured slower), 2 activation buffers (one ahead);
     // all indices static
@@ -135,16 +136,16 @@ __device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const Weigh
             _Pragma("unroll") for (int part = 0; part < 2; ++part)                                                   \
                 x[((I) + 1) & 1][pb][part] =                                                                         \
                     *reinterpret_cast<const f16x8*>(xl + part * kPlaneH + xo_ + pb * 32 * kRowH);                    \
-        /* hi*hi -> main; hi*lo and lo*hi -> cross; product-major: an accumulator is touched every 4th MFMA */       \
+        /* hi*hi, hi*lo, lo*hi into the same accumulator; product-major: an accumulator is touched every 4th MFMA */ \
         _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                                            \
             _Pragma("unroll") for (int pb = 0; pb < 2; ++pb)                                                         \
                 am[rb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[(I) & 3][rb][0], x[(I) & 1][pb][0], am[rb][pb], 0, 0, 0); \
         _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                                            \
             _Pragma("unroll") for (int pb = 0; pb < 2; ++pb)                                                         \
-                ac[rb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[(I) & 3][rb][0], x[(I) & 1][pb][1], ac[rb][pb], 0, 0, 0); \
+                am[rb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[(I) & 3][rb][0], x[(I) & 1][pb][1], am[rb][pb], 0, 0, 0); \
         _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                                            \
             _Pragma("unroll") for (int pb = 0; pb < 2; ++pb)                                                         \
-                ac[rb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[(I) & 3][rb][1], x[(I) & 1][pb][0], ac[rb][pb], 0, 0, 0); \
+                am[rb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[(I) & 3][rb][1], x[(I) & 1][pb][0], am[rb][pb], 0, 0, 0); \
         /* issue order: MFMA, global load, MFMA, LDS read, MFMA - 2*RB times (masks: 0x8 MFMA, 0x20 VMEM read, 0x100 DS read) */ \
         _Pragma("unroll") for (int q = 0; q < 2 * RB; ++q) {                                                        \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                       \
@@ -170,9 +171,11 @@ __device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const Weigh
 #undef INERF_F16_STEP
 }
 
-// epilogue: y = main + 2^-11 cross (optionally ReLU) -> hi/lo planes; optional fp32 copy to global
+// epilogue: t = acc * inv + bias' (= kActScale * layer output; optionally ReLU) -> hi/lo planes;
+// optional fp32 copy of the unscaled value to global
 template <int RB>
-__device__ __forceinline__ void wide_store_h(const f32x16 (&am)[RB][2], const f32x16 (&ac)[RB][2],
+__device__ __forceinline__ void wide_store_h(const f32x16 (&am)[RB][2], const WidePreH<RB>& pre_unused, float inv,
+                                             const f32x4 (&bias)[RB][4],
                                              _Float16* dl,   // plane_hi + (lane&31)*kRowH + 4*(lane>>5) + dcol + chan0
                                              bool relu, float& amax, float* gout /* or nullptr: + chan0 + 4*(lane>>5) */,
                                              int gstride, int valid0, int valid1) {
@@ -183,16 +186,20 @@ __device__ __forceinline__ void wide_store_h(const f32x16 (&am)[RB][2], const f3
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f16x4 hi4, lo4;
+                float t[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    float y = __builtin_fmaf(ac[rb][pb][4 * g + i], kLoInv, am[rb][pb][4 * g + i]);
-                    if (relu) y = fmaxf(y, 0.0f);
-                    const _Float16 h = (_Float16)y;
+                    t[i] = __builtin_fmaf(am[rb][pb][4 * g + i], inv, bias[rb][g][i]);
+                    if (relu) t[i] = fmaxf(t[i], 0.0f);
+                    const _Float16 h = (_Float16)t[i];
                     hi4[i] = h;
-                    lo4[i] = (_Float16)((y - (float)h) * kLoScale);
-                    amax = fmaxf(amax, fabsf(y));
-                    if (gout && (pb == 0 ? valid0 : valid1)) gout[(size_t)pb * 32 * gstride + 32 * rb + 8 * g + i] = y;
+                    lo4[i] = (_Float16)(t[i] - (float)h);
+                    if (gout && (pb == 0 ? valid0 : valid1))
+                        gout[(size_t)pb * 32 * gstride + 32 * rb + 8 * g + i] = t[i] * (1.0f / kActScale);
                 }
+                // |t| range check, two values per v_max3 (ReLU outputs need no abs, but the modifier is free)
+                amax = fmaxf(fmaxf(amax, fabsf(t[0])), fabsf(t[1]));
+                amax = fmaxf(fmaxf(amax, fabsf(t[2])), fabsf(t[3]));
                 _Float16* d = dl + pb * 32 * kRowH + 32 * rb + 8 * g;
                 *reinterpret_cast<f16x4*>(d) = hi4;
                 *reinterpret_cast<f16x4*>(d + kPlaneH) = lo4;
@@ -207,23 +214,24 @@ __device__ __forceinline__ void wide_store_h(const f32x16 (&am)[RB][2], const f3
 // skinny GEMM: 16 output rows x this wave's 16 points on v_mfma_f32_16x16x32_f16, K = 32*KB32
 // ------------------------------------------------------------------------------------------------
 template <int KB32>
-__device__ __forceinline__ f32x4 skinny_gemm_h(const WeightBuf& wb, int frag_bytes, int bias_bytes,
+__device__ __forceinline__ f32x4 skinny_gemm_h(const WeightBuf& wb, int frag_bytes, int bias_bytes, int scale_bytes,
                                                const _Float16* xs /* plane_hi + (16*wave + (lane&15))*kRowH + col + 8*(lane>>4) */,
                                                int lane) {
-    f32x4 am = wb.vec4(bias_bytes, 16 * (lane >> 4));
-    f32x4 ac = {0.0f, 0.0f, 0.0f, 0.0f};
+    const f32x4 bias = wb.vec4(bias_bytes, 16 * (lane >> 4));
+    const float inv = wb.scalar(scale_bytes);
+    f32x4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int kb = 0; kb < KB32; ++kb) {
         const f16x8 wh = wb.frag(frag_bytes + (2 * kb) * 1024), wl = wb.frag(frag_bytes + (2 * kb + 1) * 1024);
         const f16x8 xh = *reinterpret_cast<const f16x8*>(xs + 32 * kb);
         const f16x8 xl = *reinterpret_cast<const f16x8*>(xs + kPlaneH + 32 * kb);
-        am = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, am, 0, 0, 0);
-        ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, ac, 0, 0, 0);
-        ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, ac, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, a1, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, a1, 0, 0, 0);
     }
     f32x4 r;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = __builtin_fmaf(ac[i], kLoInv, am[i]);
+    for (int i = 0; i < 4; ++i) r[i] = __builtin_fmaf(a0[i] + a1[i], inv, bias[i]);
     return r;
 }
 
@@ -255,10 +263,12 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
     auto frag128 = [&](const GemmSlot& s, int kbt) { return (s.w + wave * kbt * 1 * 2 * 256) * 4; };
     auto bias256 = [&](const GemmSlot& s) { return (s.b + 64 * wave) * 4; };
     auto bias128 = [&](const GemmSlot& s) { return (s.b + 32 * wave) * 4; };
+    auto scale256 = [&](const GemmSlot& s) { return (s.b + kWidth) * 4; };     // the constant after the bias vector
+    auto scale128 = [&](const GemmSlot& s) { return (s.b + kHalf) * 4; };
 
     WidePreH<2> pre2;
     WidePreH<1> pre1;
-    wide_prefetch_h<2>(pre2, wb, frag256(L.trunk[0], 4), bias256(L.trunk[0]), lane);
+    wide_prefetch_h<2>(pre2, wb, frag256(L.trunk[0], 4), bias256(L.trunk[0]), scale256(L.trunk[0]), lane);
 
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         // ---------------- encode -> hi/lo planes ----------------
@@ -314,27 +324,37 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
         const int pt0 = tile * kPts + (lane & 31);              // this lane's points in wide results
         auto step256 = [&](const GemmSlot& s, auto kb0c, auto kb1c, int c0, int c1, int dcol, bool relu, auto&& prefetch_next) {
             constexpr int KB0 = decltype(kb0c)::value, KB1 = decltype(kb1c)::value;
-            f32x16 am[2][2], ac[2][2];
-            wide_gemm_h<2, KB0, KB1>(pre2, wb, frag256(s, KB0 + KB1), xr, c0, c1, lane, am, ac);
+            f32x16 am[2][2];
+            f32x4 bias[2][4];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bias[rb][g] = pre2.b[rb][g];
+            const float inv = pre2.inv;
+            wide_gemm_h<2, KB0, KB1>(pre2, wb, frag256(s, KB0 + KB1), xr, c0, c1, lane, am);
             prefetch_next();
-            wide_store_h<2>(am, ac, xd + dcol + 64 * wave, relu, amax, nullptr, 0, 0, 0);
+            wide_store_h<2>(am, pre2, inv, bias, xd + dcol + 64 * wave, relu, amax, nullptr, 0, 0, 0);
             __syncthreads();
         };
         auto step128 = [&](const GemmSlot& s, auto kb0c, auto kb1c, int c0, int c1, int dcol, bool relu, float* gout,
                            auto&& prefetch_next) {
             constexpr int KB0 = decltype(kb0c)::value, KB1 = decltype(kb1c)::value;
-            f32x16 am[1][2], ac[1][2];
-            wide_gemm_h<1, KB0, KB1>(pre1, wb, frag128(s, KB0 + KB1), xr, c0, c1, lane, am, ac);
+            f32x16 am[1][2];
+            f32x4 bias[1][4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bias[0][g] = pre1.b[0][g];
+            const float inv = pre1.inv;
+            wide_gemm_h<1, KB0, KB1>(pre1, wb, frag128(s, KB0 + KB1), xr, c0, c1, lane, am);
             prefetch_next();
-            wide_store_h<1>(am, ac, xd + dcol + 32 * wave, relu, amax, gout, p.channels, pt0 < p.n_points,
+            wide_store_h<1>(am, pre1, inv, bias, xd + dcol + 32 * wave, relu, amax, gout, p.channels, pt0 < p.n_points,
                             pt0 + 32 < p.n_points);
             __syncthreads();
         };
         auto pf256 = [&](const GemmSlot& s, int kbt) {
-            return [&, kbt]() { wide_prefetch_h<2>(pre2, wb, frag256(s, kbt), bias256(s), lane); };
+            return [&, kbt]() { wide_prefetch_h<2>(pre2, wb, frag256(s, kbt), bias256(s), scale256(s), lane); };
         };
         auto pf128 = [&](const GemmSlot& s, int kbt) {
-            return [&, kbt]() { wide_prefetch_h<1>(pre1, wb, frag128(s, kbt), bias128(s), lane); };
+            return [&, kbt]() { wide_prefetch_h<1>(pre1, wb, frag128(s, kbt), bias128(s), scale128(s), lane); };
         };
         using std::integral_constant;
         constexpr integral_constant<int, 0> K0{};
@@ -358,12 +378,13 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
         const bool my_valid = my_pt < p.n_points;
         float* const out_row = p.raw + (size_t)(my_valid ? my_pt : 0) * p.channels;
 
-        const f32x4 sig4 = skinny_gemm_h<8>(wb, L.alpha.w * 4, L.alpha.b * 4, xs + kColB, lane);
+        const f32x4 sig4 = skinny_gemm_h<8>(wb, L.alpha.w * 4, L.alpha.b * 4, (L.alpha.b + 16) * 4, xs + kColB, lane);
 
         if (sem) {
             step128(L.sem1, K16, K0, kColB, 0, kColA, true, nullptr, pf256(L.as1, 16));
             for (int rb = 0; rb < L.sem_rbs; ++rb) {
-                const f32x4 lg = skinny_gemm_h<4>(wb, (L.sem2.w + rb * 4 * 2 * 256) * 4, (L.sem2.b + 16 * rb) * 4, xs + kColA, lane);
+                const f32x4 lg = skinny_gemm_h<4>(wb, (L.sem2.w + rb * 4 * 2 * 256) * 4, (L.sem2.b + 16 * rb) * 4,
+                                                   (L.sem2.b + 16 * L.sem_rbs) * 4, xs + kColA, lane);
                 const int ch0 = 16 * rb + 4 * (lane >> 4);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -373,7 +394,7 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
         }
 
         step256(L.as1, K16, K0, kColB, 0, kColA, true, pf256(L.feat, 16));
-        const f32x4 as4 = skinny_gemm_h<8>(wb, L.as2.w * 4, L.as2.b * 4, xs + kColA, lane);
+        const f32x4 as4 = skinny_gemm_h<8>(wb, L.as2.w * 4, L.as2.b * 4, (L.as2.b + 16) * 4, xs + kColA, lane);
         __syncthreads();
 
         step256(L.feat, K16, K0, kColB, 0, kColA, false, pf128(L.views, 18));
@@ -382,7 +403,7 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
         if (kSsr && p.endpoint)
             ep = p.raw + (size_t)pt0 * p.channels + INERF_BASE_CHANNELS + p.n_classes + 32 * wave + 4 * (lane >> 5);
         step128(L.views, K16, K2, kColA, kColDir, kColB, true, ep, pf256(L.trunk[0], 4));
-        const f32x4 res4 = skinny_gemm_h<4>(wb, L.res.w * 4, L.res.b * 4, xs + kColB, lane);
+        const f32x4 res4 = skinny_gemm_h<4>(wb, L.res.w * 4, L.res.b * 4, (L.res.b + 16) * 4, xs + kColB, lane);
 
         if (lane < 16 && my_valid) {
             const float a0 = sigmoid_ref_h(as4[0]), a1 = sigmoid_ref_h(as4[1]), a2 = sigmoid_ref_h(as4[2]);

@@ -1,6 +1,7 @@
 // pack.cpp - host side of the C ABI: network description, canonical tensor order, weight packer.
 // Replaces (as seen by forward()) the nn.Module parameter storage of
 //   object_level/run_nerf_helpers.py:259-279 (NeRF)  and  SSR/models/semantic_nerf.py:98-118 (Semantic_NeRF).
+#include <cmath>
 #include <cstring>
 #include <functional>
 #include <string>
@@ -59,7 +60,7 @@ Net describe(const inerf_net_desc& d) {
 using Elem = std::function<float(int /*row*/, int /*virtual k*/)>;
 
 // wide GEMM: fragments of v_mfma_f32_32x32x2_f32's A operand, four k-steps per float4 (layout.h)
-void pack_wide_f32(float* dst, int n_out, int k_total, const Elem& w) {
+float pack_wide_f32(float* dst, int n_out, int k_total, const Elem& w) {
     const int rb_per_wave = n_out / (32 * inerf::kWaves), kb_count = k_total / 8;
     for (int wave = 0; wave < inerf::kWaves; ++wave)
         for (int kb = 0; kb < kb_count; ++kb)
@@ -70,10 +71,11 @@ void pack_wide_f32(float* dst, int n_out, int k_total, const Elem& w) {
                         int kv = 8 * kb + 4 * (lane >> 5) + c;
                         dst[((((int64_t)wave * kb_count + kb) * rb_per_wave + rb) * 64 + lane) * 4 + c] = w(row, kv);
                     }
+    return 1.0f;
 }
 
 // skinny GEMM: fragments of v_mfma_f32_16x16x4_f32's A operand
-void pack_skinny_f32(float* dst, int rbs, int k_total, const Elem& w) {
+float pack_skinny_f32(float* dst, int rbs, int k_total, const Elem& w) {
     const int kb_count = k_total / 16;
     for (int rb = 0; rb < rbs; ++rb)
         for (int kb = 0; kb < kb_count; ++kb)
@@ -83,20 +85,33 @@ void pack_skinny_f32(float* dst, int rbs, int k_total, const Elem& w) {
                     int kv = 16 * kb + 4 * (lane >> 4) + c;
                     dst[(((int64_t)rb * kb_count + kb) * 64 + lane) * 4 + c] = w(row, kv);
                 }
+    return 1.0f;
 }
 
-// ---- INERF_PREC_F16X3: w = hi + lo * 2^-11 with hi = f16(w), lo = f16((w - hi) * 2^11) ----
+// ---- INERF_PREC_F16X3: W' = W * 2^kw, hi = f16(W'), lo = f16(W' - hi)  (layout.h) ----
 struct HalfPair { _Float16 hi, lo; };
 
 inline HalfPair split_f16(float w) {
     const _Float16 hi = (_Float16)w;
-    const _Float16 lo = (_Float16)((w - (float)hi) * 2048.0f);
+    const _Float16 lo = (_Float16)(w - (float)hi);
     return {hi, lo};
 }
 
+// power of two that brings the largest |w| of a GEMM into (2^13, 2^14]
+float weight_scale(int rows, int k_total, const Elem& w) {
+    float m = 0.0f;
+    for (int r = 0; r < rows; ++r)
+        for (int k = 0; k < k_total; ++k) m = std::fmax(m, std::fabs(w(r, k)));
+    if (!(m > 0.0f) || !std::isfinite(m)) return 1.0f;
+    int e;
+    std::frexp(m, &e);                      // m = f * 2^e, f in [0.5, 1)
+    return std::ldexp(1.0f, 14 - e);        // m * scale in [2^13, 2^14)
+}
+
 // wide GEMM, A-operand fragments of v_mfma_f32_32x32x16_f16: [wave][kb16][rb][hi|lo][lane][8 halfs]
-void pack_wide_f16(float* dst_f, int n_out, int k_total, const Elem& w) {
+float pack_wide_f16(float* dst_f, int n_out, int k_total, const Elem& w) {
     _Float16* dst = reinterpret_cast<_Float16*>(dst_f);
+    const float sc = weight_scale(n_out, k_total, w);
     const int rb_per_wave = n_out / (32 * inerf::kWaves), kb_count = k_total / 16;
     for (int wave = 0; wave < inerf::kWaves; ++wave)
         for (int kb = 0; kb < kb_count; ++kb)
@@ -105,16 +120,18 @@ void pack_wide_f16(float* dst_f, int n_out, int k_total, const Elem& w) {
                     for (int c = 0; c < 8; ++c) {
                         const int row = wave * 32 * rb_per_wave + 32 * rb + (lane & 31);
                         const int kv = 16 * kb + 8 * (lane >> 5) + c;
-                        const HalfPair h = split_f16(w(row, kv));
+                        const HalfPair h = split_f16(w(row, kv) * sc);
                         const int64_t frag = (((int64_t)wave * kb_count + kb) * rb_per_wave + rb) * 2;
                         dst[(frag * 64 + lane) * 8 + c] = h.hi;
                         dst[((frag + 1) * 64 + lane) * 8 + c] = h.lo;
                     }
+    return sc;
 }
 
 // skinny GEMM, A-operand fragments of v_mfma_f32_16x16x32_f16: [rb][kb32][hi|lo][lane][8 halfs]
-void pack_skinny_f16(float* dst_f, int rbs, int k_total, const Elem& w) {
+float pack_skinny_f16(float* dst_f, int rbs, int k_total, const Elem& w) {
     _Float16* dst = reinterpret_cast<_Float16*>(dst_f);
+    const float sc = weight_scale(16 * rbs, k_total, w);
     const int kb_count = k_total / 32;
     for (int rb = 0; rb < rbs; ++rb)
         for (int kb = 0; kb < kb_count; ++kb)
@@ -122,11 +139,12 @@ void pack_skinny_f16(float* dst_f, int rbs, int k_total, const Elem& w) {
                 for (int c = 0; c < 8; ++c) {
                     const int row = 16 * rb + (lane & 15);
                     const int kv = 32 * kb + 8 * (lane >> 4) + c;
-                    const HalfPair h = split_f16(w(row, kv));
+                    const HalfPair h = split_f16(w(row, kv) * sc);
                     const int64_t frag = ((int64_t)rb * kb_count + kb) * 2;
                     dst[(frag * 64 + lane) * 8 + c] = h.hi;
                     dst[((frag + 1) * 64 + lane) * 8 + c] = h.lo;
                 }
+    return sc;
 }
 
 }  // namespace
@@ -177,8 +195,20 @@ int inerf_pack_weights(const inerf_net_desc* net, const float* const* tensors, i
     std::memset(out, 0, sizeof(float) * (size_t)L.total_floats);
 
     const bool f16 = net->precision == INERF_PREC_F16X3;
-    auto pack_wide = [&](float* dst, int n_out, int k, const Elem& el) { f16 ? pack_wide_f16(dst, n_out, k, el) : pack_wide_f32(dst, n_out, k, el); };
-    auto pack_skinny = [&](float* dst, int rbs, int k, const Elem& el) { f16 ? pack_skinny_f16(dst, rbs, k, el) : pack_skinny_f32(dst, rbs, k, el); };
+    float last_scale = 1.0f;            // weight scale of the most recent pack_* call
+    auto pack_wide = [&](float* dst, int n_out, int k, const Elem& el) {
+        last_scale = f16 ? pack_wide_f16(dst, n_out, k, el) : pack_wide_f32(dst, n_out, k, el);
+    };
+    auto pack_skinny = [&](float* dst, int rbs, int k, const Elem& el) {
+        last_scale = f16 ? pack_skinny_f16(dst, rbs, k, el) : pack_skinny_f32(dst, rbs, k, el);
+    };
+    // after the biases of a slot are in place: store the accumulator->output factor behind them and, for the
+    // wide (hidden) layers of the f16 format, move the biases into the scaled activation domain (layout.h)
+    auto finish_wide = [&](const GemmSlot& s, int n_out) {
+        out[s.b + n_out] = 1.0f / last_scale;
+        if (f16) for (int i = 0; i < n_out; ++i) out[s.b + i] *= kActScale;
+    };
+    auto finish_skinny = [&](const GemmSlot& s, int rbs) { out[s.b + 16 * rbs] = f16 ? 1.0f / (last_scale * kActScale) : 1.0f; };
     auto find = [&](const char* key) -> int {
         for (int i = 0; i < n_tensors; ++i)
             if (n.spec[i].name == key) return i;
@@ -206,23 +236,27 @@ int inerf_pack_weights(const inerf_net_desc* net, const float* const* tensors, i
             el = [=](int r, int kv) { return w[(int64_t)r * in + kv]; };
         pack_wide(out + L.trunk[i].w, kWidth, trunk_k(i), el);
         copy_bias(L.trunk[i].b, B(lin), kWidth);
+        finish_wide(L.trunk[i], kWidth);
     }
     // ---- sigma ----
     {
         const float* w = W("alpha_linear");
         pack_skinny(out + L.alpha.w, 1, kWidth, [=](int r, int kv) { return r == 0 ? w[kv] : 0.0f; });
         out[L.alpha.b] = B("alpha_linear")[0];
+        finish_skinny(L.alpha, 1);
     }
     // ---- semantic head (ssr) ----
     if (L.sem_rbs > 0) {
         const float* w1 = W("semantic_linear.0.0");
         pack_wide(out + L.sem1.w, kHalf, kWidth, [=](int r, int kv) { return w1[(int64_t)r * kWidth + kv]; });
         copy_bias(L.sem1.b, B("semantic_linear.0.0"), kHalf);
+        finish_wide(L.sem1, kHalf);
         const float* w2 = W("semantic_linear.1");
         const int c = net->n_classes;
         pack_skinny(out + L.sem2.w, L.sem_rbs, kHalf,
                     [=](int r, int kv) { return r < c ? w2[(int64_t)r * kHalf + kv] : 0.0f; });
         copy_bias(L.sem2.b, B("semantic_linear.1"), c);
+        finish_skinny(L.sem2, L.sem_rbs);
     }
     // ---- albedo + shading hidden layers fused into one 256-row GEMM, then one skinny output GEMM ----
     const bool obj = net->variant == INERF_VARIANT_OBJECT;
@@ -237,6 +271,7 @@ int inerf_pack_weights(const inerf_net_desc* net, const float* const* tensors, i
         });
         copy_bias(L.as1.b, B("albedo_linear1"), kHalf);
         copy_bias(L.as1.b + kHalf, B(sh1), kHalf);
+        finish_wide(L.as1, kWidth);
         const float* wa2 = W("albedo_linear2");
         const float* ws2 = W(sh2);
         pack_skinny(out + L.as2.w, 1, kWidth, [=](int r, int kv) {
@@ -246,12 +281,14 @@ int inerf_pack_weights(const inerf_net_desc* net, const float* const* tensors, i
         });
         copy_bias(L.as2.b, B("albedo_linear2"), 3);
         out[L.as2.b + 3] = B(sh2)[0];
+        finish_skinny(L.as2, 1);
     }
     // ---- feature, views, residual ----
     {
         const float* wf = W("feature_linear");
         pack_wide(out + L.feat.w, kWidth, kWidth, [=](int r, int kv) { return wf[(int64_t)r * kWidth + kv]; });
         copy_bias(L.feat.b, B("feature_linear"), kWidth);
+        finish_wide(L.feat, kWidth);
         const float* wv = W("views_linears.0");
         const int in = kWidth + dv;
         pack_wide(out + L.views.w, kHalf, kWidth + kDirCols, [=](int r, int kv) {
@@ -260,9 +297,11 @@ int inerf_pack_weights(const inerf_net_desc* net, const float* const* tensors, i
             return dc < dv ? wv[(int64_t)r * in + kWidth + dc] : 0.0f;
         });
         copy_bias(L.views.b, B("views_linears.0"), kHalf);
+        finish_wide(L.views, kHalf);
         const float* wr = W(rs);
         pack_skinny(out + L.res.w, 1, kHalf, [=](int r, int kv) { return r < 3 ? wr[(int64_t)r * kHalf + kv] : 0.0f; });
         copy_bias(L.res.b, B(rs), 3);
+        finish_skinny(L.res, 1);
     }
     return INERF_OK;
 }

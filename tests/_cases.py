@@ -32,8 +32,33 @@ def case_random_inputs(fx, device="cpu"):
 
 # oracle key -> tolerance class.  ``disp`` is ill-conditioned (1/(depth/acc)); the reference's own
 # fp32-vs-fp64 noise floor for it is 8.9e-5, so it gets a looser bound.
-def assert_maps_close(got, want, rtol, atol, tag=""):
-    """``|got - want| <= atol + rtol * |want|`` with NaNs required at identical positions."""
+def sample_pdf_sensitivity(z_coarse, weights_coarse, u):
+    """|d z_sample / d cdf| of every importance sample: (bin width) / (cdf difference of its bin).
+
+    sample_pdf interpolates ``bins_lo + (u - cdf_lo) / denom * (bins_hi - bins_lo)`` with ``denom`` as small as
+    1e-5 (run_nerf_helpers.py:440-443), so a cdf that differs by one fp32 rounding (~1e-7; it is a 62-term
+    cumulative sum of normalised weights) legitimately moves a sample in a nearly-empty bin by up to
+    ``0.06 / 1e-5 * 1e-7``.  Returns the factor per sample, [N, n_importance]."""
+    z = np.asarray(z_coarse, np.float64)
+    w = np.asarray(weights_coarse, np.float64)[:, 1:-1] + 1e-5
+    u = np.broadcast_to(np.asarray(u, np.float64), (z.shape[0], np.asarray(u).shape[-1]))
+    bins = 0.5 * (z[:, 1:] + z[:, :-1])
+    cdf = np.concatenate([np.zeros((z.shape[0], 1)), np.cumsum(w / w.sum(-1, keepdims=True), -1)], -1)
+    sens = np.zeros_like(u)
+    for r in range(z.shape[0]):
+        idx = np.searchsorted(cdf[r], u[r], side="right")
+        lo, hi = np.clip(idx - 1, 0, None), np.clip(idx, None, cdf.shape[1] - 1)
+        denom = cdf[r, hi] - cdf[r, lo]
+        denom = np.where(denom < 1e-5, 1.0, denom)
+        sens[r] = np.abs(bins[r, hi] - bins[r, lo]) / denom
+    return sens
+
+
+CDF_NOISE = 1e-6      # bound on the fp32 round-off of a cdf entry (62 adds of O(1e-2) terms: ~3e-7 observed)
+
+
+def assert_maps_close(got, want, rtol, atol, tag="", extra=None):
+    """``|got - want| <= atol + rtol * |want| (+ extra)`` with NaNs required at identical positions."""
     got = np.asarray(got, dtype=np.float64)
     want = np.asarray(want, dtype=np.float64)
     assert got.shape == want.shape, f"{tag}: shape {got.shape} vs {want.shape}"
@@ -42,6 +67,8 @@ def assert_maps_close(got, want, rtol, atol, tag=""):
     ok = ~nan_w
     err = np.abs(got[ok] - want[ok])
     bound = atol + rtol * np.abs(want[ok])
+    if extra is not None:
+        bound = bound + np.broadcast_to(np.asarray(extra, np.float64), want.shape)[ok]
     if err.size and not np.all(err <= bound):
         i = int(np.argmax(err - bound))
         raise AssertionError(f"{tag}: max violation err={err[i]:.3e} bound={bound[i]:.3e} "

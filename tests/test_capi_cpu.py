@@ -111,8 +111,9 @@ def _layout(variant, c):
         o = off
         off += (n + 3) & ~3
         return o
-    def wide(name, n_out, k): slots[name] = ("wide", take(n_out * k), take(n_out), n_out, k)
-    def skinny(name, rbs, k): slots[name] = ("skinny", take(rbs * 16 * k), take(rbs * 16), rbs, k)
+    # each bias vector is followed by 4 floats of per-GEMM constants ([0] = accumulator -> output factor)
+    def wide(name, n_out, k): slots[name] = ("wide", take(n_out * k), take(n_out + 4), n_out, k)
+    def skinny(name, rbs, k): slots[name] = ("skinny", take(rbs * 16 * k), take(rbs * 16 + 4), rbs, k)
     for i in range(8):
         wide(f"trunk{i}", 256, 64 if i == 0 else (320 if i == 5 else 256))
     skinny("alpha", 1, 256)
@@ -143,7 +144,7 @@ def test_packer_layout(capi, variant, c):
             assert np.array_equal(w[:, :63], ref[:, :63]) and not w[:, 63].any() and np.array_equal(w[:, 64:], ref[:, 63:])
         else:
             assert np.array_equal(w, ref)
-        assert np.array_equal(blob[ob:ob + 256], g(f"pts_linears.{i}.bias"))
+        assert np.array_equal(blob[ob:ob + 256], g(f"pts_linears.{i}.bias")) and blob[ob + 256] == 1.0
     # sigma
     _, ow, ob, rbs, k = slots["alpha"]
     w = _unpack_skinny(blob, ow, rbs, k)
@@ -210,39 +211,59 @@ def _unpack_skinny_f16(blob, off, rbs, k_total):
 
 
 def test_packer_f16x3_split(capi):
-    """hi + lo * 2^-11 reproduces every fp32 weight to 22 bits, in the documented fragment order."""
+    """(hi + lo) / 2^kw reproduces every fp32 weight to 22 bits, in the documented fragment order; the constants
+    behind each bias vector undo the operand scaling (csrc/layout.h)."""
     from intrinsicnerf_amd import packing
     desc = capi.net_desc(capi.VARIANT_SSR, 28, 10, 4, 10.0, precision=capi.PREC_F16X3)
     sd = oracle.make_state_dict("ssr", 28, seed=12)
     blob = packing.pack_state_dict(desc, sd).numpy()
     slots, total = _layout("ssr", 28)
     assert blob.shape[0] == total
-    def check(w_hi_lo, ref):
-        hi, lo = w_hi_lo
-        rec = hi.astype(np.float64) + lo.astype(np.float64) / 2048.0
-        assert np.array_equal(hi, ref.astype(np.float16).astype(np.float32))            # hi = round-to-nearest f16
-        assert np.max(np.abs(rec - ref)) <= 2.0 ** -22 * np.max(np.abs(ref)) + 2.0 ** -36
+    ACT = 8.0
+
+    def weight_scale(*mats):
+        m = max(float(np.abs(x).max()) for x in mats)
+        return 2.0 ** (14 - (np.frexp(m)[1]))                              # max|W| * scale in [2^13, 2^14)
+
+    def check(hi_lo, ref, sc):
+        hi, lo = hi_lo
+        assert np.array_equal(hi, (ref * sc).astype(np.float16).astype(np.float32))      # hi = round-to-nearest f16 of W * 2^kw
+        rec = (hi.astype(np.float64) + lo.astype(np.float64)) / sc
+        assert np.max(np.abs(rec - ref)) <= 2.0 ** -21 * np.max(np.abs(ref))
+
+    ref = sd["pts_linears.3.weight"].numpy()
     _, ow, ob, n_out, k = slots["trunk3"]
-    check(_unpack_wide_f16(blob, ow, n_out, k), sd["pts_linears.3.weight"].numpy())
-    assert np.array_equal(blob[ob:ob + 256], sd["pts_linears.3.bias"].numpy())            # biases stay fp32
+    sc = weight_scale(ref)
+    assert 2 ** 13 <= np.abs(ref).max() * sc < 2 ** 14
+    check(_unpack_wide_f16(blob, ow, n_out, k), ref, sc)
+    assert np.array_equal(blob[ob:ob + 256], sd["pts_linears.3.bias"].numpy() * ACT)     # hidden-layer biases live in the scaled domain
+    assert blob[ob + 256] == np.float32(1.0 / sc)
     _, ow, ob, n_out, k = slots["trunk5"]
     hi, lo = _unpack_wide_f16(blob, ow, n_out, k)
     ref = sd["pts_linears.5.weight"].numpy()
-    check((hi[:, 64:], lo[:, 64:]), ref[:, 63:])
-    check((hi[:, :63], lo[:, :63]), ref[:, :63])
+    sc = weight_scale(ref)
+    check((hi[:, 64:], lo[:, 64:]), ref[:, 63:], sc)
+    check((hi[:, :63], lo[:, :63]), ref[:, :63], sc)
     assert not hi[:, 63].any() and not lo[:, 63].any()
     _, ow, ob, n_out, k = slots["views"]
     hi, lo = _unpack_wide_f16(blob, ow, n_out, k)
     ref = sd["views_linears.0.weight"].numpy()
-    check((hi[:, :283], lo[:, :283]), ref)
+    check((hi[:, :283], lo[:, :283]), ref, weight_scale(ref))
     assert not hi[:, 283:].any()
     _, ow, ob, rbs, k = slots["sem2"]
     hi, lo = _unpack_skinny_f16(blob, ow, rbs, k)
-    check((hi[:28], lo[:28]), sd["semantic_linear.1.weight"].numpy())
+    ref = sd["semantic_linear.1.weight"].numpy()
+    sc = weight_scale(ref)
+    check((hi[:28], lo[:28]), ref, sc)
     assert not hi[28:].any() and not lo[28:].any()
-    _, ow, ob, rbs, k = slots["alpha"]
+    assert np.array_equal(blob[ob:ob + 28], sd["semantic_linear.1.bias"].numpy())        # output heads: unscaled bias ...
+    assert blob[ob + 16 * rbs] == np.float32(1.0 / (sc * ACT))                           # ... and a factor that also undoes the activation scale
+    _, ow, ob, rbs, k = slots["as2"]
     hi, lo = _unpack_skinny_f16(blob, ow, rbs, k)
-    check((hi[:1], lo[:1]), sd["alpha_linear.weight"].numpy())
+    wa, ws = sd["albedo_linear2.weight"].numpy(), sd["shading_linear2.weight"].numpy()
+    sc = weight_scale(wa, ws)
+    check((hi[:3, :128], lo[:3, :128]), wa, sc)
+    check((hi[3:4, 128:], lo[3:4, 128:]), ws, sc)
 
 
 def test_packer_rejects_bad_state_dicts(capi):

@@ -11,7 +11,8 @@ import pytest
 import torch
 
 import oracle
-from _cases import assert_maps_close, case_config, case_random_inputs, case_weights, injected_np_rand
+from _cases import (CDF_NOISE, assert_maps_close, case_config, case_random_inputs, case_weights, injected_np_rand,
+                    sample_pdf_sensitivity)
 from conftest import golden_names, load_golden
 
 pytestmark = pytest.mark.gpu
@@ -66,6 +67,12 @@ def test_fused_path_matches_reference(name):
         white_bkgd=cfg.white_bkgd, lindisp=cfg.lindisp, endpoint=cfg.endpoint_feat,
         want_raw_coarse=True, want_raw_fine=True, want_stages=True)
     torch.cuda.synchronize()
+    # new-sample depths may move by (cdf round-off) x (their bin's 1/denom amplification) - see _cases.py
+    z_extra = {}
+    if cfg.n_importance > 0:
+        u_np = fx["in_u"] if "in_u" in fx else np.linspace(0.0, 1.0, cfg.n_importance, dtype=np.float32)
+        sens = sample_pdf_sensitivity(fx["stage_z_coarse"], fx["stage_weights_coarse"], u_np)
+        z_extra = {"z_samples": CDF_NOISE * sens, "z_fine": CDF_NOISE * sens.max(-1, keepdims=True)}
     checked = 0
     for key, want in fx.items():
         if key.startswith("ref_"):
@@ -77,7 +84,7 @@ def test_fused_path_matches_reference(name):
             checked += 1
         elif key.startswith("stage_") and key != "stage_raw_coarse":
             k = key[6:]
-            assert_maps_close(out[k].cpu().numpy(), want, RTOL, ATOL, f"{name}:stage {k}")
+            assert_maps_close(out[k].cpu().numpy(), want, RTOL, ATOL, f"{name}:stage {k}", extra=z_extra.get(k))
             checked += 1
     assert checked >= 9
 
