@@ -9,9 +9,16 @@ through the product front-end ``intrinsicnerf_amd.object_level.render``.  With N
 are split into N row bands (one process per GPU) and the rendered maps are all-gathered over RCCL, so
 the total work is fixed: "scaling": "strong".  Inputs are resident in HBM before the timed region.
 
+The MLP GEMMs run in the package's default arithmetic (INERF_PRECISION, default "f16x3": fp32 operands
+split into f16 hi/lo pairs, 3 f16 MFMA products per MAC, fp32 accumulation - same error against fp64
+as the exact-fp32 MFMA kernel); "dtype" says which one ran.
+
 Prints ONE JSON line (rank 0) with the bench contract's fields plus
-  "roofline"     : achieved fp32-MFMA TFLOP/s of the dominant kernel (k_encode_mlp) from HIP-event
-                   timings of that kernel at this workload's sizes, vs the 157.3 TFLOP/s dense peak;
+  "roofline"     : algorithmic TFLOP/s (2 x 659,456 MAC per sample point) of the dominant kernel from
+                   HIP-event timings of its launches at this workload's sizes.  For the f16x3 kernel the
+                   peak is the dense f16 MFMA peak divided by the 3 products it issues per fp32 MAC
+                   (2500 / 3 = 833 TFLOP/s); for the exact-fp32 kernel it is the 157.3 TFLOP/s fp32 MFMA
+                   peak.  "roofline_f32_kernel" always carries the exact-fp32 kernel's figures too;
   "cpu_baseline" : the CPU oracle (PyTorch-CPU restatement == reference, see oracle/) timed on this
                    box's host cores on a bounded sample of the same workload.
 """
@@ -33,6 +40,7 @@ CAMERA_ANGLE_X = 0.6911112070083618          # NeRF-synthetic transforms_*.json
 NEAR, FAR = 2.0, 6.0                         # run_nerf.py:705-706
 FLOP_PER_POINT = 2 * 659456                  # BASELINE.md section 2 (GEMM MACs of one NeRF evaluation)
 PEAK_F32_MFMA_TFLOPS = 157.3                 # MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_F16_MFMA_TFLOPS = 2500.0                # MI355X_MICROARCH.md: dense f16/bf16 matrix peak
 
 
 def chair_pose(theta_deg=40.0, phi_deg=-30.0, radius=4.0):
@@ -170,34 +178,43 @@ def main():
     assert frame["rgb_map"].shape[0] == n_total and torch.isfinite(frame["rgb_map"]).all()
     rays_per_s = n_total * args.steps / dt
 
-    # ---- roofline of the dominant kernel (k_encode_mlp): HIP events around its launches, same sizes ----
-    desc = _capi.net_desc(_capi.VARIANT_OBJECT, 0, 10, 4, 1.0)
-    pc, pf = packing.packed_for_module(net_c, desc, dev), packing.packed_for_module(net_f, desc, dev)
+    # ---- roofline of the dominant kernel: HIP events around its launches, same sizes as the timed region ----
     vd = rd_l / rd_l.norm(dim=-1, keepdim=True)
     rays_l = torch.cat([ro_l, rd_l, NEAR * torch.ones_like(rd_l[:, :1]), FAR * torch.ones_like(rd_l[:, :1]), vd], -1)
     t_vals = torch.linspace(0., 1., N_SAMPLES, device=dev)
     u = torch.linspace(0., 1., N_IMPORTANCE, device=dev)
-    st = kernels.render_rays_fused(desc, pc, pf, rays_l, N_SAMPLES, N_IMPORTANCE, t_vals, u, white_bkgd=True, want_stages=True)
-    z_c, z_f = st["z_coarse"], st["z_fine"]
-    del st
-    torch.cuda.synchronize()
-    ev = lambda: torch.cuda.Event(enable_timing=True)
-    durs = []                                                  # one entry per k_encode_mlp launch [ms]
-    for _ in range(max(1, args.steps)):
-        for packed, z in ((pc, z_c), (pf, z_f)):
-            a, bb = ev(), ev()
-            a.record()
-            kernels.encode_mlp(desc, packed, rays_l, z)
-            bb.record()
-            bb.synchronize()
-            durs.append(a.elapsed_time(bb))
-    avg_ms = sum(durs) / len(durs)
     flop_per_launch = FLOP_PER_POINT * n_local * (N_SAMPLES + (N_SAMPLES + N_IMPORTANCE)) / 2.0   # mean of the two launches
-    achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12
-    roofline = {"bound": "mfma", "kernel": "k_encode_mlp", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                "avg_launch_ms": avg_ms, "launches_timed": len(durs),
-                "flop_per_launch": flop_per_launch}
+
+    def kernel_roofline(prec, reps):
+        desc = _capi.net_desc(_capi.VARIANT_OBJECT, 0, 10, 4, 1.0, prec)
+        pc, pf = packing.packed_for_module(net_c, desc, dev), packing.packed_for_module(net_f, desc, dev)
+        st = kernels.render_rays_fused(desc, pc, pf, rays_l, N_SAMPLES, N_IMPORTANCE, t_vals, u, white_bkgd=True, want_stages=True)
+        z_c, z_f = st["z_coarse"], st["z_fine"]
+        del st
+        torch.cuda.synchronize()
+        durs = []                                              # one entry per launch [ms]
+        for _ in range(reps):
+            for packed, z in ((pc, z_c), (pf, z_f)):
+                a, bb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                kernels.encode_mlp(desc, packed, rays_l, z)
+                bb.record()
+                bb.synchronize()
+                durs.append(a.elapsed_time(bb))
+        avg_ms = sum(durs) / len(durs)
+        achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12
+        f16 = prec == _capi.PREC_F16X3
+        peak = PEAK_F16_MFMA_TFLOPS / 3.0 if f16 else PEAK_F32_MFMA_TFLOPS
+        return {"bound": "mfma", "kernel": "k_encode_mlp_f16x3" if f16 else "k_encode_mlp", "achieved": achieved,
+                "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None, "avg_launch_ms": avg_ms,
+                "launches_timed": len(durs), "flop_per_launch": flop_per_launch,
+                "peak_basis": ("dense f16 MFMA 2500 TFLOP/s / 3 products per fp32 MAC" if f16
+                               else "dense fp32 MFMA 157.3 TFLOP/s"),
+                "achieved_vs_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS}
+
+    prec = _capi.default_precision()
+    roofline = kernel_roofline(prec, max(1, args.steps))
+    roofline_f32 = roofline if prec == _capi.PREC_F32 else kernel_roofline(_capi.PREC_F32, 1)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -207,12 +224,14 @@ def main():
         print(json.dumps({
             "metric": "rays/sec (64+128 samples/ray)", "value": rays_per_s, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32 (operands split into f16 hi+lo, 3 f16 MFMA products per MAC, fp32 accumulate)"
+                     if prec == _capi.PREC_F16X3 else "f32", "data": "synthetic",
             "config": {"workload": "Blender chair 800x800 frame (640000 rays), 64 coarse + 128 importance samples, "
                                    "coarse+fine intrinsic NeRF (D=8, W=256), white_bkgd, eval mode, random-init weights "
                                    "(seeds 0/1)", "rays_per_step": n_total, "parallelism": f"ray-sharded x{world}",
                        "gather": "all_gather of 12 floats/ray" if world > 1 else "none"},
-            "roofline": roofline, "cpu_baseline": cpu}))
+            "roofline": roofline, "roofline_f32_kernel": roofline_f32, "cpu_baseline": cpu}))
     if world > 1:
         dist.destroy_process_group()
 

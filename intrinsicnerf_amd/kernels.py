@@ -76,6 +76,28 @@ def check_f16_range(status, what):
             "results are invalid - re-run with precision f32 (INERF_PRECISION=f32)")
 
 
+_warned_fallback = False
+
+
+def with_f32_fallback(desc, run):
+    """``run(desc)`` and, if the split-precision kernel reports an out-of-range activation, once more in exact fp32.
+
+    ``run`` must call ``check_f16_range`` on its status word (that is the one host sync of the f16x3 mode)."""
+    global _warned_fallback
+    try:
+        return run(desc)
+    except FloatingPointError as e:
+        if desc.precision != _capi.PREC_F16X3:
+            raise
+        if not _warned_fallback:
+            import warnings
+            warnings.warn(f"{e}  Re-running this batch with the exact fp32 MFMA kernel (set INERF_PRECISION=f32 to "
+                          "skip the attempt).")
+            _warned_fallback = True
+        d32 = _capi.NetDesc(desc.variant, desc.n_classes, desc.l_xyz, desc.l_dir, desc.xyz_div, _capi.PREC_F32)
+        return run(d32)
+
+
 def encode_mlp(desc, packed, rays, z_vals, endpoint=False, status=None):
     """raw[N,S,CH]: fused encoding + MLP (run_network + NeRF.forward).
 

@@ -173,9 +173,14 @@ def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64
     rays = torch.zeros(pts.shape[0], _capi.RAY_FLOATS, dtype=torch.float32, device=pts.device)
     rays[:, 0:3], rays[:, 8:11] = pts, dirs
     z = torch.zeros(pts.shape[0], 1, dtype=torch.float32, device=pts.device)
-    status = kernels._new_status(pts) if desc.precision == _capi.PREC_F16X3 else None
-    raw = kernels.encode_mlp(desc, packing.packed_for_module(fn, desc, pts.device), rays, z, status=status)
-    kernels.check_f16_range(status, "run_network")
+
+    def run(d):
+        status = kernels._new_status(pts) if d.precision == _capi.PREC_F16X3 else None
+        out = kernels.encode_mlp(d, packing.packed_for_module(fn, d, pts.device), rays, z, status=status)
+        kernels.check_f16_range(status, "run_network")
+        return out
+
+    raw = kernels.with_f32_fallback(desc, run)
     return torch.reshape(raw, list(inputs.shape[:-1]) + [raw.shape[-1]])
 
 
@@ -260,12 +265,17 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
         u = _draw_u(n, N_importance, perturb == 0., pytest, dev) if N_importance > 0 else None
         noise_f = noise(N_samples + N_importance) if N_importance > 0 else None
         fine_net = network_fine if network_fine is not None else network_fn
-        o = kernels.render_rays_fused(
-            desc, packing.packed_for_module(network_fn, desc, dev),
-            packing.packed_for_module(fine_net, desc, dev) if N_importance > 0 else None,
-            ray_batch, N_samples, N_importance, t_vals, u, t_rand, noise_c, noise_f, white_bkgd, lindisp,
-            want_raw_coarse=retraw and N_importance == 0, want_raw_fine=retraw)
-        kernels.check_f16_range(o.pop("status", None), "render_rays")
+
+        def run(d):
+            res = kernels.render_rays_fused(
+                d, packing.packed_for_module(network_fn, d, dev),
+                packing.packed_for_module(fine_net, d, dev) if N_importance > 0 else None,
+                ray_batch, N_samples, N_importance, t_vals, u, t_rand, noise_c, noise_f, white_bkgd, lindisp,
+                want_raw_coarse=retraw and N_importance == 0, want_raw_fine=retraw)
+            kernels.check_f16_range(res.pop("status", None), "render_rays")
+            return res
+
+        o = kernels.with_f32_fallback(desc, run)
         lvl = "fine" if N_importance > 0 else "coarse"
         ret = {rk: o[f"{ok}_{lvl}"] for rk, ok in _RET_MAP}
         if retraw:

@@ -133,10 +133,15 @@ def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64
     rays = torch.zeros(pts.shape[0], _capi.RAY_FLOATS, dtype=torch.float32, device=pts.device)
     rays[:, 0:3], rays[:, 8:11] = pts, dirs
     z = torch.zeros(pts.shape[0], 1, dtype=torch.float32, device=pts.device)
-    status = kernels._new_status(pts) if desc.precision == _capi.PREC_F16X3 else None
-    raw = kernels.encode_mlp(desc, packing.packed_for_module(fn, desc, pts.device), rays, z, endpoint=show_endpoint,
-                             status=status)
-    kernels.check_f16_range(status, "run_network")
+
+    def run(d):
+        status = kernels._new_status(pts) if d.precision == _capi.PREC_F16X3 else None
+        out = kernels.encode_mlp(d, packing.packed_for_module(fn, d, pts.device), rays, z, endpoint=show_endpoint,
+                                 status=status)
+        kernels.check_f16_range(status, "run_network")
+        return out
+
+    raw = kernels.with_f32_fallback(desc, run)
     return torch.reshape(raw, list(inputs.shape[:-1]) + [raw.shape[-1]])
 
 
@@ -269,13 +274,18 @@ class SSRRenderMixin:
                  else torch.rand(n, self.N_importance, device=dev))
             noise_f = torch.randn(n, self.N_samples + self.N_importance, device=dev) * std if std > 0. else None
         ep = bool(self.endpoint_feat) and self.N_importance > 0
-        o = kernels.render_rays_fused(
-            desc, packing.packed_for_module(self.ssr_net_coarse, desc, dev),
-            packing.packed_for_module(self.ssr_net_fine, desc, dev) if self.N_importance > 0 else None,
-            ray_batch, self.N_samples, self.N_importance, t_vals, u, t_rand, noise_c, noise_f,
-            white_bkgd=self.white_bkgd, endpoint=ep, want_raw_coarse=self.return_raw, want_raw_fine=self.return_raw,
-            want_sem=bool(self.enable_semantic))
-        kernels.check_f16_range(o.pop("status", None), "volumetric_rendering")
+
+        def run(d):
+            res = kernels.render_rays_fused(
+                d, packing.packed_for_module(self.ssr_net_coarse, d, dev),
+                packing.packed_for_module(self.ssr_net_fine, d, dev) if self.N_importance > 0 else None,
+                ray_batch, self.N_samples, self.N_importance, t_vals, u, t_rand, noise_c, noise_f,
+                white_bkgd=self.white_bkgd, endpoint=ep, want_raw_coarse=self.return_raw, want_raw_fine=self.return_raw,
+                want_sem=bool(self.enable_semantic))
+            kernels.check_f16_range(res.pop("status", None), "volumetric_rendering")
+            return res
+
+        o = kernels.with_f32_fallback(desc, run)
         ret = {}
         if self.return_raw:
             ret["raw_coarse"] = o["raw_coarse"]

@@ -127,7 +127,8 @@ def _layout(variant, c):
 @pytest.mark.parametrize("variant,c", [("object", 0), ("ssr", 28), ("ssr", 101), ("ssr", 0)])
 def test_packer_layout(capi, variant, c):
     from intrinsicnerf_amd import packing
-    desc = capi.net_desc(capi.VARIANT_SSR if variant == "ssr" else capi.VARIANT_OBJECT, c, 10, 4, 10.0 if variant == "ssr" else 1.0)
+    desc = capi.net_desc(capi.VARIANT_SSR if variant == "ssr" else capi.VARIANT_OBJECT, c, 10, 4, 10.0 if variant == "ssr" else 1.0,
+                         precision=capi.PREC_F32)
     sd = oracle.make_state_dict(variant, c, seed=11)
     blob = packing.pack_state_dict(desc, sd).numpy()
     slots, total = _layout(variant, c)
@@ -283,7 +284,7 @@ def test_packer_rejects_bad_state_dicts(capi):
 def test_reduced_encoding_widths_pack(capi):
     """multires < 10 / multires_views < 4: narrower first-layer inputs land in the same padded columns."""
     from intrinsicnerf_amd import packing
-    desc = capi.net_desc(capi.VARIANT_OBJECT, 0, 6, 2, 1.0)
+    desc = capi.net_desc(capi.VARIANT_OBJECT, 0, 6, 2, 1.0, precision=capi.PREC_F32)
     table = dict(packing.tensor_table(desc))
     assert table["pts_linears.0.weight"] == (256, 39) and table["pts_linears.5.weight"] == (256, 295)
     assert table["views_linears.0.weight"] == (128, 271)

@@ -312,7 +312,7 @@ def test_f16_range_guard(precision):
     from intrinsicnerf_amd import _capi, kernels, packing
     dev = _dev()
     sd = oracle.make_state_dict("object", 0, seed=5)
-    sd["pts_linears.0.bias"] = sd["pts_linears.0.bias"] + 1.0e5          # h1 ~ 1e5 > 65504
+    sd["pts_linears.0.bias"] = sd["pts_linears.0.bias"] + 1.0e5          # 8 * h1 ~ 8e5 > 65504
     cfg = oracle.RenderConfig(variant="object")
     desc = _desc(cfg)
     rays = torch.rand(8, 11)
@@ -328,6 +328,27 @@ def test_f16_range_guard(precision):
         pts = rays[:, None, 0:3] + rays[:, None, 3:6] * z[:, :, None]
         want = oracle.query_network(sd, pts, rays[:, 8:11], cfg)
         assert_maps_close(raw.cpu().numpy(), want.numpy(), RTOL, 1e-4 * float(want.abs().max()), "raw with huge activations")
+
+
+def test_frontend_falls_back_to_f32_on_range(precision):
+    """A network whose activations leave f16's range still renders correctly through the front-end: the
+    split-precision attempt is detected (status word) and the batch re-run on the exact fp32 kernel."""
+    import warnings
+    from intrinsicnerf_amd import object_level as ol
+    dev = _dev()
+    sd = oracle.make_state_dict("object", 0, seed=5)
+    sd["pts_linears.0.bias"] = sd["pts_linears.0.bias"] + 2.0e4                # 8 * h1 > 6e4
+    embed, ch = ol.get_embedder(10, 0); embed_d, ch_d = ol.get_embedder(4, 0)
+    net = ol.NeRF(D=8, W=256, input_ch=ch, output_ch=5, skips=[4], input_ch_views=ch_d, use_viewdirs=True).to(dev)
+    net.load_state_dict(sd)
+    g = torch.Generator().manual_seed(2)
+    pts = torch.randn(40, 5, 3, generator=g)
+    vd = torch.randn(40, 3, generator=g)
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = ol.run_network(pts.to(dev), vd.to(dev), net, embed, embed_d)
+        want = oracle.query_network(sd, pts, vd, oracle.RenderConfig(variant="object"))
+    assert_maps_close(got.cpu().numpy(), want.numpy(), RTOL, 1e-4 * float(want.abs().max()), "fallback raw")
 
 
 def test_gradients_fail_loudly():
