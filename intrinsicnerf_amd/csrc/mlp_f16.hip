@@ -172,12 +172,17 @@ __device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const Weigh
 }
 
 // epilogue: t = acc * inv + bias' (= kActScale * layer output; optionally ReLU) -> hi/lo planes;
-// optional fp32 copy of the unscaled value to global
+// optional fp32 copy of the unscaled value to global.
+// Split by truncation: t_hi = t with the 13 low mantissa bits cleared is exactly representable in f16 (for
+// |t| in f16's normal range), so hi = f16(t_hi) needs no rounding and lo = f16(t - t_hi) is the exact
+// remainder rounded once - one AND and one SUB per element instead of convert / convert back / subtract.
+// Range check: packed f16 max over the |hi| pairs (inf when |t| > 65504).
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
 template <int RB>
-__device__ __forceinline__ void wide_store_h(const f32x16 (&am)[RB][2], const WidePreH<RB>& pre_unused, float inv,
-                                             const f32x4 (&bias)[RB][4],
+__device__ __forceinline__ void wide_store_h(const f32x16 (&am)[RB][2], float inv, const f32x4 (&bias)[RB][4],
                                              _Float16* dl,   // plane_hi + (lane&31)*kRowH + 4*(lane>>5) + dcol + chan0
-                                             bool relu, float& amax, float* gout /* or nullptr: + chan0 + 4*(lane>>5) */,
+                                             bool relu, f16x2& amax2, float* gout /* or nullptr: + chan0 + 4*(lane>>5) */,
                                              int gstride, int valid0, int valid1) {
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
@@ -185,21 +190,25 @@ __device__ __forceinline__ void wide_store_h(const f32x16 (&am)[RB][2], const Wi
         for (int pb = 0; pb < 2; ++pb) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                f16x4 hi4, lo4;
-                float t[4];
+                float t[4], th[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     t[i] = __builtin_fmaf(am[rb][pb][4 * g + i], inv, bias[rb][g][i]);
                     if (relu) t[i] = fmaxf(t[i], 0.0f);
-                    const _Float16 h = (_Float16)t[i];
-                    hi4[i] = h;
-                    lo4[i] = (_Float16)(t[i] - (float)h);
+                    th[i] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, t[i]) & 0xFFFFE000u);
                     if (gout && (pb == 0 ? valid0 : valid1))
                         gout[(size_t)pb * 32 * gstride + 32 * rb + 8 * g + i] = t[i] * (1.0f / kActScale);
                 }
-                // |t| range check, two values per v_max3 (ReLU outputs need no abs, but the modifier is free)
-                amax = fmaxf(fmaxf(amax, fabsf(t[0])), fabsf(t[1]));
-                amax = fmaxf(fmaxf(amax, fabsf(t[2])), fabsf(t[3]));
+                const f16x2 h01 = {(_Float16)th[0], (_Float16)th[1]}, h23 = {(_Float16)th[2], (_Float16)th[3]};
+                const f16x2 l01 = {(_Float16)(t[0] - th[0]), (_Float16)(t[1] - th[1])};
+                const f16x2 l23 = {(_Float16)(t[2] - th[2]), (_Float16)(t[3] - th[3])};
+                f16x2 a01 = h01, a23 = h23;
+                if (!relu) {     // ReLU outputs are non-negative already
+                    a01 = __builtin_bit_cast(f16x2, __builtin_bit_cast(unsigned, h01) & 0x7FFF7FFFu);
+                    a23 = __builtin_bit_cast(f16x2, __builtin_bit_cast(unsigned, h23) & 0x7FFF7FFFu);
+                }
+                amax2 = __builtin_elementwise_max(amax2, __builtin_elementwise_max(a01, a23));
+                const f16x4 hi4 = {h01[0], h01[1], h23[0], h23[1]}, lo4 = {l01[0], l01[1], l23[0], l23[1]};
                 _Float16* d = dl + pb * 32 * kRowH + 32 * rb + 8 * g;
                 *reinterpret_cast<f16x4*>(d) = hi4;
                 *reinterpret_cast<f16x4*>(d + kPlaneH) = lo4;
@@ -248,7 +257,8 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float* __restrict__ wts = p.wts;
     const NetLayout& L = p.L;
-    float amax = 0.0f;
+    float amax = 0.0f;                          // encoder inputs (fp32 running max of |scaled value|)
+    f16x2 amax2 = {(_Float16)0.0f, (_Float16)0.0f};   // layer outputs (packed f16 running max of |hi|)
 
     _Float16* const xw = ldsh + (lane & 31) * kRowH;                                   // + 8*(lane>>5) for reads, 4*(lane>>5) for writes
     const _Float16* const xr = xw + 8 * (lane >> 5);
@@ -333,7 +343,7 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
             const float inv = pre2.inv;
             wide_gemm_h<2, KB0, KB1>(pre2, wb, frag256(s, KB0 + KB1), xr, c0, c1, lane, am);
             prefetch_next();
-            wide_store_h<2>(am, pre2, inv, bias, xd + dcol + 64 * wave, relu, amax, nullptr, 0, 0, 0);
+            wide_store_h<2>(am, inv, bias, xd + dcol + 64 * wave, relu, amax2, nullptr, 0, 0, 0);
             __syncthreads();
         };
         auto step128 = [&](const GemmSlot& s, auto kb0c, auto kb1c, int c0, int c1, int dcol, bool relu, float* gout,
@@ -346,7 +356,7 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
             const float inv = pre1.inv;
             wide_gemm_h<1, KB0, KB1>(pre1, wb, frag128(s, KB0 + KB1), xr, c0, c1, lane, am);
             prefetch_next();
-            wide_store_h<1>(am, pre1, inv, bias, xd + dcol + 32 * wave, relu, amax, gout, p.channels, pt0 < p.n_points,
+            wide_store_h<1>(am, inv, bias, xd + dcol + 32 * wave, relu, amax2, gout, p.channels, pt0 < p.n_points,
                             pt0 + 32 < p.n_points);
             __syncthreads();
         };
@@ -418,7 +428,8 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
             __builtin_nontemporal_store(r0, out_row + 8); __builtin_nontemporal_store(r1, out_row + 9); __builtin_nontemporal_store(r2, out_row + 10);
         }
     }
-    if (p.status && __any(!(amax <= kF16Safe)) && lane == 0) atomicOr(p.status, INERF_STATUS_F16_RANGE);
+    const float amax_all = fmaxf(amax, fmaxf((float)amax2[0], (float)amax2[1]));
+    if (p.status && __any(!(amax_all <= kF16Safe)) && lane == 0) atomicOr(p.status, INERF_STATUS_F16_RANGE);
 }
 
 int launch_mlp_f16x3(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream) {

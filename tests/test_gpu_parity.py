@@ -80,13 +80,44 @@ def test_fused_path_matches_reference(name):
             got = out[k].cpu().numpy()
             if k.startswith("raw"):
                 got = got[: want.shape[0]]
+            if k == "raw_fine" and cfg.n_importance > 0:
+                continue          # per-sample tensor at resampled depths: checked stage-wise (test_fine_stage_...)
             assert_maps_close(got, want, _rtol(k), ATOL, f"{name}:{k}")
             checked += 1
         elif key.startswith("stage_") and key != "stage_raw_coarse":
             k = key[6:]
+            if k == "weights_fine":
+                continue          # per-sample tensor at resampled depths: checked stage-wise (test_fine_stage_...)
             assert_maps_close(out[k].cpu().numpy(), want, RTOL, ATOL, f"{name}:stage {k}", extra=z_extra.get(k))
             checked += 1
-    assert checked >= 9
+    assert checked >= 8
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names("object_") + golden_names("ssr_") if "coarse_only" not in n])
+def test_fine_stage_on_reference_depths(name):
+    """Stage-wise parity of the fine pass: the HIP MLP and compositing kernels are fed the REFERENCE's merged depths
+    (fixture ``z_fine``), so their per-sample outputs (raw_fine, weights_fine) can be held to the plain tolerance -
+    in an end-to-end run those tensors sit downstream of sample_pdf's 1/denom amplification."""
+    from intrinsicnerf_amd import kernels
+    fx = load_golden(name)
+    cfg = case_config(fx)
+    _, sd_f = case_weights(fx)
+    dev = _dev()
+    k = fx["ref_raw_fine"].shape[0]                       # rays whose reference raw_fine is stored
+    rays = torch.from_numpy(fx["rays"][:k]).to(dev)
+    z_fine = torch.from_numpy(fx["stage_z_fine"][:k]).to(dev)
+    raw = kernels.encode_mlp(_desc(cfg), _packed(cfg, sd_f), rays, z_fine, endpoint=cfg.endpoint_feat)
+    scale = np.abs(fx["ref_raw_fine"]).max(axis=(0, 1), keepdims=True)       # per-channel magnitude (sigma has cancellation)
+    assert_maps_close(raw.cpu().numpy(), fx["ref_raw_fine"], RTOL, ATOL, f"{name}:raw_fine", extra=RTOL * scale)
+    noise = torch.from_numpy(fx["in_noise_fine"][:k]).to(dev) if "in_noise_fine" in fx else None
+    ssr = cfg.variant == "ssr"
+    comp = kernels.composite(torch.from_numpy(fx["ref_raw_fine"]).to(dev), z_fine, rays[:, 3:6].contiguous(), noise,
+                             cfg.white_bkgd, n_classes=cfg.n_classes if ssr else 0,
+                             feat_dim=128 if (ssr and cfg.endpoint_feat) else 0)
+    assert_maps_close(comp["weights"].cpu().numpy(), fx["stage_weights_fine"][:k], RTOL, ATOL, f"{name}:weights_fine")
+    for key in ("rgb", "acc", "depth", "albedo", "shading", "residual", "sem", "feat"):
+        if "ref_" + key + "_fine" in fx and key in comp:
+            assert_maps_close(comp[key].cpu().numpy(), fx["ref_" + key + "_fine"][:k], RTOL, ATOL, f"{name}:{key}_fine (stage)")
 
 
 # ------------------------------------------------------------------------------------------------
