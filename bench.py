@@ -41,6 +41,9 @@ NEAR, FAR = 2.0, 6.0                         # run_nerf.py:705-706
 FLOP_PER_POINT = 2 * 659456                  # BASELINE.md section 2 (GEMM MACs of one NeRF evaluation)
 PEAK_F32_MFMA_TFLOPS = 157.3                 # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_F16_MFMA_TFLOPS = 2500.0                # MI355X_MICROARCH.md: dense f16/bf16 matrix peak
+# HBM bytes per sample point of the encode+MLP kernels from the PMC passes (FETCH_SIZE + WRITE_SIZE, separate
+# passes) in profiles/r01_mlp_pmc_traffic.txt: 311.6 MB per 6,291,456-point launch (algorithmic: 306 MB).
+PMC_HBM_BYTES_PER_POINT = 49.5
 
 
 def chair_pose(theta_deg=40.0, phi_deg=-30.0, radius=4.0):
@@ -121,12 +124,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
+    # one process per GPU.  INERF_BENCH_SHARE_GPU=1 (debug only) lets several ranks share device 0 over gloo, to
+    # exercise the sharding + gather logic on a single-GPU box; the numbers it prints mean nothing.
+    share = os.environ.get("INERF_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if share else "nccl", rank=rank, world_size=world)
 
     import __graft_entry__
     __graft_entry__.build()
@@ -176,6 +184,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert frame["rgb_map"].shape[0] == n_total and torch.isfinite(frame["rgb_map"]).all()
+    if world > 1:   # every rank must hold the same full frame, and its own band must be what it rendered
+        chk = torch.tensor([float(frame["rgb_map"].double().sum()), float(frame["acc_map"].double().sum())],
+                           device=dev, dtype=torch.float64)
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert torch.equal(lo, hi), "ranks disagree on the gathered frame"
     rays_per_s = n_total * args.steps / dt
 
     # ---- roofline of the dominant kernel: HIP events around its launches, same sizes as the timed region ----
@@ -206,7 +221,11 @@ def main():
         f16 = prec == _capi.PREC_F16X3
         peak = PEAK_F16_MFMA_TFLOPS / 3.0 if f16 else PEAK_F32_MFMA_TFLOPS
         return {"bound": "mfma", "kernel": "k_encode_mlp_f16x3" if f16 else "k_encode_mlp", "achieved": achieved,
-                "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None, "avg_launch_ms": avg_ms,
+                "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                "traffic": PMC_HBM_BYTES_PER_POINT * n_local * (N_SAMPLES + (N_SAMPLES + N_IMPORTANCE)) / 2.0,
+                "traffic_note": "HBM bytes per launch = 49.5 B/point measured by rocprofv3 PMC (FETCH_SIZE, WRITE_SIZE in "
+                                "separate passes, profiles/r01_mlp_pmc_traffic.txt) x this launch's points; 1.02x algorithmic",
+                "avg_launch_ms": avg_ms,
                 "launches_timed": len(durs), "flop_per_launch": flop_per_launch,
                 "peak_basis": ("dense f16 MFMA 2500 TFLOP/s / 3 products per fp32 MAC" if f16
                                else "dense fp32 MFMA 157.3 TFLOP/s"),

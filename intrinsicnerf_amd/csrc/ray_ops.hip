@@ -257,18 +257,47 @@ __global__ __launch_bounds__(256) void k_sample_fine(const float* __restrict__ z
     __threadfence_block();
 
     // z_vals, _ = sort(cat([z_vals, z_samples]))                               (run_nerf.py:503)
-    // rank sort: position = #(elements ordered before this one); ties broken by index (stable)
     if (!kDirect && z_merged) {
         const int n = sc + ni;
         float* __restrict__ zo = z_merged + ray * (long long)n;
-        for (int e = lane; e < n; e += 64) {
-            const float ve = sm.vals[e];
-            int rank = 0;
-            for (int f = 0; f < n; ++f) {
-                const float vf = sm.vals[f];      // same address in every lane: LDS broadcast
-                rank += (less_nan_last(vf, ve) || (!less_nan_last(ve, vf) && f < e)) ? 1 : 0;
+        // Both lists are normally already ascending (coarse depths by construction, new samples because the
+        // inverse CDF is monotone in an ascending u): then the sort is a MERGE and every element finds its slot
+        // with one binary search in the other list.  Any NaN or inversion (random u) fails the check below and
+        // takes the general stable rank sort instead.  Either way the output is the ascending multiset.
+        bool ascending = true;
+        for (int i = lane; i < sc - 1; i += 64) ascending &= sm.vals[i] <= sm.vals[i + 1];
+        for (int j = lane; j < ni - 1; j += 64) ascending &= sm.vals[sc + j] <= sm.vals[sc + j + 1];
+        if (lane == 0) ascending &= sm.vals[0] == sm.vals[0] && sm.vals[sc] == sm.vals[sc];      // a lone NaN (n == 1)
+        if (__all(ascending)) {
+            for (int i = lane; i < sc; i += 64) {           // coarse element: after the samples strictly below it
+                const float v = sm.vals[i];
+                int lo = 0, hi = ni;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (sm.vals[sc + mid] < v) lo = mid + 1; else hi = mid;
+                }
+                zo[i + lo] = v;
             }
-            zo[rank] = ve;
+            for (int j = lane; j < ni; j += 64) {           // new sample: after the coarse depths not above it
+                const float v = sm.vals[sc + j];
+                int lo = 0, hi = sc;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (sm.vals[mid] <= v) lo = mid + 1; else hi = mid;
+                }
+                zo[j + lo] = v;
+            }
+        } else {
+            // rank sort: position = #(elements ordered before this one); ties broken by index (stable)
+            for (int e = lane; e < n; e += 64) {
+                const float ve = sm.vals[e];
+                int rank = 0;
+                for (int f = 0; f < n; ++f) {
+                    const float vf = sm.vals[f];      // same address in every lane: LDS broadcast
+                    rank += (less_nan_last(vf, ve) || (!less_nan_last(ve, vf) && f < e)) ? 1 : 0;
+                }
+                zo[rank] = ve;
+            }
         }
     }
 }

@@ -269,14 +269,24 @@ def test_sample_fine_merge_sorted_and_std():
     n = z.shape[0]
     g = torch.Generator().manual_seed(4)
     wfull = torch.rand(n, 64, generator=g)
-    u = torch.rand(n, 128, generator=g)
-    zs, zm, zstd = kernels.sample_fine(z, wfull.to(dev), u.to(dev), 128)
+    wfull[3, 10:50] = 0.0                                   # empty bins: many samples collapse onto bin edges (ties)
     bins = 0.5 * (z[:, 1:] + z[:, :-1]).cpu()
-    want = oracle.inverse_cdf_sample(bins, wfull[:, 1:-1], u)
-    assert_maps_close(zs.cpu().numpy(), want.numpy(), RTOL, ATOL, "z_samples")
-    merged = torch.sort(torch.cat([z.cpu(), zs.cpu()], -1), -1)[0]
-    assert torch.equal(zm.cpu(), merged)                    # a permutation of its own inputs, ascending: bit-exact
-    assert_maps_close(zstd.cpu().numpy(), torch.std(want, -1, unbiased=False).numpy(), RTOL, ATOL, "z_std")
+    u_ties = torch.linspace(0., 1., 128).clone(); u_ties[40:60] = u_ties[40]
+    cases = {"random u (general rank sort)": torch.rand(n, 128, generator=g),
+             "ascending u (merge path)": torch.linspace(0., 1., 128),
+             "ascending u with ties": u_ties}
+    for tag, u in cases.items():
+        zs, zm, zstd = kernels.sample_fine(z, wfull.to(dev), u.to(dev), 128)
+        want = oracle.inverse_cdf_sample(bins, wfull[:, 1:-1], u if u.dim() == 2 else u.expand(n, 128))
+        assert_maps_close(zs.cpu().numpy(), want.numpy(), RTOL, ATOL, f"z_samples, {tag}")
+        merged = torch.sort(torch.cat([z.cpu(), zs.cpu()], -1), -1)[0]
+        assert torch.equal(zm.cpu(), merged), tag           # a permutation of its own inputs, ascending: bit-exact
+        assert_maps_close(zstd.cpu().numpy(), torch.std(want, -1, unbiased=False).numpy(), RTOL, ATOL, f"z_std, {tag}")
+    # a NaN among the inputs must not hang or corrupt the other rays (torch.sort puts NaN last)
+    zbad = z.clone(); zbad[5, 7] = float("nan")
+    zs, zm, _ = kernels.sample_fine(zbad, wfull.to(dev), torch.linspace(0., 1., 128).to(dev), 128)
+    ref = torch.sort(torch.cat([zbad.cpu(), zs.cpu()], -1), -1)[0]
+    assert torch.equal(torch.nan_to_num(zm.cpu(), nan=-1.0), torch.nan_to_num(ref, nan=-1.0))
 
 
 @pytest.mark.parametrize("variant,c,s", [("object", 0, 64), ("object", 0, 192), ("ssr", 28, 64), ("ssr", 3, 50)])
