@@ -235,6 +235,22 @@ def main():
     roofline = kernel_roofline(prec, max(1, args.steps))
     roofline_f32 = roofline if prec == _capi.PREC_F32 else kernel_roofline(_capi.PREC_F32, 1)
 
+    # the same frame through the product front-end with the exact-fp32 MFMA kernel, for reference (one timed step)
+    exact = None
+    if prec != _capi.PREC_F32:
+        os.environ["INERF_PRECISION"] = "f32"
+        step(); fence()
+        t1 = time.perf_counter()
+        step(); fence()
+        dt32 = time.perf_counter() - t1
+        os.environ["INERF_PRECISION"] = "f16x3"
+        if world > 1:
+            t = torch.tensor([dt32], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt32 = float(t.item())
+        exact = {"value": n_total / dt32, "unit": "rays/s", "ms_per_step": dt32 * 1e3, "steps": 1,
+                 "note": "whole path with INERF_PRECISION=f32 (v_mfma_f32_32x32x2_f32 everywhere)"}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -250,7 +266,7 @@ def main():
                                    "coarse+fine intrinsic NeRF (D=8, W=256), white_bkgd, eval mode, random-init weights "
                                    "(seeds 0/1)", "rays_per_step": n_total, "parallelism": f"ray-sharded x{world}",
                        "gather": "all_gather of 12 floats/ray" if world > 1 else "none"},
-            "roofline": roofline, "roofline_f32_kernel": roofline_f32, "cpu_baseline": cpu}))
+            "roofline": roofline, "roofline_f32_kernel": roofline_f32, "exact_f32_path": exact, "cpu_baseline": cpu}))
     if world > 1:
         dist.destroy_process_group()
 

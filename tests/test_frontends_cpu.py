@@ -103,3 +103,44 @@ def test_unknown_network_is_called_like_the_reference_does():
         return e[:, :4]
     out = ol.run_network(torch.rand(5, 3, 3), torch.rand(5, 3), fn, embed, embed_d, netchunk=4)
     assert out.shape == (5, 3, 4) and len(calls) == 4 and calls[0] == (4, 15 + 9)
+
+
+def test_reference_checkpoint_files_load(tmp_path):
+    """Checkpoints in the reference's on-disk formats load into the mirror modules unchanged:
+    object-level ``{:06d}.tar`` (run_nerf.py:1037-1042) and SSR ``{:06d}.ckpt`` (trainer.py:1042-1047)."""
+    from intrinsicnerf_amd import object_level as ol, ssr
+    sd_c, sd_f = oracle.make_state_dict("object", seed=1), oracle.make_state_dict("object", seed=2)
+    tar = tmp_path / "200000.tar"
+    torch.save({"global_step": 200000, "network_fn_state_dict": sd_c, "network_fine_state_dict": sd_f,
+                "optimizer_state_dict": {}}, tar)
+    ck = torch.load(tar)
+    net, fine = (ol.NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True) for _ in range(2))
+    net.load_state_dict(ck["network_fn_state_dict"]); fine.load_state_dict(ck["network_fine_state_dict"])
+    assert torch.equal(net.shading_linear.weight, sd_c["shading_linear.weight"])       # the residual head keeps its odd name
+    c = 13
+    ssd = oracle.make_state_dict("ssr", c, seed=3)
+    ckpt = tmp_path / "010000.ckpt"
+    torch.save({"global_step": 10000, "network_coarse_state_dict": ssd, "network_fine_state_dict": ssd, "optimizer_state_dict": {}}, ckpt)
+    snet = ssr.Semantic_NeRF(True, c, D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+    snet.load_state_dict(torch.load(ckpt)["network_coarse_state_dict"])
+    assert torch.equal(snet.semantic_linear[1].bias, ssd["semantic_linear.1.bias"])
+    # and the packer consumes exactly these dicts (both precisions)
+    from intrinsicnerf_amd import _capi, packing
+    for prec in (_capi.PREC_F32, _capi.PREC_F16X3):
+        blob = packing.pack_state_dict(_capi.net_desc(_capi.VARIANT_SSR, c, 10, 4, 10.0, prec), snet.state_dict())
+        assert blob.dtype == torch.float32 and torch.isfinite(blob).all()
+
+
+def test_create_nerf_kwargs():
+    """create_nerf returns the reference's render kwargs (run_nerf.py:334-354) with an inspectable query object."""
+    import types
+    from intrinsicnerf_amd import object_level as ol
+    args = types.SimpleNamespace(multires=10, multires_views=4, i_embed=0, use_viewdirs=True, N_importance=128, N_samples=64,
+                                 netdepth=8, netwidth=256, netdepth_fine=8, netwidth_fine=256, netchunk=65536, perturb=1.0,
+                                 white_bkgd=True, raw_noise_std=0.0, lindisp=False, dataset_type="blender", no_ndc=False)
+    train, test, grad_vars = ol.create_nerf(args, device=torch.device("cpu"))
+    assert set(train) == {"network_query_fn", "perturb", "N_importance", "network_fine", "N_samples", "network_fn",
+                          "use_viewdirs", "white_bkgd", "raw_noise_std", "ndc", "lindisp"}
+    assert test["perturb"] is False and test["raw_noise_std"] == 0. and train["perturb"] == 1.0
+    assert isinstance(train["network_query_fn"], ol.NetworkQuery) and len(grad_vars) == 2 * 32
+    assert train["network_fn"].fused_desc() is not None and train["network_fine"] is not train["network_fn"]

@@ -400,3 +400,50 @@ def test_gradients_fail_loudly():
     rays = torch.rand(4, 11, device=dev)
     with pytest.raises(NotImplementedError):
         ol.render_rays(rays, net, ol.NetworkQuery(embed, embed_d), 64)
+
+
+# ------------------------------------------------------------------------------------------------
+# awkward shapes and reduced encoders
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", range(6))
+def test_randomized_shapes_and_flags(seed):
+    """Whole path vs the oracle over odd ray counts, sample counts that do not divide the 64-point tile, 1-sample
+    importance passes, reduced multires / multires_views, lindisp, shared coarse/fine network, random C."""
+    from intrinsicnerf_amd import _capi, kernels, packing
+    rng = np.random.RandomState(100 + seed)
+    variant = "ssr" if seed % 2 else "object"
+    n = int(rng.randint(1, 90))
+    s_c = int(rng.choice([5, 17, 33, 64, 100]))
+    n_imp = int(rng.choice([0, 1, 7, 64, 128, 150]))
+    l_xyz, l_dir = int(rng.randint(0, 11)), int(rng.randint(0, 5))
+    c = int(rng.randint(1, 40)) if variant == "ssr" else 0
+    cfg = oracle.RenderConfig(variant=variant, n_samples=s_c, n_importance=n_imp, l_xyz=l_xyz, l_dir=l_dir,
+                              white_bkgd=bool(rng.randint(2)), lindisp=bool(rng.randint(2)) and variant == "object",
+                              n_classes=c, endpoint_feat=bool(rng.randint(2)) and variant == "ssr" and n_imp > 0)
+    g = torch.Generator().manual_seed(200 + seed)
+    o = torch.tensor([[2.5, 1.5, 2.0]]).expand(n, 3) * (10.0 if variant == "ssr" else 1.0) * 0.3
+    d = -o / o.norm(dim=-1, keepdim=True) + 0.2 * torch.randn(n, 3, generator=g)
+    near, far = (2.0, 6.0) if variant == "object" else (0.1, 10.0)
+    rays = torch.cat([o, d, near * torch.ones(n, 1), far * torch.ones(n, 1), d / d.norm(dim=-1, keepdim=True)], -1)
+    kw = dict(sigma_gain_log2=5, freq_decay=True, l_xyz=l_xyz, l_dir=l_dir)
+    sd_c = oracle.lcg_state_dict(variant, c, seed=300 + seed, sigma_bias=0.25, **kw)
+    sd_f = sd_c if seed % 3 == 0 else oracle.lcg_state_dict(variant, c, seed=400 + seed, sigma_bias=0.25, **kw)
+    t_vals = torch.linspace(0., 1., s_c)
+    u = torch.linspace(0., 1., n_imp) if n_imp > 0 else None
+    with torch.no_grad():
+        want = oracle.render_rays(rays, sd_c, sd_f, cfg, t_vals=t_vals, u=u)
+    ok = (oracle.conditioning_scores(rays, sd_c, sd_f, cfg, t_vals, stage_keys=()) <= 0.2).numpy()
+    if ok.sum() == 0:
+        pytest.skip("no well-conditioned ray in this draw")
+    dev = _dev()
+    desc = _capi.net_desc(_capi.VARIANT_SSR if variant == "ssr" else _capi.VARIANT_OBJECT, c, l_xyz, l_dir, cfg.xyz_div)
+    pc = packing.pack_state_dict(desc, sd_c).to(dev)
+    pf = None if sd_f is sd_c else packing.pack_state_dict(desc, sd_f).to(dev)
+    got = kernels.render_rays_fused(desc, pc, pf, rays.to(dev), s_c, n_imp, t_vals.to(dev), None if u is None else u.to(dev),
+                                    white_bkgd=cfg.white_bkgd, lindisp=cfg.lindisp, endpoint=cfg.endpoint_feat)
+    kernels.check_f16_range(got.pop("status", None), "test")
+    for k, w in want.items():
+        if k in got:
+            assert_maps_close(got[k].cpu().numpy()[ok], w.numpy()[ok], _rtol(k), ATOL,
+                              f"seed {seed} {variant} n={n} S={s_c}+{n_imp} L={l_xyz}/{l_dir} C={c}: {k}")
+    assert {k for k in want if not k.startswith(("raw", "z_", "weights"))} - {"z_std"} <= set(got) | {"z_std"}
