@@ -49,6 +49,12 @@ constexpr int kLdsBytes = kTilePoints * kLdsStride * 4;   // 156,672 B of the CU
 // Activations travel scaled by kActScale, so the float after a bias vector holds the factor that maps
 // the f16 kernel's accumulator back: 2^-kw for wide GEMMs (whose biases are stored pre-multiplied by
 // kActScale, the output staying in the scaled domain) and 2^-kw / kActScale for the skinny output heads.
+// "Register-operand" copies of the two output heads that follow a hidden layer (as2r, resr; f16 format only,
+// zero otherwise): the two-workgroups-per-CU kernel keeps that hidden layer in registers - the accumulator
+// layout of v_mfma_f32_32x32x16_f16 read back as the B operand of the next MFMA - so the head's weights are
+// stored as 32x16 A fragments whose k order follows the accumulator registers:
+//     [wave][q][hi|lo][lane][8 halfs],  row = lane & 31 (zero beyond the head's rows),
+//     hidden channel = wave * 16*Q + regop_chan(q, lane >> 5, c),  Q = k-blocks per wave (4: as2r, 2: resr).
 // Virtual k runs over the concatenation of the layer's LDS source segments (e.g. [enc64 | h256] for
 // pts_linears[5]); padded columns/rows hold zeros.  Biases are stored unpermuted (padded with zeros).
 constexpr float kActScale = 8.0f;   // INERF_PREC_F16X3: activations are split as f16 hi/lo of (8 * value)
@@ -68,9 +74,16 @@ struct NetLayout {
     GemmSlot feat;            // feature_linear                        wide, 256 out, K=256
     GemmSlot views;           // views_linears.0 over [feature256 | dir32]   wide, 128 out, K=288
     GemmSlot res;             // residual head                         skinny, K=128
+    GemmSlot as2r;            // as2 again, as register-operand fragments (w only; bias/scale are as2's)
+    GemmSlot resr;            // res again, as register-operand fragments (w only; bias/scale are res's)
     int32_t sem_rbs;          // ceil(C/16), 0 when the semantic head is absent
     int32_t total_floats;
 };
+
+// hidden channel (within a wave's block of channels) that slot s of lane-half h of k-block q carries when a
+// 32x32 accumulator (register j: row (j&3) + 8*(j>>2) + 4*h) is reused as a B operand (registers 8*(q&1) .. +7
+// of row block q>>1)
+inline int regop_chan(int q, int h, int s) { return 32 * (q >> 1) + 8 * (2 * (q & 1) + (s >> 2)) + 4 * h + (s & 3); }
 
 inline int trunk_k(int layer) { return layer == 0 ? kEncCols : (layer == kSkipInput ? kEncCols + kWidth : kWidth); }
 
@@ -94,6 +107,8 @@ inline NetLayout make_layout(const inerf_net_desc& net) {
     wide(L.feat, kWidth, kWidth);
     wide(L.views, kHalf, kWidth + kDirCols);
     skinny(L.res, 1, kHalf);
+    L.as2r.w = take(32 * kWidth);   L.as2r.b = L.as2.b;      // 4 waves x 4 k-blocks x (hi + lo) KiB
+    L.resr.w = take(32 * kHalf);    L.resr.b = L.res.b;      // 4 waves x 2 k-blocks x (hi + lo) KiB
     L.total_floats = off;
     return L;
 }

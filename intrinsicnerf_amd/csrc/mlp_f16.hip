@@ -18,6 +18,8 @@
 // LDS: two planes (hi, lo) of X[64 points][616 halfs]; 616*2 B = 77*16 B, so the 16 rows a
 // ds_read_b128 lane group touches fall on 16 distinct bank slots.  Columns as in layout.h
 // (enc 64 | dir 32 | A 256 | B 256).  157,696 B per workgroup, one workgroup per CU.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "mlp_common.h"
@@ -57,11 +59,12 @@ constexpr float kF16Safe = 6.0e4f;             // on the scaled value (kActScale
 // `amax` is a per-thread running maximum of |v| over everything that was split into f16; it is compared
 // with the representable range once, at the end of the kernel (a per-value compare-and-flag made the
 // compiler keep every |v| alive and spill).
+template <int PLANE = kPlaneH>
 __device__ __forceinline__ void split_store(_Float16* hi_ptr, float v, float& amax) {
     const float t = v * kActScale;
     const _Float16 h = (_Float16)t;
     hi_ptr[0] = h;
-    hi_ptr[kPlaneH] = (_Float16)(t - (float)h);
+    hi_ptr[PLANE] = (_Float16)(t - (float)h);
     amax = fmaxf(amax, fabsf(t));
 }
 
@@ -92,20 +95,22 @@ __device__ __forceinline__ void wide_prefetch_h(WidePreH<RB>& pre, const WeightB
     pre.inv = wb.scalar(scale_bytes);
 }
 
-template <int RB, int KB0, int KB1>
+template <int RB, int KB0, int KB1, int ROW = kRowH, int PLANE = kPlaneH, bool ZERO = true>
 __device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const WeightBuf& wb, int frag_bytes,
                                             const _Float16* xl,      // plane_hi + (lane&31)*kRowH + 8*(lane>>5)
                                             int col0, int col1, int lane, f32x16 (&am)[RB][2]) {
     constexpr int KBT = KB0 + KB1;
     static_assert(KBT % 2 == 0 && KBT >= 4, "k-block count");
+    if constexpr (ZERO) {
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
+        for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int pb = 0; pb < 2; ++pb) am[rb][pb][4 * g + i] = 0.0f;
+                    for (int pb = 0; pb < 2; ++pb) am[rb][pb][4 * g + i] = 0.0f;
+    }
     auto xoff = [&](int kb) { return kb < KB0 ? col0 + 16 * kb : col1 + 16 * (kb - KB0); };
     // 4 rotating weight buffers (two k-blocks ahead; three measured slower), 2 activation buffers (one ahead);
     // all indices static
@@ -118,7 +123,7 @@ __device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const Weigh
     for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
         for (int part = 0; part < 2; ++part)
-            x[0][pb][part] = *reinterpret_cast<const f16x8*>(xl + part * kPlaneH + xoff(0) + pb * 32 * kRowH);
+            x[0][pb][part] = *reinterpret_cast<const f16x8*>(xl + part * PLANE + xoff(0) + pb * 32 * ROW);
 
 // one k-block: request operands for k+2 (weights) / k+1 (activations) and run 3*RB*2 MFMAs on block k, with the
 // 2*RB global loads and 4 LDS reads interleaved BETWEEN the MFMAs (an f16 MFMA occupies the pipe for only 32
@@ -135,7 +140,7 @@ __device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const Weigh
         _Pragma("unroll") for (int pb = 0; pb < 2; ++pb)                                                             \
             _Pragma("unroll") for (int part = 0; part < 2; ++part)                                                   \
                 x[((I) + 1) & 1][pb][part] =                                                                         \
-                    *reinterpret_cast<const f16x8*>(xl + part * kPlaneH + xo_ + pb * 32 * kRowH);                    \
+                    *reinterpret_cast<const f16x8*>(xl + part * PLANE + xo_ + pb * 32 * ROW);                        \
         /* hi*hi, hi*lo, lo*hi into the same accumulator; product-major: an accumulator is touched every 4th MFMA */ \
         _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                                            \
             _Pragma("unroll") for (int pb = 0; pb < 2; ++pb)                                                         \
@@ -179,7 +184,7 @@ __device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const Weigh
 // Range check: packed f16 max over the |hi| pairs (inf when |t| > 65504).
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-template <int RB>
+template <int RB, int ROW = kRowH, int PLANE = kPlaneH>
 __device__ __forceinline__ void wide_store_h(const f32x16 (&am)[RB][2], float inv, const f32x4 (&bias)[RB][4],
                                              _Float16* dl,   // plane_hi + (lane&31)*kRowH + 4*(lane>>5) + dcol + chan0
                                              bool relu, f16x2& amax2, float* gout /* or nullptr: + chan0 + 4*(lane>>5) */,
@@ -209,9 +214,9 @@ __device__ __forceinline__ void wide_store_h(const f32x16 (&am)[RB][2], float in
                 }
                 amax2 = __builtin_elementwise_max(amax2, __builtin_elementwise_max(a01, a23));
                 const f16x4 hi4 = {h01[0], h01[1], h23[0], h23[1]}, lo4 = {l01[0], l01[1], l23[0], l23[1]};
-                _Float16* d = dl + pb * 32 * kRowH + 32 * rb + 8 * g;
+                _Float16* d = dl + pb * 32 * ROW + 32 * rb + 8 * g;
                 *reinterpret_cast<f16x4*>(d) = hi4;
-                *reinterpret_cast<f16x4*>(d + kPlaneH) = lo4;
+                *reinterpret_cast<f16x4*>(d + PLANE) = lo4;
             }
             // keep the scheduler from converting all 8 blocks at once (it would need >256 live VGPRs and spill)
             __builtin_amdgcn_sched_barrier(0);
@@ -222,7 +227,7 @@ __device__ __forceinline__ void wide_store_h(const f32x16 (&am)[RB][2], float in
 // ------------------------------------------------------------------------------------------------
 // skinny GEMM: 16 output rows x this wave's 16 points on v_mfma_f32_16x16x32_f16, K = 32*KB32
 // ------------------------------------------------------------------------------------------------
-template <int KB32>
+template <int KB32, int PLANE = kPlaneH>
 __device__ __forceinline__ f32x4 skinny_gemm_h(const WeightBuf& wb, int frag_bytes, int bias_bytes, int scale_bytes,
                                                const _Float16* xs /* plane_hi + (16*wave + (lane&15))*kRowH + col + 8*(lane>>4) */,
                                                int lane) {
@@ -233,7 +238,7 @@ __device__ __forceinline__ f32x4 skinny_gemm_h(const WeightBuf& wb, int frag_byt
     for (int kb = 0; kb < KB32; ++kb) {
         const f16x8 wh = wb.frag(frag_bytes + (2 * kb) * 1024), wl = wb.frag(frag_bytes + (2 * kb + 1) * 1024);
         const f16x8 xh = *reinterpret_cast<const f16x8*>(xs + 32 * kb);
-        const f16x8 xl = *reinterpret_cast<const f16x8*>(xs + kPlaneH + 32 * kb);
+        const f16x8 xl = *reinterpret_cast<const f16x8*>(xs + PLANE + 32 * kb);
         a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, a0, 0, 0, 0);
         a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, a1, 0, 0, 0);
         a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, a1, 0, 0, 0);
@@ -432,7 +437,313 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
     if (p.status && __any(!(amax_all <= kF16Safe)) && lane == 0) atomicOr(p.status, INERF_STATUS_F16_RANGE);
 }
 
+// ================================================================================================
+// Two workgroups per CU (object-level network).
+//
+// One wave per SIMD cannot hide anything: while it converts accumulators, waits on the weight stream or sits
+// at a barrier, the matrix pipe idles (measured: 57 % MFMA-busy in the kernel above).  This variant halves
+// the footprint of a workgroup - 75,776 B of LDS, <= 256 registers - so that two tiles at different stages
+// share a CU and fill each other's gaps.  What had to go:
+//   * the second activation buffer: a layer's output overwrites its input IN PLACE, which costs a barrier
+//     between the GEMM and the store (accumulators wait in registers) besides the one after the store;
+//   * the resident position encoding: layer 0 reads it from columns 0..63 of the activation buffer; the skip
+//     layer runs its h-part first, then the encoding is recomputed into the (now dead) columns 0..63 and the
+//     enc-part accumulates on top;
+//   * LDS copies of the heads' hidden layers: the albedo/shading hidden layer and the view-dependent layer stay
+//     in registers - a 32x32 accumulator, converted in place, IS the B operand of the next MFMA when the next
+//     weights are stored in accumulator k order (layout.h: as2r / resr) - and each wave's partial output sums
+//     (its 64 / 32 hidden channels) meet in a 128-byte per-point exchange area.
+// LDS per workgroup: two planes (hi, lo) of X[64 points][296 halfs] = [h 256 | dir 32 | pad 8]; 592-byte rows
+// put the 16 rows of a ds_read_b128 lane group on 16 distinct bank slots.
+// ================================================================================================
+constexpr int kRowD = kWidth + kDirCols + 8;      // 296
+constexpr int kPlaneD = kTilePoints * kRowD;
+constexpr int kLdsBytesD = 2 * kPlaneD * 2;       // 75,776
+constexpr int kColDirD = kWidth;                  // direction encoding right behind h: views reads [feature | dir] in one sweep
+constexpr int kColExD = 64;                       // exchange area: floats [wave][8] per point in columns 64..127 of the hi plane
+
+template <int RB>
+__device__ __forceinline__ void prefetch_w(WidePreH<RB>& pre, const WeightBuf& wb, int frag_bytes) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int part = 0; part < 2; ++part) pre.w[kb][rb][part] = wb.frag(frag_bytes + ((kb * RB + rb) * 2 + part) * 1024);
+}
+
+template <int RB>
+__device__ __forceinline__ void load_bias(f32x4 (&bias)[RB][4], float& inv, const WeightBuf& wb, int bias_bytes, int scale_bytes,
+                                          int lane) {
+    const int h16 = 16 * (lane >> 5);
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bias[rb][g] = wb.vec4(bias_bytes + (32 * rb + 8 * g) * 4, h16);
+    inv = wb.scalar(scale_bytes);
+}
+
+// accumulators of this wave's 32*RB channels x 64 points -> (bias, ReLU, hi/lo split) -> B operands, one per
+// 16-channel k-block q (accumulator registers 8*(q&1) .. +7 of row block q>>1) and point block
+template <int RB>
+__device__ __forceinline__ void to_operands(const f32x16 (&am)[RB][2], float inv, const f32x4 (&bias)[RB][4], f16x2& amax2,
+                                            f16x8 (&hi)[2 * RB][2], f16x8 (&lo)[2 * RB][2]) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2) {
+                f16x8 fh, fl;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int j = 8 * q2 + i;
+                    float t = fmaxf(__builtin_fmaf(am[rb][pb][j], inv, bias[rb][j >> 2][j & 3]), 0.0f);
+                    const float th = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, t) & 0xFFFFE000u);
+                    fh[i] = (_Float16)th;
+                    fl[i] = (_Float16)(t - th);
+                }
+                const f16x2 m = __builtin_elementwise_max(__builtin_elementwise_max(f16x2{fh[0], fh[1]}, f16x2{fh[2], fh[3]}),
+                                                          __builtin_elementwise_max(f16x2{fh[4], fh[5]}, f16x2{fh[6], fh[7]}));
+                amax2 = __builtin_elementwise_max(amax2, m);
+                hi[2 * rb + q2][pb] = fh;
+                lo[2 * rb + q2][pb] = fl;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+}
+
+// an output head straight from register operands: rows 0..3 of the 32-row result are the head's outputs, summed over
+// this wave's Q k-blocks only (partial sums; the caller adds the four waves')
+template <int Q>
+__device__ __forceinline__ void regop_gemm(const WeightBuf& wb, int frag_bytes, const f16x8 (&hi)[Q][2], const f16x8 (&lo)[Q][2],
+                                           f32x4 (&part)[2]) {
+    f32x16 acc[2];
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[pb][r] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const f16x8 wh = wb.frag(frag_bytes + (2 * q) * 1024), wl = wb.frag(frag_bytes + (2 * q + 1) * 1024);
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hi[q][pb], acc[pb], 0, 0, 0);
+            acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, lo[q][pb], acc[pb], 0, 0, 0);
+            acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, hi[q][pb], acc[pb], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) part[pb] = f32x4{acc[pb][0], acc[pb][1], acc[pb][2], acc[pb][3]};   // rows 0..3: lanes 0..31
+}
+
+__global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParams p) {
+    constexpr int kPts = kTilePoints;
+    constexpr int kParts = 256 / kPts;
+    extern __shared__ __attribute__((aligned(16))) _Float16 ldsd[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const NetLayout& L = p.L;
+    float amax = 0.0f;
+    f16x2 amax2 = {(_Float16)0.0f, (_Float16)0.0f};
+
+    _Float16* const xw = ldsd + (lane & 31) * kRowD;
+    const _Float16* const xr = xw + 8 * (lane >> 5);                       // wide GEMM operand reads (+ column)
+    _Float16* const xd = xw + 4 * (lane >> 5) + 64 * wave;                 // wide stores: this wave's 64 channels
+    const _Float16* const xs = ldsd + (16 * wave + (lane & 15)) * kRowD + 8 * (lane >> 4);   // skinny operand reads
+
+    WeightBuf wb;
+    wb.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wts), 0, L.total_floats * 4, 0x00020000);
+    wb.voff = lane * 16;
+    auto frag256 = [&](const GemmSlot& s, int kbt) { return (s.w + wave * kbt * 2 * 2 * 256) * 4; };
+    auto frag128 = [&](const GemmSlot& s, int kbt) { return (s.w + wave * kbt * 1 * 2 * 256) * 4; };
+
+    WidePreH<2> pre2;
+    WidePreH<1> pre1;
+    prefetch_w<2>(pre2, wb, frag256(L.trunk[0], 4));
+
+    for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+        // ---------------- encode -> hi/lo planes (xyz: columns 0..63, dir: columns 256..287) ----------------
+        auto encode = [&](bool with_dir) {
+            const int pt = tid % kPts, part = tid / kPts;
+            int gp = tile * kPts + pt;
+            gp = gp < p.n_points ? gp : p.n_points - 1;
+            const int ray = gp / p.n_samples;
+            const float* __restrict__ r = p.rays + (size_t)ray * INERF_RAY_FLOATS;
+            const float zz = __builtin_nontemporal_load(p.z + gp);
+            _Float16* row = ldsd + pt * kRowD;
+            float x[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) x[c] = __fadd_rn(r[c], __fmul_rn(r[3 + c], zz));       // run_nerf.py:488
+            for (int f = part; f < p.l_xyz; f += kParts) {
+                const float s = (float)(1 << f);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float sn, cs;
+                    sincosf(x[c] * s, &sn, &cs);
+                    split_store<kPlaneD>(row + 3 + 6 * f + c, sn, amax);
+                    split_store<kPlaneD>(row + 6 + 6 * f + c, cs, amax);
+                }
+            }
+            if (part == 2) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) split_store<kPlaneD>(row + c, x[c], amax);
+                for (int c = 3 + 6 * p.l_xyz; c < kEncCols; ++c) { row[c] = (_Float16)0.0f; row[kPlaneD + c] = (_Float16)0.0f; }
+            }
+            if (with_dir) {
+                const int fd = kParts - 1 - part;
+                if (fd < p.l_dir) {
+                    const float s = (float)(1 << fd);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        float sn, cs;
+                        sincosf(r[8 + c] * s, &sn, &cs);
+                        split_store<kPlaneD>(row + kColDirD + 3 + 6 * fd + c, sn, amax);
+                        split_store<kPlaneD>(row + kColDirD + 6 + 6 * fd + c, cs, amax);
+                    }
+                }
+                if (part == 3) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) split_store<kPlaneD>(row + kColDirD + c, r[8 + c], amax);
+                    for (int c = 3 + 6 * p.l_dir; c < kDirCols; ++c) { row[kColDirD + c] = (_Float16)0.0f; row[kPlaneD + kColDirD + c] = (_Float16)0.0f; }
+                }
+            }
+        };
+        encode(true);
+        __syncthreads();
+
+        // a 256-wide layer in place: GEMM over columns [0, 16*KBT) | barrier | store to columns [0, 256) | barrier
+        f32x16 am2[2][2];
+        f32x4 bias2[2][4];
+        float inv2;
+        auto store256 = [&](const GemmSlot& s, bool relu, auto&& prefetch_next) {
+            load_bias<2>(bias2, inv2, wb, (s.b + 64 * wave) * 4, (s.b + kWidth) * 4, lane);
+            prefetch_next();
+            __syncthreads();                       // every wave has read the layer's input
+            wide_store_h<2, kRowD, kPlaneD>(am2, inv2, bias2, xd, relu, amax2, nullptr, 0, 0, 0);
+            __syncthreads();
+        };
+        auto pf256 = [&](const GemmSlot& s, int kbt) { return [&, kbt]() { prefetch_w<2>(pre2, wb, frag256(s, kbt)); }; };
+        auto pf256_at = [&](const GemmSlot& s, int kbt, int kb_first) {
+            return [&, kbt, kb_first]() { prefetch_w<2>(pre2, wb, frag256(s, kbt) + kb_first * 2 * 2 * 1024); };
+        };
+        auto pf128 = [&](const GemmSlot& s, int kbt) { return [&, kbt]() { prefetch_w<1>(pre1, wb, frag128(s, kbt)); }; };
+
+        // ---------------- trunk ----------------
+        wide_gemm_h<2, 4, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.trunk[0], 4), xr, 0, 0, lane, am2);
+        store256(L.trunk[0], true, pf256(L.trunk[1], 16));
+#pragma unroll 1
+        for (int layer = 1; layer < kSkipInput; ++layer) {
+            wide_gemm_h<2, 16, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.trunk[layer], 16), xr, 0, 0, lane, am2);
+            if (layer + 1 < kSkipInput) store256(L.trunk[layer], true, pf256(L.trunk[layer + 1], 16));
+            else                        store256(L.trunk[layer], true, pf256_at(L.trunk[kSkipInput], 20, 4));
+        }
+        {   // pts_linears[5] over cat([pts, h]): h-part (k-blocks 4..19 of the stream), then the encoding again
+            const GemmSlot& s = L.trunk[kSkipInput];
+            wide_gemm_h<2, 16, 0, kRowD, kPlaneD>(pre2, wb, frag256(s, 20) + 4 * 2 * 2 * 1024, xr, 0, 0, lane, am2);
+            prefetch_w<2>(pre2, wb, frag256(s, 20));
+            __syncthreads();
+            encode(false);
+            __syncthreads();
+            wide_gemm_h<2, 4, 0, kRowD, kPlaneD, false>(pre2, wb, frag256(s, 20), xr, 0, 0, lane, am2);
+            store256(s, true, pf256(L.trunk[6], 16));
+        }
+        wide_gemm_h<2, 16, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.trunk[6], 16), xr, 0, 0, lane, am2);
+        store256(L.trunk[6], true, pf256(L.trunk[7], 16));
+        wide_gemm_h<2, 16, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.trunk[7], 16), xr, 0, 0, lane, am2);
+        store256(L.trunk[7], true, pf256(L.as1, 16));
+
+        // ---------------- heads ----------------
+        const int my_pt = tile * kPts + 16 * wave + (lane & 15);
+        const bool my_valid = my_pt < p.n_points;
+        float* const out_row = p.raw + (size_t)(my_valid ? my_pt : 0) * p.channels;
+        const f32x4 sig4 = skinny_gemm_h<8, kPlaneD>(wb, L.alpha.w * 4, L.alpha.b * 4, (L.alpha.b + 16) * 4, xs, lane);
+
+        // albedo + shading: hidden layer (this wave: 64 of its 256 channels) -> registers -> partial output sums
+        f32x4 part_as[2], part_res[2];
+        {
+            wide_gemm_h<2, 16, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.as1, 16), xr, 0, 0, lane, am2);
+            load_bias<2>(bias2, inv2, wb, (L.as1.b + 64 * wave) * 4, (L.as1.b + kWidth) * 4, lane);
+            prefetch_w<2>(pre2, wb, frag256(L.feat, 16));
+            f16x8 hi[4][2], lo[4][2];
+            to_operands<2>(am2, inv2, bias2, amax2, hi, lo);
+            regop_gemm<4>(wb, (L.as2r.w + wave * 4 * 2 * 256) * 4, hi, lo, part_as);
+        }
+        // feature (no activation) in place of h7, then the view-dependent layer over [feature | dir] -> registers
+        wide_gemm_h<2, 16, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.feat, 16), xr, 0, 0, lane, am2);
+        store256(L.feat, false, pf128(L.views, 18));
+        {
+            f32x16 am1[1][2];
+            f32x4 bias1[1][4];
+            float inv1;
+            wide_gemm_h<1, 18, 0, kRowD, kPlaneD>(pre1, wb, frag128(L.views, 18), xr, 0, 0, lane, am1);
+            load_bias<1>(bias1, inv1, wb, (L.views.b + 32 * wave) * 4, (L.views.b + kHalf) * 4, lane);
+            prefetch_w<2>(pre2, wb, frag256(L.trunk[0], 4));
+            f16x8 hi[2][2], lo[2][2];
+            to_operands<1>(am1, inv1, bias1, amax2, hi, lo);
+            regop_gemm<2>(wb, (L.resr.w + wave * 2 * 2 * 256) * 4, hi, lo, part_res);
+        }
+        __syncthreads();                           // feature / dir columns are dead: exchange area may be written
+        if (lane < 32) {
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                float* ex = reinterpret_cast<float*>(ldsd + (lane + 32 * pb) * kRowD + kColExD) + 8 * wave;
+                *reinterpret_cast<f32x4*>(ex) = part_as[pb];
+                *reinterpret_cast<f32x4*>(ex + 4) = part_res[pb];
+            }
+        }
+        __syncthreads();
+        if (lane < 16 && my_valid) {
+            const float* ex = reinterpret_cast<const float*>(ldsd + (16 * wave + lane) * kRowD + kColExD);
+            f32x4 as4 = {0.0f, 0.0f, 0.0f, 0.0f}, res4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                as4 += *reinterpret_cast<const f32x4*>(ex + 8 * w);
+                res4 += *reinterpret_cast<const f32x4*>(ex + 8 * w + 4);
+            }
+            const f32x4 b_as = wb.vec4(L.as2.b * 4, 0), b_res = wb.vec4(L.res.b * 4, 0);
+            const float inv_as = wb.scalar((L.as2.b + 16) * 4), inv_res = wb.scalar((L.res.b + 16) * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                as4[i] = __builtin_fmaf(as4[i], inv_as, b_as[i]);
+                res4[i] = __builtin_fmaf(res4[i], inv_res, b_res[i]);
+            }
+            const float a0 = sigmoid_ref_h(as4[0]), a1 = sigmoid_ref_h(as4[1]), a2 = sigmoid_ref_h(as4[2]);
+            const float sh = sigmoid_ref_h(as4[3]);
+            const float r0 = sigmoid_ref_h(res4[0]), r1 = sigmoid_ref_h(res4[1]), r2 = sigmoid_ref_h(res4[2]);
+            __builtin_nontemporal_store(__fadd_rn(__fmul_rn(a0, sh), r0), out_row + 0);          // run_nerf_helpers.py:320
+            __builtin_nontemporal_store(__fadd_rn(__fmul_rn(a1, sh), r1), out_row + 1);
+            __builtin_nontemporal_store(__fadd_rn(__fmul_rn(a2, sh), r2), out_row + 2);
+            __builtin_nontemporal_store(sig4[0], out_row + 3);
+            __builtin_nontemporal_store(a0, out_row + 4); __builtin_nontemporal_store(a1, out_row + 5); __builtin_nontemporal_store(a2, out_row + 6);
+            __builtin_nontemporal_store(sh, out_row + 7);
+            __builtin_nontemporal_store(r0, out_row + 8); __builtin_nontemporal_store(r1, out_row + 9); __builtin_nontemporal_store(r2, out_row + 10);
+        }
+    }
+    const float amax_all = fmaxf(amax, fmaxf((float)amax2[0], (float)amax2[1]));
+    if (p.status && __any(!(amax_all <= kF16Safe)) && lane == 0) atomicOr(p.status, INERF_STATUS_F16_RANGE);
+}
+
+static int launch_dual(MlpParams& p, int64_t n_points, hipStream_t stream) {
+    p.n_tiles = (int)((n_points + kTilePoints - 1) / kTilePoints);
+    const int max_grid = 2 * device_cus();
+    const int grid = p.n_tiles < max_grid ? p.n_tiles : max_grid;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_encode_mlp_f16x3_dual),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesD);
+        if (e != hipSuccess) return record(e);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_encode_mlp_f16x3_dual, dim3(grid), dim3(256), kLdsBytesD, stream, p);
+    return record(hipGetLastError());
+}
+
 int launch_mlp_f16x3(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream) {
+    // object-level network: two workgroups per CU; INERF_F16_KERNEL=single keeps the one-workgroup kernel (A/B runs)
+    const char* form = getenv("INERF_F16_KERNEL");
+    if (!ssr && !(form && form[0] == 's')) return launch_dual(p, n_points, stream);
     p.n_tiles = (int)((n_points + kTilePoints - 1) / kTilePoints);
     const int grid = p.n_tiles < device_cus() ? p.n_tiles : device_cus();
     void (*kern)(const MlpParams) = ssr ? k_encode_mlp_f16x3<true> : k_encode_mlp_f16x3<false>;

@@ -147,6 +147,24 @@ float pack_skinny_f16(float* dst_f, int rbs, int k_total, const Elem& w) {
     return sc;
 }
 
+// register-operand copy of an output head (layout.h: as2r / resr): 32-row A fragments, k in accumulator order;
+// same scale as the skinny copy of the same weights
+void pack_regop_f16(float* dst_f, int q_per_wave, int rows, int k_total, const Elem& w) {
+    _Float16* dst = reinterpret_cast<_Float16*>(dst_f);
+    const float sc = weight_scale(rows, k_total, w);
+    for (int wave = 0; wave < inerf::kWaves; ++wave)
+        for (int q = 0; q < q_per_wave; ++q)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int c = 0; c < 8; ++c) {
+                    const int row = lane & 31;
+                    const int kv = wave * 16 * q_per_wave + inerf::regop_chan(q, lane >> 5, c);
+                    const HalfPair h = split_f16(row < rows ? w(row, kv) * sc : 0.0f);
+                    const int64_t frag = ((int64_t)wave * q_per_wave + q) * 2;
+                    dst[(frag * 64 + lane) * 8 + c] = h.hi;
+                    dst[((frag + 1) * 64 + lane) * 8 + c] = h.lo;
+                }
+}
+
 }  // namespace
 
 extern "C" {
@@ -274,11 +292,13 @@ int inerf_pack_weights(const inerf_net_desc* net, const float* const* tensors, i
         finish_wide(L.as1, kWidth);
         const float* wa2 = W("albedo_linear2");
         const float* ws2 = W(sh2);
-        pack_skinny(out + L.as2.w, 1, kWidth, [=](int r, int kv) {
+        const Elem as2 = [=](int r, int kv) {
             if (r < 3) return kv < kHalf ? wa2[(int64_t)r * kHalf + kv] : 0.0f;
             if (r == 3) return kv >= kHalf ? ws2[kv - kHalf] : 0.0f;
             return 0.0f;
-        });
+        };
+        pack_skinny(out + L.as2.w, 1, kWidth, as2);
+        if (f16) pack_regop_f16(out + L.as2r.w, 4, 16, kWidth, as2);
         copy_bias(L.as2.b, B("albedo_linear2"), 3);
         out[L.as2.b + 3] = B(sh2)[0];
         finish_skinny(L.as2, 1);
@@ -299,7 +319,9 @@ int inerf_pack_weights(const inerf_net_desc* net, const float* const* tensors, i
         copy_bias(L.views.b, B("views_linears.0"), kHalf);
         finish_wide(L.views, kHalf);
         const float* wr = W(rs);
-        pack_skinny(out + L.res.w, 1, kHalf, [=](int r, int kv) { return r < 3 ? wr[(int64_t)r * kHalf + kv] : 0.0f; });
+        const Elem res = [=](int r, int kv) { return r < 3 ? wr[(int64_t)r * kHalf + kv] : 0.0f; };
+        pack_skinny(out + L.res.w, 1, kHalf, res);
+        if (f16) pack_regop_f16(out + L.resr.w, 2, 16, kHalf, res);
         copy_bias(L.res.b, B(rs), 3);
         finish_skinny(L.res, 1);
     }

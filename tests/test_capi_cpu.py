@@ -121,6 +121,9 @@ def _layout(variant, c):
         wide("sem1", 128, 256)
         skinny("sem2", (c + 15) // 16, 128)
     wide("as1", 256, 256); skinny("as2", 1, 256); wide("feat", 256, 256); wide("views", 128, 288); skinny("res", 1, 128)
+    # register-operand copies of the two output heads (f16 format only; zeros otherwise): weights only
+    slots["as2r"] = ("regop", take(32 * 256), slots["as2"][2], 4, 256)
+    slots["resr"] = ("regop", take(32 * 128), slots["res"][2], 2, 128)
     return slots, off
 
 
@@ -209,6 +212,41 @@ def _unpack_skinny_f16(blob, off, rbs, k_total):
                 hi[16 * rb + (lane & 15), k0:k0 + 8] = halfs[rb, kb, 0, lane]
                 lo[16 * rb + (lane & 15), k0:k0 + 8] = halfs[rb, kb, 1, lane]
     return hi, lo
+
+
+def _unpack_regop_f16(blob, off, q_per_wave, k_total):
+    """(hi, lo)[32 rows, k_total] from the register-operand fragments (csrc/layout.h: as2r / resr): k follows the
+    accumulator registers of v_mfma_f32_32x32x16_f16 (regop_chan)."""
+    halfs = blob[off: off + 32 * k_total].view(np.float16).reshape(4, q_per_wave, 2, 64, 8)
+    hi = np.zeros((32, k_total), np.float32); lo = np.zeros_like(hi)
+    for wave in range(4):
+        for q in range(q_per_wave):
+            for lane in range(64):
+                for c in range(8):
+                    chan = wave * 16 * q_per_wave + 32 * (q >> 1) + 8 * (2 * (q & 1) + (c >> 2)) + 4 * (lane >> 5) + (c & 3)
+                    hi[lane & 31, chan] = halfs[wave, q, 0, lane, c]
+                    lo[lane & 31, chan] = halfs[wave, q, 1, lane, c]
+    return hi, lo
+
+
+def test_packer_regop_heads(capi):
+    """The register-operand copies of the output heads hold the same split weights as the skinny copies, permuted
+    into accumulator order, and cover every hidden channel exactly once; the fp32 format leaves them zero."""
+    from intrinsicnerf_amd import packing
+    for variant, c in (("object", 0), ("ssr", 5)):
+        desc = capi.net_desc(capi.VARIANT_SSR if variant == "ssr" else capi.VARIANT_OBJECT, c, 10, 4, 1.0, precision=capi.PREC_F16X3)
+        sd = oracle.make_state_dict(variant, c, seed=13)
+        blob = packing.pack_state_dict(desc, sd).numpy()
+        slots, total = _layout(variant, c)
+        assert blob.shape[0] == total
+        for reg, skinny, q, k in (("as2r", "as2", 4, 256), ("resr", "res", 2, 128)):
+            hi_r, lo_r = _unpack_regop_f16(blob, slots[reg][1], q, k)
+            hi_s, lo_s = _unpack_skinny_f16(blob, slots[skinny][1], 1, k)
+            assert np.array_equal(hi_r[:16], hi_s) and np.array_equal(lo_r[:16], lo_s)
+            assert not hi_r[16:].any() and not lo_r[16:].any() and hi_r[:3].any()
+        desc32 = capi.net_desc(capi.VARIANT_SSR if variant == "ssr" else capi.VARIANT_OBJECT, c, 10, 4, 1.0, precision=capi.PREC_F32)
+        blob32 = packing.pack_state_dict(desc32, sd).numpy()
+        assert not blob32[slots["as2r"][1]:].any()
 
 
 def test_packer_f16x3_split(capi):

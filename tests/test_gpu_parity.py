@@ -18,10 +18,15 @@ from conftest import golden_names, load_golden
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["f32", "f16x3"])
+@pytest.fixture(autouse=True, params=["f32", "f16x3", "f16x3-1wg"])
 def precision(request, monkeypatch):
-    """Every GPU parity test runs against both MLP kernels: exact-fp32 MFMA and the f16 hi/lo split one."""
-    monkeypatch.setenv("INERF_PRECISION", request.param)
+    """Every GPU parity test runs against every MLP kernel: exact-fp32 MFMA, the f16 hi/lo split one in its default
+    form (object-level network: two workgroups per CU) and in its one-workgroup form (the SSR network always uses it)."""
+    monkeypatch.setenv("INERF_PRECISION", request.param.split("-")[0])
+    if request.param.endswith("-1wg"):
+        monkeypatch.setenv("INERF_F16_KERNEL", "single")
+    else:
+        monkeypatch.delenv("INERF_F16_KERNEL", raising=False)
     return request.param
 
 RTOL, ATOL, RTOL_DISP = 1e-4, 1e-5, 5e-4
@@ -360,7 +365,7 @@ def test_f16_range_guard(precision):
     z = torch.rand(8, 64) + 2
     status = torch.zeros(1, dtype=torch.int32, device=dev)
     raw = kernels.encode_mlp(desc, packing.pack_state_dict(desc, sd).to(dev), rays.to(dev), z.to(dev), status=status)
-    if precision == "f16x3":
+    if precision.startswith("f16x3"):
         assert int(status.item()) & _capi.STATUS_F16_RANGE
         with pytest.raises(FloatingPointError):
             kernels.check_f16_range(status, "test")
