@@ -18,6 +18,9 @@
 // LDS: two planes (hi, lo) of X[64 points][616 halfs]; 616*2 B = 77*16 B, so the 16 rows a
 // ds_read_b128 lane group touches fall on 16 distinct bank slots.  Columns as in layout.h
 // (enc 64 | dir 32 | A 256 | B 256).  157,696 B per workgroup, one workgroup per CU.
+//
+// Two kernels: k_encode_mlp_f16x3 (the layout above; SSR network) and, further down,
+// k_encode_mlp_f16x3_dual (object-level network: half the LDS and registers, two workgroups per CU).
 #include <stdlib.h>
 
 #include <type_traits>
