@@ -141,6 +141,18 @@ int inerf_composite(const float* raw, const float* z_vals, const float* rays_d, 
                     int64_t n_rays, int n_samples, int channels, int n_classes, int feat_dim, uint32_t flags,
                     const inerf_composite_out* out, void* stream);
 
+/* Backward of the alpha compositing: d_raw[N,S,CH] = sum over the given output gradients of
+ * d(output)/d(raw).  Replaces what autograd records for raw2outputs when the trainers call
+ * loss.backward() (run_nerf.py:1018 through :359-412; trainer.py:990 through model_utils.py:39-116).
+ * Same inputs as inerf_composite (the forward pass is recomputed, nothing has to be saved); `grads`
+ * holds dL/d(output) for every output the loss used, NULL for the others (const pointers, the
+ * struct is inerf_composite_out read as inputs; `weights` is dL/d weights[N,S]).  z_vals, rays_d
+ * and noise get no gradient (the reference detaches the resampled depths, run_nerf.py:501, and the
+ * rays are data).  Every element of d_raw is written (zero where nothing depends on it). */
+int inerf_composite_backward(const float* raw, const float* z_vals, const float* rays_d, int rays_d_stride,
+                             const float* noise, int64_t n_rays, int n_samples, int channels, int n_classes,
+                             int feat_dim, uint32_t flags, const inerf_composite_out* grads, float* d_raw, void* stream);
+
 /* Hierarchical resampling + merge.  Replaces z_vals_mid + sample_pdf + sort(cat(...)) + std:
  * run_nerf.py:499-503,519 + run_nerf_helpers.py:402-445 / trainer.py:758-766,799 + rays.py:176-220.
  * z_coarse[N,Sc], weights[N,Sc] (the full coarse weights; the kernel takes [1:-1] itself);

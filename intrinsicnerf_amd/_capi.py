@@ -54,6 +54,7 @@ SYMBOLS = {
     "inerf_sample_coarse": (_I, [_P, _P, _P, _L, _I, _U, _P, _P]),
     "inerf_encode_mlp": (_I, [C.POINTER(NetDesc), _P, _P, _P, _L, _I, _U, _P, _P, _P]),
     "inerf_composite": (_I, [_P, _P, _P, _I, _P, _L, _I, _I, _I, _I, _U, C.POINTER(CompositeOut), _P]),
+    "inerf_composite_backward": (_I, [_P, _P, _P, _I, _P, _L, _I, _I, _I, _I, _U, C.POINTER(CompositeOut), _P, _P]),
     "inerf_sample_fine": (_I, [_P, _P, _P, _L, _I, _I, _U, _P, _P, _P, _P]),
     "inerf_sample_pdf": (_I, [_P, _P, _P, _L, _I, _I, _U, _P, _P]),
     "inerf_workspace_bytes": (_L, [C.POINTER(NetDesc), _L, _I, _I, _U]),

@@ -158,6 +158,151 @@ __global__ __launch_bounds__(256) void k_composite(const float* __restrict__ raw
 }
 
 // ------------------------------------------------------------------------------------------------
+// compositing, backward: one ray per wave; recomputes alpha / transmittance / weights, then
+//   G_s      = dL/dw_s      = <g_maps, raw[s, map channels]> + g_depth * z_s + g_acc + g_weights[s]
+//   dL/da_s  = G_s * T_s - (sum_{k>s} G_k w_k) / (1 - a_s + 1e-10)        (w_k = a_k * prod_{j<k} (1 - a_j + 1e-10))
+//   dL/dsigma_s = dL/da_s * dist_s * exp(-sigma_s * dist_s), through relu
+// with the white-background and disparity terms folded into g_acc / g_depth first.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_suffix_excl(float v, int lane, float& total) {
+    // exclusive suffix sum over the wave: result[lane] = sum_{l > lane} v[l]; total = sum over all lanes
+    float incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float dn = __shfl_down(incl, o);
+        if (lane + o < 64) incl += dn;
+    }
+    total = __shfl(incl, 0);
+    return incl - v;
+}
+
+__global__ __launch_bounds__(256) void k_composite_bwd(const float* __restrict__ raw, const float* __restrict__ z,
+                                                       const float* __restrict__ rays_d, int d_stride,
+                                                       const float* __restrict__ noise, long long n_rays, int s_count, int ch,
+                                                       int n_classes, int feat_dim, int white_bkgd, inerf_composite_out g,
+                                                       float* __restrict__ d_raw) {
+    const int lane = threadIdx.x & 63;
+    const long long ray = blockIdx.x * (long long)kRaysPerBlock + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const float* __restrict__ rr = raw + ray * (long long)s_count * ch;
+    const float* __restrict__ zr = z + ray * (long long)s_count;
+    float* __restrict__ dr = d_raw + ray * (long long)s_count * ch;
+    const float* d = rays_d + ray * (long long)d_stride;
+    const float dnorm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
+    const int chunks = (s_count + 63) >> 6;
+    __shared__ float smem[kRaysPerBlock][3][64 * kMaxChunks];   // alpha-complement, transmittance, weight per sample
+    float* const f_s = smem[threadIdx.x >> 6][0] + lane;
+    float* const t_s = smem[threadIdx.x >> 6][1] + lane;
+    float* const w_s = smem[threadIdx.x >> 6][2] + lane;
+
+    // ---- forward recompute (same arithmetic as k_composite) ----
+    float carry = 1.0f, acc = 0.0f, depth = 0.0f;
+#pragma unroll 1
+    for (int c = 0; c < chunks; ++c) {
+        const int s = c * 64 + lane;
+        const bool in = s < s_count;
+        float alpha = 0.0f, zz = 0.0f;
+        if (in) {
+            zz = zr[s];
+            const float gap = s + 1 < s_count ? __fsub_rn(zr[s + 1], zz) : 1e10f;
+            const float dist = __fmul_rn(gap, dnorm);
+            float sigma = rr[(long long)s * ch + 3];
+            if (noise) sigma = __fadd_rn(sigma, noise[ray * (long long)s_count + s]);
+            alpha = __fsub_rn(1.0f, expf(-__fmul_rn(fmaxf(sigma, 0.0f), dist)));
+            if (sigma != sigma) alpha = sigma;
+        }
+        const float f = in ? __fadd_rn(__fsub_rn(1.0f, alpha), 1e-10f) : 1.0f;
+        float incl = f;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float up = __shfl_up(incl, o);
+            if (lane >= o) incl = __fmul_rn(incl, up);
+        }
+        float excl = __shfl_up(incl, 1);
+        if (lane == 0) excl = 1.0f;
+        const float trans = __fmul_rn(carry, excl);
+        const float wt = in ? __fmul_rn(alpha, trans) : 0.0f;
+        f_s[c * 64] = f;
+        t_s[c * 64] = trans;
+        w_s[c * 64] = wt;
+        carry = __fmul_rn(carry, __shfl(incl, 63));
+        acc += wt;
+        depth += __fmul_rn(wt, zz);
+    }
+    acc = wave_sum(acc);
+    depth = wave_sum(depth);
+
+    // ---- per-ray output gradients (wave-uniform) ----
+    float gm[INERF_BASE_CHANNELS];
+#pragma unroll
+    for (int k = 0; k < INERF_BASE_CHANNELS; ++k) gm[k] = 0.0f;
+    if (g.rgb) { for (int k = 0; k < 3; ++k) gm[k] = g.rgb[ray * 3 + k]; }
+    if (g.albedo) { for (int k = 0; k < 3; ++k) gm[4 + k] = g.albedo[ray * 3 + k]; }
+    if (g.shading) gm[7] = g.shading[ray];
+    if (g.residual) { for (int k = 0; k < 3; ++k) gm[8 + k] = g.residual[ray * 3 + k]; }
+    const float* gsem = (g.sem && n_classes > 0) ? g.sem + ray * (long long)n_classes : nullptr;
+    const float* gfeat = (g.feat && feat_dim > 0) ? g.feat + ray * (long long)feat_dim : nullptr;
+    float g_acc = g.acc ? g.acc[ray] : 0.0f;
+    float g_depth = g.depth ? g.depth[ray] : 0.0f;
+    if (white_bkgd) {       // rgb, albedo, shading (and sem) += 1 - acc   (run_nerf.py:407-410, model_utils.py:113-114)
+        g_acc -= gm[0] + gm[1] + gm[2] + gm[4] + gm[5] + gm[6] + gm[7];
+        if (gsem) {
+            float t = 0.0f;
+            for (int k = lane; k < n_classes; k += 64) t += gsem[k];
+            g_acc -= wave_sum(t);
+        }
+    }
+    if (g.disp) {           // disp = 1 / max(1e-10, depth / acc)            (run_nerf.py:404)
+        const float q = __fdiv_rn(depth, acc);
+        if (!(q <= 1e-10f)) {                  // q > 1e-10, or NaN (0/0): NaN reaches depth and acc like in autograd
+            const float dq = -g.disp[ray] / (q * q);
+            g_depth += dq / acc;
+            g_acc -= dq * q / acc;
+        }
+    }
+
+    // ---- samples, last chunk first (suffix sums run towards the camera) ----
+    float behind = 0.0f;            // sum of G_k w_k over the chunks already done (all k beyond this chunk)
+#pragma unroll 1
+    for (int c = chunks - 1; c >= 0; --c) {
+        const int s = c * 64 + lane;
+        const bool in = s < s_count;
+        float gw = 0.0f, wt = 0.0f;
+        if (in) {
+            const float* __restrict__ rs = rr + (long long)s * ch;
+            wt = w_s[c * 64];
+#pragma unroll
+            for (int k = 0; k < INERF_BASE_CHANNELS; ++k)
+                if (k != 3) gw += gm[k] * rs[k];
+            if (gsem) for (int k = 0; k < n_classes; ++k) gw += gsem[k] * rs[INERF_BASE_CHANNELS + k];
+            if (gfeat) for (int k = 0; k < feat_dim; ++k) gw += gfeat[k] * rs[ch - feat_dim + k];
+            gw += g_depth * zr[s] + g_acc;
+            if (g.weights) gw += g.weights[ray * (long long)s_count + s];
+        }
+        float total;
+        const float after = wave_suffix_excl(in ? gw * wt : 0.0f, lane, total) + behind;
+        behind += total;
+        if (in) {
+            const float* __restrict__ rs = rr + (long long)s * ch;
+            float* __restrict__ ds = dr + (long long)s * ch;
+            const float d_alpha = gw * t_s[c * 64] - after / f_s[c * 64];
+            const float gap = s + 1 < s_count ? __fsub_rn(zr[s + 1], zr[s]) : 1e10f;
+            const float dist = __fmul_rn(gap, dnorm);
+            float sigma = rs[3];
+            if (noise) sigma = __fadd_rn(sigma, noise[ray * (long long)s_count + s]);
+            // d alpha / d sigma = dist * exp(-sigma * dist) for sigma > 0 (relu: zero at and below 0); NaN stays NaN
+            float d_sigma = sigma > 0.0f ? d_alpha * (dist * expf(-__fmul_rn(sigma, dist))) : 0.0f;
+            if (sigma != sigma) d_sigma = sigma;
+#pragma unroll
+            for (int k = 0; k < INERF_BASE_CHANNELS; ++k) ds[k] = k == 3 ? d_sigma : wt * gm[k];
+            for (int k = INERF_BASE_CHANNELS; k < ch; ++k) ds[k] = 0.0f;
+            if (gsem) for (int k = 0; k < n_classes; ++k) ds[INERF_BASE_CHANNELS + k] = wt * gsem[k];
+            if (gfeat) for (int k = 0; k < feat_dim; ++k) ds[ch - feat_dim + k] = wt * gfeat[k];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // hierarchical resampling + merge: one ray per wave, everything staged in LDS
 // ------------------------------------------------------------------------------------------------
 constexpr int kMaxCoarse = 256;
@@ -335,6 +480,23 @@ extern "C" int inerf_composite(const float* raw, const float* z_vals, const floa
     hipLaunchKernelGGL(k_composite, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, raw, z_vals, rays_d,
                        rays_d_stride, noise, (long long)n_rays, n_samples, channels, n_classes, feat_dim,
                        (flags & INERF_FLAG_WHITE_BKGD) ? 1 : 0, *out);
+    return record(hipGetLastError());
+}
+
+extern "C" int inerf_composite_backward(const float* raw, const float* z_vals, const float* rays_d, int rays_d_stride,
+                                        const float* noise, int64_t n_rays, int n_samples, int channels, int n_classes,
+                                        int feat_dim, uint32_t flags, const inerf_composite_out* grads, float* d_raw,
+                                        void* stream) {
+    using namespace inerf;
+    if (!raw || !z_vals || !rays_d || !grads || !d_raw || n_rays < 0 || n_samples < 1 || rays_d_stride < 3) return INERF_E_INVALID;
+    if (channels < INERF_BASE_CHANNELS + n_classes + feat_dim || n_classes < 0 || feat_dim < 0) return INERF_E_INVALID;
+    if (n_samples > 64 * kMaxChunks) return INERF_E_UNSUPPORTED;
+    if (n_rays == 0) return INERF_OK;
+    const long long blocks = (n_rays + kRaysPerBlock - 1) / kRaysPerBlock;
+    if (blocks > 0x7fffffffLL) return INERF_E_UNSUPPORTED;
+    hipLaunchKernelGGL(k_composite_bwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, raw, z_vals, rays_d,
+                       rays_d_stride, noise, (long long)n_rays, n_samples, channels, n_classes, feat_dim,
+                       (flags & INERF_FLAG_WHITE_BKGD) ? 1 : 0, *grads, d_raw);
     return record(hipGetLastError());
 }
 

@@ -116,8 +116,78 @@ def encode_mlp(desc, packed, rays, z_vals, endpoint=False, status=None):
     return raw
 
 
+_COMPOSITE_KEYS = ("rgb", "disp", "acc", "depth", "albedo", "shading", "residual", "sem", "feat", "weights")
+
+
 def composite(raw, z_vals, rays_d, noise=None, white_bkgd=False, n_classes=0, feat_dim=0, want_weights=True):
-    """raw2outputs (run_nerf.py:359-412 / model_utils.py:39-116) -> dict of maps."""
+    """raw2outputs (run_nerf.py:359-412 / model_utils.py:39-116) -> dict of maps.
+
+    When ``raw`` requires grad (a training step through the staged path) the maps carry a grad_fn whose backward
+    is the HIP kernel behind ``inerf_composite_backward``; ``z_vals`` / ``rays_d`` / ``noise`` get no gradient,
+    as in the reference (resampled depths are detached, run_nerf.py:501)."""
+    if torch.is_grad_enabled() and isinstance(raw, torch.Tensor) and raw.requires_grad:
+        keys, maps = _CompositeFn.run(raw, z_vals, rays_d, noise, white_bkgd, n_classes, feat_dim, want_weights)
+        return dict(zip(keys, maps))
+    return _composite_forward(raw, z_vals, rays_d, noise, white_bkgd, n_classes, feat_dim, want_weights)
+
+
+def composite_backward(raw, z_vals, rays_d, grads, noise=None, white_bkgd=False, n_classes=0, feat_dim=0):
+    """d_raw[N,S,CH] for the output gradients in ``grads`` (dict: subset of rgb, disp, acc, depth, albedo, shading,
+    residual, sem, feat, weights) - what autograd computes for raw2outputs in the reference's training step."""
+    raw = _dev(raw, "raw", (None, None, None))
+    n, s, ch = raw.shape
+    z_vals = _dev(z_vals, "z_vals", (n, s))
+    rays_d = _dev(rays_d, "rays_d", (n, 3))
+    noise = _opt(noise, "noise", (n, s), raw)
+    shapes = {"rgb": (n, 3), "albedo": (n, 3), "residual": (n, 3), "disp": (n,), "acc": (n,), "depth": (n,), "shading": (n,),
+              "sem": (n, n_classes), "feat": (n, feat_dim), "weights": (n, s)}
+    held = {}
+    for k, t in grads.items():
+        if k not in shapes:
+            raise KeyError(f"unknown output {k!r}")
+        if t is not None:
+            held[k] = _dev(t, "grad of " + k, shapes[k])
+    d_raw = _new(raw, n, s, ch)
+    co = CompositeOut(**{k: t.data_ptr() for k, t in held.items()})
+    with torch.cuda.device(raw.device):
+        rc = _capi.lib().inerf_composite_backward(_ptr(raw), _ptr(z_vals), _ptr(rays_d), 3, _ptr(noise), n, s, ch, n_classes,
+                                                  feat_dim, FLAG_WHITE_BKGD if white_bkgd else 0, C.byref(co), _ptr(d_raw),
+                                                  _stream(raw))
+    _capi.check(rc, "inerf_composite_backward")
+    return d_raw
+
+
+class _CompositeFn(torch.autograd.Function):
+    """Differentiable raw2outputs: HIP forward, HIP backward (the forward is recomputed there: only inputs are saved)."""
+
+    @staticmethod
+    def run(raw, z_vals, rays_d, noise, white_bkgd, n_classes, feat_dim, want_weights):
+        keys = [k for k in _COMPOSITE_KEYS if not (k == "sem" and n_classes == 0) and not (k == "feat" and feat_dim == 0)
+                and not (k == "weights" and not want_weights)]
+        maps = _CompositeFn.apply(raw, z_vals, rays_d, noise, white_bkgd, n_classes, feat_dim, tuple(keys))
+        return keys, maps
+
+    @staticmethod
+    def forward(ctx, raw, z_vals, rays_d, noise, white_bkgd, n_classes, feat_dim, keys):
+        raw_c, z_c, d_c = raw.detach().float().contiguous(), z_vals.detach().float().contiguous(), rays_d.detach().float().contiguous()
+        noise_c = None if noise is None else noise.detach().float().contiguous()
+        out = _composite_forward(raw_c, z_c, d_c, noise_c, white_bkgd, n_classes, feat_dim, "weights" in keys)
+        ctx.save_for_backward(raw_c, z_c, d_c, *([] if noise_c is None else [noise_c]))
+        ctx.cfg = (white_bkgd, n_classes, feat_dim, keys, noise_c is not None)
+        return tuple(out[k] for k in keys)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        white_bkgd, n_classes, feat_dim, keys, has_noise = ctx.cfg
+        saved = ctx.saved_tensors
+        raw, z_vals, rays_d = saved[:3]
+        noise = saved[3] if has_noise else None
+        grads = {k: g for k, g in zip(keys, gouts) if g is not None}
+        d_raw = composite_backward(raw, z_vals, rays_d, grads, noise, white_bkgd, n_classes, feat_dim)
+        return d_raw, None, None, None, None, None, None, None
+
+
+def _composite_forward(raw, z_vals, rays_d, noise=None, white_bkgd=False, n_classes=0, feat_dim=0, want_weights=True):
     raw = _dev(raw, "raw", (None, None, None))
     n, s, ch = raw.shape
     z_vals = _dev(z_vals, "z_vals", (n, s))

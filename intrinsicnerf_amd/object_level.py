@@ -143,11 +143,37 @@ def _fusable(network_fn, embed_fn, embeddirs_fn):
     return desc
 
 
-def _no_grad_guard(what, *modules):
-    if torch.is_grad_enabled() and any(p.requires_grad for m in modules if m is not None for p in m.parameters()):
-        raise NotImplementedError(
-            f"{what}: gradients were requested, but the HIP path is forward-only in this release (the "
-            "backward kernels are SURVEY.md section 8(f) row 1).  Call under torch.no_grad().")
+def _wants_grad(*modules):
+    """True inside a training step: autograd is recording and some network parameter is trainable."""
+    return torch.is_grad_enabled() and any(p.requires_grad for m in modules if isinstance(m, nn.Module) for p in m.parameters())
+
+
+_told_training_path = False
+
+
+def _training_path_notice(what):
+    """Training steps (run_nerf.py:942-1018, trainer.py:882-990) take the STAGED path: sampling and compositing run
+    on the HIP kernels - compositing with its HIP backward (inerf_composite_backward) - while the networks are
+    evaluated by their torch ``forward`` so that autograd records them; the fused encode+MLP kernel has no backward
+    yet.  Said once per process, so the switch is never silent."""
+    global _told_training_path
+    if not _told_training_path:
+        import warnings
+        warnings.warn(f"{what}: gradients requested - using the staged training path (HIP sampling / compositing with HIP "
+                      "backward; network layers through torch autograd).  Render under torch.no_grad() for the fused path.")
+        _told_training_path = True
+
+
+def _run_network_torch(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk):
+    """run_nerf.py:42-56 as written there: torch-evaluated embedding, ``fn`` applied in ``netchunk`` pieces.  Used for
+    networks the fused kernel does not implement and for training steps (autograd records the layers)."""
+    flat = torch.reshape(inputs, [-1, inputs.shape[-1]])
+    emb = embed_fn(flat)
+    if viewdirs is not None:
+        dirs = viewdirs[:, None].expand(inputs.shape)
+        emb = torch.cat([emb, embeddirs_fn(torch.reshape(dirs, [-1, dirs.shape[-1]]))], -1)
+    out = torch.cat([fn(emb[i:i + netchunk]) for i in range(0, emb.shape[0], netchunk)], 0) if netchunk else fn(emb)
+    return torch.reshape(out, list(inputs.shape[:-1]) + [out.shape[-1]])
 
 
 def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64):
@@ -159,14 +185,10 @@ def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64
     """
     desc = _fusable(fn, embed_fn, embeddirs_fn) if viewdirs is not None else None
     if desc is None:
-        flat = torch.reshape(inputs, [-1, inputs.shape[-1]])
-        emb = embed_fn(flat)
-        if viewdirs is not None:
-            dirs = viewdirs[:, None].expand(inputs.shape)
-            emb = torch.cat([emb, embeddirs_fn(torch.reshape(dirs, [-1, dirs.shape[-1]]))], -1)
-        out = torch.cat([fn(emb[i:i + netchunk]) for i in range(0, emb.shape[0], netchunk)], 0) if netchunk else fn(emb)
-        return torch.reshape(out, list(inputs.shape[:-1]) + [out.shape[-1]])
-    _no_grad_guard("run_network", fn)
+        return _run_network_torch(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk)
+    if _wants_grad(fn):
+        _training_path_notice("run_network")
+        return _run_network_torch(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk)
     # arbitrary points: one "ray" per point with origin = point, direction = 0, depth 0 -> o + 0*0 = o
     pts = torch.reshape(inputs, [-1, 3]).float()
     dirs = torch.reshape(viewdirs[:, None].expand(inputs.shape), [-1, 3]).float()
@@ -259,8 +281,10 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
             nz = torch.Tensor(np.random.rand(n, s) * raw_noise_std).to(dev)
         return nz
 
+    if desc is not None and _wants_grad(network_fn, network_fine):
+        _training_path_notice("render_rays")
+        desc = None
     if desc is not None:
-        _no_grad_guard("render_rays", network_fn, network_fine)
         noise_c = noise(N_samples)
         u = _draw_u(n, N_importance, perturb == 0., pytest, dev) if N_importance > 0 else None
         noise_f = noise(N_samples + N_importance) if N_importance > 0 else None
@@ -285,7 +309,8 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
                 ret[rk] = o[ok + "_coarse"]
             ret["z_std"] = o["z_std"]
     else:
-        # user-supplied network: the stages still run on the HIP kernels, the network is called as given
+        # user-supplied network, or a training step: the stages run on the HIP kernels (compositing differentiably),
+        # the network is called as given / through its torch forward
         rays_o, rays_d, viewdirs = ray_batch[:, 0:3], ray_batch[:, 3:6].contiguous(), ray_batch[:, -3:]
         z_vals = kernels.sample_coarse(ray_batch, t_vals, t_rand, lindisp)
         pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]

@@ -16,7 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _capi, kernels, packing
-from .object_level import Embedder, _no_grad_guard
+from .object_level import Embedder, _run_network_torch, _training_path_notice, _wants_grad
 
 __all__ = ["get_embedder", "Semantic_NeRF", "run_network", "raw2outputs", "sample_pdf", "create_rays",
            "get_rays_camera", "get_rays_world", "batchify_rays", "SSRRenderMixin", "SSRRenderer"]
@@ -120,14 +120,11 @@ def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64
     reference expresses as ``lambda x: net(x, self.endpoint_feat)`` (trainer.py:770)."""
     desc = _fusable(fn, embed_fn, embeddirs_fn) if viewdirs is not None else None
     if desc is None:
-        flat = torch.reshape(inputs, [-1, inputs.shape[-1]])
-        emb = embed_fn(flat)
-        if viewdirs is not None:
-            dirs = viewdirs[:, None].expand(inputs.shape)
-            emb = torch.cat([emb, embeddirs_fn(torch.reshape(dirs, [-1, dirs.shape[-1]]))], -1)
-        out = torch.cat([fn(emb[i:i + netchunk]) for i in range(0, emb.shape[0], netchunk)], 0) if netchunk else fn(emb)
-        return torch.reshape(out, list(inputs.shape[:-1]) + [out.shape[-1]])
-    _no_grad_guard("run_network", fn)
+        return _run_network_torch(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk)
+    if _wants_grad(fn):      # training step: the layers go through torch autograd (object_level._training_path_notice)
+        _training_path_notice("run_network")
+        call = (lambda x: fn(x, True)) if show_endpoint else fn          # trainer.py:770
+        return _run_network_torch(inputs, viewdirs, call, embed_fn, embeddirs_fn, netchunk)
     pts = torch.reshape(inputs, [-1, 3]).float()
     dirs = torch.reshape(viewdirs[:, None].expand(inputs.shape), [-1, 3]).float()
     rays = torch.zeros(pts.shape[0], _capi.RAY_FLOATS, dtype=torch.float32, device=pts.device)
@@ -260,7 +257,6 @@ class SSRRenderMixin:
         if desc is None or (self.N_importance > 0 and _fusable(self.ssr_net_fine, self.embed_fn, self.embeddirs_fn) is None):
             raise NotImplementedError("networks / encoders outside the fused kernel's architecture (D=8, W=256, "
                                       "skips=[4], multires<=10, multires_views<=4); there is no eager fallback")
-        _no_grad_guard("volumetric_rendering", self.ssr_net_coarse, self.ssr_net_fine)
         training = bool(self.training)
         t_vals = torch.linspace(0., 1., steps=self.N_samples, device=dev)
         # RNG draws in the reference's order: t_rand (:744), coarse noise (model_utils.py:70), u (rays.py:197), fine noise
@@ -285,7 +281,11 @@ class SSRRenderMixin:
             kernels.check_f16_range(res.pop("status", None), "volumetric_rendering")
             return res
 
-        o = kernels.with_f32_fallback(desc, run)
+        if _wants_grad(self.ssr_net_coarse, self.ssr_net_fine):
+            _training_path_notice("volumetric_rendering")
+            o = self._staged(ray_batch, t_vals, t_rand, noise_c, u, noise_f, ep)
+        else:
+            o = kernels.with_f32_fallback(desc, run)
         ret = {}
         if self.return_raw:
             ret["raw_coarse"] = o["raw_coarse"]
@@ -308,6 +308,27 @@ class SSRRenderMixin:
                 if torch.isnan(ret[k]).any() or torch.isinf(ret[k]).any():
                     print(f"! [Numerical Error] {k} contains nan or inf.")
         return ret
+
+    def _staged(self, ray_batch, t_vals, t_rand, noise_c, u, noise_f, ep):
+        """trainer.py:717-808 stage by stage, for training steps: HIP sampling, HIP compositing with its HIP backward,
+        the two networks through their torch forward (autograd).  Same keys as kernels.render_rays_fused."""
+        rays_o, rays_d, viewdirs = ray_batch[:, 0:3], ray_batch[:, 3:6].contiguous(), ray_batch[:, -3:]
+        c_sem = self.num_valid_semantic_class if self.enable_semantic else 0
+        z_vals = kernels.sample_coarse(ray_batch, t_vals, t_rand, False)
+        pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
+        raw = run_network(pts, viewdirs, self.ssr_net_coarse, self.embed_fn, self.embeddirs_fn, self.netchunk)
+        c = kernels.composite(raw, z_vals, rays_d, noise_c, self.white_bkgd, n_classes=c_sem)
+        o = {k + "_coarse": v for k, v in c.items()}
+        o["raw_coarse"] = raw
+        if self.N_importance > 0:
+            # the resampled depths carry no gradient (z_samples.detach(), trainer.py:762)
+            z_samples, z_fine, z_std = kernels.sample_fine(z_vals, c["weights"].detach(), u, self.N_importance)
+            pts = rays_o[..., None, :] + rays_d[..., None, :] * z_fine[..., :, None]
+            raw = run_network(pts, viewdirs, self.ssr_net_fine, self.embed_fn, self.embeddirs_fn, self.netchunk, show_endpoint=ep)
+            f = kernels.composite(raw, z_fine, rays_d, noise_f, self.white_bkgd, n_classes=c_sem, feat_dim=128 if ep else 0)
+            o.update({k + "_fine": v for k, v in f.items()})
+            o["raw_fine"], o["z_std"] = raw, z_std
+        return o
 
     def create_ssr(self):
         """Build coarse + fine Semantic_NeRF and the encoders - trainer.py:811-846 (optimiser included)."""

@@ -1,0 +1,198 @@
+"""Backward of the path, first part: compositing.
+
+CPU: autograd through the oracle reproduces the gradients the REFERENCE's autograd produced
+(tests/golden/make_golden_grad.py), so the oracle's backward is pinned like its forward.
+GPU (-m gpu): the HIP backward kernel (inerf_composite_backward) against the same reference gradients, through
+the C ABI and through the autograd wiring of the front-ends; then a whole training-step gradient (both networks)
+through the front-end's staged path against the reference's parameter gradients."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from _cases import assert_maps_close, case_config, case_weights
+from conftest import golden_names, load_golden
+
+OBJ_KEYS = ["rgb", "disp", "acc", "weights", "depth", "albedo", "shading", "residual"]
+SSR_KEYS = OBJ_KEYS + ["sem", "feat"]
+# gradients are sums of O(100) products of O(1) numbers; the reference's own fp32 autograd differs from an fp64
+# evaluation by ~1e-6 relative to the largest entry of a ray.  Bound: 1e-4 relative + 1e-5 of the tensor's scale.
+RTOL = 1e-4
+
+
+def _atol(want):
+    w = np.asarray(want, np.float64)
+    return 1e-5 * float(np.nanmax(np.abs(w))) if np.isfinite(w).any() else 1e-5
+
+
+def _cfg(fx):
+    ssr = "n_classes" in fx
+    return oracle.RenderConfig(variant="ssr" if ssr else "object", white_bkgd=bool(fx["white_bkgd"]),
+                               n_classes=int(fx["n_classes"]) if ssr else 0, endpoint_feat=ssr), ssr
+
+
+@pytest.mark.parametrize("name", golden_names("grad_composite_"))
+def test_oracle_autograd_matches_reference(name):
+    fx = load_golden(name)
+    cfg, ssr = _cfg(fx)
+    keys = SSR_KEYS if ssr else OBJ_KEYS
+    for noise_key, want_key in ((None, "d_raw"), ("noise", "d_raw_noise")):
+        if want_key not in fx:
+            continue
+        raw = torch.from_numpy(fx["raw"]).clone().requires_grad_(True)
+        noise = None if noise_key is None else torch.from_numpy(fx[noise_key])
+        out = oracle.composite(raw, torch.from_numpy(fx["z"]), torch.from_numpy(fx["rays_d"]), cfg, noise, feat=ssr)
+        (d,) = torch.autograd.grad(sum((torch.from_numpy(fx["cot_" + k]) * out[k]).sum() for k in keys), raw)
+        assert_maps_close(d.numpy(), fx[want_key], 1e-6, 1e-6 * _atol(fx[want_key]) / 1e-5, f"{name}/{want_key}")
+
+
+def test_oracle_parameter_gradients_match_reference():
+    """Whole path, both networks: digests (norm, projection, leading entries) of every parameter gradient."""
+    fx = load_golden("grad_render_object")
+    src = load_golden(str(fx["source_fixture"]))
+    cfg = case_config(src)
+    sd_c, sd_f = case_weights(src)
+    pc = {k: v.clone().requires_grad_(True) for k, v in sd_c.items()}
+    pf = {k: v.clone().requires_grad_(True) for k, v in sd_f.items()}
+    out = oracle.render_rays(torch.from_numpy(fx["rays"]), pc, pf, cfg, t_vals=torch.from_numpy(src["t_vals"]))
+    loss = sum((torch.from_numpy(fx[k]) * out[k[4:]]).sum() for k in fx if k.startswith("cot_"))
+    loss.backward()
+    checked = 0
+    for tag, params in (("coarse", pc), ("fine", pf)):
+        for i, (name, p) in enumerate(params.items()):
+            want = fx[f"grad_{tag}/{name}"]
+            got = _digest(p.grad, 1000 + i)
+            assert abs(got[0] - want[0]) <= 1e-6 * want[0], (tag, name)
+            assert abs(got[1] - want[1]) <= 1e-5 * want[0] * np.sqrt(p.numel()), (tag, name)
+            np.testing.assert_allclose(got[2:], want[2:], rtol=1e-5, atol=1e-6 * want[0])
+            checked += 1
+    assert checked == 2 * len(sd_c)
+
+
+def _digest(t, seed, head=16):
+    t = t.detach().double().flatten().cpu()
+    g = torch.Generator().manual_seed(seed)
+    proj = torch.randn(t.numel(), generator=g, dtype=torch.float64)
+    return np.concatenate([[float(t.norm())], [float((t * proj).sum())], t[:head].numpy()])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GPU
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", golden_names("grad_composite_"))
+def test_hip_composite_backward_vs_reference(name):
+    from intrinsicnerf_amd import kernels
+    dev = torch.device("cuda:0")
+    fx = load_golden(name)
+    cfg, ssr = _cfg(fx)
+    keys = SSR_KEYS if ssr else OBJ_KEYS
+    c = cfg.n_classes if ssr else 0
+    feat = 128 if ssr else 0
+    t = lambda k: torch.from_numpy(fx[k]).to(dev)
+    grads = {k: t("cot_" + k) for k in keys}
+    for noise_key, want_key in ((None, "d_raw"), ("noise", "d_raw_noise")):
+        if want_key not in fx:
+            continue
+        noise = None if noise_key is None else t(noise_key)
+        d = kernels.composite_backward(t("raw"), t("z"), t("rays_d"), grads, noise, cfg.white_bkgd, c, feat)
+        assert_maps_close(d.cpu().numpy(), fx[want_key], RTOL, _atol(fx[want_key]), f"{name}/{want_key}")
+        # the same through autograd: a leaf raw, the front-end's differentiable composite, loss.backward()
+        raw = t("raw").clone().requires_grad_(True)
+        out = kernels.composite(raw, t("z"), t("rays_d"), noise, cfg.white_bkgd, c, feat)
+        assert all(out[k].grad_fn is not None for k in keys)
+        sum((grads[k] * out[k]).sum() for k in keys).backward()
+        assert_maps_close(raw.grad.cpu().numpy(), fx[want_key], RTOL, _atol(fx[want_key]), f"{name}/{want_key} (autograd)")
+
+
+@pytest.mark.gpu
+def test_hip_composite_backward_subsets_and_linearity():
+    """Only some outputs carry gradient (NULL pointers for the rest); the backward is linear in the cotangents."""
+    from intrinsicnerf_amd import kernels
+    dev = torch.device("cuda:0")
+    fx = load_golden("grad_composite_object_wb1")
+    t = lambda k: torch.from_numpy(fx[k]).to(dev)
+    raw, z, d = t("raw"), t("z"), t("rays_d")
+    full = {k: t("cot_" + k) for k in OBJ_KEYS}
+    total = kernels.composite_backward(raw, z, d, full, None, True)
+    parts = sum(kernels.composite_backward(raw, z, d, {k: full[k]}, None, True) for k in OBJ_KEYS)
+    assert torch.equal(torch.isnan(total), torch.isnan(parts))       # rays with acc == 0: NaN through disp, in both
+    assert bool(torch.isnan(total).any()) and not bool(torch.isnan(total[3:]).all())
+    scale = float(torch.nan_to_num(total).abs().max())
+    assert float(torch.nan_to_num(total - parts).abs().max()) <= 1e-5 * scale
+    no_disp = kernels.composite_backward(raw, z, d, {k: v for k, v in full.items() if k != "disp"}, None, True)
+    assert not bool(torch.isnan(no_disp).any())                      # without a disp gradient nothing is NaN
+    assert float(kernels.composite_backward(raw, z, d, {}, None, True).abs().max()) == 0.0
+    with pytest.raises(KeyError):
+        kernels.composite_backward(raw, z, d, {"colour": full["rgb"]}, None, True)
+
+
+@pytest.mark.gpu
+def test_training_step_gradients_vs_reference():
+    """loss.backward() through the object-level front-end (render_rays with trainable networks): every parameter
+    gradient of both networks against the reference's autograd (digests in grad_render_object.npz)."""
+    from intrinsicnerf_amd import object_level as ol
+    dev = torch.device("cuda:0")
+    fx = load_golden("grad_render_object")
+    src = load_golden(str(fx["source_fixture"]))
+    sd_c, sd_f = case_weights(src)
+    embed, ch = ol.get_embedder(10, 0); embed_d, ch_d = ol.get_embedder(4, 0)
+    mk = lambda: ol.NeRF(D=8, W=256, input_ch=ch, output_ch=5, skips=[4], input_ch_views=ch_d, use_viewdirs=True).to(dev)
+    net_c, net_f = mk(), mk()
+    net_c.load_state_dict(sd_c); net_f.load_state_dict(sd_f)
+    rays = torch.from_numpy(fx["rays"]).to(dev)
+    ret = ol.render_rays(rays, net_c, ol.NetworkQuery(embed, embed_d), 64, retraw=True, N_importance=128, network_fine=net_f,
+                         white_bkgd=True)
+    name_of = {"rgb_fine": "rgb_map", "albedo_fine": "albedo_map", "shading_fine": "shading_map", "residual_fine": "residual_map",
+               "disp_fine": "disp_map", "acc_fine": "acc_map", "rgb_coarse": "rgb0", "albedo_coarse": "albedo0",
+               "shading_coarse": "shading0", "residual_coarse": "residual0", "acc_coarse": "acc0"}
+    loss = sum((torch.from_numpy(fx["cot_" + k]).to(dev) * ret[name_of[k]]).sum() for k in name_of)
+    loss.backward()
+    for tag, net in (("coarse", net_c), ("fine", net_f)):
+        for i, (name, p) in enumerate(net.named_parameters()):
+            want = fx[f"grad_{tag}/{name}"]
+            assert p.grad is not None, (tag, name)
+            got = _digest(p.grad, 1000 + i)
+            # per tensor: norm to 1e-4, projection onto a random direction to 1e-4 of norm * sqrt(numel), leading entries
+            assert abs(got[0] - want[0]) <= 1e-4 * want[0], (tag, name, got[0], want[0])
+            assert abs(got[1] - want[1]) <= 1e-4 * want[0] * np.sqrt(p.numel()), (tag, name)
+            np.testing.assert_allclose(got[2:], want[2:], rtol=1e-3, atol=1e-4 * want[0], err_msg=f"{tag}/{name}")
+
+
+@pytest.mark.gpu
+def test_ssr_training_step_gradients_vs_oracle():
+    """SSRTrainer.step's backward (trainer.py:882-990) through the SSR front-end: semantic logits, depth, endpoint feature
+    and the intrinsic maps all carry gradient; every parameter gradient against autograd through the CPU oracle
+    (whose backward is pinned to the reference's by the tests above)."""
+    import warnings
+    from intrinsicnerf_amd import ssr
+    dev = torch.device("cuda:0")
+    src = load_golden("ssr_endpoint_c5_wb")
+    cfg = case_config(src)
+    sd_c, sd_f = case_weights(src)
+    rays = torch.from_numpy(src["rays"])[:6].contiguous()
+    pc = {k: v.clone().requires_grad_(True) for k, v in sd_c.items()}
+    pf = {k: v.clone().requires_grad_(True) for k, v in sd_f.items()}
+    want = oracle.render_rays(rays, pc, pf, cfg, t_vals=torch.from_numpy(src["t_vals"]))
+    keys = {"rgb_fine": "rgb_fine", "albedo_fine": "albedo_fine", "shading_fine": "shading_fine", "residual_fine": "residual_fine",
+            "depth_fine": "depth_fine", "sem_fine": "sem_logits_fine", "feat_fine": "feat_map_fine", "rgb_coarse": "rgb_coarse",
+            "depth_coarse": "depth_coarse", "sem_coarse": "sem_logits_coarse", "acc_coarse": "acc_coarse"}
+    g = torch.Generator().manual_seed(11)
+    cot = {k: torch.randn(want[k].shape, generator=g) for k in keys}
+    sum((cot[k] * want[k]).sum() for k in keys).backward()
+
+    r = ssr.SSRRenderer(cfg.n_classes, white_bkgd=cfg.white_bkgd, endpoint_feat=cfg.endpoint_feat, device=dev)
+    r.ssr_net_coarse.load_state_dict(sd_c); r.ssr_net_fine.load_state_dict(sd_f)
+    r.check_numerics = False
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ret = r.render_rays(rays.to(dev))
+    for ok, fk in keys.items():       # forward values of the staged path first
+        assert_maps_close(ret[fk].detach().cpu().numpy(), want[ok].detach().numpy(), 2e-4, 2e-5, fk)
+    sum((cot[ok].to(dev) * ret[fk]).sum() for ok, fk in keys.items()).backward()
+    for tag, net, params in (("coarse", r.ssr_net_coarse, pc), ("fine", r.ssr_net_fine, pf)):
+        for name, p in net.named_parameters():
+            w = params[name].grad.double()
+            assert p.grad is not None, (tag, name)
+            err = float((p.grad.double().cpu() - w).norm())
+            assert err <= 2e-4 * float(w.norm()) + 1e-12, (tag, name, err, float(w.norm()))

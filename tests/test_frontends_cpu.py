@@ -88,8 +88,12 @@ def test_render_on_cpu_fails_loudly():
         r = ssr.SSRRenderer(5, device="cpu")
         with pytest.raises(RuntimeError, match="HIP device"):
             r.render_rays(rays)
-    with pytest.raises(NotImplementedError, match="gradients"):           # grad mode: forward-only release
-        ol.render_rays(rays, net, ol.NetworkQuery(embed, embed_d), 64)
+    # grad mode selects the staged training path (HIP sampling / compositing, torch layers): still no CPU route
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with pytest.raises(RuntimeError, match="HIP device"):
+            ol.render_rays(rays, net, ol.NetworkQuery(embed, embed_d), 64)
 
 
 def test_unknown_network_is_called_like_the_reference_does():

@@ -397,14 +397,30 @@ def test_frontend_falls_back_to_f32_on_range(precision):
     assert_maps_close(got.cpu().numpy(), want.numpy(), RTOL, 1e-4 * float(want.abs().max()), "fallback raw")
 
 
-def test_gradients_fail_loudly():
+def test_training_step_takes_the_staged_path_loudly():
+    """Under autograd with trainable networks the front-end says (once per process) that it switches to the staged
+    path, returns maps with a grad_fn, and the same call under no_grad goes back to the fused kernel with equal maps."""
+    import warnings
     from intrinsicnerf_amd import object_level as ol
     dev = _dev()
     embed, ch = ol.get_embedder(10, 0); embed_d, ch_d = ol.get_embedder(4, 0)
     net = ol.NeRF(D=8, W=256, input_ch=ch, output_ch=5, skips=[4], input_ch_views=ch_d, use_viewdirs=True).to(dev)
-    rays = torch.rand(4, 11, device=dev)
-    with pytest.raises(NotImplementedError):
-        ol.render_rays(rays, net, ol.NetworkQuery(embed, embed_d), 64)
+    fx = load_golden("object_chair_det")
+    net.load_state_dict(case_weights(fx)[0])
+    rays = torch.from_numpy(fx["rays"][:6]).to(dev)
+    ol._told_training_path = False
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        ret = ol.render_rays(rays, net, ol.NetworkQuery(embed, embed_d), 64, N_importance=32, white_bkgd=True)
+    assert any("staged training path" in str(w.message) for w in rec)
+    assert ret["rgb_map"].grad_fn is not None and ret["rgb0"].grad_fn is not None
+    ret["rgb_map"].sum().backward()
+    assert net.alpha_linear.weight.grad is not None and float(net.alpha_linear.weight.grad.abs().sum()) > 0
+    with torch.no_grad():
+        fused = ol.render_rays(rays, net, ol.NetworkQuery(embed, embed_d), 64, N_importance=32, white_bkgd=True)
+    for k in ("rgb_map", "acc_map", "albedo_map", "shading_map", "residual_map", "rgb0", "acc0"):
+        assert fused[k].grad_fn is None
+        assert_maps_close(ret[k].detach().cpu().numpy(), fused[k].cpu().numpy(), 2e-4, 2e-5, k)
 
 
 # ------------------------------------------------------------------------------------------------
