@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Training-step timing through the object-level front-end (staged path: HIP sampling / compositing with HIP backward,
+network layers through torch autograd) and the compositing kernels' HBM rates.
+
+    python scripts/bench_train_step.py [--rays 2048] [--iters 10]
+The batch is the reference's: N_rand = 1024 rays plus one neighbour each (run_nerf.py:918-929), 64 + 128 samples.
+"""
+import argparse
+import os
+import sys
+import time
+import warnings
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__  # noqa: E402
+
+__graft_entry__.build()
+from intrinsicnerf_amd import kernels, object_level as ol  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rays", type=int, default=2048)
+ap.add_argument("--iters", type=int, default=10)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+embed, ch = ol.get_embedder(10, 0); embed_d, ch_d = ol.get_embedder(4, 0)
+mk = lambda: ol.NeRF(D=8, W=256, input_ch=ch, output_ch=5, skips=[4], input_ch_views=ch_d, use_viewdirs=True).to(dev)
+net_c, net_f = mk(), mk()
+opt = torch.optim.Adam(list(net_c.parameters()) + list(net_f.parameters()), lr=5e-4)
+n = a.rays
+o = torch.tensor([[2.5, 1.5, 2.0]]).expand(n, 3)
+d = -o / o.norm(dim=-1, keepdim=True) + 0.2 * torch.randn(n, 3)
+rays = torch.cat([o, d, 2 * torch.ones(n, 1), 6 * torch.ones(n, 1), d / d.norm(dim=-1, keepdim=True)], -1).to(dev)
+target = torch.rand(n, 3, device=dev)
+q = ol.NetworkQuery(embed, embed_d)
+
+
+def step():
+    ret = ol.render_rays(rays, net_c, q, 64, retraw=True, perturb=1.0, N_importance=128, network_fine=net_f, white_bkgd=True,
+                         raw_noise_std=0.0)
+    loss = ((ret["rgb_map"] - target) ** 2).mean() + ((ret["rgb0"] - target) ** 2).mean() \
+        + 0.01 * ret["albedo_map"].abs().mean() + 0.01 * (ret["shading_map"] - 0.5).pow(2).mean() + 0.01 * ret["residual_map"].abs().mean()
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    return float(loss.detach()) if False else loss
+
+
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.iters):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.iters
+print(f"training step (staged path): {n} rays x (64+128) samples: {dt * 1e3:.1f} ms -> {n / dt:.0f} rays/s")
+
+# compositing kernels alone, fine-pass shape
+s, chn = 192, 11
+raw = torch.rand(n * 16, s, chn, device=dev)
+z = torch.sort(torch.rand(n * 16, s, device=dev) * 4 + 2, -1)[0]
+dd = torch.randn(n * 16, 3, device=dev)
+grads = {k: torch.randn(n * 16, 3, device=dev) for k in ("rgb", "albedo", "residual")}
+grads.update({k: torch.randn(n * 16, device=dev) for k in ("acc", "depth", "shading")})
+for name, fn, nbytes in (("k_composite", lambda: kernels.composite(raw, z, dd, None, True), raw.numel() * 4 + 2 * z.numel() * 4),
+                         ("k_composite_bwd", lambda: kernels.composite_backward(raw, z, dd, grads, None, True), 2 * raw.numel() * 4 + z.numel() * 4)):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        fn()
+    e1.record(); e1.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    print(f"{name}: {n * 16} rays x {s} samples x {chn} ch: {ms:.3f} ms -> {nbytes / ms / 1e6:.0f} GB/s algorithmic")
