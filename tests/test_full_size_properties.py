@@ -73,3 +73,17 @@ def test_full_chunk_properties():
     for k in ("rgb_fine", "albedo_fine", "shading_fine", "residual_fine", "acc_fine", "depth_fine"):
         got = out[k][idx.to(dev)].cpu()
         assert torch.allclose(got[ok], want[k][ok], rtol=1e-4, atol=1e-5), k
+
+
+def test_psnr_delta_within_budget(monkeypatch):
+    """BASELINE.json: <= 1e-4 dB PSNR delta vs the reference.  scripts/psnr_delta.py renders a crop of the chair view
+    with the HIP path and with the CPU oracle (== reference) and compares their PSNRs against a synthetic ~30 dB target."""
+    import importlib.util
+    import os
+    import sys
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "psnr_delta.py")
+    spec = importlib.util.spec_from_file_location("psnr_delta", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(sys, "argv", ["psnr_delta.py", "--side", "16"])
+    assert mod.main() <= 1e-4
