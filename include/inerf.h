@@ -118,6 +118,52 @@ int inerf_sample_coarse(const float* rays, const float* t_vals, const float* t_r
 int inerf_encode_mlp(const inerf_net_desc* net, const float* packed_weights, const float* rays, const float* z_vals,
                      int64_t n_rays, int n_samples, uint32_t flags, float* raw_out, int32_t* status, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Training: what autograd records for the network when the trainers call loss.backward()
+ * (run_nerf.py:1018 through run_nerf_helpers.py:284-321; trainer.py:990 through
+ * semantic_nerf.py:123-181).  Split-precision (INERF_PREC_F16X3) path only.
+ *   forward : inerf_encode_mlp_train  = inerf_encode_mlp + every layer's output kept in `save`
+ *   backward: inerf_mlp_backward_inputs: d raw -> pre-activation gradient dZ of every layer
+ *             (the input-gradient chain, MFMA); the weight gradients are then plain GEMMs over the
+ *             sample points, dW_l = dZ_l^T X_l, db_l = column sums of dZ_l, left to the caller's
+ *             GEMM library.
+ * `save` and `dz` are fp32 buffers of inerf_mlp_save_floats() floats laid out [slot][point][width]
+ * (every slot a row-major [n_points, width] matrix; inerf_mlp_save_slot() gives offset and width):
+ *   slot 0 enc 64 | 1 dir 32 | 2..9 h0..h7 256 | 10 albedo|shading hidden 256 | 11 feature 256 |
+ *   12 views hidden 128 | 13 semantic hidden 128 (SSR with classes, else width 0) |
+ *   14 (dz only) head pre-activation gradients 8: albedo 3, shading 1, residual 3, sigma 1.
+ * The gradient w.r.t. the semantic logits is d_raw[..., 11:11+C] itself (no activation).
+ * ------------------------------------------------------------------------------------------- */
+#define INERF_SAVE_SLOTS 15
+int64_t inerf_mlp_save_floats(const inerf_net_desc* net, int64_t n_points);
+int inerf_mlp_save_slot(const inerf_net_desc* net, int slot, int64_t n_points, int64_t* offset_floats, int* width);
+int inerf_encode_mlp_train(const inerf_net_desc* net, const float* packed_weights, const float* rays, const float* z_vals,
+                           int64_t n_rays, int n_samples, uint32_t flags, float* raw_out, float* save_out, int32_t* status,
+                           void* stream);
+
+/* Transposed weights for the input-gradient chain, [host] -> [host] like inerf_pack_weights. */
+int64_t inerf_bwd_packed_floats(const inerf_net_desc* net);
+int inerf_pack_weights_bwd(const inerf_net_desc* net, const float* const* tensors /*[host]*/, int n_tensors,
+                           float* packed_out /*[host]*/, int64_t packed_capacity_floats);
+
+/* raw / d_raw: [n_points, CH] (CH as for inerf_encode_mlp with the same flags); save: from
+ * inerf_encode_mlp_train on the same points; dz_out: every slot is written for every point. */
+int inerf_mlp_backward_inputs(const inerf_net_desc* net, const float* packed_bwd, const float* raw, const float* d_raw,
+                              const float* save, int64_t n_points, uint32_t flags, float* dz_out, int32_t* status,
+                              void* stream);
+
+/* Where every element of a packed blob comes from, so that a caller can re-pack ON THE DEVICE after each
+ * optimiser step (a gather, a per-group max for the power-of-two scales, an f16 hi/lo split) instead of moving the
+ * weights through the host.  backward = 0: the INERF_PREC_F16X3 blob of inerf_pack_weights; 1: the blob of
+ * inerf_pack_weights_bwd.  Per half-precision position of the blob (2 per float): half_src = 1 + index into the
+ * flat concatenation of the tensors in canonical order (0 = zero padding), half_grp = scale group g (>= 0: the
+ * "hi" half, f16(v * 2^k_g); < 0: the "lo" half of group -g-1, f16(v * 2^k_g - hi)), 2^k_g bringing the group's
+ * largest |v| into [2^13, 2^14).  Per fp32 constant: c_code 0: flat[c_src - 1] * c_mult; 1: 2^-k_g; 2: 2^-k_g / 8
+ * (g = c_group).  [host] arrays; returns the number of constants or a negative INERF_E_*. */
+int64_t inerf_pack_map(const inerf_net_desc* net, int backward, int32_t* half_src, int32_t* half_grp, int64_t half_capacity,
+                       int32_t* c_dst, int32_t* c_src, int32_t* c_group, int32_t* c_code, float* c_mult, int64_t const_capacity,
+                       int32_t* n_groups);
+
 /* Alpha compositing.  Replaces raw2outputs: run_nerf.py:359-412 / model_utils.py:39-116.
  * raw[N,S,CH]; z[N,S]; rays_d: pointer to the first direction, consecutive rays `rays_d_stride`
  * floats apart (3 for a [N,3] tensor, 11 for the d-part of a packed ray batch);

@@ -113,6 +113,80 @@ inline NetLayout make_layout(const inerf_net_desc& net) {
     return L;
 }
 
+// ---- training: activations kept by the forward pass / pre-activation gradients produced by the backward pass ----
+// One fp32 buffer of [slot][point][width]: every slot is a plain row-major [n_points, width] matrix, which is what the
+// weight-gradient GEMMs (dW = dZ^T X, K = n_points) consume.  The same slot list serves both buffers; the gradient
+// buffer leaves SAVE_ENC / SAVE_DIR unused and holds the heads' pre-activation gradients in SAVE_DPRE instead
+// (8 floats per point: albedo 3, shading 1, residual 3, sigma 1).
+enum SaveSlot {
+    SAVE_ENC = 0,      // 64  encoded position (63 + zero pad)
+    SAVE_DIR,          // 32  encoded view direction (27 + zero pad)
+    SAVE_H0,           // 256 x 8: trunk layer outputs h0..h7 (post-ReLU)
+    SAVE_H7 = SAVE_H0 + 7,
+    SAVE_AS1H,         // 256 albedo hidden (0..127) | shading hidden (128..255), post-ReLU
+    SAVE_FEAT,         // 256 feature_linear output (no activation)
+    SAVE_VH,           // 128 views_linears.0 output, post-ReLU
+    SAVE_SEMH,         // 128 semantic hidden, post-ReLU (SSR with classes only; width 0 otherwise)
+    SAVE_DPRE,         // 8   (gradient buffer only)
+    SAVE_SLOTS
+};
+
+inline int save_width(const inerf_net_desc& net, int slot) {
+    if (slot == SAVE_ENC) return kEncCols;
+    if (slot == SAVE_DIR) return kDirCols;
+    if (slot >= SAVE_H0 && slot <= SAVE_H7) return kWidth;
+    if (slot == SAVE_AS1H || slot == SAVE_FEAT) return kWidth;
+    if (slot == SAVE_VH) return kHalf;
+    if (slot == SAVE_SEMH) return (net.variant == INERF_VARIANT_SSR && net.n_classes > 0) ? kHalf : 0;
+    if (slot == SAVE_DPRE) return 8;
+    return 0;
+}
+
+inline int64_t save_offset(const inerf_net_desc& net, int slot, int64_t n_points) {     // in floats
+    int64_t w = 0;
+    for (int s = 0; s < slot; ++s) w += save_width(net, s);
+    return w * n_points;
+}
+
+// ---- packed blob of the input-gradient (dgrad) chain, mlp_bwd.hip ----
+// The transposed layers in the wide f16 fragment format above (rows = the forward layer's INPUT channels, k = its
+// output channels), preceded by nothing and followed by 4 constants ([0] = accumulator -> output factor).  The three
+// matrices whose products are summed into d h7 (feature_linear^T, as1^T, sem1^T) share ONE weight scale so that they
+// can share one accumulator.  The small heads are plain fp32, laid out for per-channel VALU use:
+//   res_w[128][4]   residual head: (W[0][c], W[1][c], W[2][c], 0)
+//   as2_w[256][4]   c < 128: (albedo_linear2[0..2][c], 0); c >= 128: (0, 0, 0, shading out[c-128])
+//   alpha_w[256]    alpha_linear
+//   sem2_w[C][128]  semantic_linear.1, transposed: [class][hidden]
+struct BwdLayout {
+    GemmSlot views_t;         // 256 x 128  (feature part of views_linears.0)
+    GemmSlot feat_t;          // 256 x 256
+    GemmSlot as1_t;           // 256 x 256
+    GemmSlot sem1_t;          // 256 x 128  (ssr with classes)
+    GemmSlot trunk_t[kDepth]; // [1..7]: 256 x 256 (layer 5: its h part); [0] unused
+    int32_t res_w, as2_w, alpha_w, sem2_w;
+    int32_t has_sem;
+    int32_t total_floats;
+};
+
+inline BwdLayout make_bwd_layout(const inerf_net_desc& net) {
+    BwdLayout L{};
+    int32_t off = 0;
+    auto take = [&](int32_t n) { int32_t o = off; off += (n + 3) & ~3; return o; };
+    auto wide = [&](GemmSlot& s, int n_out, int k) { s.w = take(n_out * k); s.b = take(4); };
+    wide(L.views_t, kWidth, kHalf);
+    wide(L.feat_t, kWidth, kWidth);
+    wide(L.as1_t, kWidth, kWidth);
+    L.has_sem = (net.variant == INERF_VARIANT_SSR && net.n_classes > 0) ? 1 : 0;
+    if (L.has_sem) wide(L.sem1_t, kWidth, kHalf);
+    for (int i = 1; i < kDepth; ++i) wide(L.trunk_t[i], kWidth, kWidth);
+    L.res_w = take(kHalf * 4);
+    L.as2_w = take(kWidth * 4);
+    L.alpha_w = take(kWidth);
+    L.sem2_w = L.has_sem ? take(net.n_classes * kHalf) : 0;
+    L.total_floats = off;
+    return L;
+}
+
 inline bool net_supported(const inerf_net_desc& n) {
     if (n.variant != INERF_VARIANT_OBJECT && n.variant != INERF_VARIANT_SSR) return false;
     if (n.l_xyz < 0 || n.l_xyz > kMaxLxyz || n.l_dir < 0 || n.l_dir > kMaxLdir) return false;

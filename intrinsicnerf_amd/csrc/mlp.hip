@@ -401,9 +401,37 @@ int launch_mlp_f32(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream)
 
 }  // namespace inerf
 
+static int encode_mlp_impl(const inerf_net_desc* net, const float* packed, const float* rays, const float* z, int64_t n_rays,
+                           int n_samples, uint32_t flags, float* raw_out, float* save, int32_t* status, void* stream);
+
 extern "C" int inerf_encode_mlp(const inerf_net_desc* net, const float* packed, const float* rays, const float* z,
                                 int64_t n_rays, int n_samples, uint32_t flags, float* raw_out, int32_t* status,
                                 void* stream) {
+    return encode_mlp_impl(net, packed, rays, z, n_rays, n_samples, flags, raw_out, nullptr, status, stream);
+}
+
+extern "C" int64_t inerf_mlp_save_floats(const inerf_net_desc* net, int64_t n_points) {
+    if (!net || !inerf::net_supported(*net) || n_points < 0) return INERF_E_INVALID;
+    return inerf::save_offset(*net, inerf::SAVE_SLOTS, n_points);
+}
+
+extern "C" int inerf_mlp_save_slot(const inerf_net_desc* net, int slot, int64_t n_points, int64_t* offset_floats, int* width) {
+    if (!net || !inerf::net_supported(*net) || slot < 0 || slot >= inerf::SAVE_SLOTS || n_points < 0) return INERF_E_INVALID;
+    if (offset_floats) *offset_floats = inerf::save_offset(*net, slot, n_points);
+    if (width) *width = inerf::save_width(*net, slot);
+    return INERF_OK;
+}
+
+extern "C" int inerf_encode_mlp_train(const inerf_net_desc* net, const float* packed, const float* rays, const float* z,
+                                      int64_t n_rays, int n_samples, uint32_t flags, float* raw_out, float* save_out,
+                                      int32_t* status, void* stream) {
+    if (!save_out || !net) return INERF_E_INVALID;
+    if (net->precision != INERF_PREC_F16X3) return INERF_E_UNSUPPORTED;
+    return encode_mlp_impl(net, packed, rays, z, n_rays, n_samples, flags, raw_out, save_out, status, stream);
+}
+
+static int encode_mlp_impl(const inerf_net_desc* net, const float* packed, const float* rays, const float* z, int64_t n_rays,
+                           int n_samples, uint32_t flags, float* raw_out, float* save, int32_t* status, void* stream) {
     using namespace inerf;
     if (!net || !packed || !rays || !z || !raw_out || n_rays < 0 || n_samples < 1) return INERF_E_INVALID;
     if (!net_supported(*net)) return INERF_E_UNSUPPORTED;
@@ -413,6 +441,8 @@ extern "C" int inerf_encode_mlp(const inerf_net_desc* net, const float* packed, 
     const bool ssr = net->variant == INERF_VARIANT_SSR;
     MlpParams p;
     p.wts = packed; p.rays = rays; p.z = z; p.raw = raw_out; p.status = status;
+    p.save = save;
+    for (int s = 0; s < SAVE_SLOTS; ++s) p.save_off[s] = save_offset(*net, s, n_points);
     p.L = make_layout(*net);
     p.n_points = (int)n_points;
     p.n_samples = n_samples;

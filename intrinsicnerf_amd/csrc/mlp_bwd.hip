@@ -1,0 +1,340 @@
+// mlp_bwd.hip - input-gradient (dgrad) chain of the intrinsic-NeRF MLP, the first half of its backward pass
+// (what autograd records for NeRF.forward / Semantic_NeRF.forward when the trainers call loss.backward():
+// run_nerf.py:1018 through run_nerf_helpers.py:284-321; trainer.py:990 through semantic_nerf.py:123-181).
+//
+// Given d loss / d raw[P, CH] and the activations the training forward kept (k_encode_mlp_f16x3<.., kSave>,
+// layout.h SaveSlot), one launch walks every tile of 64 sample points backwards through the network and writes the
+// pre-activation gradient dZ of EVERY layer (same slot layout as the activations).  The weight gradients are then
+// plain GEMMs over the sample points, dW_l = dZ_l^T X_l with K = P, left to the caller (library GEMM).
+//
+// Same machinery as the forward kernel (mlp_f16.hip): activations - here gradients - live in LDS as f16 hi/lo planes
+// X[point][channel], each layer is D[channel][point] = sum_k W^T[channel][k] X[point][k] on v_mfma_f32_32x32x16_f16
+// with the transposed weights streamed from L2 in fragment order (layout.h BwdLayout), three products per fp32 MAC.
+// Differences:
+//   * gradients have no natural scale, so every point's chain is normalised by a power of two s_p >= its largest head
+//     gradient (exact; columns of a GEMM scale independently) and scaled back when dZ is written;
+//   * the ReLU masks come from the saved activations (h > 0), read where the epilogue needs them;
+//   * the heads with 1-4 outputs (sigma, albedo/shading outputs, residual) are outer products: VALU, not MFMA;
+//   * the three matrices that feed d h7 (feature_linear^T, as1^T, sem1^T) share a weight scale and one accumulator.
+#include "mlp_f16_dev.h"
+
+namespace inerf {
+
+struct BwdParams {
+    const float* wts;       // packed transposed weights (inerf_pack_weights_bwd)
+    const float* raw;       // [P, channels] forward output (for the sigmoid derivatives)
+    const float* d_raw;     // [P, channels]
+    const float* save;      // activations kept by the training forward
+    float* dz;              // out: pre-activation gradients, same slot layout
+    int32_t* status;
+    int64_t off[SAVE_SLOTS];
+    BwdLayout L;
+    int n_points, n_tiles, channels, n_classes, endpoint;
+};
+
+// epilogue of one transposed layer: t = acc * inv (+ per-channel vector x per-point scalar), ReLU mask from the saved
+// activation, hi/lo split into LDS (normalised, kActScale domain) and the true gradient to global memory
+template <int RB>
+__device__ __forceinline__ void bwd_store(const f32x16 (&am)[RB][2], float inv, const float* mask_src /* + pt0*mstride + chan0 + 4h */,
+                                          int mstride, const f32x4 (*extra)[4] /* [RB][4] or nullptr */, float ex0, float ex1,
+                                          _Float16* dl /* plane_hi + (lane&31)*kRowH + 4h + dcol + chan0 */, f16x2& amax2,
+                                          float* gout /* + pt0*gstride + chan0 + 4h */, int gstride, float s0, float s1,
+                                          bool valid0, bool valid1) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            const bool valid = pb == 0 ? valid0 : valid1;
+            const float ex = pb == 0 ? ex0 : ex1;
+            const float back = (pb == 0 ? s0 : s1) * (1.0f / kActScale);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float t[4], th[4];
+                f32x4 m4 = {1.0f, 1.0f, 1.0f, 1.0f};
+                if (mask_src) m4 = valid ? *reinterpret_cast<const f32x4*>(mask_src + (size_t)pb * 32 * mstride + 32 * rb + 8 * g)
+                                         : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    t[i] = am[rb][pb][4 * g + i] * inv;
+                    if (extra) t[i] = __builtin_fmaf(extra[rb][g][i], ex, t[i]);
+                    t[i] = m4[i] > 0.0f ? t[i] : 0.0f;
+                    th[i] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, t[i]) & 0xFFFFE000u);
+                }
+                const f16x2 h01 = {(_Float16)th[0], (_Float16)th[1]}, h23 = {(_Float16)th[2], (_Float16)th[3]};
+                const f16x2 l01 = {(_Float16)(t[0] - th[0]), (_Float16)(t[1] - th[1])};
+                const f16x2 l23 = {(_Float16)(t[2] - th[2]), (_Float16)(t[3] - th[3])};
+                const f16x2 a01 = __builtin_bit_cast(f16x2, __builtin_bit_cast(unsigned, h01) & 0x7FFF7FFFu);
+                const f16x2 a23 = __builtin_bit_cast(f16x2, __builtin_bit_cast(unsigned, h23) & 0x7FFF7FFFu);
+                amax2 = __builtin_elementwise_max(amax2, __builtin_elementwise_max(a01, a23));
+                const f16x4 hi4 = {h01[0], h01[1], h23[0], h23[1]}, lo4 = {l01[0], l01[1], l23[0], l23[1]};
+                _Float16* d = dl + pb * 32 * kRowH + 32 * rb + 8 * g;
+                *reinterpret_cast<f16x4*>(d) = hi4;
+                *reinterpret_cast<f16x4*>(d + kPlaneH) = lo4;
+                if (valid)
+                    *reinterpret_cast<f32x4*>(gout + (size_t)pb * 32 * gstride + 32 * rb + 8 * g) = f32x4{t[0], t[1], t[2], t[3]} * back;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// four consecutive channels of one point -> hi/lo planes (normalised value v, stored as kActScale * v)
+__device__ __forceinline__ void split_store4(_Float16* hi_ptr, const float (&v)[4], f16x2& amax2) {
+    float t[4], th[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        t[i] = v[i] * kActScale;
+        th[i] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, t[i]) & 0xFFFFE000u);
+    }
+    const f16x2 h01 = {(_Float16)th[0], (_Float16)th[1]}, h23 = {(_Float16)th[2], (_Float16)th[3]};
+    const f16x4 hi4 = {h01[0], h01[1], h23[0], h23[1]};
+    const f16x4 lo4 = {(_Float16)(t[0] - th[0]), (_Float16)(t[1] - th[1]), (_Float16)(t[2] - th[2]), (_Float16)(t[3] - th[3])};
+    const f16x2 a01 = __builtin_bit_cast(f16x2, __builtin_bit_cast(unsigned, h01) & 0x7FFF7FFFu);
+    const f16x2 a23 = __builtin_bit_cast(f16x2, __builtin_bit_cast(unsigned, h23) & 0x7FFF7FFFu);
+    amax2 = __builtin_elementwise_max(amax2, __builtin_elementwise_max(a01, a23));
+    *reinterpret_cast<f16x4*>(hi_ptr) = hi4;
+    *reinterpret_cast<f16x4*>(hi_ptr + kPlaneH) = lo4;
+}
+
+template <bool kSsr>
+__global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
+    constexpr int kPts = kTilePoints;
+    extern __shared__ __attribute__((aligned(16))) _Float16 ldsb[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const BwdLayout& L = p.L;
+    f16x2 amax2 = {(_Float16)0.0f, (_Float16)0.0f};
+
+    _Float16* const xw = ldsb + (lane & 31) * kRowH;
+    const _Float16* const xr = xw + 8 * (lane >> 5);              // wide GEMM operand reads (+ column)
+    _Float16* const xd = xw + 4 * (lane >> 5) + 64 * wave;        // wide stores: this wave's 64 channels (+ column)
+    auto ptf = [&](int pt) { return reinterpret_cast<float*>(ldsb + pt * kRowH); };   // per-point scratch in the enc columns:
+                                                                                      // [0..7] head gradients / s, [8] s, [9] 1/s
+    WeightBuf wb;
+    wb.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wts), 0, L.total_floats * 4, 0x00020000);
+    wb.voff = lane * 16;
+    auto frag = [&](const GemmSlot& s, int kbt) { return (s.w + wave * kbt * 2 * 2 * 256) * 4; };
+    const bool sem = kSsr && L.has_sem;
+    const int ch = p.channels;
+
+    WidePreH<2> preA, preB;
+    prefetch_w<2>(preA, wb, frag(L.views_t, 8));
+
+    for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+        // ---------------- heads: pre-activation gradients of the output heads, per-point scale ----------------
+        if (tid < kPts) {
+            const int gp = tile * kPts + tid;
+            float dp[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            float s = 1.0f;
+            if (gp < p.n_points) {
+                const float* __restrict__ r = p.raw + (size_t)gp * ch;
+                const float* __restrict__ g = p.d_raw + (size_t)gp * ch;
+                const float sh = r[7];
+                float dsh = g[7];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float a = r[4 + k], rs = r[8 + k];
+                    dp[k] = (g[k] * sh + g[4 + k]) * (a * (1.0f - a));            // rgb = albedo * shading + residual, sigmoid'
+                    dsh += g[k] * a;
+                    dp[4 + k] = (g[k] + g[8 + k]) * (rs * (1.0f - rs));
+                }
+                dp[3] = dsh * (sh * (1.0f - sh));
+                dp[7] = g[3];                                                      // sigma has no activation inside the network
+                float m = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) m = fmaxf(m, fabsf(dp[k]));
+                if (sem) for (int j = 0; j < p.n_classes; ++j) m = fmaxf(m, fabsf(g[INERF_BASE_CHANNELS + j]));
+                if (kSsr && p.endpoint) for (int c = 0; c < INERF_ENDPOINT_DIM; ++c) m = fmaxf(m, fabsf(g[ch - INERF_ENDPOINT_DIM + c]));
+                if (m > 0.0f && m < 3.0e38f) { int e; frexpf(m, &e); s = ldexpf(1.0f, e); }
+                float* __restrict__ o = p.dz + p.off[SAVE_DPRE] + (size_t)gp * 8;
+                *reinterpret_cast<f32x4*>(o) = f32x4{dp[0], dp[1], dp[2], dp[3]};
+                *reinterpret_cast<f32x4*>(o + 4) = f32x4{dp[4], dp[5], dp[6], dp[7]};
+            }
+            float* f = ptf(tid);
+            const float is = 1.0f / s;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f[k] = dp[k] * is;
+            f[8] = s;
+            f[9] = is;
+        }
+        __syncthreads();
+
+        // ---------------- dZ of the view-dependent layer: relu'(vh) * (W_res^T d_res [+ d endpoint feature]) -> A ----------------
+        {
+            const int c4 = (tid & 31) * 4;
+            f32x4 w4[4];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) w4[cc] = *reinterpret_cast<const f32x4*>(p.wts + L.res_w + 4 * (c4 + cc));
+#pragma unroll 2
+            for (int i = 0; i < 8; ++i) {
+                const int pt = (tid >> 5) + 8 * i;
+                const int gp = tile * kPts + pt;
+                const bool valid = gp < p.n_points;
+                const float* f = ptf(pt);
+                const float d0 = f[4], d1 = f[5], d2 = f[6];
+                float v[4];
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) v[cc] = w4[cc][0] * d0 + w4[cc][1] * d1 + w4[cc][2] * d2;
+                f32x4 act = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (valid) {
+                    act = *reinterpret_cast<const f32x4*>(p.save + p.off[SAVE_VH] + (size_t)gp * kHalf + c4);
+                    if (kSsr && p.endpoint) {       // raw[..., -128:] is this layer's output itself (semantic_nerf.py:163-164)
+                        const float* ge = p.d_raw + (size_t)gp * ch + ch - INERF_ENDPOINT_DIM + c4;
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc) v[cc] = __builtin_fmaf(ge[cc], f[9], v[cc]);
+                    }
+                }
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) v[cc] = act[cc] > 0.0f ? v[cc] : 0.0f;
+                split_store4(ldsb + pt * kRowH + kColA + c4, v, amax2);
+                if (valid)
+                    *reinterpret_cast<f32x4*>(p.dz + p.off[SAVE_VH] + (size_t)gp * kHalf + c4) = f32x4{v[0], v[1], v[2], v[3]} * f[8];
+            }
+        }
+        __syncthreads();
+
+        const int pt0 = tile * kPts + (lane & 31);
+        const bool valid0 = pt0 < p.n_points, valid1 = pt0 + 32 < p.n_points;
+        const float s0 = ptf(lane & 31)[8], s1 = ptf((lane & 31) + 32)[8];
+        auto gptr = [&](const float* base, int slot) { return base + p.off[slot] + (size_t)pt0 * kWidth + 64 * wave + 4 * (lane >> 5); };
+        f32x16 am[2][2];
+
+        // ---------------- d feature = W_views^T[:256] dZ_vh -> B (feature_linear has no activation: this is its dZ) ----------------
+        wide_gemm_h<2, 8, 0>(preA, wb, frag(L.views_t, 8), xr, kColA, 0, lane, am);
+        {
+            const float inv = wb.scalar(L.views_t.b * 4);
+            prefetch_w<2>(preA, wb, frag(L.feat_t, 16));
+            prefetch_w<2>(preB, wb, frag(L.as1_t, 16));
+            bwd_store<2>(am, inv, nullptr, 0, nullptr, 0.0f, 0.0f, xd + kColB, amax2, const_cast<float*>(gptr(p.dz, SAVE_FEAT)), kWidth,
+                         s0, s1, valid0, valid1);
+        }
+        __syncthreads();                     // A (dZ_vh) has been read by every wave, B (d feature) is complete
+
+        // ---------------- dZ of the albedo | shading hidden layer: relu'(as1h) * (W_as2^T [d_albedo, d_shading]) -> A ----------------
+        {
+            const int c4 = (tid & 63) * 4;
+            f32x4 w4[4];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) w4[cc] = *reinterpret_cast<const f32x4*>(p.wts + L.as2_w + 4 * (c4 + cc));
+#pragma unroll 2
+            for (int i = 0; i < 16; ++i) {
+                const int pt = (tid >> 6) + 4 * i;
+                const int gp = tile * kPts + pt;
+                const bool valid = gp < p.n_points;
+                const float* f = ptf(pt);
+                const float d0 = f[0], d1 = f[1], d2 = f[2], d3 = f[3];
+                float v[4];
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) v[cc] = w4[cc][0] * d0 + w4[cc][1] * d1 + w4[cc][2] * d2 + w4[cc][3] * d3;
+                const f32x4 act = valid ? *reinterpret_cast<const f32x4*>(p.save + p.off[SAVE_AS1H] + (size_t)gp * kWidth + c4)
+                                        : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) v[cc] = act[cc] > 0.0f ? v[cc] : 0.0f;
+                split_store4(ldsb + pt * kRowH + kColA + c4, v, amax2);
+                if (valid)
+                    *reinterpret_cast<f32x4*>(p.dz + p.off[SAVE_AS1H] + (size_t)gp * kWidth + c4) = f32x4{v[0], v[1], v[2], v[3]} * f[8];
+            }
+        }
+        __syncthreads();
+
+        // ---------------- d h7 = W_feat^T d feature + W_as1^T dZ_as1 (+ W_sem1^T dZ_semh) + w_alpha d sigma ----------------
+        wide_gemm_h<2, 16, 0>(preA, wb, frag(L.feat_t, 16), xr, kColB, 0, lane, am);
+        if (sem) prefetch_w<2>(preA, wb, frag(L.sem1_t, 8));
+        else     prefetch_w<2>(preA, wb, frag(L.trunk_t[7], 16));
+        wide_gemm_h<2, 16, 0, kRowH, kPlaneH, false>(preB, wb, frag(L.as1_t, 16), xr, kColA, 0, lane, am);
+        if (sem) {
+            __syncthreads();                 // A and B are free
+            const int c4 = (tid & 31) * 4;
+#pragma unroll 1
+            for (int i = 0; i < 8; ++i) {
+                const int pt = (tid >> 5) + 8 * i;
+                const int gp = tile * kPts + pt;
+                const bool valid = gp < p.n_points;
+                const float* f = ptf(pt);
+                float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                f32x4 act = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (valid) {
+                    const float* gl = p.d_raw + (size_t)gp * ch + INERF_BASE_CHANNELS;       // logits: no activation
+                    for (int j = 0; j < p.n_classes; ++j) {
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(p.wts + L.sem2_w + (size_t)j * kHalf + c4);
+                        const float gj = gl[j] * f[9];
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc) v[cc] = __builtin_fmaf(w[cc], gj, v[cc]);
+                    }
+                    act = *reinterpret_cast<const f32x4*>(p.save + p.off[SAVE_SEMH] + (size_t)gp * kHalf + c4);
+                }
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) v[cc] = act[cc] > 0.0f ? v[cc] : 0.0f;
+                split_store4(ldsb + pt * kRowH + kColA + c4, v, amax2);
+                if (valid)
+                    *reinterpret_cast<f32x4*>(p.dz + p.off[SAVE_SEMH] + (size_t)gp * kHalf + c4) = f32x4{v[0], v[1], v[2], v[3]} * f[8];
+            }
+            __syncthreads();
+            wide_gemm_h<2, 8, 0, kRowH, kPlaneH, false>(preA, wb, frag(L.sem1_t, 8), xr, kColA, 0, lane, am);
+            prefetch_w<2>(preA, wb, frag(L.trunk_t[7], 16));
+        }
+        {
+            const float inv = wb.scalar(L.feat_t.b * 4);            // common scale of feat_t / as1_t / sem1_t
+            f32x4 aw[2][4];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    aw[rb][g] = wb.vec4((L.alpha_w + 64 * wave + 32 * rb + 8 * g) * 4, 16 * (lane >> 5)) * kActScale;
+            const float e0 = ptf(lane & 31)[7], e1 = ptf((lane & 31) + 32)[7];
+            __syncthreads();                 // every wave is done reading A and B
+            bwd_store<2>(am, inv, gptr(p.save, SAVE_H7), kWidth, aw, e0, e1, xd + kColA, amax2, const_cast<float*>(gptr(p.dz, SAVE_H7)),
+                         kWidth, s0, s1, valid0, valid1);
+        }
+        __syncthreads();
+
+        // ---------------- trunk, layers 7..1: dZ_{l-1} = relu'(h_{l-1}) * W_l^T dZ_l, ping-pong A <-> B ----------------
+#pragma unroll 1
+        for (int l = kDepth - 1; l >= 1; --l) {
+            const int src = ((kDepth - 1 - l) & 1) ? kColB : kColA;
+            const int dst = ((kDepth - 1 - l) & 1) ? kColA : kColB;
+            wide_gemm_h<2, 16, 0>(preA, wb, frag(L.trunk_t[l], 16), xr, src, 0, lane, am);
+            const float inv = wb.scalar(L.trunk_t[l].b * 4);
+            if (l > 1) prefetch_w<2>(preA, wb, frag(L.trunk_t[l - 1], 16));
+            else       prefetch_w<2>(preA, wb, frag(L.views_t, 8));
+            bwd_store<2>(am, inv, gptr(p.save, SAVE_H0 + l - 1), kWidth, nullptr, 0.0f, 0.0f, xd + dst, amax2,
+                         const_cast<float*>(gptr(p.dz, SAVE_H0 + l - 1)), kWidth, s0, s1, valid0, valid1);
+            __syncthreads();
+        }
+    }
+    const float amax_all = fmaxf((float)amax2[0], (float)amax2[1]);
+    if (p.status && __any(!(amax_all <= kF16Safe)) && lane == 0) atomicOr(p.status, INERF_STATUS_F16_RANGE);
+}
+
+}  // namespace inerf
+
+extern "C" int inerf_mlp_backward_inputs(const inerf_net_desc* net, const float* packed_bwd, const float* raw, const float* d_raw,
+                                         const float* save, int64_t n_points, uint32_t flags, float* dz_out, int32_t* status,
+                                         void* stream) {
+    using namespace inerf;
+    if (!net || !packed_bwd || !raw || !d_raw || !save || !dz_out || n_points < 0) return INERF_E_INVALID;
+    if (!net_supported(*net)) return INERF_E_UNSUPPORTED;
+    if (n_points == 0) return INERF_OK;
+    if (n_points >= (int64_t)1 << 31) return INERF_E_UNSUPPORTED;
+    const bool ssr = net->variant == INERF_VARIANT_SSR;
+    BwdParams p;
+    p.wts = packed_bwd; p.raw = raw; p.d_raw = d_raw; p.save = save; p.dz = dz_out; p.status = status;
+    for (int s = 0; s < SAVE_SLOTS; ++s) p.off[s] = save_offset(*net, s, n_points);
+    p.L = make_bwd_layout(*net);
+    p.n_points = (int)n_points;
+    p.n_tiles = (int)((n_points + kTilePoints - 1) / kTilePoints);
+    p.endpoint = (ssr && (flags & INERF_FLAG_ENDPOINT)) ? 1 : 0;
+    p.n_classes = ssr ? net->n_classes : 0;
+    p.channels = INERF_BASE_CHANNELS + p.n_classes + (p.endpoint ? INERF_ENDPOINT_DIM : 0);
+    const int grid = p.n_tiles < device_cus() ? p.n_tiles : device_cus();
+    void (*kern)(const BwdParams) = ssr ? k_mlp_dgrad<true> : k_mlp_dgrad<false>;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[ssr]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesH);
+        if (e != hipSuccess) return record(e);
+        attr_set[ssr] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kLdsBytesH, (hipStream_t)stream, p);
+    return record(hipGetLastError());
+}

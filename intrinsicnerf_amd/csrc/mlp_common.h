@@ -13,6 +13,8 @@ struct MlpParams {
     const float* z;         // [N,S]
     float* raw;             // [N*S, channels]
     int32_t* status;        // optional device word for INERF_STATUS_* bits
+    float* save;            // training forward: activation buffer (layout.h SaveSlot), else nullptr
+    int64_t save_off[SAVE_SLOTS];   // float offsets of the slots for this launch's n_points
     NetLayout L;
     int n_points;           // N*S  (< 2^31, checked on the host)
     int n_samples;
@@ -28,6 +30,6 @@ int device_cus();
 int tile_blocks();
 int record(hipError_t e);
 int launch_mlp_f32(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream);
-int launch_mlp_f16x3(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream);
+int launch_mlp_f16x3(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream);   // p.save != nullptr: saving variant
 
 }  // namespace inerf

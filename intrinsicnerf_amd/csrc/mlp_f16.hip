@@ -23,239 +23,14 @@
 // k_encode_mlp_f16x3_dual (object-level network: half the LDS and registers, two workgroups per CU).
 #include <stdlib.h>
 
-#include <type_traits>
-
-#include "mlp_common.h"
+#include "mlp_f16_dev.h"
 
 namespace inerf {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// Weight / bias fetches go through ONE buffer descriptor over the packed blob: the per-lane part of the
-// address (lane * 16 B) is a single VGPR shared by every layer and the layer / wave / k-block part is a
-// wave-uniform SGPR offset.  With plain 64-bit global addresses the compiler materialised a VGPR address
-// pair per layer, kept ~60 of them live across the tile loop and spilled them to scratch - whose 43 MB
-// footprint then thrashed the L2 the weights are supposed to stay in.
-struct WeightBuf {
-    __amdgpu_buffer_rsrc_t rsrc;
-    int voff;                                     // lane * 16 bytes
-    __device__ __forceinline__ f16x8 frag(int byte_off) const {          // byte_off: wave-uniform
-        return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, byte_off, 0));
-    }
-    __device__ __forceinline__ f32x4 vec4(int byte_off, int lane_bytes) const {   // small per-lane offset on top
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_bytes, byte_off, 0));
-    }
-    __device__ __forceinline__ float scalar(int byte_off) const {
-        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, 0, byte_off, 0));
-    }
-};
-
-constexpr int kRowH = kColB + kWidth + 8;      // 616 halfs per row
-constexpr int kPlaneH = kTilePoints * kRowH;   // halfs per plane
-constexpr int kLdsBytesH = 2 * kPlaneH * 2;    // 157,696
-constexpr float kF16Safe = 6.0e4f;             // on the scaled value (kActScale * activation)
-
-// `amax` is a per-thread running maximum of |v| over everything that was split into f16; it is compared
-// with the representable range once, at the end of the kernel (a per-value compare-and-flag made the
-// compiler keep every |v| alive and spill).
-template <int PLANE = kPlaneH>
-__device__ __forceinline__ void split_store(_Float16* hi_ptr, float v, float& amax) {
-    const float t = v * kActScale;
-    const _Float16 h = (_Float16)t;
-    hi_ptr[0] = h;
-    hi_ptr[PLANE] = (_Float16)(t - (float)h);
-    amax = fmaxf(amax, fabsf(t));
-}
-
 // ------------------------------------------------------------------------------------------------
-// wide GEMM: RB blocks of 32 channels per wave x 2 blocks of 32 points, K = 16 * (KB0 + KB1)
-// ------------------------------------------------------------------------------------------------
-template <int RB>
-struct WidePreH {
-    f16x8 w[2][RB][2];      // k-block 0/1, row block, hi/lo
-    f32x4 b[RB][4];         // bias (already in the scaled activation domain)
-    float inv;              // accumulator -> scaled output factor (2^-kw)
-};
-
-template <int RB>
-__device__ __forceinline__ void wide_prefetch_h(WidePreH<RB>& pre, const WeightBuf& wb, int frag_bytes /* wave's stream */,
-                                                int bias_bytes /* wave's first channel */, int scale_bytes, int lane) {
-    const int h16 = 16 * (lane >> 5);
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-            for (int part = 0; part < 2; ++part) pre.w[kb][rb][part] = wb.frag(frag_bytes + ((kb * RB + rb) * 2 + part) * 1024);
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) pre.b[rb][g] = wb.vec4(bias_bytes + (32 * rb + 8 * g) * 4, h16);
-    pre.inv = wb.scalar(scale_bytes);
-}
-
-template <int RB, int KB0, int KB1, int ROW = kRowH, int PLANE = kPlaneH, bool ZERO = true>
-__device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const WeightBuf& wb, int frag_bytes,
-                                            const _Float16* xl,      // plane_hi + (lane&31)*kRowH + 8*(lane>>5)
-                                            int col0, int col1, int lane, f32x16 (&am)[RB][2]) {
-    constexpr int KBT = KB0 + KB1;
-    static_assert(KBT % 2 == 0 && KBT >= 4, "k-block count");
-    if constexpr (ZERO) {
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int pb = 0; pb < 2; ++pb) am[rb][pb][4 * g + i] = 0.0f;
-    }
-    auto xoff = [&](int kb) { return kb < KB0 ? col0 + 16 * kb : col1 + 16 * (kb - KB0); };
-    // 4 rotating weight buffers (two k-blocks ahead; three measured slower), 2 activation buffers (one ahead);
-    // all indices static
-    f16x8 w[4][RB][2], x[2][2][2];
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-        for (int part = 0; part < 2; ++part) { w[0][rb][part] = pre.w[0][rb][part]; w[1][rb][part] = pre.w[1][rb][part]; }
-#pragma unroll
-    for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-        for (int part = 0; part < 2; ++part)
-            x[0][pb][part] = *reinterpret_cast<const f16x8*>(xl + part * PLANE + xoff(0) + pb * 32 * ROW);
-
-// one k-block: request operands for k+2 (weights) / k+1 (activations) and run 3*RB*2 MFMAs on block k, with the
-// 2*RB global loads and 4 LDS reads interleaved BETWEEN the MFMAs (an f16 MFMA occupies the pipe for only 32
-// cycles, so a burst of 8 memory instructions ahead of them is not hidden; measured +x % vs the burst form).
-// A macro, not a lambda: the buffer indices must stay compile-time constants for the arrays to live in registers.
-#define INERF_F16_STEP(K, I)                                                                                         \
-    {                                                                                                                \
-        const int k1_ = (K) + 1 < KBT ? (K) + 1 : KBT - 1;                                                           \
-        const int k2_ = (K) + 2 < KBT ? (K) + 2 : KBT - 1;                                                           \
-        const int xo_ = xoff(k1_);                                                                                   \
-        _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                                            \
-            _Pragma("unroll") for (int part = 0; part < 2; ++part)                                                   \
-                w[((I) + 2) & 3][rb][part] = wb.frag(frag_bytes + ((k2_ * RB + rb) * 2 + part) * 1024);              \
-        _Pragma("unroll") for (int pb = 0; pb < 2; ++pb)                                                             \
-            _Pragma("unroll") for (int part = 0; part < 2; ++part)                                                   \
-                x[((I) + 1) & 1][pb][part] =                                                                         \
-                    *reinterpret_cast<const f16x8*>(xl + part * PLANE + xo_ + pb * 32 * ROW);                        \
-        /* hi*hi, hi*lo, lo*hi into the same accumulator; product-major: an accumulator is touched every 4th MFMA */ \
-        _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                                            \
-            _Pragma("unroll") for (int pb = 0; pb < 2; ++pb)                                                         \
-                am[rb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[(I) & 3][rb][0], x[(I) & 1][pb][0], am[rb][pb], 0, 0, 0); \
-        _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                                            \
-            _Pragma("unroll") for (int pb = 0; pb < 2; ++pb)                                                         \
-                am[rb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[(I) & 3][rb][0], x[(I) & 1][pb][1], am[rb][pb], 0, 0, 0); \
-        _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                                            \
-            _Pragma("unroll") for (int pb = 0; pb < 2; ++pb)                                                         \
-                am[rb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[(I) & 3][rb][1], x[(I) & 1][pb][0], am[rb][pb], 0, 0, 0); \
-        /* issue order: MFMA, global load, MFMA, LDS read, MFMA - 2*RB times (masks: 0x8 MFMA, 0x20 VMEM read, 0x100 DS read) */ \
-        _Pragma("unroll") for (int q = 0; q < 2 * RB; ++q) {                                                        \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                       \
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                       \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                       \
-            __builtin_amdgcn_sched_group_barrier(0x100, 4 / (2 * RB), 0);                                            \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                       \
-        }                                                                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-    }
-    constexpr int KB4 = KBT & ~3;
-#pragma unroll 1
-    for (int kb = 0; kb < KB4; kb += 4) {
-        INERF_F16_STEP(kb + 0, 0)
-        INERF_F16_STEP(kb + 1, 1)
-        INERF_F16_STEP(kb + 2, 2)
-        INERF_F16_STEP(kb + 3, 3)
-    }
-    if constexpr (KBT - KB4 == 2) {
-        INERF_F16_STEP(KB4 + 0, 0)
-        INERF_F16_STEP(KB4 + 1, 1)
-    }
-#undef INERF_F16_STEP
-}
-
-// epilogue: t = acc * inv + bias' (= kActScale * layer output; optionally ReLU) -> hi/lo planes;
-// optional fp32 copy of the unscaled value to global.
-// Split by truncation: t_hi = t with the 13 low mantissa bits cleared is exactly representable in f16 (for
-// |t| in f16's normal range), so hi = f16(t_hi) needs no rounding and lo = f16(t - t_hi) is the exact
-// remainder rounded once - one AND and one SUB per element instead of convert / convert back / subtract.
-// Range check: packed f16 max over the |hi| pairs (inf when |t| > 65504).
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-
-template <int RB, int ROW = kRowH, int PLANE = kPlaneH>
-__device__ __forceinline__ void wide_store_h(const f32x16 (&am)[RB][2], float inv, const f32x4 (&bias)[RB][4],
-                                             _Float16* dl,   // plane_hi + (lane&31)*kRowH + 4*(lane>>5) + dcol + chan0
-                                             bool relu, f16x2& amax2, float* gout /* or nullptr: + chan0 + 4*(lane>>5) */,
-                                             int gstride, int valid0, int valid1) {
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-#pragma unroll
-        for (int pb = 0; pb < 2; ++pb) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float t[4], th[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    t[i] = __builtin_fmaf(am[rb][pb][4 * g + i], inv, bias[rb][g][i]);
-                    if (relu) t[i] = fmaxf(t[i], 0.0f);
-                    th[i] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, t[i]) & 0xFFFFE000u);
-                    if (gout && (pb == 0 ? valid0 : valid1))
-                        gout[(size_t)pb * 32 * gstride + 32 * rb + 8 * g + i] = t[i] * (1.0f / kActScale);
-                }
-                const f16x2 h01 = {(_Float16)th[0], (_Float16)th[1]}, h23 = {(_Float16)th[2], (_Float16)th[3]};
-                const f16x2 l01 = {(_Float16)(t[0] - th[0]), (_Float16)(t[1] - th[1])};
-                const f16x2 l23 = {(_Float16)(t[2] - th[2]), (_Float16)(t[3] - th[3])};
-                f16x2 a01 = h01, a23 = h23;
-                if (!relu) {     // ReLU outputs are non-negative already
-                    a01 = __builtin_bit_cast(f16x2, __builtin_bit_cast(unsigned, h01) & 0x7FFF7FFFu);
-                    a23 = __builtin_bit_cast(f16x2, __builtin_bit_cast(unsigned, h23) & 0x7FFF7FFFu);
-                }
-                amax2 = __builtin_elementwise_max(amax2, __builtin_elementwise_max(a01, a23));
-                const f16x4 hi4 = {h01[0], h01[1], h23[0], h23[1]}, lo4 = {l01[0], l01[1], l23[0], l23[1]};
-                _Float16* d = dl + pb * 32 * ROW + 32 * rb + 8 * g;
-                *reinterpret_cast<f16x4*>(d) = hi4;
-                *reinterpret_cast<f16x4*>(d + PLANE) = lo4;
-            }
-            // keep the scheduler from converting all 8 blocks at once (it would need >256 live VGPRs and spill)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// skinny GEMM: 16 output rows x this wave's 16 points on v_mfma_f32_16x16x32_f16, K = 32*KB32
-// ------------------------------------------------------------------------------------------------
-template <int KB32, int PLANE = kPlaneH>
-__device__ __forceinline__ f32x4 skinny_gemm_h(const WeightBuf& wb, int frag_bytes, int bias_bytes, int scale_bytes,
-                                               const _Float16* xs /* plane_hi + (16*wave + (lane&15))*kRowH + col + 8*(lane>>4) */,
-                                               int lane) {
-    const f32x4 bias = wb.vec4(bias_bytes, 16 * (lane >> 4));
-    const float inv = wb.scalar(scale_bytes);
-    f32x4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int kb = 0; kb < KB32; ++kb) {
-        const f16x8 wh = wb.frag(frag_bytes + (2 * kb) * 1024), wl = wb.frag(frag_bytes + (2 * kb + 1) * 1024);
-        const f16x8 xh = *reinterpret_cast<const f16x8*>(xs + 32 * kb);
-        const f16x8 xl = *reinterpret_cast<const f16x8*>(xs + PLANE + 32 * kb);
-        a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, a1, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, a1, 0, 0, 0);
-    }
-    f32x4 r;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = __builtin_fmaf(a0[i] + a1[i], inv, bias[i]);
-    return r;
-}
-
-__device__ __forceinline__ float sigmoid_ref_h(float x) { return __fdiv_rn(1.0f, 1.0f + expf(-x)); }
-
-// ------------------------------------------------------------------------------------------------
-template <bool kSsr>
+// kSave: training forward - every layer's output (and the encodings) is also written to p.save as fp32
+// (layout.h SaveSlot) for the backward pass (mlp_bwd.hip)
+template <bool kSsr, bool kSave>
 __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) {
     constexpr int kPts = kTilePoints;
     constexpr int kParts = 256 / kPts;
@@ -298,6 +73,9 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
             const float* __restrict__ r = p.rays + (size_t)ray * INERF_RAY_FLOATS;
             const float zz = __builtin_nontemporal_load(p.z + gp);     // streamed once: keep it out of the L2 the weights live in
             _Float16* row = ldsh + pt * kRowH;
+            const bool sv_ok = kSave && tile * kPts + pt < p.n_points;
+            float* const sv_enc = kSave ? p.save + p.save_off[SAVE_ENC] + (size_t)gp * kEncCols : nullptr;
+            float* const sv_dir = kSave ? p.save + p.save_off[SAVE_DIR] + (size_t)gp * kDirCols : nullptr;
             float x[3], v[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -313,6 +91,7 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
                     sincosf(x[c] * s, &sn, &cs);
                     split_store(row + kColEnc + 3 + 6 * f + c, sn, amax);
                     split_store(row + kColEnc + 6 + 6 * f + c, cs, amax);
+                    if (kSave && sv_ok) { sv_enc[3 + 6 * f + c] = sn; sv_enc[6 + 6 * f + c] = cs; }
                 }
             }
             const int fd = kParts - 1 - part;
@@ -324,23 +103,38 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
                     sincosf(v[c] * s, &sn, &cs);
                     split_store(row + kColDir + 3 + 6 * fd + c, sn, amax);
                     split_store(row + kColDir + 6 + 6 * fd + c, cs, amax);
+                    if (kSave && sv_ok) { sv_dir[3 + 6 * fd + c] = sn; sv_dir[6 + 6 * fd + c] = cs; }
                 }
             }
             if (part == 2) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) split_store(row + kColEnc + c, x[c], amax);
                 for (int c = 3 + 6 * p.l_xyz; c < kEncCols; ++c) { row[kColEnc + c] = (_Float16)0.0f; row[kPlaneH + kColEnc + c] = (_Float16)0.0f; }
+                if (kSave && sv_ok) {
+                    for (int c = 0; c < 3; ++c) sv_enc[c] = x[c];
+                    for (int c = 3 + 6 * p.l_xyz; c < kEncCols; ++c) sv_enc[c] = 0.0f;
+                }
             }
             if (part == 3) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) split_store(row + kColDir + c, v[c], amax);
                 for (int c = 3 + 6 * p.l_dir; c < kDirCols; ++c) { row[kColDir + c] = (_Float16)0.0f; row[kPlaneH + kColDir + c] = (_Float16)0.0f; }
+                if (kSave && sv_ok) {
+                    for (int c = 0; c < 3; ++c) sv_dir[c] = v[c];
+                    for (int c = 3 + 6 * p.l_dir; c < kDirCols; ++c) sv_dir[c] = 0.0f;
+                }
             }
         }
         __syncthreads();
 
         const int pt0 = tile * kPts + (lane & 31);              // this lane's points in wide results
-        auto step256 = [&](const GemmSlot& s, auto kb0c, auto kb1c, int c0, int c1, int dcol, bool relu, auto&& prefetch_next) {
+        // training forward: fp32 copy of a layer's output, this lane's first point / first channel of its wave
+        auto save_ptr = [&](int slot, int width, int chan0) -> float* {
+            if (!kSave) return nullptr;
+            return p.save + p.save_off[slot] + (size_t)pt0 * width + chan0 + 4 * (lane >> 5);
+        };
+        auto step256 = [&](const GemmSlot& s, auto kb0c, auto kb1c, int c0, int c1, int dcol, bool relu, int slot,
+                           auto&& prefetch_next) {
             constexpr int KB0 = decltype(kb0c)::value, KB1 = decltype(kb1c)::value;
             f32x16 am[2][2];
             f32x4 bias[2][4];
@@ -351,10 +145,11 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
             const float inv = pre2.inv;
             wide_gemm_h<2, KB0, KB1>(pre2, wb, frag256(s, KB0 + KB1), xr, c0, c1, lane, am);
             prefetch_next();
-            wide_store_h<2>(am, inv, bias, xd + dcol + 64 * wave, relu, amax2, nullptr, 0, 0, 0);
+            wide_store_h<2>(am, inv, bias, xd + dcol + 64 * wave, relu, amax2, nullptr, 0, pt0 < p.n_points, pt0 + 32 < p.n_points,
+                            save_ptr(slot, kWidth, 64 * wave), kWidth);
             __syncthreads();
         };
-        auto step128 = [&](const GemmSlot& s, auto kb0c, auto kb1c, int c0, int c1, int dcol, bool relu, float* gout,
+        auto step128 = [&](const GemmSlot& s, auto kb0c, auto kb1c, int c0, int c1, int dcol, bool relu, float* gout, int slot,
                            auto&& prefetch_next) {
             constexpr int KB0 = decltype(kb0c)::value, KB1 = decltype(kb1c)::value;
             f32x16 am[1][2];
@@ -365,7 +160,7 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
             wide_gemm_h<1, KB0, KB1>(pre1, wb, frag128(s, KB0 + KB1), xr, c0, c1, lane, am);
             prefetch_next();
             wide_store_h<1>(am, inv, bias, xd + dcol + 32 * wave, relu, amax2, gout, p.channels, pt0 < p.n_points,
-                            pt0 + 32 < p.n_points);
+                            pt0 + 32 < p.n_points, save_ptr(slot, kHalf, 32 * wave), kHalf);
             __syncthreads();
         };
         auto pf256 = [&](const GemmSlot& s, int kbt) {
@@ -381,15 +176,15 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
         constexpr integral_constant<int, 16> K16{};
         const bool sem = kSsr && L.sem_rbs > 0;
         // ---------------- trunk ----------------
-        step256(L.trunk[0], K4, K0, kColEnc, 0, kColA, true, pf256(L.trunk[1], 16));
-        step256(L.trunk[1], K16, K0, kColA, 0, kColB, true, pf256(L.trunk[2], 16));
-        step256(L.trunk[2], K16, K0, kColB, 0, kColA, true, pf256(L.trunk[3], 16));
-        step256(L.trunk[3], K16, K0, kColA, 0, kColB, true, pf256(L.trunk[4], 16));
-        step256(L.trunk[4], K16, K0, kColB, 0, kColA, true, pf256(L.trunk[5], 20));
-        step256(L.trunk[5], K4, K16, kColEnc, kColA, kColB, true, pf256(L.trunk[6], 16));
-        step256(L.trunk[6], K16, K0, kColB, 0, kColA, true, pf256(L.trunk[7], 16));
-        if (sem) step256(L.trunk[7], K16, K0, kColA, 0, kColB, true, pf128(L.sem1, 16));
-        else     step256(L.trunk[7], K16, K0, kColA, 0, kColB, true, pf256(L.as1, 16));
+        step256(L.trunk[0], K4, K0, kColEnc, 0, kColA, true, SAVE_H0 + 0, pf256(L.trunk[1], 16));
+        step256(L.trunk[1], K16, K0, kColA, 0, kColB, true, SAVE_H0 + 1, pf256(L.trunk[2], 16));
+        step256(L.trunk[2], K16, K0, kColB, 0, kColA, true, SAVE_H0 + 2, pf256(L.trunk[3], 16));
+        step256(L.trunk[3], K16, K0, kColA, 0, kColB, true, SAVE_H0 + 3, pf256(L.trunk[4], 16));
+        step256(L.trunk[4], K16, K0, kColB, 0, kColA, true, SAVE_H0 + 4, pf256(L.trunk[5], 20));
+        step256(L.trunk[5], K4, K16, kColEnc, kColA, kColB, true, SAVE_H0 + 5, pf256(L.trunk[6], 16));
+        step256(L.trunk[6], K16, K0, kColB, 0, kColA, true, SAVE_H0 + 6, pf256(L.trunk[7], 16));
+        if (sem) step256(L.trunk[7], K16, K0, kColA, 0, kColB, true, SAVE_H7, pf128(L.sem1, 16));
+        else     step256(L.trunk[7], K16, K0, kColA, 0, kColB, true, SAVE_H7, pf256(L.as1, 16));
 
         // ---------------- heads ----------------
         const int my_pt = tile * kPts + 16 * wave + (lane & 15);
@@ -399,7 +194,7 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
         const f32x4 sig4 = skinny_gemm_h<8>(wb, L.alpha.w * 4, L.alpha.b * 4, (L.alpha.b + 16) * 4, xs + kColB, lane);
 
         if (sem) {
-            step128(L.sem1, K16, K0, kColB, 0, kColA, true, nullptr, pf256(L.as1, 16));
+            step128(L.sem1, K16, K0, kColB, 0, kColA, true, nullptr, SAVE_SEMH, pf256(L.as1, 16));
             for (int rb = 0; rb < L.sem_rbs; ++rb) {
                 const f32x4 lg = skinny_gemm_h<4>(wb, (L.sem2.w + rb * 4 * 2 * 256) * 4, (L.sem2.b + 16 * rb) * 4,
                                                    (L.sem2.b + 16 * L.sem_rbs) * 4, xs + kColA, lane);
@@ -411,16 +206,16 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
             __syncthreads();
         }
 
-        step256(L.as1, K16, K0, kColB, 0, kColA, true, pf256(L.feat, 16));
+        step256(L.as1, K16, K0, kColB, 0, kColA, true, SAVE_AS1H, pf256(L.feat, 16));
         const f32x4 as4 = skinny_gemm_h<8>(wb, L.as2.w * 4, L.as2.b * 4, (L.as2.b + 16) * 4, xs + kColA, lane);
         __syncthreads();
 
-        step256(L.feat, K16, K0, kColB, 0, kColA, false, pf128(L.views, 18));
+        step256(L.feat, K16, K0, kColB, 0, kColA, false, SAVE_FEAT, pf128(L.views, 18));
         // endpoint feature (semantic_nerf.py:163-164): the fp32 views activation goes straight to raw
         float* ep = nullptr;
         if (kSsr && p.endpoint)
             ep = p.raw + (size_t)pt0 * p.channels + INERF_BASE_CHANNELS + p.n_classes + 32 * wave + 4 * (lane >> 5);
-        step128(L.views, K16, K2, kColA, kColDir, kColB, true, ep, pf256(L.trunk[0], 4));
+        step128(L.views, K16, K2, kColA, kColDir, kColB, true, ep, SAVE_VH, pf256(L.trunk[0], 4));
         const f32x4 res4 = skinny_gemm_h<4>(wb, L.res.w * 4, L.res.b * 4, (L.res.b + 16) * 4, xs + kColB, lane);
 
         if (lane < 16 && my_valid) {
@@ -464,27 +259,6 @@ constexpr int kPlaneD = kTilePoints * kRowD;
 constexpr int kLdsBytesD = 2 * kPlaneD * 2;       // 75,776
 constexpr int kColDirD = kWidth;                  // direction encoding right behind h: views reads [feature | dir] in one sweep
 constexpr int kColExD = 64;                       // exchange area: floats [wave][8] per point in columns 64..127 of the hi plane
-
-template <int RB>
-__device__ __forceinline__ void prefetch_w(WidePreH<RB>& pre, const WeightBuf& wb, int frag_bytes) {
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-            for (int part = 0; part < 2; ++part) pre.w[kb][rb][part] = wb.frag(frag_bytes + ((kb * RB + rb) * 2 + part) * 1024);
-}
-
-template <int RB>
-__device__ __forceinline__ void load_bias(f32x4 (&bias)[RB][4], float& inv, const WeightBuf& wb, int bias_bytes, int scale_bytes,
-                                          int lane) {
-    const int h16 = 16 * (lane >> 5);
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bias[rb][g] = wb.vec4(bias_bytes + (32 * rb + 8 * g) * 4, h16);
-    inv = wb.scalar(scale_bytes);
-}
 
 // accumulators of this wave's 32*RB channels x 64 points -> (bias, ReLU, hi/lo split) -> B operands, one per
 // 16-channel k-block q (accumulator registers 8*(q&1) .. +7 of row block q>>1) and point block
@@ -746,16 +520,19 @@ static int launch_dual(MlpParams& p, int64_t n_points, hipStream_t stream) {
 int launch_mlp_f16x3(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream) {
     // object-level network: two workgroups per CU; INERF_F16_KERNEL=single keeps the one-workgroup kernel (A/B runs)
     const char* form = getenv("INERF_F16_KERNEL");
-    if (!ssr && !(form && form[0] == 's')) return launch_dual(p, n_points, stream);
+    if (!ssr && !p.save && !(form && form[0] == 's')) return launch_dual(p, n_points, stream);
     p.n_tiles = (int)((n_points + kTilePoints - 1) / kTilePoints);
     const int grid = p.n_tiles < device_cus() ? p.n_tiles : device_cus();
-    void (*kern)(const MlpParams) = ssr ? k_encode_mlp_f16x3<true> : k_encode_mlp_f16x3<false>;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[ssr]) {
+    const bool save = p.save != nullptr;
+    void (*kern)(const MlpParams) = ssr ? (save ? k_encode_mlp_f16x3<true, true> : k_encode_mlp_f16x3<true, false>)
+                                        : (save ? k_encode_mlp_f16x3<false, true> : k_encode_mlp_f16x3<false, false>);
+    static bool attr_set[4] = {false, false, false, false};
+    const int variant = 2 * (int)ssr + (int)save;
+    if (!attr_set[variant]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            kLdsBytesH);
         if (e != hipSuccess) return record(e);
-        attr_set[ssr] = true;
+        attr_set[variant] = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kLdsBytesH, stream, p);
     return record(hipGetLastError());

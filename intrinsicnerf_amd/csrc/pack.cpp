@@ -59,6 +59,40 @@ Net describe(const inerf_net_desc& d) {
 
 using Elem = std::function<float(int /*row*/, int /*virtual k*/)>;
 
+// ---- map mode ------------------------------------------------------------------------------------------------------
+// The same packing code can, instead of packing values, record WHERE every packed element comes from: it is then run on
+// "index tensors" (element j of tensor i holds 1 + its position in the flat concatenation of all parameters; 0 = padding)
+// and writes, per half-precision position of the blob, the source index and the scale group (one group per per-GEMM
+// power-of-two scale), and per fp32 constant its recipe.  The Python side turns that map into a device-side packer
+// (a gather, a per-group max, a split) so that a training step never moves weights through the host
+// (intrinsicnerf_amd/packing.py: DevicePacker).  Only the f16 formats are mapped.
+struct FloatEntry { int32_t dst, src, group, code; float mult; };   // code 0: flat[src] * mult; 1: 1/scale[group]; 2: 1/(scale[group] * kActScale)
+struct MapSink {
+    float* base;                       // scratch blob the packing code writes into (index values in the float regions)
+    int32_t* half_src;                 // [2 * total_floats]
+    int32_t* half_grp;                 // [2 * total_floats]: g >= 0 hi of group g; g < 0 lo of group (-g - 1)
+    std::vector<char> is_weight;       // per blob float
+    std::vector<FloatEntry> consts;
+    std::vector<std::pair<int32_t, int32_t>> times8;   // float ranges [first, last) whose biases live in the kActScale domain
+    int32_t group = -1;                // group of the most recent pack_* call
+    int32_t next_group = 0;
+    int32_t pinned = -1;               // >= 0: the following pack_* calls share this group (a common forced scale)
+};
+thread_local MapSink* g_map = nullptr;
+
+inline void map_pair(_Float16* dst_hi, _Float16* dst_lo, float index_value) {
+    MapSink& m = *g_map;
+    const int64_t hi = dst_hi - reinterpret_cast<_Float16*>(m.base), lo = dst_lo - reinterpret_cast<_Float16*>(m.base);
+    m.half_src[hi] = m.half_src[lo] = (int32_t)index_value;
+    m.half_grp[hi] = m.group;
+    m.half_grp[lo] = -m.group - 1;
+    m.is_weight[hi / 2] = m.is_weight[lo / 2] = 1;
+}
+inline void map_new_group() {
+    MapSink& m = *g_map;
+    m.group = m.pinned >= 0 ? m.pinned : m.next_group++;
+}
+
 // wide GEMM: fragments of v_mfma_f32_32x32x2_f32's A operand, four k-steps per float4 (layout.h)
 float pack_wide_f32(float* dst, int n_out, int k_total, const Elem& w) {
     const int rb_per_wave = n_out / (32 * inerf::kWaves), kb_count = k_total / 8;
@@ -109,9 +143,10 @@ float weight_scale(int rows, int k_total, const Elem& w) {
 }
 
 // wide GEMM, A-operand fragments of v_mfma_f32_32x32x16_f16: [wave][kb16][rb][hi|lo][lane][8 halfs]
-float pack_wide_f16(float* dst_f, int n_out, int k_total, const Elem& w) {
+float pack_wide_f16(float* dst_f, int n_out, int k_total, const Elem& w, float forced_scale = 0.0f) {
     _Float16* dst = reinterpret_cast<_Float16*>(dst_f);
-    const float sc = weight_scale(n_out, k_total, w);
+    if (g_map) map_new_group();
+    const float sc = g_map ? 1.0f : (forced_scale > 0.0f ? forced_scale : weight_scale(n_out, k_total, w));
     const int rb_per_wave = n_out / (32 * inerf::kWaves), kb_count = k_total / 16;
     for (int wave = 0; wave < inerf::kWaves; ++wave)
         for (int kb = 0; kb < kb_count; ++kb)
@@ -120,8 +155,9 @@ float pack_wide_f16(float* dst_f, int n_out, int k_total, const Elem& w) {
                     for (int c = 0; c < 8; ++c) {
                         const int row = wave * 32 * rb_per_wave + 32 * rb + (lane & 31);
                         const int kv = 16 * kb + 8 * (lane >> 5) + c;
-                        const HalfPair h = split_f16(w(row, kv) * sc);
                         const int64_t frag = (((int64_t)wave * kb_count + kb) * rb_per_wave + rb) * 2;
+                        if (g_map) { map_pair(dst + (frag * 64 + lane) * 8 + c, dst + ((frag + 1) * 64 + lane) * 8 + c, w(row, kv)); continue; }
+                        const HalfPair h = split_f16(w(row, kv) * sc);
                         dst[(frag * 64 + lane) * 8 + c] = h.hi;
                         dst[((frag + 1) * 64 + lane) * 8 + c] = h.lo;
                     }
@@ -131,7 +167,8 @@ float pack_wide_f16(float* dst_f, int n_out, int k_total, const Elem& w) {
 // skinny GEMM, A-operand fragments of v_mfma_f32_16x16x32_f16: [rb][kb32][hi|lo][lane][8 halfs]
 float pack_skinny_f16(float* dst_f, int rbs, int k_total, const Elem& w) {
     _Float16* dst = reinterpret_cast<_Float16*>(dst_f);
-    const float sc = weight_scale(16 * rbs, k_total, w);
+    if (g_map) map_new_group();
+    const float sc = g_map ? 1.0f : weight_scale(16 * rbs, k_total, w);
     const int kb_count = k_total / 32;
     for (int rb = 0; rb < rbs; ++rb)
         for (int kb = 0; kb < kb_count; ++kb)
@@ -139,8 +176,9 @@ float pack_skinny_f16(float* dst_f, int rbs, int k_total, const Elem& w) {
                 for (int c = 0; c < 8; ++c) {
                     const int row = 16 * rb + (lane & 15);
                     const int kv = 32 * kb + 8 * (lane >> 4) + c;
-                    const HalfPair h = split_f16(w(row, kv) * sc);
                     const int64_t frag = ((int64_t)rb * kb_count + kb) * 2;
+                    if (g_map) { map_pair(dst + (frag * 64 + lane) * 8 + c, dst + ((frag + 1) * 64 + lane) * 8 + c, w(row, kv)); continue; }
+                    const HalfPair h = split_f16(w(row, kv) * sc);
                     dst[(frag * 64 + lane) * 8 + c] = h.hi;
                     dst[((frag + 1) * 64 + lane) * 8 + c] = h.lo;
                 }
@@ -151,15 +189,20 @@ float pack_skinny_f16(float* dst_f, int rbs, int k_total, const Elem& w) {
 // same scale as the skinny copy of the same weights
 void pack_regop_f16(float* dst_f, int q_per_wave, int rows, int k_total, const Elem& w) {
     _Float16* dst = reinterpret_cast<_Float16*>(dst_f);
-    const float sc = weight_scale(rows, k_total, w);
+    // same matrix as the skinny copy packed just before: same scale, and in map mode the same scale group
+    const float sc = g_map ? 1.0f : weight_scale(rows, k_total, w);
     for (int wave = 0; wave < inerf::kWaves; ++wave)
         for (int q = 0; q < q_per_wave; ++q)
             for (int lane = 0; lane < 64; ++lane)
                 for (int c = 0; c < 8; ++c) {
                     const int row = lane & 31;
                     const int kv = wave * 16 * q_per_wave + inerf::regop_chan(q, lane >> 5, c);
-                    const HalfPair h = split_f16(row < rows ? w(row, kv) * sc : 0.0f);
                     const int64_t frag = ((int64_t)wave * q_per_wave + q) * 2;
+                    if (g_map) {
+                        map_pair(dst + (frag * 64 + lane) * 8 + c, dst + ((frag + 1) * 64 + lane) * 8 + c, row < rows ? w(row, kv) : 0.0f);
+                        continue;
+                    }
+                    const HalfPair h = split_f16(row < rows ? w(row, kv) * sc : 0.0f);
                     dst[(frag * 64 + lane) * 8 + c] = h.hi;
                     dst[((frag + 1) * 64 + lane) * 8 + c] = h.lo;
                 }
@@ -200,6 +243,79 @@ int inerf_raw_channels(const inerf_net_desc* net, uint32_t flags, int fine) {
     return ch;
 }
 
+int64_t inerf_bwd_packed_floats(const inerf_net_desc* net) {
+    if (!net || !inerf::net_supported(*net)) return INERF_E_INVALID;
+    return inerf::make_bwd_layout(*net).total_floats;
+}
+
+// Transposed layers for the input-gradient chain (layout.h BwdLayout); always the f16 hi/lo fragment format.
+int inerf_pack_weights_bwd(const inerf_net_desc* net, const float* const* tensors, int n_tensors, float* out,
+                           int64_t capacity) {
+    using namespace inerf;
+    if (!net || !tensors || !out || !net_supported(*net)) return INERF_E_INVALID;
+    const Net n = describe(*net);
+    if (n_tensors != (int)n.spec.size()) return INERF_E_INVALID;
+    for (int i = 0; i < n_tensors; ++i)
+        if (!tensors[i]) return INERF_E_INVALID;
+    const BwdLayout L = make_bwd_layout(*net);
+    if (capacity < L.total_floats) return INERF_E_INVALID;
+    std::memset(out, 0, sizeof(float) * (size_t)L.total_floats);
+    auto find = [&](const std::string& key) -> int {
+        for (int i = 0; i < n_tensors; ++i)
+            if (n.spec[i].name == key) return i;
+        return -1;
+    };
+    auto W = [&](const std::string& lin) { return tensors[find(lin + ".weight")]; };
+    auto put = [&](const GemmSlot& s, int n_out, int k, const Elem& el, float forced = 0.0f) {
+        const float sc = pack_wide_f16(out + s.w, n_out, k, el, forced);
+        if (g_map) g_map->consts.push_back({s.b, 0, g_map->group, 1, 1.0f});
+        else out[s.b] = 1.0f / sc;
+    };
+    const bool obj = net->variant == INERF_VARIANT_OBJECT;
+    const std::string sh1 = obj ? "test_linear1" : "shading_linear1";
+    const std::string sh2 = obj ? "test_linear2" : "shading_linear2";
+    const std::string rs = obj ? "shading_linear" : "residual_linear";
+    const int e = n.e, dv = n.dv;
+    // views^T (feature columns only): row = feature channel, k = views output
+    const float* wv = W("views_linears.0");
+    const int vin = kWidth + dv;
+    put(L.views_t, kWidth, kHalf, [=](int r, int k) { return wv[(int64_t)k * vin + r]; });
+    // the three matrices summed into d h7: one common scale
+    const float* wf = W("feature_linear");
+    const float* wa = W("albedo_linear1");
+    const float* ws = W(sh1);
+    const float* w1 = L.has_sem ? W("semantic_linear.0.0") : nullptr;
+    const Elem feat_t = [=](int r, int k) { return wf[(int64_t)k * kWidth + r]; };
+    const Elem as1_t = [=](int r, int k) { return k < kHalf ? wa[(int64_t)k * kWidth + r] : ws[(int64_t)(k - kHalf) * kWidth + r]; };
+    const Elem sem1_t = [=](int r, int k) { return w1[(int64_t)k * kWidth + r]; };
+    float common = std::fmin(weight_scale(kWidth, kWidth, feat_t), weight_scale(kWidth, kWidth, as1_t));
+    if (L.has_sem) common = std::fmin(common, weight_scale(kWidth, kHalf, sem1_t));
+    if (g_map) g_map->pinned = g_map->next_group++;
+    put(L.feat_t, kWidth, kWidth, feat_t, common);
+    put(L.as1_t, kWidth, kWidth, as1_t, common);
+    if (L.has_sem) put(L.sem1_t, kWidth, kHalf, sem1_t, common);
+    if (g_map) g_map->pinned = -1;
+    for (int i = 1; i < kDepth; ++i) {
+        const std::string lin = "pts_linears." + std::to_string(i);
+        const float* w = W(lin);
+        const int in = (int)n.spec[find(lin + ".weight")].cols;
+        const int skip = i == kSkipInput ? e : 0;          // cat([pts, h]): only the h columns carry a gradient onward
+        put(L.trunk_t[i], kWidth, kWidth, [=](int r, int k) { return w[(int64_t)k * in + skip + r]; });
+    }
+    const float* wr = W(rs);
+    for (int c = 0; c < kHalf; ++c)
+        for (int j = 0; j < 3; ++j) out[L.res_w + 4 * c + j] = wr[(int64_t)j * kHalf + c];
+    const float* wa2 = W("albedo_linear2");
+    const float* ws2 = W(sh2);
+    for (int c = 0; c < kHalf; ++c) {
+        for (int j = 0; j < 3; ++j) out[L.as2_w + 4 * c + j] = wa2[(int64_t)j * kHalf + c];
+        out[L.as2_w + 4 * (kHalf + c) + 3] = ws2[c];
+    }
+    std::memcpy(out + L.alpha_w, W("alpha_linear"), sizeof(float) * kWidth);
+    if (L.has_sem) std::memcpy(out + L.sem2_w, W("semantic_linear.1"), sizeof(float) * (size_t)net->n_classes * kHalf);
+    return INERF_OK;
+}
+
 int inerf_pack_weights(const inerf_net_desc* net, const float* const* tensors, int n_tensors, float* out,
                        int64_t capacity) {
     using namespace inerf;
@@ -223,10 +339,18 @@ int inerf_pack_weights(const inerf_net_desc* net, const float* const* tensors, i
     // after the biases of a slot are in place: store the accumulator->output factor behind them and, for the
     // wide (hidden) layers of the f16 format, move the biases into the scaled activation domain (layout.h)
     auto finish_wide = [&](const GemmSlot& s, int n_out) {
+        if (g_map) {
+            g_map->consts.push_back({s.b + n_out, 0, g_map->group, 1, 1.0f});
+            g_map->times8.push_back({s.b, s.b + n_out});
+            return;
+        }
         out[s.b + n_out] = 1.0f / last_scale;
         if (f16) for (int i = 0; i < n_out; ++i) out[s.b + i] *= kActScale;
     };
-    auto finish_skinny = [&](const GemmSlot& s, int rbs) { out[s.b + 16 * rbs] = f16 ? 1.0f / (last_scale * kActScale) : 1.0f; };
+    auto finish_skinny = [&](const GemmSlot& s, int rbs) {
+        if (g_map) { g_map->consts.push_back({s.b + 16 * rbs, 0, g_map->group, 2, 1.0f}); return; }
+        out[s.b + 16 * rbs] = f16 ? 1.0f / (last_scale * kActScale) : 1.0f;
+    };
     auto find = [&](const char* key) -> int {
         for (int i = 0; i < n_tensors; ++i)
             if (n.spec[i].name == key) return i;
@@ -326,6 +450,63 @@ int inerf_pack_weights(const inerf_net_desc* net, const float* const* tensors, i
         finish_skinny(L.res, 1);
     }
     return INERF_OK;
+}
+
+// Where every element of a packed blob comes from (see "map mode" above).  backward = 0: inerf_pack_weights blob in the
+// INERF_PREC_F16X3 format; 1: inerf_pack_weights_bwd blob.  half_src / half_grp: 2 * packed floats entries each.
+// The constants (biases, plain fp32 weights, scale factors) come back as up to const_capacity entries; returns their
+// number, or a negative INERF_E_*.
+int64_t inerf_pack_map(const inerf_net_desc* net, int backward, int32_t* half_src, int32_t* half_grp, int64_t half_capacity,
+                       int32_t* c_dst, int32_t* c_src, int32_t* c_group, int32_t* c_code, float* c_mult, int64_t const_capacity,
+                       int32_t* n_groups) {
+    using namespace inerf;
+    if (!net || !half_src || !half_grp || !c_dst || !c_src || !c_group || !c_code || !c_mult || !n_groups) return INERF_E_INVALID;
+    inerf_net_desc d = *net;
+    d.precision = INERF_PREC_F16X3;
+    if (!net_supported(d)) return INERF_E_INVALID;
+    const int64_t total = backward ? make_bwd_layout(d).total_floats : make_layout(d).total_floats;
+    if (half_capacity < 2 * total) return INERF_E_INVALID;
+    const Net n = describe(d);
+    std::vector<std::vector<float>> index_tensors;
+    std::vector<const float*> ptrs;
+    int64_t flat = 0;
+    for (const TensorSpec& t : n.spec) {
+        const int64_t count = t.rows * (t.cols ? t.cols : 1);
+        std::vector<float> v((size_t)count);
+        for (int64_t j = 0; j < count; ++j) v[(size_t)j] = (float)(flat + j + 1);       // < 2^24: exact
+        flat += count;
+        index_tensors.push_back(std::move(v));
+    }
+    for (const auto& v : index_tensors) ptrs.push_back(v.data());
+    std::vector<float> scratch((size_t)total, 0.0f);
+    std::memset(half_src, 0, sizeof(int32_t) * 2 * (size_t)total);
+    std::memset(half_grp, 0, sizeof(int32_t) * 2 * (size_t)total);
+    MapSink sink;
+    sink.base = scratch.data();
+    sink.half_src = half_src;
+    sink.half_grp = half_grp;
+    sink.is_weight.assign((size_t)total, 0);
+    g_map = &sink;
+    const int rc = backward ? inerf_pack_weights_bwd(&d, ptrs.data(), (int)ptrs.size(), scratch.data(), total)
+                            : inerf_pack_weights(&d, ptrs.data(), (int)ptrs.size(), scratch.data(), total);
+    g_map = nullptr;
+    if (rc != INERF_OK) return rc;
+    std::vector<char> is_const((size_t)total, 0);
+    for (const FloatEntry& e : sink.consts) is_const[(size_t)e.dst] = 1;
+    std::vector<FloatEntry> all = sink.consts;
+    for (int64_t f = 0; f < total; ++f) {
+        if (sink.is_weight[(size_t)f] || is_const[(size_t)f] || scratch[(size_t)f] == 0.0f) continue;
+        float mult = 1.0f;
+        for (const auto& r : sink.times8)
+            if (f >= r.first && f < r.second) mult = kActScale;
+        all.push_back({(int32_t)f, (int32_t)scratch[(size_t)f], 0, 0, mult});
+    }
+    if ((int64_t)all.size() > const_capacity) return INERF_E_INVALID;
+    for (size_t i = 0; i < all.size(); ++i) {
+        c_dst[i] = all[i].dst; c_src[i] = all[i].src; c_group[i] = all[i].group; c_code[i] = all[i].code; c_mult[i] = all[i].mult;
+    }
+    *n_groups = sink.next_group;
+    return (int64_t)all.size();
 }
 
 }  // extern "C"

@@ -334,3 +334,171 @@ def render_rays_fused(desc, packed_coarse, packed_fine, rays, n_samples, n_impor
     # `ws` and the input tensors are kept alive by the caching allocator's stream semantics: they are
     # released on the same stream the kernels were enqueued on.
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# training: fused forward that keeps the activations, MFMA input-gradient chain, weight gradients as library GEMMs
+# ---------------------------------------------------------------------------------------------------------------------
+(SAVE_ENC, SAVE_DIR, SAVE_H0, SAVE_AS1H, SAVE_FEAT, SAVE_VH, SAVE_SEMH, SAVE_DPRE, SAVE_SLOTS) = (0, 1, 2, 10, 11, 12, 13, 14, 15)
+
+
+def save_slot_views(desc, buf, n_points):
+    """The [n_points, width] matrices of an activation / gradient buffer (include/inerf.h: slot list)."""
+    views = []
+    off, width = C.c_int64(), C.c_int()
+    for slot in range(SAVE_SLOTS):
+        _capi.check(_capi.lib().inerf_mlp_save_slot(desc, slot, n_points, C.byref(off), C.byref(width)), "inerf_mlp_save_slot")
+        views.append(buf[off.value: off.value + n_points * width.value].view(n_points, width.value))
+    return views
+
+
+def encode_mlp_train(desc, packed, rays, z_vals, endpoint=False, status=None):
+    """``encode_mlp`` that also returns the activation buffer the backward pass needs (PREC_F16X3 only)."""
+    rays = _dev(rays, "rays", (None, RAY_FLOATS))
+    z_vals = _dev(z_vals, "z_vals", (rays.shape[0], None))
+    packed = _dev(packed, "packed weights", (None,))
+    n, s = z_vals.shape
+    flags = FLAG_ENDPOINT if endpoint else 0
+    ch = _capi.lib().inerf_raw_channels(desc, flags, 1)
+    raw = _new(rays, n, s, ch)
+    save = _new(rays, _capi.lib().inerf_mlp_save_floats(desc, n * s))
+    with torch.cuda.device(rays.device):
+        rc = _capi.lib().inerf_encode_mlp_train(desc, _ptr(packed), _ptr(rays), _ptr(z_vals), n, s, flags, _ptr(raw), _ptr(save),
+                                                None if status is None else C.c_void_p(status.data_ptr()), _stream(rays))
+    _capi.check(rc, "inerf_encode_mlp_train")
+    return raw, save
+
+
+def mlp_backward_inputs(desc, packed_bwd, raw, d_raw, save, endpoint=False, status=None):
+    """Pre-activation gradients of every layer (same slot layout as ``save``) from d loss / d raw."""
+    raw = _dev(raw, "raw", (None, None))
+    p, ch = raw.shape
+    d_raw = _dev(d_raw, "d_raw", (p, ch))
+    save = _dev(save, "save", (None,))
+    packed_bwd = _dev(packed_bwd, "packed transposed weights", (None,))
+    dz = _new(raw, save.shape[0])
+    with torch.cuda.device(raw.device):
+        rc = _capi.lib().inerf_mlp_backward_inputs(desc, _ptr(packed_bwd), _ptr(raw), _ptr(d_raw), _ptr(save), p,
+                                                   FLAG_ENDPOINT if endpoint else 0, _ptr(dz),
+                                                   None if status is None else C.c_void_p(status.data_ptr()), _stream(raw))
+    _capi.check(rc, "inerf_mlp_backward_inputs")
+    return dz
+
+
+def _head_names(desc):
+    if desc.variant == _capi.VARIANT_OBJECT:      # run_nerf_helpers.py:259-279: 'shading_linear' is the residual head
+        return "test_linear1", "test_linear2", "shading_linear"
+    return "shading_linear1", "shading_linear2", "residual_linear"
+
+
+def _split_k(n_points, target=96):
+    """Largest divisor of n_points not above ``target``: dW = dZ^T X has a tiny output (<= 256 x 320) and K = n_points in
+    the hundreds of thousands, which a GEMM library runs on a handful of workgroups; as a batched GEMM over K-chunks plus
+    a sum it fills the chip."""
+    for nc in range(min(target, n_points), 0, -1):
+        if n_points % nc == 0:
+            return nc
+    return 1
+
+
+def _tn(g, x, nc):
+    """g^T @ x for g[P, M], x[P, N], split over P into nc chunks."""
+    if nc == 1:
+        return g.t() @ x
+    p = g.shape[0]
+    return torch.bmm(g.view(nc, p // nc, g.shape[1]).transpose(1, 2), x.view(nc, p // nc, x.shape[1])).sum(0)
+
+
+def _colsum(g, nc):
+    return g.sum(0) if nc == 1 else g.view(nc, g.shape[0] // nc, g.shape[1]).sum(1).sum(0)
+
+
+def mlp_weight_gradients(desc, names, save, dz, d_raw, n_points, endpoint=False):
+    """dW = dZ^T X and db = column sums of dZ for every layer, as library GEMMs over the sample points.  Returns a dict
+    name -> gradient with the reference's parameter names and shapes."""
+    X = save_slot_views(desc, save, n_points)
+    G = save_slot_views(desc, dz, n_points)
+    e, dv = 3 + 6 * desc.l_xyz, 3 + 6 * desc.l_dir
+    sh1, sh2, res = _head_names(desc)
+    out = {}
+
+    nc = _split_k(n_points)
+
+    def lin(name, g, x):
+        out[name + ".weight"] = _tn(g, x, nc)
+        out[name + ".bias"] = _colsum(g, nc)
+
+    enc, h = X[SAVE_ENC], [X[SAVE_H0 + i] for i in range(8)]        # enc / dir: zero-padded columns, cut from the products
+    out["pts_linears.0.weight"] = _tn(G[SAVE_H0], enc, nc)[:, :e]
+    out["pts_linears.0.bias"] = _colsum(G[SAVE_H0], nc)
+    for i in range(1, 8):
+        if i == 5:         # cat([pts, h]) (run_nerf_helpers.py:290-291)
+            g = G[SAVE_H0 + 5]
+            out["pts_linears.5.weight"] = torch.cat([_tn(g, enc, nc)[:, :e], _tn(g, h[4], nc)], 1)
+            out["pts_linears.5.bias"] = _colsum(g, nc)
+        else:
+            lin(f"pts_linears.{i}", G[SAVE_H0 + i], h[i - 1])
+    dpre = G[SAVE_DPRE]
+    # everything that reads h7: one GEMM
+    sem = desc.variant == _capi.VARIANT_SSR and desc.n_classes > 0
+    parts = [G[SAVE_AS1H], G[SAVE_FEAT], dpre[:, 7:8]] + ([G[SAVE_SEMH]] if sem else [])
+    gcat = torch.cat(parts, 1)
+    wcat, bcat = _tn(gcat, h[7], nc), _colsum(gcat, nc)
+    out["albedo_linear1.weight"], out["albedo_linear1.bias"] = wcat[0:128], bcat[0:128]
+    out[sh1 + ".weight"], out[sh1 + ".bias"] = wcat[128:256], bcat[128:256]
+    out["feature_linear.weight"], out["feature_linear.bias"] = wcat[256:512], bcat[256:512]
+    out["alpha_linear.weight"], out["alpha_linear.bias"] = wcat[512:513], bcat[512:513]
+    if sem:
+        out["semantic_linear.0.0.weight"], out["semantic_linear.0.0.bias"] = wcat[513:641], bcat[513:641]
+        c = desc.n_classes
+        lin("semantic_linear.1", d_raw[:, BASE_CHANNELS:BASE_CHANNELS + c], X[SAVE_SEMH])
+    as1h = X[SAVE_AS1H]
+    lin("albedo_linear2", dpre[:, 0:3], as1h[:, :128])
+    lin(sh2, dpre[:, 3:4], as1h[:, 128:])
+    g = G[SAVE_VH]
+    out["views_linears.0.weight"] = torch.cat([_tn(g, X[SAVE_FEAT], nc), _tn(g, X[SAVE_DIR], nc)[:, :dv]], 1)
+    out["views_linears.0.bias"] = _colsum(g, nc)
+    lin(res, dpre[:, 4:7], X[SAVE_VH])
+    return {k: out[k] for k in names}
+
+
+class _FusedMlpFn(torch.autograd.Function):
+    """raw = MLP(encode(o + d z), encode(viewdir)) with a HIP forward AND backward: fused split-f16 forward that keeps the
+    activations, MFMA input-gradient chain, weight gradients by library GEMMs.  Parameters are re-packed on the device
+    (packing.DevicePacker).  rays / z get no gradient (as in the reference: rays are data, resampled depths are detached)."""
+
+    @staticmethod
+    def forward(ctx, rays, z_vals, desc, endpoint, names, *params):
+        from . import packing
+        named = dict(zip(names, params))
+        status = _new_status(rays)
+        packed = packing.device_packer(desc, False, rays.device)(named)
+        raw, save = encode_mlp_train(desc, packed, rays.detach(), z_vals.detach(), endpoint, status)
+        check_f16_range(status, "training forward")
+        ctx.save_for_backward(raw, save, *params)
+        ctx.cfg = (desc, endpoint, names)
+        return raw
+
+    @staticmethod
+    def backward(ctx, d_raw):
+        from . import packing
+        desc, endpoint, names = ctx.cfg
+        raw, save = ctx.saved_tensors[:2]
+        params = ctx.saved_tensors[2:]
+        n, s, ch = raw.shape
+        status = _new_status(raw)
+        packed_bwd = packing.device_packer(desc, True, raw.device)(dict(zip(names, params)))
+        d2 = d_raw.contiguous().view(n * s, ch).float()
+        dz = mlp_backward_inputs(desc, packed_bwd, raw.view(n * s, ch), d2, save, endpoint, status)
+        check_f16_range(status, "training backward")
+        grads = mlp_weight_gradients(desc, names, save, dz, d2, n * s, endpoint)
+        return (None, None, None, None, None) + tuple(grads[k] for k in names)
+
+
+def mlp_train(desc, module, rays, z_vals, endpoint=False):
+    """Differentiable fused network evaluation for a training step: ``module``'s parameters receive gradients."""
+    from . import packing
+    d = _capi.NetDesc(desc.variant, desc.n_classes, desc.l_xyz, desc.l_dir, desc.xyz_div, _capi.PREC_F16X3)
+    names = tuple(name for name, _ in packing.tensor_table(d))
+    named = dict(module.named_parameters())
+    return _FusedMlpFn.apply(rays, z_vals, d, bool(endpoint), names, *[named[k] for k in names])

@@ -153,15 +153,34 @@ _told_training_path = False
 
 def _training_path_notice(what):
     """Training steps (run_nerf.py:942-1018, trainer.py:882-990) take the STAGED path: sampling and compositing run
-    on the HIP kernels - compositing with its HIP backward (inerf_composite_backward) - while the networks are
-    evaluated by their torch ``forward`` so that autograd records them; the fused encode+MLP kernel has no backward
-    yet.  Said once per process, so the switch is never silent."""
+    on the HIP kernels - compositing with its HIP backward (inerf_composite_backward) - and each network is one
+    autograd node (kernels.mlp_train): fused HIP forward that keeps the activations, HIP input-gradient chain, weight
+    gradients as library GEMMs.  ``INERF_TRAIN_MLP=torch`` (or a precision other than f16x3, or a network outside the
+    fused architecture) evaluates the layers with their torch ``forward`` instead.  Said once per process."""
     global _told_training_path
     if not _told_training_path:
         import warnings
-        warnings.warn(f"{what}: gradients requested - using the staged training path (HIP sampling / compositing with HIP "
-                      "backward; network layers through torch autograd).  Render under torch.no_grad() for the fused path.")
+        warnings.warn(f"{what}: gradients requested - using the staged training path (HIP sampling, HIP compositing and "
+                      "network kernels with HIP backward).  Render under torch.no_grad() for the fully fused path.")
         _told_training_path = True
+
+
+def _train_desc(desc):
+    """Descriptor for the fused training evaluation of a fusable network, or None when torch autograd has to do it."""
+    import os
+    if desc is None or _capi.default_precision() != _capi.PREC_F16X3 or os.environ.get("INERF_TRAIN_MLP", "hip") == "torch":
+        return None
+    return desc
+
+
+def _train_query(train_desc, fn, ray_batch, z_vals, endpoint=False):
+    """raw for a training step through kernels.mlp_train; None if this batch has to go through torch (f16 range)."""
+    try:
+        return kernels.mlp_train(train_desc, fn, ray_batch, z_vals, endpoint)
+    except FloatingPointError as e:
+        import warnings
+        warnings.warn(f"{e}  Evaluating this batch with torch autograd instead.")
+        return None
 
 
 def _run_network_torch(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk):
@@ -281,9 +300,10 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
             nz = torch.Tensor(np.random.rand(n, s) * raw_noise_std).to(dev)
         return nz
 
+    train_desc = None
     if desc is not None and _wants_grad(network_fn, network_fine):
         _training_path_notice("render_rays")
-        desc = None
+        train_desc, desc = _train_desc(desc), None
     if desc is not None:
         noise_c = noise(N_samples)
         u = _draw_u(n, N_importance, perturb == 0., pytest, dev) if N_importance > 0 else None
@@ -312,17 +332,22 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
         # user-supplied network, or a training step: the stages run on the HIP kernels (compositing differentiably),
         # the network is called as given / through its torch forward
         rays_o, rays_d, viewdirs = ray_batch[:, 0:3], ray_batch[:, 3:6].contiguous(), ray_batch[:, -3:]
+        def query(z, fn):
+            raw = _train_query(train_desc, fn, ray_batch, z) if train_desc is not None else None
+            if raw is None:
+                pts = rays_o[..., None, :] + rays_d[..., None, :] * z[..., :, None]
+                raw = network_query_fn(pts, viewdirs, fn)
+            return raw
+
         z_vals = kernels.sample_coarse(ray_batch, t_vals, t_rand, lindisp)
-        pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
-        raw = network_query_fn(pts, viewdirs, network_fn)
+        raw = query(z_vals, network_fn)
         c = kernels.composite(raw.float(), z_vals, rays_d, noise(N_samples), white_bkgd)
         ret = {rk: c[ok] for rk, ok in _RET_MAP}
         if N_importance > 0:
             c0 = c
             u = _draw_u(n, N_importance, perturb == 0., pytest, dev)
             z_samples, z_vals, z_std = kernels.sample_fine(z_vals, c0["weights"], u, N_importance)
-            pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
-            raw = network_query_fn(pts, viewdirs, network_fn if network_fine is None else network_fine)
+            raw = query(z_vals, network_fn if network_fine is None else network_fine)
             c = kernels.composite(raw.float(), z_vals, rays_d, noise(N_samples + N_importance), white_bkgd)
             ret = {rk: c[ok] for rk, ok in _RET_MAP}
             for rk, ok in _RET_0:

@@ -16,7 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _capi, kernels, packing
-from .object_level import Embedder, _run_network_torch, _training_path_notice, _wants_grad
+from .object_level import Embedder, _run_network_torch, _train_desc, _train_query, _training_path_notice, _wants_grad
 
 __all__ = ["get_embedder", "Semantic_NeRF", "run_network", "raw2outputs", "sample_pdf", "create_rays",
            "get_rays_camera", "get_rays_world", "batchify_rays", "SSRRenderMixin", "SSRRenderer"]
@@ -283,7 +283,7 @@ class SSRRenderMixin:
 
         if _wants_grad(self.ssr_net_coarse, self.ssr_net_fine):
             _training_path_notice("volumetric_rendering")
-            o = self._staged(ray_batch, t_vals, t_rand, noise_c, u, noise_f, ep)
+            o = self._staged(ray_batch, t_vals, t_rand, noise_c, u, noise_f, ep, _train_desc(desc))
         else:
             o = kernels.with_f32_fallback(desc, run)
         ret = {}
@@ -309,22 +309,29 @@ class SSRRenderMixin:
                     print(f"! [Numerical Error] {k} contains nan or inf.")
         return ret
 
-    def _staged(self, ray_batch, t_vals, t_rand, noise_c, u, noise_f, ep):
-        """trainer.py:717-808 stage by stage, for training steps: HIP sampling, HIP compositing with its HIP backward,
-        the two networks through their torch forward (autograd).  Same keys as kernels.render_rays_fused."""
+    def _staged(self, ray_batch, t_vals, t_rand, noise_c, u, noise_f, ep, train_desc=None):
+        """trainer.py:717-808 stage by stage, for training steps: HIP sampling, HIP compositing with its HIP backward, each
+        network one autograd node with HIP forward and backward (kernels.mlp_train; torch ``forward`` when ``train_desc`` is
+        None).  Same keys as kernels.render_rays_fused."""
         rays_o, rays_d, viewdirs = ray_batch[:, 0:3], ray_batch[:, 3:6].contiguous(), ray_batch[:, -3:]
         c_sem = self.num_valid_semantic_class if self.enable_semantic else 0
+
+        def query(z, fn, endpoint=False):
+            raw = _train_query(train_desc, fn, ray_batch, z, endpoint) if train_desc is not None else None
+            if raw is None:
+                pts = rays_o[..., None, :] + rays_d[..., None, :] * z[..., :, None]
+                raw = run_network(pts, viewdirs, fn, self.embed_fn, self.embeddirs_fn, self.netchunk, show_endpoint=endpoint)
+            return raw
+
         z_vals = kernels.sample_coarse(ray_batch, t_vals, t_rand, False)
-        pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
-        raw = run_network(pts, viewdirs, self.ssr_net_coarse, self.embed_fn, self.embeddirs_fn, self.netchunk)
+        raw = query(z_vals, self.ssr_net_coarse)
         c = kernels.composite(raw, z_vals, rays_d, noise_c, self.white_bkgd, n_classes=c_sem)
         o = {k + "_coarse": v for k, v in c.items()}
         o["raw_coarse"] = raw
         if self.N_importance > 0:
             # the resampled depths carry no gradient (z_samples.detach(), trainer.py:762)
             z_samples, z_fine, z_std = kernels.sample_fine(z_vals, c["weights"].detach(), u, self.N_importance)
-            pts = rays_o[..., None, :] + rays_d[..., None, :] * z_fine[..., :, None]
-            raw = run_network(pts, viewdirs, self.ssr_net_fine, self.embed_fn, self.embeddirs_fn, self.netchunk, show_endpoint=ep)
+            raw = query(z_fine, self.ssr_net_fine, ep)
             f = kernels.composite(raw, z_fine, rays_d, noise_f, self.white_bkgd, n_classes=c_sem, feat_dim=128 if ep else 0)
             o.update({k + "_fine": v for k, v in f.items()})
             o["raw_fine"], o["z_std"] = raw, z_std
