@@ -196,3 +196,81 @@ def test_ssr_training_step_gradients_vs_oracle():
             assert p.grad is not None, (tag, name)
             err = float((p.grad.double().cpu() - w).norm())
             assert err <= 2e-4 * float(w.norm()) + 1e-12, (tag, name, err, float(w.norm()))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# network backward: fused training forward + MFMA input-gradient chain + weight-gradient GEMMs (kernels.mlp_train)
+# ---------------------------------------------------------------------------------------------------------------------
+def _torch_reference_grads(module, embed, embed_d, rays, z, cot, endpoint=False):
+    """raw and parameter gradients of the same network through torch autograd (the module's own forward)."""
+    pts = rays[:, None, 0:3] + rays[:, None, 3:6] * z[:, :, None]
+    emb = torch.cat([embed(pts.reshape(-1, 3)), embed_d(rays[:, None, 8:11].expand(pts.shape).reshape(-1, 3))], -1)
+    raw = module(emb, True) if endpoint else module(emb)
+    raw = raw.reshape(z.shape[0], z.shape[1], -1)
+    module.zero_grad()
+    (raw * cot).sum().backward()
+    return raw.detach(), {k: p.grad.clone() for k, p in module.named_parameters()}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant,c,endpoint,n,s", [("object", 0, False, 37, 5), ("object", 0, False, 64, 64),
+                                                    ("ssr", 5, True, 23, 11), ("ssr", 28, False, 16, 192), ("ssr", 0, False, 9, 7)])
+def test_network_backward_vs_torch_autograd(variant, c, endpoint, n, s):
+    """One network, arbitrary cotangent on raw (every channel: sigma, the sigmoid heads, logits, endpoint feature), ragged
+    point counts: raw and every parameter gradient of kernels.mlp_train against torch autograd through the module's own
+    forward on the same GPU."""
+    from intrinsicnerf_amd import kernels, object_level as ol, ssr
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(7 + n)
+    sd = oracle.lcg_state_dict(variant, c, seed=21, sigma_gain_log2=3, freq_decay=True)
+    if variant == "object":
+        embed, ch = ol.get_embedder(10, 0); embed_d, ch_d = ol.get_embedder(4, 0)
+        net = ol.NeRF(D=8, W=256, input_ch=ch, output_ch=5, skips=[4], input_ch_views=ch_d, use_viewdirs=True).to(dev)
+    else:
+        embed, ch = ssr.get_embedder(10, 0, scalar_factor=10); embed_d, ch_d = ssr.get_embedder(4, 0, scalar_factor=1)
+        net = ssr.Semantic_NeRF(c > 0, c, D=8, W=256, input_ch=ch, output_ch=5, skips=[4], input_ch_views=ch_d, use_viewdirs=True).to(dev)
+    net.load_state_dict(sd)
+    o = torch.rand(n, 3, generator=g) * 2 - 1
+    d = torch.randn(n, 3, generator=g)
+    rays = torch.cat([o, d, torch.zeros(n, 2), d / d.norm(dim=-1, keepdim=True)], -1).to(dev)
+    z = torch.sort(torch.rand(n, s, generator=g) * 3 + 0.5, -1)[0].to(dev)
+    chn = 11 + c + (128 if endpoint else 0)
+    cot = (torch.randn(n, s, chn, generator=g) * torch.logspace(-3, 1, n, base=10.0)[:, None, None]).to(dev)   # 4 decades of scale
+    want_raw, want = _torch_reference_grads(net, embed, embed_d, rays, z, cot, endpoint)
+    net.zero_grad()
+    desc = net.fused_desc()
+    desc.xyz_div = embed.scalar_factor
+    raw = kernels.mlp_train(desc, net, rays, z, endpoint)
+    assert type(raw.grad_fn).__name__ == "_FusedMlpFnBackward"
+    assert_maps_close(raw.detach().cpu().numpy(), want_raw.cpu().numpy(), 1e-4, 1e-5 * float(want_raw.abs().max()), "raw")
+    (raw * cot).sum().backward()
+    for name, p in net.named_parameters():
+        w = want[name].double()
+        err = float((p.grad.double() - w).norm())
+        assert err <= 2e-4 * float(w.norm()) + 1e-10, (name, err, float(w.norm()))
+
+
+@pytest.mark.gpu
+def test_training_step_uses_the_hip_network_backward(monkeypatch):
+    """The front-end's training step wires kernels.mlp_train in by default and torch's layers with INERF_TRAIN_MLP=torch."""
+    import warnings
+    from intrinsicnerf_amd import object_level as ol
+    dev = torch.device("cuda:0")
+    fx = load_golden("object_chair_det")
+    embed, ch = ol.get_embedder(10, 0); embed_d, ch_d = ol.get_embedder(4, 0)
+    net = ol.NeRF(D=8, W=256, input_ch=ch, output_ch=5, skips=[4], input_ch_views=ch_d, use_viewdirs=True).to(dev)
+    net.load_state_dict(case_weights(fx)[0])
+    rays = torch.from_numpy(fx["rays"][:5]).to(dev)
+    grads = {}
+    for mode in ("hip", "torch"):
+        monkeypatch.setenv("INERF_TRAIN_MLP", mode)
+        net.zero_grad()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ret = ol.render_rays(rays, net, ol.NetworkQuery(embed, embed_d), 64, retraw=True, N_importance=16, white_bkgd=True)
+        assert (type(ret["raw"].grad_fn).__name__ == "_FusedMlpFnBackward") == (mode == "hip")
+        (ret["rgb_map"].sum() + ret["albedo_map"].sum() + ret["rgb0"].sum()).backward()
+        grads[mode] = {k: p.grad.clone() for k, p in net.named_parameters()}
+    for k in grads["hip"]:
+        w = grads["torch"][k].double()
+        assert float((grads["hip"][k].double() - w).norm()) <= 2e-4 * float(w.norm()) + 1e-10, k

@@ -332,3 +332,21 @@ def test_reduced_encoding_widths_pack(capi):
     w = _unpack_wide(blob, slots["trunk5"][1], 256, 320)
     assert np.array_equal(w[:, :39], sd["pts_linears.5.weight"].numpy()[:, :39]) and not w[:, 39:64].any()
     assert np.array_equal(w[:, 64:], sd["pts_linears.5.weight"].numpy()[:, 39:])
+
+
+@pytest.mark.parametrize("variant,c", [("object", 0), ("ssr", 28), ("ssr", 0)])
+def test_device_packer_is_bit_identical_to_host_packer(capi, variant, c):
+    """packing.DevicePacker (torch ops driven by inerf_pack_map; used after every optimiser step of a training run)
+    reproduces inerf_pack_weights and inerf_pack_weights_bwd bit for bit - here on CPU tensors."""
+    from intrinsicnerf_amd import packing
+    desc = capi.net_desc(capi.VARIANT_SSR if variant == "ssr" else capi.VARIANT_OBJECT, c, 10, 4, 10.0 if variant == "ssr" else 1.0,
+                         precision=capi.PREC_F16X3)
+    for seed in (3, 4):
+        sd = oracle.make_state_dict(variant, c, seed=seed)
+        if seed == 4:
+            sd["pts_linears.2.weight"] = sd["pts_linears.2.weight"] * 0.0          # an all-zero GEMM: scale 1
+            sd["feature_linear.weight"] = sd["feature_linear.weight"] * 1000.0     # moves the common scale of the d h7 group
+        for backward in (False, True):
+            host = packing.pack_state_dict_bwd(desc, sd) if backward else packing.pack_state_dict(desc, sd)
+            dev = packing.device_packer(desc, backward, "cpu")(sd)
+            assert torch.equal(host.view(torch.int32), dev.view(torch.int32)), (variant, c, seed, backward)
