@@ -129,9 +129,13 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
 
         const int pt0 = tile * kPts + (lane & 31);              // this lane's points in wide results
         // training forward: fp32 copy of a layer's output, this lane's first point / first channel of its wave
-        auto save_ptr = [&](int slot, int width, int chan0) -> float* {
-            if (!kSave) return nullptr;
-            return p.save + p.save_off[slot] + (size_t)pt0 * width + chan0 + 4 * (lane >> 5);
+        auto save_dst = [&](int slot, int width, int chan0) {
+            SaveDst d;
+            d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save + (kSave ? p.save_off[slot] : 0), 0,
+                                                       kSave ? p.n_points * width * 4 : 0, 0x00020000);
+            d.voff = (pt0 * width + chan0 + 4 * (lane >> 5)) * 4;
+            d.stride = width;
+            return d;
         };
         auto step256 = [&](const GemmSlot& s, auto kb0c, auto kb1c, int c0, int c1, int dcol, bool relu, int slot,
                            auto&& prefetch_next) {
@@ -145,8 +149,8 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
             const float inv = pre2.inv;
             wide_gemm_h<2, KB0, KB1>(pre2, wb, frag256(s, KB0 + KB1), xr, c0, c1, lane, am);
             prefetch_next();
-            wide_store_h<2>(am, inv, bias, xd + dcol + 64 * wave, relu, amax2, nullptr, 0, pt0 < p.n_points, pt0 + 32 < p.n_points,
-                            save_ptr(slot, kWidth, 64 * wave), kWidth);
+            const SaveDst sv = save_dst(slot, kWidth, 64 * wave);
+            wide_store_h<2, kRowH, kPlaneH, kSave>(am, inv, bias, xd + dcol + 64 * wave, relu, amax2, nullptr, 0, 0, 0, &sv);
             __syncthreads();
         };
         auto step128 = [&](const GemmSlot& s, auto kb0c, auto kb1c, int c0, int c1, int dcol, bool relu, float* gout, int slot,
@@ -159,8 +163,9 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
             const float inv = pre1.inv;
             wide_gemm_h<1, KB0, KB1>(pre1, wb, frag128(s, KB0 + KB1), xr, c0, c1, lane, am);
             prefetch_next();
-            wide_store_h<1>(am, inv, bias, xd + dcol + 32 * wave, relu, amax2, gout, p.channels, pt0 < p.n_points,
-                            pt0 + 32 < p.n_points, save_ptr(slot, kHalf, 32 * wave), kHalf);
+            const SaveDst sv = save_dst(slot, kHalf, 32 * wave);
+            wide_store_h<1, kRowH, kPlaneH, kSave>(am, inv, bias, xd + dcol + 32 * wave, relu, amax2, gout, p.channels, pt0 < p.n_points,
+                                                  pt0 + 32 < p.n_points, &sv);
             __syncthreads();
         };
         auto pf256 = [&](const GemmSlot& s, int kbt) {

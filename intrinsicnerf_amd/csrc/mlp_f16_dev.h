@@ -167,13 +167,20 @@ __device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const Weigh
 // Range check: packed f16 max over the |hi| pairs (inf when |t| > 65504).
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-template <int RB, int ROW = kRowH, int PLANE = kPlaneH>
+// The optional training copy goes through a buffer descriptor (one per activation slot, wave-uniform) and ONE per-lane
+// byte offset shared by all slots: with 64-bit global addresses the compiler kept an address pair per layer alive across
+// the tile loop and spilled ~300 registers.  Points beyond the end of the slot are dropped by the descriptor's range check.
+struct SaveDst {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff;          // bytes: (pt0 * width + chan0 + 4 * (lane >> 5)) * 4
+    int stride;        // floats per point
+};
+
+template <int RB, int ROW = kRowH, int PLANE = kPlaneH, bool SAVE = false>
 __device__ __forceinline__ void wide_store_h(const f32x16 (&am)[RB][2], float inv, const f32x4 (&bias)[RB][4],
                                              _Float16* dl,   // plane_hi + (lane&31)*kRowH + 4*(lane>>5) + dcol + chan0
                                              bool relu, f16x2& amax2, float* gout /* or nullptr: + chan0 + 4*(lane>>5) */,
-                                             int gstride, int valid0, int valid1,
-                                             float* gsave = nullptr /* second fp32 copy (training forward), same addressing */,
-                                             int sstride = 0) {
+                                             int gstride, int valid0, int valid1, const SaveDst* sv = nullptr) {
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
 #pragma unroll
@@ -189,9 +196,11 @@ __device__ __forceinline__ void wide_store_h(const f32x16 (&am)[RB][2], float in
                     if (gout && (pb == 0 ? valid0 : valid1))
                         gout[(size_t)pb * 32 * gstride + 32 * rb + 8 * g + i] = t[i] * (1.0f / kActScale);
                 }
-                if (gsave && (pb == 0 ? valid0 : valid1))
-                    *reinterpret_cast<f32x4*>(gsave + (size_t)pb * 32 * sstride + 32 * rb + 8 * g) =
-                        f32x4{t[0], t[1], t[2], t[3]} * (1.0f / kActScale);
+                if constexpr (SAVE) {
+                    const f32x4 v = f32x4{t[0], t[1], t[2], t[3]} * (1.0f / kActScale);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), sv->rsrc,
+                                                           sv->voff + (pb * 32 * sv->stride + 32 * rb + 8 * g) * 4, 0, 0);
+                }
                 const f16x2 h01 = {(_Float16)th[0], (_Float16)th[1]}, h23 = {(_Float16)th[2], (_Float16)th[3]};
                 const f16x2 l01 = {(_Float16)(t[0] - th[0]), (_Float16)(t[1] - th[1])};
                 const f16x2 l23 = {(_Float16)(t[2] - th[2]), (_Float16)(t[3] - th[3])};

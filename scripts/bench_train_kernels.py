@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Timing of the two training kernels alone (training forward with activation saving, input-gradient chain) and of the
+weight-gradient GEMMs, on the reference's fine-pass batch shape.   python scripts/bench_train_kernels.py [--rays 2048]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__  # noqa: E402
+
+__graft_entry__.build()
+import oracle  # noqa: E402
+from intrinsicnerf_amd import _capi, kernels, packing  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rays", type=int, default=2048)
+ap.add_argument("--samples", type=int, default=192)
+ap.add_argument("--iters", type=int, default=5)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+desc = _capi.net_desc(_capi.VARIANT_OBJECT, 0, 10, 4, 1.0, _capi.PREC_F16X3)
+sd = {k: v.to(dev) for k, v in oracle.make_state_dict("object", 0, seed=0).items()}
+pf, pb = packing.device_packer(desc, False, dev)(sd), packing.device_packer(desc, True, dev)(sd)
+names = tuple(n for n, _ in packing.tensor_table(desc))
+n, s = a.rays, a.samples
+g = torch.Generator().manual_seed(0)
+o = torch.tensor([[2.5, 1.5, 2.0]]).expand(n, 3)
+d = -o / o.norm(dim=-1, keepdim=True) + 0.2 * torch.randn(n, 3, generator=g)
+rays = torch.cat([o, d, 2 * torch.ones(n, 1), 6 * torch.ones(n, 1), d / d.norm(dim=-1, keepdim=True)], -1).to(dev)
+z = torch.sort(torch.rand(n, s, generator=g) * 4 + 2, -1)[0].to(dev)
+d_raw = torch.randn(n * s, 11, device=dev)
+
+
+def timed(fn):
+    fn(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(a.iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); out = fn(); e1.record(); e1.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return sorted(ts)[len(ts) // 2], out
+
+
+flop = 2 * 659456 * n * s
+t_inf, _ = timed(lambda: kernels.encode_mlp(desc, pf, rays, z))
+t_fwd, (raw, save) = timed(lambda: kernels.encode_mlp_train(desc, pf, rays, z))
+t_bwd, dz = timed(lambda: kernels.mlp_backward_inputs(desc, pb, raw.view(n * s, 11), d_raw, save))
+t_wg, _ = timed(lambda: kernels.mlp_weight_gradients(desc, names, save, dz, d_raw, n * s))
+gb = save.numel() * 4 / 1e9
+print(f"{n} rays x {s} samples = {n * s} points; activation buffer {gb:.2f} GB")
+print(f"inference forward        {t_inf:7.3f} ms  {flop / t_inf / 1e9:6.1f} TFLOP/s")
+print(f"training forward (save)  {t_fwd:7.3f} ms  {flop / t_fwd / 1e9:6.1f} TFLOP/s   writes {gb / t_fwd * 1e3:5.2f} TB/s")
+print(f"input-gradient chain     {t_bwd:7.3f} ms  {0.89 * flop / t_bwd / 1e9:6.1f} TFLOP/s   reads+writes {2 * gb / t_bwd * 1e3:5.2f} TB/s")
+print(f"weight-gradient GEMMs    {t_wg:7.3f} ms  {flop / t_wg / 1e9:6.1f} TFLOP/s")
