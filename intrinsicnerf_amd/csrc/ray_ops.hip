@@ -130,15 +130,20 @@ __global__ __launch_bounds__(256) void k_composite(const float* __restrict__ raw
 #pragma unroll
     for (int k = 0; k < INERF_BASE_CHANNELS; ++k) m[k] = k == 3 ? 0.0f : wave_sum(m[k]);
 
-    // optional channels (semantic logits, endpoint feature): sum_s w[s] * raw[s, channel], one channel at a time
-    auto channel_sum = [&](int channel) -> float {
+    // optional channels (semantic logits, endpoint feature): lanes = channels.  Every sample's channels are contiguous in
+    // raw, so 64 lanes read 256 contiguous bytes per sample and each lane accumulates its own channel over the samples in
+    // order; the weight of sample s is an LDS broadcast.  No cross-lane reduction.
+    const float* const w_ray = w_smem[threadIdx.x >> 6];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the lanes now read weights other lanes of this wave wrote
+    __builtin_amdgcn_wave_barrier();
+    auto channel_block = [&](int first, int count) -> float {        // channel first + lane, lanes >= count idle
         float v = 0.0f;
-#pragma unroll 1
-        for (int c = 0; c < chunks; ++c) {
-            const int s = c * 64 + lane;
-            if (s < s_count) v += __fmul_rn(w[c * 64], rr[(long long)s * ch + channel]);
+        if (lane < count) {
+            const float* __restrict__ col = rr + first + lane;
+#pragma unroll 4
+            for (int s = 0; s < s_count; ++s) v += __fmul_rn(w_ray[s], col[(long long)s * ch]);
         }
-        return wave_sum(v);
+        return v;
     };
     if (lane == 0) {
         // white background is added to rgb, albedo and shading but NOT to residual (run_nerf.py:407-410)
@@ -156,15 +161,17 @@ __global__ __launch_bounds__(256) void k_composite(const float* __restrict__ raw
         }
     }
     if (out.sem && n_classes > 0) {            // model_utils.py:90-94,113-114
-        for (int k = 0; k < n_classes; ++k) {
-            const float v = channel_sum(INERF_BASE_CHANNELS + k);
-            if (lane == 0) out.sem[ray * (long long)n_classes + k] = white_bkgd ? __fadd_rn(v, bg) : v;
+        for (int k0 = 0; k0 < n_classes; k0 += 64) {
+            const int cnt = n_classes - k0 < 64 ? n_classes - k0 : 64;
+            const float v = channel_block(INERF_BASE_CHANNELS + k0, cnt);
+            if (lane < cnt) out.sem[ray * (long long)n_classes + k0 + lane] = white_bkgd ? __fadd_rn(v, bg) : v;
         }
     }
     if (out.feat && feat_dim > 0) {            // the LAST feat_dim channels (model_utils.py:99-103)
-        for (int k = 0; k < feat_dim; ++k) {
-            const float v = channel_sum(ch - feat_dim + k);
-            if (lane == 0) out.feat[ray * (long long)feat_dim + k] = v;
+        for (int k0 = 0; k0 < feat_dim; k0 += 64) {
+            const int cnt = feat_dim - k0 < 64 ? feat_dim - k0 : 64;
+            const float v = channel_block(ch - feat_dim + k0, cnt);
+            if (lane < cnt) out.feat[ray * (long long)feat_dim + k0 + lane] = v;
         }
     }
 }

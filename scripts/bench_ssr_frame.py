@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[3]: a Replica room_0-like 320x240 frame through the SSR front-end (Semantic_NeRF with C = 28
+classes, reflectance + shading + residual + semantic heads, 64 + 128 samples, depth range [0.1, 10], xyz / 10 encoding,
+eval mode).  Synthetic camera and random-init weights (the dataset is not available here).
+
+    python scripts/bench_ssr_frame.py [--frames 3] [--classes 28]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__  # noqa: E402
+
+__graft_entry__.build()
+from intrinsicnerf_amd import ssr  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--frames", type=int, default=3)
+ap.add_argument("--classes", type=int, default=28)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+H, W = 240, 320
+fx = fy = W / 2.0 / np.tan(np.deg2rad(45.0))          # hfov 90 deg (trainer.py:68-74)
+cx, cy = (W - 1) / 2.0, (H - 1) / 2.0
+T = torch.eye(4)[None]                                   # rays are built on the host and moved, as trainer.py:608-624 does
+rays = ssr.create_rays(1, T, H, W, fx, fy, cx, cy, 0.1, 10.0).reshape(-1, 11).contiguous().to(dev)
+r = ssr.SSRRenderer(a.classes, white_bkgd=False, endpoint_feat=False, device=dev)
+r.return_raw = False
+r.check_numerics = False
+with torch.no_grad():
+    ret = r.render_rays(rays)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.frames):
+        ret = r.render_rays(rays)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.frames
+flop = 2 * (659456 + 32768 + 128 * a.classes) * rays.shape[0] * 256
+print(f"SSR frame {W}x{H} = {rays.shape[0]} rays, C = {a.classes}, 64+128 samples: {dt * 1e3:.1f} ms per frame -> {rays.shape[0] / dt:.0f} rays/s "
+      f"({flop / dt / 1e12:.0f} TFLOP/s algorithmic over the whole frame); keys: {sorted(ret.keys())[:4]}...")
