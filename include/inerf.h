@@ -138,8 +138,9 @@ int inerf_encode_mlp(const inerf_net_desc* net, const float* packed_weights, con
 int64_t inerf_mlp_save_floats(const inerf_net_desc* net, int64_t n_points);
 int inerf_mlp_save_slot(const inerf_net_desc* net, int slot, int64_t n_points, int64_t* offset_floats, int* width);
 int inerf_encode_mlp_train(const inerf_net_desc* net, const float* packed_weights, const float* rays, const float* z_vals,
-                           int64_t n_rays, int n_samples, uint32_t flags, float* raw_out, float* save_out, int32_t* status,
-                           void* stream);
+                           int64_t n_rays, int n_samples, uint32_t flags, float* raw_out, float* save_out,
+                           float* act_max /* optional device float the kernel max-es |activation| into (caller zeroes it) */,
+                           int32_t* status, void* stream);
 
 /* Transposed weights for the input-gradient chain, [host] -> [host] like inerf_pack_weights. */
 int64_t inerf_bwd_packed_floats(const inerf_net_desc* net);
@@ -149,8 +150,21 @@ int inerf_pack_weights_bwd(const inerf_net_desc* net, const float* const* tensor
 /* raw / d_raw: [n_points, CH] (CH as for inerf_encode_mlp with the same flags); save: from
  * inerf_encode_mlp_train on the same points; dz_out: every slot is written for every point. */
 int inerf_mlp_backward_inputs(const inerf_net_desc* net, const float* packed_bwd, const float* raw, const float* d_raw,
-                              const float* save, int64_t n_points, uint32_t flags, float* dz_out, int32_t* status,
-                              void* stream);
+                              const float* save, int64_t n_points, uint32_t flags, float* dz_out,
+                              float* dz_max /* optional device float the kernel max-es |dz| into (caller zeroes it) */,
+                              int32_t* status, void* stream);
+
+/* One weight gradient: workgroup g of inerf_wgrad_grid(n_points) writes sum over its sample points of G[p, m] * X[p, n]
+ * (row-major [M, N]) at partial + g * partial_stride and, if bias_partial is given, its sums of G[p, m] ([M]) at
+ * bias_partial + g * partial_stride; the caller adds the grid's tiles (deterministic, no atomics; several gradients can
+ * share one [grid, partial_stride] buffer and one final sum).  G[P, ldg] / X[P, ldx]: row-major device
+ * matrices (a slot of the gradient / activation buffers, or a 32-column-aligned part of one; pointers 16-byte
+ * aligned, ld a multiple of 4); M in {128, 256}, N in {32, 64, 128, 256}.  ranges: device floats {gmax, xmax}, upper
+ * bounds of |G| and |X| (e.g. the dz_max of inerf_mlp_backward_inputs; 7.5e3 for activations that passed the forward's
+ * range check): the kernel scales the operands by the powers of two that bring those bounds into [2^13, 2^14). */
+int inerf_wgrad_grid(int64_t n_points);
+int inerf_mlp_weight_gradient(const float* G, int ldg, const float* X, int ldx, int64_t n_points, int M, int N,
+                              const float* ranges, float* partial, float* bias_partial, int64_t partial_stride, void* stream);
 
 /* Where every element of a packed blob comes from, so that a caller can re-pack ON THE DEVICE after each
  * optimiser step (a gather, a per-group max for the power-of-two scales, an f16 hi/lo split) instead of moving the

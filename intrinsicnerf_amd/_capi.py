@@ -55,10 +55,12 @@ SYMBOLS = {
     "inerf_encode_mlp": (_I, [C.POINTER(NetDesc), _P, _P, _P, _L, _I, _U, _P, _P, _P]),
     "inerf_mlp_save_floats": (_L, [C.POINTER(NetDesc), _L]),
     "inerf_mlp_save_slot": (_I, [C.POINTER(NetDesc), _I, _L, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
-    "inerf_encode_mlp_train": (_I, [C.POINTER(NetDesc), _P, _P, _P, _L, _I, _U, _P, _P, _P, _P]),
+    "inerf_encode_mlp_train": (_I, [C.POINTER(NetDesc), _P, _P, _P, _L, _I, _U, _P, _P, _P, _P, _P]),
     "inerf_bwd_packed_floats": (_L, [C.POINTER(NetDesc)]),
     "inerf_pack_weights_bwd": (_I, [C.POINTER(NetDesc), C.POINTER(_P), _I, _P, _L]),
-    "inerf_mlp_backward_inputs": (_I, [C.POINTER(NetDesc), _P, _P, _P, _P, _L, _U, _P, _P, _P]),
+    "inerf_mlp_backward_inputs": (_I, [C.POINTER(NetDesc), _P, _P, _P, _P, _L, _U, _P, _P, _P, _P]),
+    "inerf_wgrad_grid": (_I, [_L]),
+    "inerf_mlp_weight_gradient": (_I, [_P, _I, _P, _I, _L, _I, _I, _P, _P, _P, _L, _P]),
     "inerf_pack_map": (_L, [C.POINTER(NetDesc), _I, _P, _P, _L, _P, _P, _P, _P, _P, _L, C.POINTER(C.c_int32)]),
     "inerf_composite": (_I, [_P, _P, _P, _I, _P, _L, _I, _I, _I, _I, _U, C.POINTER(CompositeOut), _P]),
     "inerf_composite_backward": (_I, [_P, _P, _P, _I, _P, _L, _I, _I, _I, _I, _U, C.POINTER(CompositeOut), _P, _P]),

@@ -402,12 +402,12 @@ int launch_mlp_f32(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream)
 }  // namespace inerf
 
 static int encode_mlp_impl(const inerf_net_desc* net, const float* packed, const float* rays, const float* z, int64_t n_rays,
-                           int n_samples, uint32_t flags, float* raw_out, float* save, int32_t* status, void* stream);
+                           int n_samples, uint32_t flags, float* raw_out, float* save, float* act_max, int32_t* status, void* stream);
 
 extern "C" int inerf_encode_mlp(const inerf_net_desc* net, const float* packed, const float* rays, const float* z,
                                 int64_t n_rays, int n_samples, uint32_t flags, float* raw_out, int32_t* status,
                                 void* stream) {
-    return encode_mlp_impl(net, packed, rays, z, n_rays, n_samples, flags, raw_out, nullptr, status, stream);
+    return encode_mlp_impl(net, packed, rays, z, n_rays, n_samples, flags, raw_out, nullptr, nullptr, status, stream);
 }
 
 extern "C" int64_t inerf_mlp_save_floats(const inerf_net_desc* net, int64_t n_points) {
@@ -424,15 +424,15 @@ extern "C" int inerf_mlp_save_slot(const inerf_net_desc* net, int slot, int64_t 
 
 extern "C" int inerf_encode_mlp_train(const inerf_net_desc* net, const float* packed, const float* rays, const float* z,
                                       int64_t n_rays, int n_samples, uint32_t flags, float* raw_out, float* save_out,
-                                      int32_t* status, void* stream) {
+                                      float* act_max, int32_t* status, void* stream) {
     if (!save_out || !net) return INERF_E_INVALID;
     if (net->precision != INERF_PREC_F16X3) return INERF_E_UNSUPPORTED;
     if (n_rays * (int64_t)n_samples > 4000000) return INERF_E_UNSUPPORTED;     // one activation slot stays below 4 GiB (buffer descriptors)
-    return encode_mlp_impl(net, packed, rays, z, n_rays, n_samples, flags, raw_out, save_out, status, stream);
+    return encode_mlp_impl(net, packed, rays, z, n_rays, n_samples, flags, raw_out, save_out, act_max, status, stream);
 }
 
 static int encode_mlp_impl(const inerf_net_desc* net, const float* packed, const float* rays, const float* z, int64_t n_rays,
-                           int n_samples, uint32_t flags, float* raw_out, float* save, int32_t* status, void* stream) {
+                           int n_samples, uint32_t flags, float* raw_out, float* save, float* act_max, int32_t* status, void* stream) {
     using namespace inerf;
     if (!net || !packed || !rays || !z || !raw_out || n_rays < 0 || n_samples < 1) return INERF_E_INVALID;
     if (!net_supported(*net)) return INERF_E_UNSUPPORTED;
@@ -443,6 +443,7 @@ static int encode_mlp_impl(const inerf_net_desc* net, const float* packed, const
     MlpParams p;
     p.wts = packed; p.rays = rays; p.z = z; p.raw = raw_out; p.status = status;
     p.save = save;
+    p.act_max = act_max;
     for (int s = 0; s < SAVE_SLOTS; ++s) p.save_off[s] = save_offset(*net, s, n_points);
     p.L = make_layout(*net);
     p.n_points = (int)n_points;

@@ -26,6 +26,7 @@ struct BwdParams {
     const float* d_raw;     // [P, channels]
     const float* save;      // activations kept by the training forward
     float* dz;              // out: pre-activation gradients, same slot layout
+    float* dz_max;          // out: max |dz| over every slot (caller zeroes it): the weight-gradient kernel's operand scale
     int32_t* status;
     int64_t off[SAVE_SLOTS];
     BwdLayout L;
@@ -39,7 +40,7 @@ __device__ __forceinline__ void bwd_store(const f32x16 (&am)[RB][2], float inv, 
                                           int mstride, const f32x4 (*extra)[4] /* [RB][4] or nullptr */, float ex0, float ex1,
                                           _Float16* dl /* plane_hi + (lane&31)*kRowH + 4h + dcol + chan0 */, f16x2& amax2,
                                           float* gout /* + pt0*gstride + chan0 + 4h */, int gstride, float s0, float s1,
-                                          bool valid0, bool valid1) {
+                                          bool valid0, bool valid1, float& gmax) {
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
 #pragma unroll
@@ -72,6 +73,8 @@ __device__ __forceinline__ void bwd_store(const f32x16 (&am)[RB][2], float inv, 
                 *reinterpret_cast<f16x4*>(d + kPlaneH) = lo4;
                 if (valid)
                     *reinterpret_cast<f32x4*>(gout + (size_t)pb * 32 * gstride + 32 * rb + 8 * g) = f32x4{t[0], t[1], t[2], t[3]} * back;
+                // invalid points carry zeros: no need to exclude them from the running maximum
+                gmax = fmaxf(gmax, fmaxf(fmaxf(fabsf(t[0]), fabsf(t[1])), fmaxf(fabsf(t[2]), fabsf(t[3]))) * back);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -105,6 +108,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const BwdLayout& L = p.L;
     f16x2 amax2 = {(_Float16)0.0f, (_Float16)0.0f};
+    float gmax = 0.0f;
 
     _Float16* const xw = ldsb + (lane & 31) * kRowH;
     const _Float16* const xr = xw + 8 * (lane >> 5);              // wide GEMM operand reads (+ column)
@@ -188,8 +192,11 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) v[cc] = act[cc] > 0.0f ? v[cc] : 0.0f;
                 split_store4(ldsb + pt * kRowH + kColA + c4, v, amax2);
-                if (valid)
-                    *reinterpret_cast<f32x4*>(p.dz + p.off[SAVE_VH] + (size_t)gp * kHalf + c4) = f32x4{v[0], v[1], v[2], v[3]} * f[8];
+                if (valid) {
+                    const f32x4 o = f32x4{v[0], v[1], v[2], v[3]} * f[8];
+                    *reinterpret_cast<f32x4*>(p.dz + p.off[SAVE_VH] + (size_t)gp * kHalf + c4) = o;
+                    gmax = fmaxf(gmax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+                }
             }
         }
         __syncthreads();
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
             prefetch_w<2>(preA, wb, frag(L.feat_t, 16));
             prefetch_w<2>(preB, wb, frag(L.as1_t, 16));
             bwd_store<2>(am, inv, nullptr, 0, nullptr, 0.0f, 0.0f, xd + kColB, amax2, const_cast<float*>(gptr(p.dz, SAVE_FEAT)), kWidth,
-                         s0, s1, valid0, valid1);
+                         s0, s1, valid0, valid1, gmax);
         }
         __syncthreads();                     // A (dZ_vh) has been read by every wave, B (d feature) is complete
 
@@ -232,8 +239,11 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) v[cc] = act[cc] > 0.0f ? v[cc] : 0.0f;
                 split_store4(ldsb + pt * kRowH + kColA + c4, v, amax2);
-                if (valid)
-                    *reinterpret_cast<f32x4*>(p.dz + p.off[SAVE_AS1H] + (size_t)gp * kWidth + c4) = f32x4{v[0], v[1], v[2], v[3]} * f[8];
+                if (valid) {
+                    const f32x4 o = f32x4{v[0], v[1], v[2], v[3]} * f[8];
+                    *reinterpret_cast<f32x4*>(p.dz + p.off[SAVE_AS1H] + (size_t)gp * kWidth + c4) = o;
+                    gmax = fmaxf(gmax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+                }
             }
         }
         __syncthreads();
@@ -267,8 +277,11 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) v[cc] = act[cc] > 0.0f ? v[cc] : 0.0f;
                 split_store4(ldsb + pt * kRowH + kColA + c4, v, amax2);
-                if (valid)
-                    *reinterpret_cast<f32x4*>(p.dz + p.off[SAVE_SEMH] + (size_t)gp * kHalf + c4) = f32x4{v[0], v[1], v[2], v[3]} * f[8];
+                if (valid) {
+                    const f32x4 o = f32x4{v[0], v[1], v[2], v[3]} * f[8];
+                    *reinterpret_cast<f32x4*>(p.dz + p.off[SAVE_SEMH] + (size_t)gp * kHalf + c4) = o;
+                    gmax = fmaxf(gmax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+                }
             }
             __syncthreads();
             wide_gemm_h<2, 8, 0, kRowH, kPlaneH, false>(preA, wb, frag(L.sem1_t, 8), xr, kColA, 0, lane, am);
@@ -285,7 +298,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
             const float e0 = ptf(lane & 31)[7], e1 = ptf((lane & 31) + 32)[7];
             __syncthreads();                 // every wave is done reading A and B
             bwd_store<2>(am, inv, gptr(p.save, SAVE_H7), kWidth, aw, e0, e1, xd + kColA, amax2, const_cast<float*>(gptr(p.dz, SAVE_H7)),
-                         kWidth, s0, s1, valid0, valid1);
+                         kWidth, s0, s1, valid0, valid1, gmax);
         }
         __syncthreads();
 
@@ -299,19 +312,24 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
             if (l > 1) prefetch_w<2>(preA, wb, frag(L.trunk_t[l - 1], 16));
             else       prefetch_w<2>(preA, wb, frag(L.views_t, 8));
             bwd_store<2>(am, inv, gptr(p.save, SAVE_H0 + l - 1), kWidth, nullptr, 0.0f, 0.0f, xd + dst, amax2,
-                         const_cast<float*>(gptr(p.dz, SAVE_H0 + l - 1)), kWidth, s0, s1, valid0, valid1);
+                         const_cast<float*>(gptr(p.dz, SAVE_H0 + l - 1)), kWidth, s0, s1, valid0, valid1, gmax);
             __syncthreads();
         }
     }
     const float amax_all = fmaxf((float)amax2[0], (float)amax2[1]);
     if (p.status && __any(!(amax_all <= kF16Safe)) && lane == 0) atomicOr(p.status, INERF_STATUS_F16_RANGE);
+    if (p.dz_max) {                       // non-negative floats order like their bit patterns
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o));
+        if (lane == 0 && gmax == gmax) atomicMax(reinterpret_cast<unsigned int*>(p.dz_max), __builtin_bit_cast(unsigned int, gmax));
+    }
 }
 
 }  // namespace inerf
 
 extern "C" int inerf_mlp_backward_inputs(const inerf_net_desc* net, const float* packed_bwd, const float* raw, const float* d_raw,
-                                         const float* save, int64_t n_points, uint32_t flags, float* dz_out, int32_t* status,
-                                         void* stream) {
+                                         const float* save, int64_t n_points, uint32_t flags, float* dz_out, float* dz_max,
+                                         int32_t* status, void* stream) {
     using namespace inerf;
     if (!net || !packed_bwd || !raw || !d_raw || !save || !dz_out || n_points < 0) return INERF_E_INVALID;
     if (!net_supported(*net)) return INERF_E_UNSUPPORTED;
@@ -319,7 +337,7 @@ extern "C" int inerf_mlp_backward_inputs(const inerf_net_desc* net, const float*
     if (n_points >= (int64_t)1 << 31) return INERF_E_UNSUPPORTED;
     const bool ssr = net->variant == INERF_VARIANT_SSR;
     BwdParams p;
-    p.wts = packed_bwd; p.raw = raw; p.d_raw = d_raw; p.save = save; p.dz = dz_out; p.status = status;
+    p.wts = packed_bwd; p.raw = raw; p.d_raw = d_raw; p.save = save; p.dz = dz_out; p.dz_max = dz_max; p.status = status;
     for (int s = 0; s < SAVE_SLOTS; ++s) p.off[s] = save_offset(*net, s, n_points);
     p.L = make_bwd_layout(*net);
     p.n_points = (int)n_points;

@@ -14,6 +14,7 @@ struct MlpParams {
     float* raw;             // [N*S, channels]
     int32_t* status;        // optional device word for INERF_STATUS_* bits
     float* save;            // training forward: activation buffer (layout.h SaveSlot), else nullptr
+    float* act_max;         // training forward, optional: device float that receives max |activation| (caller zeroes it)
     int64_t save_off[SAVE_SLOTS];   // float offsets of the slots for this launch's n_points
     NetLayout L;
     int n_points;           // N*S  (< 2^31, checked on the host)

@@ -238,6 +238,12 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
     }
     const float amax_all = fmaxf(amax, fmaxf((float)amax2[0], (float)amax2[1]));
     if (p.status && __any(!(amax_all <= kF16Safe)) && lane == 0) atomicOr(p.status, INERF_STATUS_F16_RANGE);
+    if (kSave && p.act_max) {             // bound of every saved activation (they were split as kActScale * value)
+        float m = amax_all * (1.0f / kActScale);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0 && m == m) atomicMax(reinterpret_cast<unsigned int*>(p.act_max), __builtin_bit_cast(unsigned int, m));
+    }
 }
 
 // ================================================================================================

@@ -352,8 +352,9 @@ def save_slot_views(desc, buf, n_points):
     return views
 
 
-def encode_mlp_train(desc, packed, rays, z_vals, endpoint=False, status=None):
-    """``encode_mlp`` that also returns the activation buffer the backward pass needs (PREC_F16X3 only)."""
+def encode_mlp_train(desc, packed, rays, z_vals, endpoint=False, status=None, act_max=None):
+    """``encode_mlp`` that also returns the activation buffer the backward pass needs (PREC_F16X3 only).  ``act_max``:
+    optional zeroed float32[1] device tensor that receives max |activation|."""
     rays = _dev(rays, "rays", (None, RAY_FLOATS))
     z_vals = _dev(z_vals, "z_vals", (rays.shape[0], None))
     packed = _dev(packed, "packed weights", (None,))
@@ -364,13 +365,15 @@ def encode_mlp_train(desc, packed, rays, z_vals, endpoint=False, status=None):
     save = _new(rays, _capi.lib().inerf_mlp_save_floats(desc, n * s))
     with torch.cuda.device(rays.device):
         rc = _capi.lib().inerf_encode_mlp_train(desc, _ptr(packed), _ptr(rays), _ptr(z_vals), n, s, flags, _ptr(raw), _ptr(save),
-                                                None if status is None else C.c_void_p(status.data_ptr()), _stream(rays))
+                                                _ptr(act_max), None if status is None else C.c_void_p(status.data_ptr()),
+                                                _stream(rays))
     _capi.check(rc, "inerf_encode_mlp_train")
     return raw, save
 
 
-def mlp_backward_inputs(desc, packed_bwd, raw, d_raw, save, endpoint=False, status=None):
-    """Pre-activation gradients of every layer (same slot layout as ``save``) from d loss / d raw."""
+def mlp_backward_inputs(desc, packed_bwd, raw, d_raw, save, endpoint=False, status=None, dz_max=None):
+    """Pre-activation gradients of every layer (same slot layout as ``save``) from d loss / d raw.  ``dz_max``: optional
+    zeroed float32[1] device tensor that receives max |dz| (the weight-gradient kernel's operand range)."""
     raw = _dev(raw, "raw", (None, None))
     p, ch = raw.shape
     d_raw = _dev(d_raw, "d_raw", (p, ch))
@@ -379,7 +382,7 @@ def mlp_backward_inputs(desc, packed_bwd, raw, d_raw, save, endpoint=False, stat
     dz = _new(raw, save.shape[0])
     with torch.cuda.device(raw.device):
         rc = _capi.lib().inerf_mlp_backward_inputs(desc, _ptr(packed_bwd), _ptr(raw), _ptr(d_raw), _ptr(save), p,
-                                                   FLAG_ENDPOINT if endpoint else 0, _ptr(dz),
+                                                   FLAG_ENDPOINT if endpoint else 0, _ptr(dz), _ptr(dz_max),
                                                    None if status is None else C.c_void_p(status.data_ptr()), _stream(raw))
     _capi.check(rc, "inerf_mlp_backward_inputs")
     return dz
@@ -409,55 +412,133 @@ def _tn(g, x, nc):
     return torch.bmm(g.view(nc, p // nc, g.shape[1]).transpose(1, 2), x.view(nc, p // nc, x.shape[1])).sum(0)
 
 
+def _pow2_scale(t):
+    """Device scalar 2^k with max|t| * 2^k in [2^13, 2^14) (1 for an all-zero tensor) - no host sync."""
+    m = t.abs().amax()
+    _, e = torch.frexp(m)
+    return torch.where((m > 0) & torch.isfinite(m), torch.ldexp(torch.ones_like(m), 14 - e), torch.ones_like(m))
+
+
+ACTIVATION_RANGE = 6.0e4 / 8.0          # what the forward's f16 range check admits
+
+
+class _WgradBatch:
+    """Several ``G^T X`` products (and the column sums of their G) through inerf_mlp_weight_gradient, every workgroup's
+    partial tiles side by side in ONE [grid, total] buffer: one launch per product, one sum at the end."""
+
+    def __init__(self, n_points, ranges, like):
+        self.p, self.ranges, self.like = n_points, ranges, like
+        self.jobs, self.total = [], 0
+
+    def add(self, g, x, m, n, want_bias=False):
+        """Schedules g[:, :m]^T @ x[:, :n]; returns a key for ``result`` (and ``bias`` if want_bias)."""
+        job = dict(g=g, x=x, m=m, n=n, off=self.total, boff=None)
+        self.total += m * n
+        if want_bias:
+            job["boff"] = self.total
+            self.total += m
+        self.jobs.append(job)
+        return len(self.jobs) - 1
+
+    def run(self):
+        lib = _capi.lib()
+        grid = lib.inerf_wgrad_grid(self.p)
+        buf = _new(self.like, grid, self.total)
+        with torch.cuda.device(self.like.device):
+            for j in self.jobs:
+                g, x = j["g"], j["x"]
+                base = buf.data_ptr()
+                rc = lib.inerf_mlp_weight_gradient(C.c_void_p(g.data_ptr()), g.stride(0), C.c_void_p(x.data_ptr()), x.stride(0), self.p,
+                                                   j["m"], j["n"], _ptr(self.ranges), C.c_void_p(base + 4 * j["off"]),
+                                                   None if j["boff"] is None else C.c_void_p(base + 4 * j["boff"]), self.total,
+                                                   _stream(self.like))
+                _capi.check(rc, "inerf_mlp_weight_gradient")
+        self.sums = buf.sum(0)
+
+    def result(self, key):
+        j = self.jobs[key]
+        return self.sums[j["off"]: j["off"] + j["m"] * j["n"]].view(j["m"], j["n"])
+
+    def bias(self, key):
+        j = self.jobs[key]
+        return self.sums[j["boff"]: j["boff"] + j["m"]]
+
+
+def weight_gradient(g, x, m, n, ranges=None, want_bias=False):
+    """g[:, :m]^T @ x[:, :n] (and optionally the column sums of g[:, :m]) through the HIP split-K kernel.  g / x: row-major
+    fp32 matrices (or 32-column-aligned views of one); m in {128, 256}, n in {32, 64, 128, 256}; ``ranges``: float32[2] device
+    tensor with upper bounds of |g| and |x| (computed here when absent - two extra passes over the data)."""
+    if ranges is None:
+        ranges = torch.stack([g[:, :m].abs().amax(), x[:, :n].abs().amax()]).float()
+    b = _WgradBatch(g.shape[0], ranges, g)
+    k = b.add(g, x, m, n, want_bias)
+    b.run()
+    return (b.result(k), b.bias(k)) if want_bias else b.result(k)
+
+
 def _colsum(g, nc):
     return g.sum(0) if nc == 1 else g.view(nc, g.shape[0] // nc, g.shape[1]).sum(1).sum(0)
 
 
-def mlp_weight_gradients(desc, names, save, dz, d_raw, n_points, endpoint=False):
-    """dW = dZ^T X and db = column sums of dZ for every layer, as library GEMMs over the sample points.  Returns a dict
-    name -> gradient with the reference's parameter names and shapes."""
+def mlp_weight_gradients(desc, names, save, dz, d_raw, n_points, endpoint=False, ranges=None):
+    """dW = dZ^T X and db = column sums of dZ for every layer.  The 128/256-row layers go through the HIP split-K kernel when
+    ``ranges`` (float32[2] device tensor: max |dz|, max |activation|, as delivered by the two training kernels) is given, else
+    - and the 1-4-row heads always - through library GEMMs split over K.  Returns a dict name -> gradient with the
+    reference's parameter names and shapes."""
     X = save_slot_views(desc, save, n_points)
     G = save_slot_views(desc, dz, n_points)
     e, dv = 3 + 6 * desc.l_xyz, 3 + 6 * desc.l_dir
     sh1, sh2, res = _head_names(desc)
-    out = {}
-
+    sem = desc.variant == _capi.VARIANT_SSR and desc.n_classes > 0
     nc = _split_k(n_points)
+    enc, h = X[SAVE_ENC], [X[SAVE_H0 + i] for i in range(8)]        # enc / dir: zero-padded columns, cut from the products
+    # (G slot, X slot, rows, columns): the products with 128 / 256 rows; the first product of a G slot also delivers its bias
+    big = {"t0": (SAVE_H0, SAVE_ENC, 256, 64), "t5e": (SAVE_H0 + 5, SAVE_ENC, 256, 64), "as1": (SAVE_AS1H, SAVE_H0 + 7, 256, 256),
+           "feat": (SAVE_FEAT, SAVE_H0 + 7, 256, 256), "vf": (SAVE_VH, SAVE_FEAT, 128, 256), "vd": (SAVE_VH, SAVE_DIR, 128, 32)}
+    for i in range(1, 8):
+        big[f"t{i}"] = (SAVE_H0 + i, SAVE_H0 + i - 1, 256, 256)
+    if sem:
+        big["sem1"] = (SAVE_SEMH, SAVE_H0 + 7, 128, 256)
+    W, B = {}, {}
+    if ranges is not None:
+        batch, keys, seen = _WgradBatch(n_points, ranges, save), {}, set()
+        for k, (gs, xs, m, n) in big.items():
+            keys[k] = batch.add(G[gs], X[xs], m, n, want_bias=gs not in seen)
+            seen.add(gs)
+        batch.run()
+        for k, (gs, xs, m, n) in big.items():
+            W[k] = batch.result(keys[k])
+            if batch.jobs[keys[k]]["boff"] is not None:
+                B[gs] = batch.bias(keys[k])
+    else:
+        for k, (gs, xs, m, n) in big.items():
+            W[k] = _tn(G[gs], X[xs], nc)
+            if gs not in B:
+                B[gs] = _colsum(G[gs], nc)
+    out = {}
 
     def lin(name, g, x):
         out[name + ".weight"] = _tn(g, x, nc)
         out[name + ".bias"] = _colsum(g, nc)
 
-    enc, h = X[SAVE_ENC], [X[SAVE_H0 + i] for i in range(8)]        # enc / dir: zero-padded columns, cut from the products
-    out["pts_linears.0.weight"] = _tn(G[SAVE_H0], enc, nc)[:, :e]
-    out["pts_linears.0.bias"] = _colsum(G[SAVE_H0], nc)
+    out["pts_linears.0.weight"] = W["t0"][:, :e]
     for i in range(1, 8):
-        if i == 5:         # cat([pts, h]) (run_nerf_helpers.py:290-291)
-            g = G[SAVE_H0 + 5]
-            out["pts_linears.5.weight"] = torch.cat([_tn(g, enc, nc)[:, :e], _tn(g, h[4], nc)], 1)
-            out["pts_linears.5.bias"] = _colsum(g, nc)
-        else:
-            lin(f"pts_linears.{i}", G[SAVE_H0 + i], h[i - 1])
+        out[f"pts_linears.{i}.weight"] = torch.cat([W["t5e"][:, :e], W["t5"]], 1) if i == 5 else W[f"t{i}"]   # cat([pts, h]), helpers:290-291
+    for i in range(8):
+        out[f"pts_linears.{i}.bias"] = B[SAVE_H0 + i]
+    out["albedo_linear1.weight"], out["albedo_linear1.bias"] = W["as1"][0:128], B[SAVE_AS1H][0:128]
+    out[sh1 + ".weight"], out[sh1 + ".bias"] = W["as1"][128:256], B[SAVE_AS1H][128:256]
+    out["feature_linear.weight"], out["feature_linear.bias"] = W["feat"], B[SAVE_FEAT]
+    out["views_linears.0.weight"], out["views_linears.0.bias"] = torch.cat([W["vf"], W["vd"][:, :dv]], 1), B[SAVE_VH]
     dpre = G[SAVE_DPRE]
-    # everything that reads h7: one GEMM
-    sem = desc.variant == _capi.VARIANT_SSR and desc.n_classes > 0
-    parts = [G[SAVE_AS1H], G[SAVE_FEAT], dpre[:, 7:8]] + ([G[SAVE_SEMH]] if sem else [])
-    gcat = torch.cat(parts, 1)
-    wcat, bcat = _tn(gcat, h[7], nc), _colsum(gcat, nc)
-    out["albedo_linear1.weight"], out["albedo_linear1.bias"] = wcat[0:128], bcat[0:128]
-    out[sh1 + ".weight"], out[sh1 + ".bias"] = wcat[128:256], bcat[128:256]
-    out["feature_linear.weight"], out["feature_linear.bias"] = wcat[256:512], bcat[256:512]
-    out["alpha_linear.weight"], out["alpha_linear.bias"] = wcat[512:513], bcat[512:513]
+    lin("alpha_linear", dpre[:, 7:8], h[7])
     if sem:
-        out["semantic_linear.0.0.weight"], out["semantic_linear.0.0.bias"] = wcat[513:641], bcat[513:641]
+        out["semantic_linear.0.0.weight"], out["semantic_linear.0.0.bias"] = W["sem1"], B[SAVE_SEMH]
         c = desc.n_classes
         lin("semantic_linear.1", d_raw[:, BASE_CHANNELS:BASE_CHANNELS + c], X[SAVE_SEMH])
     as1h = X[SAVE_AS1H]
     lin("albedo_linear2", dpre[:, 0:3], as1h[:, :128])
     lin(sh2, dpre[:, 3:4], as1h[:, 128:])
-    g = G[SAVE_VH]
-    out["views_linears.0.weight"] = torch.cat([_tn(g, X[SAVE_FEAT], nc), _tn(g, X[SAVE_DIR], nc)[:, :dv]], 1)
-    out["views_linears.0.bias"] = _colsum(g, nc)
     lin(res, dpre[:, 4:7], X[SAVE_VH])
     return {k: out[k] for k in names}
 
@@ -472,10 +553,11 @@ class _FusedMlpFn(torch.autograd.Function):
         from . import packing
         named = dict(zip(names, params))
         status = _new_status(rays)
+        act_max = torch.zeros(1, dtype=torch.float32, device=rays.device)
         packed = packing.device_packer(desc, False, rays.device)(named)
-        raw, save = encode_mlp_train(desc, packed, rays.detach(), z_vals.detach(), endpoint, status)
+        raw, save = encode_mlp_train(desc, packed, rays.detach(), z_vals.detach(), endpoint, status, act_max)
         check_f16_range(status, "training forward")
-        ctx.save_for_backward(raw, save, *params)
+        ctx.save_for_backward(raw, save, act_max, *params)
         ctx.cfg = (desc, endpoint, names)
         return raw
 
@@ -483,15 +565,18 @@ class _FusedMlpFn(torch.autograd.Function):
     def backward(ctx, d_raw):
         from . import packing
         desc, endpoint, names = ctx.cfg
-        raw, save = ctx.saved_tensors[:2]
-        params = ctx.saved_tensors[2:]
+        raw, save, act_max = ctx.saved_tensors[:3]
+        params = ctx.saved_tensors[3:]
         n, s, ch = raw.shape
         status = _new_status(raw)
+        dz_max = torch.zeros(1, dtype=torch.float32, device=raw.device)
         packed_bwd = packing.device_packer(desc, True, raw.device)(dict(zip(names, params)))
         d2 = d_raw.contiguous().view(n * s, ch).float()
-        dz = mlp_backward_inputs(desc, packed_bwd, raw.view(n * s, ch), d2, save, endpoint, status)
+        dz = mlp_backward_inputs(desc, packed_bwd, raw.view(n * s, ch), d2, save, endpoint, status, dz_max)
         check_f16_range(status, "training backward")
-        grads = mlp_weight_gradients(desc, names, save, dz, d2, n * s, endpoint)
+        import os
+        ranges = None if os.environ.get("INERF_WGRAD", "hip") == "library" else torch.cat([dz_max, act_max])
+        grads = mlp_weight_gradients(desc, names, save, dz, d2, n * s, endpoint, ranges)
         return (None, None, None, None, None) + tuple(grads[k] for k in names)
 
 
