@@ -301,3 +301,25 @@ def test_network_backward_splits_large_batches(monkeypatch):
     assert torch.equal(raw_a, raw_b)
     for k in g_a:
         assert float((g_a[k] - g_b[k]).norm()) <= 1e-5 * float(g_a[k].norm()) + 1e-12, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p,m,n", [(64, 256, 256), (1000, 256, 256), (12345, 256, 64), (777, 128, 256), (4097, 128, 32), (70001, 256, 256)])
+def test_weight_gradient_kernel_vs_fp64(p, m, n):
+    """G^T X and the column sums of G from the split-K MFMA kernel against an fp64 product: ragged point counts, gradients
+    spanning four decades, every supported tile shape; also with operands that are column-aligned views of wider buffers."""
+    from intrinsicnerf_amd import kernels
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(p)
+    G = (torch.randn(p, 256, generator=g) * torch.logspace(-4, 0, p)[:, None]).to(dev)
+    X = torch.relu(torch.randn(p, 320, generator=g)).to(dev)
+    gv, xv = G[:, 256 - m:], X[:, 64:64 + n]                       # views: row strides 256 / 320, 16-byte aligned starts
+    w, b = kernels.weight_gradient(gv, xv, m, n, want_bias=True)
+    want_w = gv.double().t() @ xv.double()
+    want_b = gv.double().sum(0)
+    assert float((w.double() - want_w).norm()) <= 2e-6 * float(want_w.norm())
+    assert float((b.double() - want_b).norm()) <= 2e-6 * float(want_b.norm()) + 1e-12
+    # explicit ranges (upper bounds, as the training kernels deliver them) instead of the measured maxima
+    ranges = torch.tensor([float(gv.abs().max()) * 3.0, 7.5e3], device=dev)
+    w2 = kernels.weight_gradient(gv, xv, m, n, ranges)
+    assert float((w2.double() - want_w).norm()) <= 2e-5 * float(want_w.norm())
