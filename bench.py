@@ -251,6 +251,39 @@ def main():
         exact = {"value": n_total / dt32, "unit": "rays/s", "ms_per_step": dt32 * 1e3, "steps": 1,
                  "note": "whole path with INERF_PRECISION=f32 (v_mfma_f32_32x32x2_f32 everywhere)"}
 
+    # the reference's training step through the same front-end (rank 0, N = 1 only; untimed
+    # relative to `value`): 1024 rays + one neighbour each (run_nerf.py:918-929), 64 + 128 samples, forward + backward + Adam
+    train = None
+    if rank == 0 and world == 1 and prec == _capi.PREC_F16X3:
+        import warnings
+        tnet_c, tnet_f = mk(), mk()
+        query = ol.NetworkQuery(embed, embed_d)
+        opt = torch.optim.Adam(list(tnet_c.parameters()) + list(tnet_f.parameters()), lr=5e-4)
+        tr = rays_l[torch.randperm(rays_l.shape[0], device=dev)[:2048]].contiguous()
+        target = torch.rand(tr.shape[0], 3, device=dev)
+
+        def train_step():
+            ret = ol.render_rays(tr, tnet_c, query, N_SAMPLES, retraw=True, perturb=1.0, N_importance=N_IMPORTANCE,
+                                 network_fine=tnet_f, white_bkgd=True)
+            loss = ((ret["rgb_map"] - target) ** 2).mean() + ((ret["rgb0"] - target) ** 2).mean() + 0.01 * ret["albedo_map"].abs().mean()
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for _ in range(2):
+                train_step()
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                train_step()
+            fence()
+        t_train = (time.perf_counter() - t1) / 5
+        train = {"ms_per_step": t_train * 1e3, "rays": int(tr.shape[0]), "rays_per_s": tr.shape[0] / t_train,
+                 "note": "the reference's training batch (2048 rays x (64+128) samples) through object_level.render_rays under "
+                         "autograd: HIP forward + backward (networks, compositing) + torch Adam; not part of `value`"}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -266,7 +299,8 @@ def main():
                                    "coarse+fine intrinsic NeRF (D=8, W=256), white_bkgd, eval mode, random-init weights "
                                    "(seeds 0/1)", "rays_per_step": n_total, "parallelism": f"ray-sharded x{world}",
                        "gather": "all_gather of 12 floats/ray" if world > 1 else "none"},
-            "roofline": roofline, "roofline_f32_kernel": roofline_f32, "exact_f32_path": exact, "cpu_baseline": cpu}))
+            "roofline": roofline, "roofline_f32_kernel": roofline_f32, "exact_f32_path": exact, "train_step": train,
+            "cpu_baseline": cpu}))
     if world > 1:
         dist.destroy_process_group()
 
