@@ -22,9 +22,41 @@ from intrinsicnerf_amd import kernels, object_level as ol  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--rays", type=int, default=2048)
 ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--ssr", type=int, default=-1, help="C >= 0: the SSR network with C classes through ssr.SSRRenderer instead")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
+if a.ssr >= 0:          # trainer.py:876-991: 1024 rays (512 + neighbours), depth range [0.1, 10], semantic cross-entropy + photometric loss
+    from intrinsicnerf_amd import ssr
+    n = a.rays
+    r = ssr.SSRRenderer(a.ssr, white_bkgd=False, endpoint_feat=False, device=dev)
+    r.training, r.check_numerics = True, False
+    opt = torch.optim.Adam(list(r.ssr_net_coarse.parameters()) + list(r.ssr_net_fine.parameters()), lr=5e-4)
+    o = torch.tensor([[0.5, 0.2, 0.1]]).expand(n, 3)
+    d = torch.randn(n, 3); d = d / d.norm(dim=-1, keepdim=True)
+    rays = torch.cat([o, d, 0.1 * torch.ones(n, 1), 10 * torch.ones(n, 1), d], -1).to(dev)
+    target = torch.rand(n, 3, device=dev)
+    labels = torch.randint(0, max(a.ssr, 1), (n,), device=dev)
+
+    def sstep():
+        ret = r.render_rays(rays)
+        loss = ((ret["rgb_fine"] - target) ** 2).mean() + ((ret["rgb_coarse"] - target) ** 2).mean()
+        if a.ssr > 0:
+            loss = loss + 0.04 * torch.nn.functional.cross_entropy(ret["sem_logits_fine"], labels) \
+                + 0.04 * torch.nn.functional.cross_entropy(ret["sem_logits_coarse"], labels)
+        opt.zero_grad(); loss.backward(); opt.step()
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(3):
+            sstep()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(a.iters):
+            sstep()
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.iters
+    print(f"SSR training step (C = {a.ssr}): {n} rays x (64+128) samples: {dt * 1e3:.1f} ms -> {n / dt:.0f} rays/s "
+          f"[{os.environ.get('INERF_TRAIN_MLP', 'hip')} network backward]")
+    sys.exit(0)
 embed, ch = ol.get_embedder(10, 0); embed_d, ch_d = ol.get_embedder(4, 0)
 mk = lambda: ol.NeRF(D=8, W=256, input_ch=ch, output_ch=5, skips=[4], input_ch_views=ch_d, use_viewdirs=True).to(dev)
 net_c, net_f = mk(), mk()
