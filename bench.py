@@ -43,7 +43,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3                 # MI355X_MICROARCH.md: dense fp32 m
 PEAK_F16_MFMA_TFLOPS = 2500.0                # MI355X_MICROARCH.md: dense f16/bf16 matrix peak
 # HBM bytes per sample point of the encode+MLP kernels from the PMC passes (FETCH_SIZE + WRITE_SIZE, separate
 # passes) in profiles/r01_mlp_pmc_traffic.txt: 311.6 MB per 6,291,456-point launch (algorithmic: 306 MB).
-PMC_HBM_BYTES_PER_POINT = 49.5
+PMC_HBM_BYTES_PER_POINT = {"f16x3": 55.9, "f32": 49.5}    # rocprofv3 PMC, profiles/r01_mlp_pmc_traffic.txt
 
 
 def chair_pose(theta_deg=40.0, phi_deg=-30.0, radius=4.0):
@@ -222,9 +222,10 @@ def main():
         peak = PEAK_F16_MFMA_TFLOPS / 3.0 if f16 else PEAK_F32_MFMA_TFLOPS
         return {"bound": "mfma", "kernel": "k_encode_mlp_f16x3_dual" if f16 else "k_encode_mlp", "achieved": achieved,
                 "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                "traffic": PMC_HBM_BYTES_PER_POINT * n_local * (N_SAMPLES + (N_SAMPLES + N_IMPORTANCE)) / 2.0,
-                "traffic_note": "HBM bytes per launch = 49.5 B/point measured by rocprofv3 PMC (FETCH_SIZE, WRITE_SIZE in "
-                                "separate passes, profiles/r01_mlp_pmc_traffic.txt) x this launch's points; 1.02x algorithmic",
+                "traffic": PMC_HBM_BYTES_PER_POINT["f16x3" if f16 else "f32"] * n_local * (N_SAMPLES + (N_SAMPLES + N_IMPORTANCE)) / 2.0,
+                "traffic_note": f"HBM bytes per launch = {PMC_HBM_BYTES_PER_POINT['f16x3' if f16 else 'f32']} B/point measured by "
+                                "rocprofv3 PMC (FETCH_SIZE, WRITE_SIZE in separate passes, profiles/r01_mlp_pmc_traffic.txt) x this "
+                                f"launch's points; {'1.15' if f16 else '1.02'}x algorithmic",
                 "avg_launch_ms": avg_ms,
                 "launches_timed": len(durs), "flop_per_launch": flop_per_launch,
                 "peak_basis": ("dense f16 MFMA 2500 TFLOP/s / 3 products per fp32 MAC" if f16
