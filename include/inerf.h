@@ -152,7 +152,14 @@ int inerf_pack_weights_bwd(const inerf_net_desc* net, const float* const* tensor
 int inerf_mlp_backward_inputs(const inerf_net_desc* net, const float* packed_bwd, const float* raw, const float* d_raw,
                               const float* save, int64_t n_points, uint32_t flags, float* dz_out,
                               float* dz_max /* optional device float the kernel max-es |dz| into (caller zeroes it) */,
+                              float* head_partial /* optional [inerf_mlp_backward_grid()][inerf_mlp_head_partial_floats()]:
+                                 per-workgroup weight / bias gradients of the 1-4-row heads, to be summed by the caller:
+                                 residual W [3][128] | albedo,shading outputs [4][256] (rows 0-2: columns 0..127 are
+                                 albedo_linear2, row 3: columns 128..255 the shading output) | alpha W [256] |
+                                 biases albedo 3, shading 1, residual 3, sigma 1 */,
                               int32_t* status, void* stream);
+int inerf_mlp_head_partial_floats(void);
+int inerf_mlp_backward_grid(int64_t n_points);
 
 /* One weight gradient: workgroup g of inerf_wgrad_grid(n_points) writes sum over its sample points of G[p, m] * X[p, n]
  * (row-major [M, N]) at partial + g * partial_stride and, if bias_partial is given, its sums of G[p, m] ([M]) at

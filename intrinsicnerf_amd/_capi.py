@@ -58,7 +58,9 @@ SYMBOLS = {
     "inerf_encode_mlp_train": (_I, [C.POINTER(NetDesc), _P, _P, _P, _L, _I, _U, _P, _P, _P, _P, _P]),
     "inerf_bwd_packed_floats": (_L, [C.POINTER(NetDesc)]),
     "inerf_pack_weights_bwd": (_I, [C.POINTER(NetDesc), C.POINTER(_P), _I, _P, _L]),
-    "inerf_mlp_backward_inputs": (_I, [C.POINTER(NetDesc), _P, _P, _P, _P, _L, _U, _P, _P, _P, _P]),
+    "inerf_mlp_backward_inputs": (_I, [C.POINTER(NetDesc), _P, _P, _P, _P, _L, _U, _P, _P, _P, _P, _P]),
+    "inerf_mlp_head_partial_floats": (_I, []),
+    "inerf_mlp_backward_grid": (_I, [_L]),
     "inerf_wgrad_grid": (_I, [_L]),
     "inerf_mlp_weight_gradient": (_I, [_P, _I, _P, _I, _L, _I, _I, _P, _P, _P, _L, _P]),
     "inerf_pack_map": (_L, [C.POINTER(NetDesc), _I, _P, _P, _L, _P, _P, _P, _P, _P, _L, C.POINTER(C.c_int32)]),

@@ -27,11 +27,21 @@ struct BwdParams {
     const float* save;      // activations kept by the training forward
     float* dz;              // out: pre-activation gradients, same slot layout
     float* dz_max;          // out: max |dz| over every slot (caller zeroes it): the weight-gradient kernel's operand scale
+    float* head_partial;    // out, optional: [grid][kHeadFloats] weight / bias gradients of the 1-4-row heads, per workgroup
     int32_t* status;
     int64_t off[SAVE_SLOTS];
     BwdLayout L;
     int n_points, n_tiles, channels, n_classes, endpoint;
 };
+
+// Per-workgroup partial gradients of the heads with 1-4 output rows (their operands pass through this kernel's
+// registers anyway): the caller sums the workgroups.
+//   [0, 384)      residual head weight   [3][128]      (d_res_pre^T vh)
+//   [384, 1408)   albedo|shading outputs [4][256]      row j < 3: d_albedo_pre[j]^T as1h, row 3: d_shading_pre^T as1h
+//                 (the caller keeps columns 0..127 of rows 0..2 and columns 128..255 of row 3)
+//   [1408, 1664)  alpha_linear weight    [256]         (d_sigma^T h7)
+//   [1664, 1672)  biases: albedo 3, shading 1, residual 3, sigma 1  (sums of the head gradients)
+constexpr int kHeadRes = 0, kHeadAs2 = 384, kHeadAlpha = 1408, kHeadBias = 1664, kHeadFloats = 1672;
 
 // epilogue of one transposed layer: t = acc * inv (+ per-channel vector x per-point scalar), ReLU mask from the saved
 // activation, hi/lo split into LDS (normalised, kActScale domain) and the true gradient to global memory
@@ -40,7 +50,8 @@ __device__ __forceinline__ void bwd_store(const f32x16 (&am)[RB][2], float inv, 
                                           int mstride, const f32x4 (*extra)[4] /* [RB][4] or nullptr */, float ex0, float ex1,
                                           _Float16* dl /* plane_hi + (lane&31)*kRowH + 4h + dcol + chan0 */, f16x2& amax2,
                                           float* gout /* + pt0*gstride + chan0 + 4h */, int gstride, float s0, float s1,
-                                          bool valid0, bool valid1, float& gmax) {
+                                          bool valid0, bool valid1, float& gmax,
+                                          f32x4 (*alpha_acc)[4] = nullptr /* [RB][4]: += (true d sigma of the point) * saved activation */) {
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
 #pragma unroll
@@ -54,6 +65,7 @@ __device__ __forceinline__ void bwd_store(const f32x16 (&am)[RB][2], float inv, 
                 f32x4 m4 = {1.0f, 1.0f, 1.0f, 1.0f};
                 if (mask_src) m4 = valid ? *reinterpret_cast<const f32x4*>(mask_src + (size_t)pb * 32 * mstride + 32 * rb + 8 * g)
                                          : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                if (alpha_acc) alpha_acc[rb][g] += m4 * (ex * (pb == 0 ? s0 : s1));      // m4 = h7 itself (zero for invalid points)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     t[i] = am[rb][pb][4 * g + i] * inv;
@@ -125,6 +137,19 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
     WidePreH<2> preA, preB;
     prefetch_w<2>(preA, wb, frag(L.views_t, 8));
 
+    // head weight gradients, accumulated over this workgroup's tiles (see kHead*)
+    const bool heads = p.head_partial != nullptr;
+    float hb[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};     // threads 0..63: sums of the head gradients
+    f32x4 hres[3], has2[4], halpha[2][4];                                  // [row][4 channels]; alpha: [rb][g]
+#pragma unroll
+    for (int j = 0; j < 3; ++j) hres[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) has2[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) halpha[rb][g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         // ---------------- heads: pre-activation gradients of the output heads, per-point scale ----------------
         if (tid < kPts) {
@@ -154,6 +179,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
                 float* __restrict__ o = p.dz + p.off[SAVE_DPRE] + (size_t)gp * 8;
                 *reinterpret_cast<f32x4*>(o) = f32x4{dp[0], dp[1], dp[2], dp[3]};
                 *reinterpret_cast<f32x4*>(o + 4) = f32x4{dp[4], dp[5], dp[6], dp[7]};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) hb[k] += dp[k];
             }
             float* f = ptf(tid);
             const float is = 1.0f / s;
@@ -188,6 +215,11 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
 #pragma unroll
                         for (int cc = 0; cc < 4; ++cc) v[cc] = __builtin_fmaf(ge[cc], f[9], v[cc]);
                     }
+                }
+                if (heads) {                   // d W_res[j][c] += (true d_res_pre[j] of the point) * vh[c]
+                    hres[0] += act * (d0 * f[8]);
+                    hres[1] += act * (d1 * f[8]);
+                    hres[2] += act * (d2 * f[8]);
                 }
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) v[cc] = act[cc] > 0.0f ? v[cc] : 0.0f;
@@ -236,6 +268,12 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
                 for (int cc = 0; cc < 4; ++cc) v[cc] = w4[cc][0] * d0 + w4[cc][1] * d1 + w4[cc][2] * d2 + w4[cc][3] * d3;
                 const f32x4 act = valid ? *reinterpret_cast<const f32x4*>(p.save + p.off[SAVE_AS1H] + (size_t)gp * kWidth + c4)
                                         : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                if (heads) {
+                    has2[0] += act * (d0 * f[8]);
+                    has2[1] += act * (d1 * f[8]);
+                    has2[2] += act * (d2 * f[8]);
+                    has2[3] += act * (d3 * f[8]);
+                }
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) v[cc] = act[cc] > 0.0f ? v[cc] : 0.0f;
                 split_store4(ldsb + pt * kRowH + kColA + c4, v, amax2);
@@ -298,7 +336,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
             const float e0 = ptf(lane & 31)[7], e1 = ptf((lane & 31) + 32)[7];
             __syncthreads();                 // every wave is done reading A and B
             bwd_store<2>(am, inv, gptr(p.save, SAVE_H7), kWidth, aw, e0, e1, xd + kColA, amax2, const_cast<float*>(gptr(p.dz, SAVE_H7)),
-                         kWidth, s0, s1, valid0, valid1, gmax);
+                         kWidth, s0, s1, valid0, valid1, gmax, heads ? halpha : nullptr);
         }
         __syncthreads();
 
@@ -316,6 +354,58 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
             __syncthreads();
         }
     }
+    if (heads) {                          // reduce over the threads / lanes that shared a channel group, through LDS
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(ldsb);            // [256 threads][28]: hres 12 | has2 16
+        float* mine = red + tid * 28;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) mine[4 * j + cc] = hres[j][cc];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) mine[12 + 4 * j + cc] = has2[j][cc];
+        float* alpha_red = red + 256 * 28;                      // [4 waves][64 lanes][32]: halpha
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) alpha_red[(wave * 64 + lane) * 33 + 16 * rb + 4 * g + i] = halpha[rb][g][i];
+        float* bias_red = alpha_red + 256 * 33;                 // [64][8]
+        if (tid < kPts)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) bias_red[tid * 8 + k] = hb[k];
+        __syncthreads();
+        float* out = p.head_partial + (size_t)blockIdx.x * kHeadFloats;
+        // residual: channel c = 4 * (tid & 31) + cc was accumulated by the 8 threads tid & 31 + 32 * k
+        for (int e = tid; e < 3 * kHalf; e += 256) {
+            const int j = e / kHalf, c = e % kHalf;
+            float v = 0.0f;
+            for (int k = 0; k < 8; ++k) v += red[((c >> 2) + 32 * k) * 28 + 4 * j + (c & 3)];
+            out[kHeadRes + e] = v;
+        }
+        // albedo|shading outputs: channel c = 4 * (tid & 63) + cc, 4 threads tid & 63 + 64 * k
+        for (int e = tid; e < 4 * kWidth; e += 256) {
+            const int j = e / kWidth, c = e % kWidth;
+            float v = 0.0f;
+            for (int k = 0; k < 4; ++k) v += red[((c >> 2) + 64 * k) * 28 + 12 + 4 * j + (c & 3)];
+            out[kHeadAs2 + e] = v;
+        }
+        // alpha: channel c of wave w = c >> 6: register slot (rb, g, i) with c & 63 = 32 rb + 8 g + 4 h + i; sum over the 32 lanes of half h
+        {
+            const int c = tid, w = c >> 6, cl = c & 63, rb = cl >> 5, g = (cl >> 3) & 3, hh = (cl >> 2) & 1, i = cl & 3;
+            float v = 0.0f;
+            for (int l = 0; l < 32; ++l) v += alpha_red[(w * 64 + 32 * hh + l) * 33 + 16 * rb + 4 * g + i];
+            out[kHeadAlpha + c] = v;
+        }
+        if (tid < 8) {
+            float v = 0.0f;
+            for (int k = 0; k < kPts; ++k) v += bias_red[k * 8 + tid];
+            out[kHeadBias + tid] = v;
+        }
+    }
     const float amax_all = fmaxf((float)amax2[0], (float)amax2[1]);
     if (p.status && __any(!(amax_all <= kF16Safe)) && lane == 0) atomicOr(p.status, INERF_STATUS_F16_RANGE);
     if (p.dz_max) {                       // non-negative floats order like their bit patterns
@@ -327,9 +417,18 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
 
 }  // namespace inerf
 
+// floats per workgroup of the head-gradient partials, and the number of workgroups inerf_mlp_backward_inputs launches
+extern "C" int inerf_mlp_head_partial_floats(void) { return inerf::kHeadFloats; }
+extern "C" int inerf_mlp_backward_grid(int64_t n_points) {
+    using namespace inerf;
+    if (n_points <= 0) return 0;
+    const int64_t tiles = (n_points + kTilePoints - 1) / kTilePoints;
+    return (int)(tiles < device_cus() ? tiles : device_cus());
+}
+
 extern "C" int inerf_mlp_backward_inputs(const inerf_net_desc* net, const float* packed_bwd, const float* raw, const float* d_raw,
                                          const float* save, int64_t n_points, uint32_t flags, float* dz_out, float* dz_max,
-                                         int32_t* status, void* stream) {
+                                         float* head_partial, int32_t* status, void* stream) {
     using namespace inerf;
     if (!net || !packed_bwd || !raw || !d_raw || !save || !dz_out || n_points < 0) return INERF_E_INVALID;
     if (!net_supported(*net)) return INERF_E_UNSUPPORTED;
@@ -337,7 +436,7 @@ extern "C" int inerf_mlp_backward_inputs(const inerf_net_desc* net, const float*
     if (n_points >= (int64_t)1 << 31) return INERF_E_UNSUPPORTED;
     const bool ssr = net->variant == INERF_VARIANT_SSR;
     BwdParams p;
-    p.wts = packed_bwd; p.raw = raw; p.d_raw = d_raw; p.save = save; p.dz = dz_out; p.dz_max = dz_max; p.status = status;
+    p.wts = packed_bwd; p.raw = raw; p.d_raw = d_raw; p.save = save; p.dz = dz_out; p.dz_max = dz_max; p.head_partial = head_partial; p.status = status;
     for (int s = 0; s < SAVE_SLOTS; ++s) p.off[s] = save_offset(*net, s, n_points);
     p.L = make_bwd_layout(*net);
     p.n_points = (int)n_points;

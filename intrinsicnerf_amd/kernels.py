@@ -371,21 +371,23 @@ def encode_mlp_train(desc, packed, rays, z_vals, endpoint=False, status=None, ac
     return raw, save
 
 
-def mlp_backward_inputs(desc, packed_bwd, raw, d_raw, save, endpoint=False, status=None, dz_max=None):
+def mlp_backward_inputs(desc, packed_bwd, raw, d_raw, save, endpoint=False, status=None, dz_max=None, want_heads=False):
     """Pre-activation gradients of every layer (same slot layout as ``save``) from d loss / d raw.  ``dz_max``: optional
-    zeroed float32[1] device tensor that receives max |dz| (the weight-gradient kernel's operand range)."""
+    zeroed float32[1] device tensor that receives max |dz| (the weight-gradient kernel's operand range).  ``want_heads``:
+    also return the summed weight / bias gradients of the 1-4-row heads (see include/inerf.h) as a second value."""
     raw = _dev(raw, "raw", (None, None))
     p, ch = raw.shape
     d_raw = _dev(d_raw, "d_raw", (p, ch))
     save = _dev(save, "save", (None,))
     packed_bwd = _dev(packed_bwd, "packed transposed weights", (None,))
     dz = _new(raw, save.shape[0])
+    heads = _new(raw, _capi.lib().inerf_mlp_backward_grid(p), _capi.lib().inerf_mlp_head_partial_floats()) if want_heads else None
     with torch.cuda.device(raw.device):
         rc = _capi.lib().inerf_mlp_backward_inputs(desc, _ptr(packed_bwd), _ptr(raw), _ptr(d_raw), _ptr(save), p,
-                                                   FLAG_ENDPOINT if endpoint else 0, _ptr(dz), _ptr(dz_max),
+                                                   FLAG_ENDPOINT if endpoint else 0, _ptr(dz), _ptr(dz_max), _ptr(heads),
                                                    None if status is None else C.c_void_p(status.data_ptr()), _stream(raw))
     _capi.check(rc, "inerf_mlp_backward_inputs")
-    return dz
+    return (dz, heads.sum(0)) if want_heads else dz
 
 
 def _head_names(desc):
@@ -480,7 +482,7 @@ def _colsum(g, nc):
     return g.sum(0) if nc == 1 else g.view(nc, g.shape[0] // nc, g.shape[1]).sum(1).sum(0)
 
 
-def mlp_weight_gradients(desc, names, save, dz, d_raw, n_points, endpoint=False, ranges=None):
+def mlp_weight_gradients(desc, names, save, dz, d_raw, n_points, endpoint=False, ranges=None, heads=None):
     """dW = dZ^T X and db = column sums of dZ for every layer.  The 128/256-row layers go through the HIP split-K kernel when
     ``ranges`` (float32[2] device tensor: max |dz|, max |activation|, as delivered by the two training kernels) is given, else
     - and the 1-4-row heads always - through library GEMMs split over K.  Returns a dict name -> gradient with the
@@ -531,15 +533,23 @@ def mlp_weight_gradients(desc, names, save, dz, d_raw, n_points, endpoint=False,
     out["feature_linear.weight"], out["feature_linear.bias"] = W["feat"], B[SAVE_FEAT]
     out["views_linears.0.weight"], out["views_linears.0.bias"] = torch.cat([W["vf"], W["vd"][:, :dv]], 1), B[SAVE_VH]
     dpre = G[SAVE_DPRE]
-    lin("alpha_linear", dpre[:, 7:8], h[7])
+    if heads is None:
+        lin("alpha_linear", dpre[:, 7:8], h[7])
     if sem:
         out["semantic_linear.0.0.weight"], out["semantic_linear.0.0.bias"] = W["sem1"], B[SAVE_SEMH]
         c = desc.n_classes
         lin("semantic_linear.1", d_raw[:, BASE_CHANNELS:BASE_CHANNELS + c], X[SAVE_SEMH])
-    as1h = X[SAVE_AS1H]
-    lin("albedo_linear2", dpre[:, 0:3], as1h[:, :128])
-    lin(sh2, dpre[:, 3:4], as1h[:, 128:])
-    lin(res, dpre[:, 4:7], X[SAVE_VH])
+    if heads is None:
+        as1h = X[SAVE_AS1H]
+        lin("albedo_linear2", dpre[:, 0:3], as1h[:, :128])
+        lin(sh2, dpre[:, 3:4], as1h[:, 128:])
+        lin(res, dpre[:, 4:7], X[SAVE_VH])
+    else:                      # accumulated by the chain kernel itself (layout: include/inerf.h)
+        as2 = heads[384:1408].view(4, 256)
+        out[res + ".weight"], out[res + ".bias"] = heads[0:384].view(3, 128), heads[1668:1671]
+        out["albedo_linear2.weight"], out["albedo_linear2.bias"] = as2[0:3, 0:128], heads[1664:1667]
+        out[sh2 + ".weight"], out[sh2 + ".bias"] = as2[3:4, 128:256], heads[1667:1668]
+        out["alpha_linear.weight"], out["alpha_linear.bias"] = heads[1408:1664].view(1, 256), heads[1671:1672]
     return {k: out[k] for k in names}
 
 
@@ -572,11 +582,15 @@ class _FusedMlpFn(torch.autograd.Function):
         dz_max = torch.zeros(1, dtype=torch.float32, device=raw.device)
         packed_bwd = packing.device_packer(desc, True, raw.device)(dict(zip(names, params)))
         d2 = d_raw.contiguous().view(n * s, ch).float()
-        dz = mlp_backward_inputs(desc, packed_bwd, raw.view(n * s, ch), d2, save, endpoint, status, dz_max)
-        check_f16_range(status, "training backward")
         import os
-        ranges = None if os.environ.get("INERF_WGRAD", "hip") == "library" else torch.cat([dz_max, act_max])
-        grads = mlp_weight_gradients(desc, names, save, dz, d2, n * s, endpoint, ranges)
+        hip_wgrad = os.environ.get("INERF_WGRAD", "hip") != "library"
+        dz = mlp_backward_inputs(desc, packed_bwd, raw.view(n * s, ch), d2, save, endpoint, status, dz_max, want_heads=hip_wgrad)
+        heads = None
+        if hip_wgrad:
+            dz, heads = dz
+        check_f16_range(status, "training backward")
+        ranges = torch.cat([dz_max, act_max]) if hip_wgrad else None
+        grads = mlp_weight_gradients(desc, names, save, dz, d2, n * s, endpoint, ranges, heads)
         return (None, None, None, None, None) + tuple(grads[k] for k in names)
 
 
