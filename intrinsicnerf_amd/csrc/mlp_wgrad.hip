@@ -104,28 +104,57 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
 
-    // LDS: X operands of one tile: [cb][ph][q][plane] fragments
-    auto xfrag = [&](int cb, int ph, int q, int plane) { return ldsw + ((((cb * 2 + ph) * 2 + q) * 2 + plane) * kWgFragBytes) + lane * 16; };
+    // LDS: X operands of two tiles (double buffer): [buf][cb][ph][q][plane] fragments
+    constexpr int kBufBytes = CB * 8 * kWgFragBytes;
+    auto xfrag = [&](int buf, int cb, int ph, int q, int plane) {
+        return ldsw + buf * kBufBytes + ((((cb * 2 + ph) * 2 + q) * 2 + plane) * kWgFragBytes) + lane * 16;
+    };
+    constexpr int XS = (CB + NW - 1) / NW;        // column blocks of X this wave converts (cb = wave + NW * i)
 
+    // The next tile's X rows (this wave's share) are requested before the contraction and converted after it; G's rows
+    // are requested at the top of a tile and arrive while the X share is converted.  One barrier per tile.
+    float xraw[XS][2][2][8];
+    auto load_x = [&](int tile) {
+        const int pt_base = tile * kTilePoints;
+#pragma unroll
+        for (int i = 0; i < XS; ++i) {
+            const int cb = wave + NW * i;
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+                    if (cb < CB) load_piece(p.X, p.ldx, pt_base + 32 * ph + lp, p.n_points, 32 * cb + 16 * g + 8 * lh, xraw[i][ph][g]);
+        }
+    };
+
+    int buf = 0;
+    if ((int)blockIdx.x < p.n_tiles) load_x(blockIdx.x);
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         const int pt_base = tile * kTilePoints;
-        // ---- X: every wave transposes its share of the column blocks and parks the operands in LDS ----
-#pragma unroll 1
-        for (int cb = wave; cb < CB; cb += NW) {
+        float graw[2][2][8];
 #pragma unroll
-            for (int ph = 0; ph < 2; ++ph) {
-                float v0[8], v1[8];
-                load_piece(p.X, p.ldx, pt_base + 32 * ph + lp, p.n_points, 32 * cb + 8 * lh, v0);
-                load_piece(p.X, p.ldx, pt_base + 32 * ph + lp, p.n_points, 32 * cb + 16 + 8 * lh, v1);
-                f16x8 h0, l0, h1, l1, th[2], tl[2];
-                split8(v0, sx, h0, l0);
-                split8(v1, sx, h1, l1);
-                transpose_block(h0, h1, id0, id1, th);
-                transpose_block(l0, l1, id0, id1, tl);
+        for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    *reinterpret_cast<f16x8*>(xfrag(cb, ph, q, 0)) = th[q];
-                    *reinterpret_cast<f16x8*>(xfrag(cb, ph, q, 1)) = tl[q];
+            for (int g = 0; g < 2; ++g)
+                load_piece(p.G, p.ldg, pt_base + 32 * ph + lp, p.n_points, 32 * wave + 16 * g + 8 * lh, graw[ph][g]);
+        // ---- X: every wave transposes its share of the column blocks and parks the operands in LDS[buf] ----
+#pragma unroll
+        for (int i = 0; i < XS; ++i) {
+            const int cb = wave + NW * i;
+            if (cb < CB) {
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph) {
+                    f16x8 h0, l0, h1, l1, th[2], tl[2];
+                    split8(xraw[i][ph][0], sx, h0, l0);
+                    split8(xraw[i][ph][1], sx, h1, l1);
+                    transpose_block(h0, h1, id0, id1, th);
+                    transpose_block(l0, l1, id0, id1, tl);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        *reinterpret_cast<f16x8*>(xfrag(buf, cb, ph, q, 0)) = th[q];
+                        *reinterpret_cast<f16x8*>(xfrag(buf, cb, ph, q, 1)) = tl[q];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -133,17 +162,15 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
         f16x8 gh[2][2], gl[2][2];          // [ph][q]
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {
-            const int col = 32 * wave;
-            float v0[8], v1[8];
-            load_piece(p.G, p.ldg, pt_base + 32 * ph + lp, p.n_points, col + 8 * lh, v0);
-            load_piece(p.G, p.ldg, pt_base + 32 * ph + lp, p.n_points, col + 16 + 8 * lh, v1);
             f16x8 h0, l0, h1, l1;
-            split8(v0, sg, h0, l0);
-            split8(v1, sg, h1, l1);
+            split8(graw[ph][0], sg, h0, l0);
+            split8(graw[ph][1], sg, h1, l1);
             bias_sum += transpose_block(h0, h1, id0, id1, gh[ph]);
             bias_sum += transpose_block(l0, l1, id0, id1, gl[ph]);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
+        if (tile + (int)gridDim.x < p.n_tiles) load_x(tile + gridDim.x);
+        __syncthreads();                   // LDS[buf] complete; LDS[buf ^ 1] (last read before the previous barrier) is free
         // ---- contraction over the 64 points of the tile ----
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph)
@@ -151,13 +178,13 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
             for (int q = 0; q < 2; ++q)
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb) {
-                    const f16x8 xh = *reinterpret_cast<const f16x8*>(xfrag(cb, ph, q, 0));
-                    const f16x8 xl = *reinterpret_cast<const f16x8*>(xfrag(cb, ph, q, 1));
+                    const f16x8 xh = *reinterpret_cast<const f16x8*>(xfrag(buf, cb, ph, q, 0));
+                    const f16x8 xl = *reinterpret_cast<const f16x8*>(xfrag(buf, cb, ph, q, 1));
                     acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[ph][q], xh, acc[cb], 0, 0, 0);
                     acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[ph][q], xl, acc[cb], 0, 0, 0);
                     acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl[ph][q], xh, acc[cb], 0, 0, 0);
                 }
-        __syncthreads();
+        buf ^= 1;
     }
 
     // ---- this workgroup's partial tile: row m = channel of G, column n = channel of X ----
@@ -205,13 +232,17 @@ extern "C" int inerf_mlp_weight_gradient(const float* G, int ldg, const float* X
     const int grid = inerf_wgrad_grid(n_points);
     const int cb = N / 32;
     if ((M != 128 && M != 256) || N % 32 || cb < 1 || cb > 8) return INERF_E_UNSUPPORTED;
-    const int lds = cb * 8 * kWgFragBytes;
+    const int lds = 2 * cb * 8 * kWgFragBytes;          // double-buffered X operands
     void (*kern)(const WgradParams) = nullptr;
 #define INERF_WG_CASE(NWV, CBV) if (M == 32 * NWV && cb == CBV) kern = k_mlp_wgrad<NWV, CBV>;
     INERF_WG_CASE(8, 8) INERF_WG_CASE(8, 2) INERF_WG_CASE(4, 8) INERF_WG_CASE(4, 1) INERF_WG_CASE(8, 1) INERF_WG_CASE(4, 2)
     INERF_WG_CASE(8, 4) INERF_WG_CASE(4, 4)
 #undef INERF_WG_CASE
     if (!kern) return INERF_E_UNSUPPORTED;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return record(e);
+    }
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return record(e);
