@@ -76,8 +76,8 @@ __device__ __forceinline__ float transpose_block(f16x8 g0, f16x8 g1, f16x8 id0, 
 
 // NW waves, each owning one 32-row block of the output (M = 32 * NW); CB: 32-column blocks of the output (N = 32 * CB).
 // M = 256 runs as 8 waves of <= 256 registers (128 of them accumulators): two waves per SIMD, so that one wave's loads and
-// conversions overlap the other's MFMAs - the kernel has no software pipelining (a register-prefetching version spilled
-// and was 20 % slower).
+// conversions overlap the other's MFMAs.  (With 4 waves x 64 rows - 256 accumulator registers per lane - prefetching the
+// next tile spilled and was 20 % slower than not prefetching at all.)
 template <int NW, int CB>
 __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) char ldsw[];
