@@ -47,13 +47,13 @@ flop = 2 * 659456 * n * s
 t_inf, _ = timed(lambda: kernels.encode_mlp(desc, pf, rays, z))
 act_max, dz_max = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
 t_fwd, (raw, save) = timed(lambda: kernels.encode_mlp_train(desc, pf, rays, z, act_max=act_max))
-t_bwd, dz = timed(lambda: kernels.mlp_backward_inputs(desc, pb, raw.view(n * s, 11), d_raw, save, dz_max=dz_max))
+t_bwd, (dz, heads) = timed(lambda: kernels.mlp_backward_inputs(desc, pb, raw.view(n * s, 11), d_raw, save, dz_max=dz_max, want_heads=True))
 t_wl, _ = timed(lambda: kernels.mlp_weight_gradients(desc, names, save, dz, d_raw, n * s))
-t_wg, _ = timed(lambda: kernels.mlp_weight_gradients(desc, names, save, dz, d_raw, n * s, ranges=torch.cat([dz_max, act_max])))
+t_wg, _ = timed(lambda: kernels.mlp_weight_gradients(desc, names, save, dz, d_raw, n * s, ranges=torch.cat([dz_max, act_max]), heads=heads))
 gb = save.numel() * 4 / 1e9
 print(f"{n} rays x {s} samples = {n * s} points; activation buffer {gb:.2f} GB")
 print(f"inference forward        {t_inf:7.3f} ms  {flop / t_inf / 1e9:6.1f} TFLOP/s")
 print(f"training forward (save)  {t_fwd:7.3f} ms  {flop / t_fwd / 1e9:6.1f} TFLOP/s   writes {gb / t_fwd * 1e3:5.2f} TB/s")
-print(f"input-gradient chain     {t_bwd:7.3f} ms  {0.89 * flop / t_bwd / 1e9:6.1f} TFLOP/s   reads+writes {2 * gb / t_bwd * 1e3:5.2f} TB/s")
+print(f"input-gradient chain (+ head gradients) {t_bwd:7.3f} ms  {0.89 * flop / t_bwd / 1e9:6.1f} TFLOP/s   reads+writes {2 * gb / t_bwd * 1e3:5.2f} TB/s")
 print(f"weight gradients, library GEMMs {t_wl:7.3f} ms  {flop / t_wl / 1e9:6.1f} TFLOP/s")
 print(f"weight gradients, HIP kernel    {t_wg:7.3f} ms  {flop / t_wg / 1e9:6.1f} TFLOP/s")
