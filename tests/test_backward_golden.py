@@ -323,3 +323,39 @@ def test_weight_gradient_kernel_vs_fp64(p, m, n):
     ranges = torch.tensor([float(gv.abs().max()) * 3.0, 7.5e3], device=dev)
     w2 = kernels.weight_gradient(gv, xv, m, n, ranges)
     assert float((w2.double() - want_w).norm()) <= 2e-5 * float(want_w.norm())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8))
+def test_composite_backward_randomized_shapes(seed):
+    """Compositing backward against autograd through the oracle over ragged sample counts (chunks of 64 with a partial last
+    chunk, a single sample, more than four chunks), optional noise / white background / semantic and feature channels and
+    cotangents on a random subset of the outputs."""
+    from intrinsicnerf_amd import kernels
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(300 + seed)
+    n = int(rng.randint(1, 40))
+    s = int(rng.choice([1, 2, 5, 63, 64, 65, 100, 192, 257, 300]))
+    c = int(rng.choice([0, 0, 1, 7, 33]))
+    feat = bool(rng.rand() < 0.3) and c > 0
+    wb = bool(rng.rand() < 0.5)
+    with_noise = bool(rng.rand() < 0.5)
+    g = torch.Generator().manual_seed(seed)
+    ch = 11 + c + (128 if feat else 0)
+    raw = torch.rand(n, s, ch, generator=g)
+    raw[..., 3] = torch.randn(n, s, generator=g) * 2 + 0.3
+    z = torch.sort(torch.rand(n, s, generator=g) * 4 + 2, -1)[0]
+    d = torch.randn(n, 3, generator=g)
+    noise = torch.randn(n, s, generator=g) * 0.3 if with_noise else None
+    cfg = oracle.RenderConfig(variant="ssr" if c > 0 else "object", white_bkgd=wb, n_classes=c, endpoint_feat=feat)
+    r = raw.clone().requires_grad_(True)
+    out = oracle.composite(r, z, d, cfg, noise, feat=feat)
+    keys = [k for k in (SSR_KEYS if c > 0 else OBJ_KEYS) if out.get(k) is not None and k != "disp"]
+    if bool((out["acc"] > 1e-3).all()):
+        keys.append("disp")                      # disp is 1 / (depth / acc): only pinned away from acc ~ 0
+    used = [k for k in keys if rng.rand() < 0.7] or ["rgb"]
+    cot = {k: torch.randn(out[k].shape, generator=g) for k in used}
+    (want,) = torch.autograd.grad(sum((cot[k] * out[k]).sum() for k in used), r)
+    got = kernels.composite_backward(raw.to(dev), z.to(dev), d.to(dev), {k: v.to(dev) for k, v in cot.items()},
+                                     None if noise is None else noise.to(dev), wb, c, 128 if feat else 0)
+    assert_maps_close(got.cpu().numpy(), want.numpy(), 2e-4, 2e-5 * float(want.abs().max()) + 1e-12, f"seed {seed}: n={n} s={s} c={c} feat={feat}")
