@@ -273,9 +273,9 @@ constexpr int kColExD = 64;                       // exchange area: floats [wave
 
 // accumulators of this wave's 32*RB channels x 64 points -> (bias, ReLU, hi/lo split) -> B operands, one per
 // 16-channel k-block q (accumulator registers 8*(q&1) .. +7 of row block q>>1) and point block
-template <int RB>
+template <int RB, bool SAVE = false>
 __device__ __forceinline__ void to_operands(const f32x16 (&am)[RB][2], float inv, const f32x4 (&bias)[RB][4], f16x2& amax2,
-                                            f16x8 (&hi)[2 * RB][2], f16x8 (&lo)[2 * RB][2]) {
+                                            f16x8 (&hi)[2 * RB][2], f16x8 (&lo)[2 * RB][2], const SaveDst* sv = nullptr) {
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -283,6 +283,7 @@ __device__ __forceinline__ void to_operands(const f32x16 (&am)[RB][2], float inv
 #pragma unroll
             for (int q2 = 0; q2 < 2; ++q2) {
                 f16x8 fh, fl;
+                float tv[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int j = 8 * q2 + i;
@@ -290,6 +291,15 @@ __device__ __forceinline__ void to_operands(const f32x16 (&am)[RB][2], float inv
                     const float th = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, t) & 0xFFFFE000u);
                     fh[i] = (_Float16)th;
                     fl[i] = (_Float16)(t - th);
+                    tv[i] = t;
+                }
+                if constexpr (SAVE) {          // registers 8*q2 .. +7 are channels 32*rb + 8*(2*q2) + 4h .. +3 and + 8*(2*q2 + 1) + 4h .. +3
+#pragma unroll
+                    for (int gg = 0; gg < 2; ++gg) {
+                        const f32x4 v = f32x4{tv[4 * gg], tv[4 * gg + 1], tv[4 * gg + 2], tv[4 * gg + 3]} * (1.0f / kActScale);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), sv->rsrc,
+                                                               sv->voff + (pb * 32 * sv->stride + 32 * rb + 8 * (2 * q2 + gg)) * 4, 0, 0);
+                    }
                 }
                 const f16x2 m = __builtin_elementwise_max(__builtin_elementwise_max(f16x2{fh[0], fh[1]}, f16x2{fh[2], fh[3]}),
                                                           __builtin_elementwise_max(f16x2{fh[4], fh[5]}, f16x2{fh[6], fh[7]}));
@@ -325,6 +335,7 @@ __device__ __forceinline__ void regop_gemm(const WeightBuf& wb, int frag_bytes, 
     for (int pb = 0; pb < 2; ++pb) part[pb] = f32x4{acc[pb][0], acc[pb][1], acc[pb][2], acc[pb][3]};   // rows 0..3: lanes 0..31
 }
 
+template <bool kSave>
 __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParams p) {
     constexpr int kPts = kTilePoints;
     constexpr int kParts = 256 / kPts;
@@ -361,6 +372,9 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
             const float* __restrict__ r = p.rays + (size_t)ray * INERF_RAY_FLOATS;
             const float zz = __builtin_nontemporal_load(p.z + gp);
             _Float16* row = ldsd + pt * kRowD;
+            const bool sv_ok = kSave && with_dir && tile * kPts + pt < p.n_points;       // the skip layer's second pass re-computes only
+            float* const sv_enc = kSave ? p.save + p.save_off[SAVE_ENC] + (size_t)gp * kEncCols : nullptr;
+            float* const sv_dir = kSave ? p.save + p.save_off[SAVE_DIR] + (size_t)gp * kDirCols : nullptr;
             float x[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) x[c] = __fadd_rn(r[c], __fmul_rn(r[3 + c], zz));       // run_nerf.py:488
@@ -372,12 +386,17 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
                     sincosf(x[c] * s, &sn, &cs);
                     split_store<kPlaneD>(row + 3 + 6 * f + c, sn, amax);
                     split_store<kPlaneD>(row + 6 + 6 * f + c, cs, amax);
+                    if (sv_ok) { sv_enc[3 + 6 * f + c] = sn; sv_enc[6 + 6 * f + c] = cs; }
                 }
             }
             if (part == 2) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) split_store<kPlaneD>(row + c, x[c], amax);
                 for (int c = 3 + 6 * p.l_xyz; c < kEncCols; ++c) { row[c] = (_Float16)0.0f; row[kPlaneD + c] = (_Float16)0.0f; }
+                if (sv_ok) {
+                    for (int c = 0; c < 3; ++c) sv_enc[c] = x[c];
+                    for (int c = 3 + 6 * p.l_xyz; c < kEncCols; ++c) sv_enc[c] = 0.0f;
+                }
             }
             if (with_dir) {
                 const int fd = kParts - 1 - part;
@@ -389,12 +408,17 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
                         sincosf(r[8 + c] * s, &sn, &cs);
                         split_store<kPlaneD>(row + kColDirD + 3 + 6 * fd + c, sn, amax);
                         split_store<kPlaneD>(row + kColDirD + 6 + 6 * fd + c, cs, amax);
+                        if (sv_ok) { sv_dir[3 + 6 * fd + c] = sn; sv_dir[6 + 6 * fd + c] = cs; }
                     }
                 }
                 if (part == 3) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) split_store<kPlaneD>(row + kColDirD + c, r[8 + c], amax);
                     for (int c = 3 + 6 * p.l_dir; c < kDirCols; ++c) { row[kColDirD + c] = (_Float16)0.0f; row[kPlaneD + kColDirD + c] = (_Float16)0.0f; }
+                    if (sv_ok) {
+                        for (int c = 0; c < 3; ++c) sv_dir[c] = r[8 + c];
+                        for (int c = 3 + 6 * p.l_dir; c < kDirCols; ++c) sv_dir[c] = 0.0f;
+                    }
                 }
             }
         };
@@ -405,11 +429,21 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
         f32x16 am2[2][2];
         f32x4 bias2[2][4];
         float inv2;
-        auto store256 = [&](const GemmSlot& s, bool relu, auto&& prefetch_next) {
+        const int pt0 = tile * kPts + (lane & 31);
+        auto save_dst = [&](int slot, int width, int chan0) {
+            SaveDst d;
+            d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save + (kSave ? p.save_off[slot] : 0), 0, kSave ? p.n_points * width * 4 : 0,
+                                                       0x00020000);
+            d.voff = (pt0 * width + chan0 + 4 * (lane >> 5)) * 4;
+            d.stride = width;
+            return d;
+        };
+        auto store256 = [&](const GemmSlot& s, bool relu, int slot, auto&& prefetch_next) {
             load_bias<2>(bias2, inv2, wb, (s.b + 64 * wave) * 4, (s.b + kWidth) * 4, lane);
             prefetch_next();
+            const SaveDst sv = save_dst(slot, kWidth, 64 * wave);
             __syncthreads();                       // every wave has read the layer's input
-            wide_store_h<2, kRowD, kPlaneD>(am2, inv2, bias2, xd, relu, amax2, nullptr, 0, 0, 0);
+            wide_store_h<2, kRowD, kPlaneD, kSave>(am2, inv2, bias2, xd, relu, amax2, nullptr, 0, 0, 0, &sv);
             __syncthreads();
         };
         auto pf256 = [&](const GemmSlot& s, int kbt) { return [&, kbt]() { prefetch_w<2>(pre2, wb, frag256(s, kbt)); }; };
@@ -420,12 +454,12 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
 
         // ---------------- trunk ----------------
         wide_gemm_h<2, 4, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.trunk[0], 4), xr, 0, 0, lane, am2);
-        store256(L.trunk[0], true, pf256(L.trunk[1], 16));
+        store256(L.trunk[0], true, SAVE_H0, pf256(L.trunk[1], 16));
 #pragma unroll 1
         for (int layer = 1; layer < kSkipInput; ++layer) {
             wide_gemm_h<2, 16, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.trunk[layer], 16), xr, 0, 0, lane, am2);
-            if (layer + 1 < kSkipInput) store256(L.trunk[layer], true, pf256(L.trunk[layer + 1], 16));
-            else                        store256(L.trunk[layer], true, pf256_at(L.trunk[kSkipInput], 20, 4));
+            if (layer + 1 < kSkipInput) store256(L.trunk[layer], true, SAVE_H0 + layer, pf256(L.trunk[layer + 1], 16));
+            else                        store256(L.trunk[layer], true, SAVE_H0 + layer, pf256_at(L.trunk[kSkipInput], 20, 4));
         }
         {   // pts_linears[5] over cat([pts, h]): h-part (k-blocks 4..19 of the stream), then the encoding again
             const GemmSlot& s = L.trunk[kSkipInput];
@@ -435,12 +469,12 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
             encode(false);
             __syncthreads();
             wide_gemm_h<2, 4, 0, kRowD, kPlaneD, false>(pre2, wb, frag256(s, 20), xr, 0, 0, lane, am2);
-            store256(s, true, pf256(L.trunk[6], 16));
+            store256(s, true, SAVE_H0 + kSkipInput, pf256(L.trunk[6], 16));
         }
         wide_gemm_h<2, 16, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.trunk[6], 16), xr, 0, 0, lane, am2);
-        store256(L.trunk[6], true, pf256(L.trunk[7], 16));
+        store256(L.trunk[6], true, SAVE_H0 + 6, pf256(L.trunk[7], 16));
         wide_gemm_h<2, 16, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.trunk[7], 16), xr, 0, 0, lane, am2);
-        store256(L.trunk[7], true, pf256(L.as1, 16));
+        store256(L.trunk[7], true, SAVE_H7, pf256(L.as1, 16));
 
         // ---------------- heads ----------------
         const int my_pt = tile * kPts + 16 * wave + (lane & 15);
@@ -455,12 +489,13 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
             load_bias<2>(bias2, inv2, wb, (L.as1.b + 64 * wave) * 4, (L.as1.b + kWidth) * 4, lane);
             prefetch_w<2>(pre2, wb, frag256(L.feat, 16));
             f16x8 hi[4][2], lo[4][2];
-            to_operands<2>(am2, inv2, bias2, amax2, hi, lo);
+            const SaveDst sv = save_dst(SAVE_AS1H, kWidth, 64 * wave);
+            to_operands<2, kSave>(am2, inv2, bias2, amax2, hi, lo, &sv);
             regop_gemm<4>(wb, (L.as2r.w + wave * 4 * 2 * 256) * 4, hi, lo, part_as);
         }
         // feature (no activation) in place of h7, then the view-dependent layer over [feature | dir] -> registers
         wide_gemm_h<2, 16, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.feat, 16), xr, 0, 0, lane, am2);
-        store256(L.feat, false, pf128(L.views, 18));
+        store256(L.feat, false, SAVE_FEAT, pf128(L.views, 18));
         {
             f32x16 am1[1][2];
             f32x4 bias1[1][4];
@@ -469,7 +504,8 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
             load_bias<1>(bias1, inv1, wb, (L.views.b + 32 * wave) * 4, (L.views.b + kHalf) * 4, lane);
             prefetch_w<2>(pre2, wb, frag256(L.trunk[0], 4));
             f16x8 hi[2][2], lo[2][2];
-            to_operands<1>(am1, inv1, bias1, amax2, hi, lo);
+            const SaveDst sv = save_dst(SAVE_VH, kHalf, 32 * wave);
+            to_operands<1, kSave>(am1, inv1, bias1, amax2, hi, lo, &sv);
             regop_gemm<2>(wb, (L.resr.w + wave * 2 * 2 * 256) * 4, hi, lo, part_res);
         }
         __syncthreads();                           // feature / dir columns are dead: exchange area may be written
@@ -511,27 +547,34 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
     }
     const float amax_all = fmaxf(amax, fmaxf((float)amax2[0], (float)amax2[1]));
     if (p.status && __any(!(amax_all <= kF16Safe)) && lane == 0) atomicOr(p.status, INERF_STATUS_F16_RANGE);
+    if (kSave && p.act_max) {
+        float m = amax_all * (1.0f / kActScale);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0 && m == m) atomicMax(reinterpret_cast<unsigned int*>(p.act_max), __builtin_bit_cast(unsigned int, m));
+    }
 }
 
 static int launch_dual(MlpParams& p, int64_t n_points, hipStream_t stream) {
     p.n_tiles = (int)((n_points + kTilePoints - 1) / kTilePoints);
     const int max_grid = 2 * device_cus();
     const int grid = p.n_tiles < max_grid ? p.n_tiles : max_grid;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_encode_mlp_f16x3_dual),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesD);
+    const bool save = p.save != nullptr;
+    void (*kern)(const MlpParams) = save ? k_encode_mlp_f16x3_dual<true> : k_encode_mlp_f16x3_dual<false>;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[save]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesD);
         if (e != hipSuccess) return record(e);
-        attr_set = true;
+        attr_set[save] = true;
     }
-    hipLaunchKernelGGL(k_encode_mlp_f16x3_dual, dim3(grid), dim3(256), kLdsBytesD, stream, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kLdsBytesD, stream, p);
     return record(hipGetLastError());
 }
 
 int launch_mlp_f16x3(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream) {
     // object-level network: two workgroups per CU; INERF_F16_KERNEL=single keeps the one-workgroup kernel (A/B runs)
     const char* form = getenv("INERF_F16_KERNEL");
-    if (!ssr && !p.save && !(form && form[0] == 's')) return launch_dual(p, n_points, stream);
+    if (!ssr && !(form && form[0] == 's')) return launch_dual(p, n_points, stream);
     p.n_tiles = (int)((n_points + kTilePoints - 1) / kTilePoints);
     const int grid = p.n_tiles < device_cus() ? p.n_tiles : device_cus();
     const bool save = p.save != nullptr;
