@@ -5,9 +5,11 @@ for d in sys.argv[1:]:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "k_encode_mlp" in r["Kernel_Name"]:
-                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            name = r["Kernel_Name"]
+            for kern in ("k_encode_mlp", "k_mlp_dgrad", "k_mlp_wgrad<8, 8>"):
+                if kern in name:
+                    agg[(kern if kern != "k_encode_mlp" else name.split("(")[0][-40:], r["Counter_Name"])].append(float(r["Counter_Value"]))
         print(d)
         for k in sorted(agg):
             v = agg[k]
-            print(f"  {k:30s} {sum(v) / len(v):.5g}")
+            print(f"  {k[0]:42s} {k[1]:28s} mean {sum(v) / len(v):.5g}  (n={len(v)})")
