@@ -44,11 +44,11 @@ extern "C" int64_t inerf_workspace_bytes(const inerf_net_desc* net, int64_t n_ra
 }
 
 extern "C" int inerf_render_rays(const inerf_render_args* a, void* stream) {
+    if (a && a->n_rays == 0) return inerf::net_supported(a->net) ? INERF_OK : INERF_E_UNSUPPORTED;   // empty batch: null pointers allowed
     if (!a || !a->packed_coarse || !a->rays || !a->t_vals || a->n_rays < 0 || a->n_samples < 1 || a->n_importance < 0)
         return INERF_E_INVALID;
     if (!inerf::net_supported(a->net)) return INERF_E_UNSUPPORTED;
     if (a->n_importance > 0 && !a->u) return INERF_E_INVALID;
-    if (a->n_rays == 0) return INERF_OK;
     const Plan p = plan(a->net, a->n_rays, a->n_samples, a->n_importance, a->flags);
     if (!a->workspace || a->workspace_bytes < p.total) return INERF_E_WORKSPACE;
     char* ws = static_cast<char*>(a->workspace);

@@ -425,6 +425,7 @@ extern "C" int inerf_mlp_save_slot(const inerf_net_desc* net, int slot, int64_t 
 extern "C" int inerf_encode_mlp_train(const inerf_net_desc* net, const float* packed, const float* rays, const float* z,
                                       int64_t n_rays, int n_samples, uint32_t flags, float* raw_out, float* save_out,
                                       float* act_max, int32_t* status, void* stream) {
+    if (net && n_rays == 0) return INERF_OK;
     if (!save_out || !net) return INERF_E_INVALID;
     if (net->precision != INERF_PREC_F16X3) return INERF_E_UNSUPPORTED;
     if (n_rays * (int64_t)n_samples > 4000000) return INERF_E_UNSUPPORTED;     // one activation slot stays below 4 GiB (buffer descriptors)
@@ -434,6 +435,7 @@ extern "C" int inerf_encode_mlp_train(const inerf_net_desc* net, const float* pa
 static int encode_mlp_impl(const inerf_net_desc* net, const float* packed, const float* rays, const float* z, int64_t n_rays,
                            int n_samples, uint32_t flags, float* raw_out, float* save, float* act_max, int32_t* status, void* stream) {
     using namespace inerf;
+    if (net && n_rays == 0) return net_supported(*net) ? INERF_OK : INERF_E_UNSUPPORTED;      // empty batch: pointers may be null
     if (!net || !packed || !rays || !z || !raw_out || n_rays < 0 || n_samples < 1) return INERF_E_INVALID;
     if (!net_supported(*net)) return INERF_E_UNSUPPORTED;
     if (n_rays == 0) return INERF_OK;

@@ -430,6 +430,7 @@ extern "C" int inerf_mlp_backward_inputs(const inerf_net_desc* net, const float*
                                          const float* save, int64_t n_points, uint32_t flags, float* dz_out, float* dz_max,
                                          float* head_partial, int32_t* status, void* stream) {
     using namespace inerf;
+    if (net && n_points == 0) return INERF_OK;
     if (!net || !packed_bwd || !raw || !d_raw || !save || !dz_out || n_points < 0) return INERF_E_INVALID;
     if (!net_supported(*net)) return INERF_E_UNSUPPORTED;
     if (n_points == 0) return INERF_OK;

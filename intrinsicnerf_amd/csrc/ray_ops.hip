@@ -474,8 +474,8 @@ __global__ __launch_bounds__(256) void k_sample_fine(const float* __restrict__ z
 extern "C" int inerf_sample_coarse(const float* rays, const float* t_vals, const float* t_rand, int64_t n_rays,
                                    int n_samples, uint32_t flags, float* z_out, void* stream) {
     using namespace inerf;
+    if (n_rays == 0) return INERF_OK;              // an empty batch: its (possibly null) pointers are never touched
     if (!rays || !t_vals || !z_out || n_rays < 0 || n_samples < 1) return INERF_E_INVALID;
-    if (n_rays == 0) return INERF_OK;
     const long long total = (long long)n_rays * n_samples;
     long long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
@@ -488,6 +488,7 @@ extern "C" int inerf_composite(const float* raw, const float* z_vals, const floa
                                const float* noise, int64_t n_rays, int n_samples, int channels, int n_classes, int feat_dim,
                                uint32_t flags, const inerf_composite_out* out, void* stream) {
     using namespace inerf;
+    if (n_rays == 0 && out) return INERF_OK;
     if (!raw || !z_vals || !rays_d || !out || n_rays < 0 || n_samples < 1 || rays_d_stride < 3) return INERF_E_INVALID;
     if (channels < INERF_BASE_CHANNELS || n_classes < 0 || feat_dim < 0 ||
         INERF_BASE_CHANNELS + n_classes + feat_dim > channels)
@@ -507,6 +508,7 @@ extern "C" int inerf_composite_backward(const float* raw, const float* z_vals, c
                                         int feat_dim, uint32_t flags, const inerf_composite_out* grads, float* d_raw,
                                         void* stream) {
     using namespace inerf;
+    if (n_rays == 0 && grads) return INERF_OK;
     if (!raw || !z_vals || !rays_d || !grads || !d_raw || n_rays < 0 || n_samples < 1 || rays_d_stride < 3) return INERF_E_INVALID;
     if (channels < INERF_BASE_CHANNELS + n_classes + feat_dim || n_classes < 0 || feat_dim < 0) return INERF_E_INVALID;
     if (n_samples > 64 * kMaxChunks) return INERF_E_UNSUPPORTED;
@@ -523,6 +525,7 @@ extern "C" int inerf_sample_fine(const float* z_coarse, const float* weights, co
                                  int n_importance, uint32_t flags, float* z_samples, float* z_merged, float* z_std,
                                  void* stream) {
     using namespace inerf;
+    if (n_rays == 0) return INERF_OK;
     if (!z_coarse || !weights || !u || n_rays < 0) return INERF_E_INVALID;
     if (n_coarse < 3 || n_coarse > kMaxCoarse || n_importance < 1 || n_importance > kMaxImportance) return INERF_E_UNSUPPORTED;
     if (n_rays == 0) return INERF_OK;
@@ -537,6 +540,7 @@ extern "C" int inerf_sample_fine(const float* z_coarse, const float* weights, co
 extern "C" int inerf_sample_pdf(const float* bins, const float* weights, const float* u, int64_t n_rays, int n_bins,
                                 int n_samples, uint32_t flags, float* samples, void* stream) {
     using namespace inerf;
+    if (n_rays == 0) return INERF_OK;
     if (!bins || !weights || !u || !samples || n_rays < 0) return INERF_E_INVALID;
     if (n_bins < 2 || n_bins > kMaxCoarse || n_samples < 1 || n_samples > kMaxImportance) return INERF_E_UNSUPPORTED;
     if (n_rays == 0) return INERF_OK;

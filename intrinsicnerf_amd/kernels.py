@@ -444,6 +444,9 @@ class _WgradBatch:
 
     def run(self):
         lib = _capi.lib()
+        if self.p == 0:                        # no sample points: every gradient is zero
+            self.sums = torch.zeros(self.total, dtype=torch.float32, device=self.like.device)
+            return
         grid = lib.inerf_wgrad_grid(self.p)
         buf = _new(self.like, grid, self.total)
         with torch.cuda.device(self.like.device):

@@ -468,3 +468,30 @@ def test_randomized_shapes_and_flags(seed):
             assert_maps_close(got[k].cpu().numpy()[ok], w.numpy()[ok], _rtol(k), ATOL,
                               f"seed {seed} {variant} n={n} S={s_c}+{n_imp} L={l_xyz}/{l_dir} C={c}: {k}")
     assert {k for k in want if not k.startswith(("raw", "z_", "weights"))} - {"z_std"} <= set(got) | {"z_std"}
+
+
+def test_empty_batches():
+    """Zero rays: every stage, the fused path and the front-end return correctly shaped empty tensors (the reference's
+    torch ops do the same on an empty ray batch)."""
+    from intrinsicnerf_amd import _capi, kernels, object_level as ol, packing
+    dev = _dev()
+    desc = _capi.net_desc(_capi.VARIANT_OBJECT, 0, 10, 4, 1.0)
+    sd = oracle.make_state_dict("object", 0, seed=1)
+    packed = packing.pack_state_dict(desc, sd).to(dev)
+    rays = torch.zeros(0, 11, device=dev)
+    t = torch.linspace(0., 1., 64, device=dev)
+    z = kernels.sample_coarse(rays, t)
+    assert tuple(z.shape) == (0, 64)
+    raw = kernels.encode_mlp(desc, packed, rays, z)
+    assert tuple(raw.shape) == (0, 64, 11)
+    c = kernels.composite(raw, z, rays[:, 3:6].contiguous(), None, True)
+    assert tuple(c["rgb"].shape) == (0, 3) and tuple(c["weights"].shape) == (0, 64)
+    zs, zm, zstd = kernels.sample_fine(z, c["weights"], torch.linspace(0., 1., 128, device=dev), 128)
+    assert tuple(zs.shape) == (0, 128) and tuple(zm.shape) == (0, 192) and tuple(zstd.shape) == (0,)
+    out = kernels.render_rays_fused(desc, packed, packed, rays, 64, 128, t, torch.linspace(0., 1., 128, device=dev), white_bkgd=True)
+    assert tuple(out["rgb_fine"].shape) == (0, 3) and tuple(out["z_std"].shape) == (0,)
+    embed, ch = ol.get_embedder(10, 0); embed_d, ch_d = ol.get_embedder(4, 0)
+    net = ol.NeRF(D=8, W=256, input_ch=ch, output_ch=5, skips=[4], input_ch_views=ch_d, use_viewdirs=True).to(dev)
+    with torch.no_grad():
+        ret = ol.render_rays(rays, net, ol.NetworkQuery(embed, embed_d), 64, N_importance=128, white_bkgd=True, retraw=True)
+    assert tuple(ret["rgb_map"].shape) == (0, 3) and tuple(ret["raw"].shape) == (0, 192, 11)
