@@ -43,6 +43,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3                 # MI355X_MICROARCH.md: dense fp32 m
 PEAK_F16_MFMA_TFLOPS = 2500.0                # MI355X_MICROARCH.md: dense f16/bf16 matrix peak
 # HBM bytes per sample point of the encode+MLP kernels from the PMC passes (FETCH_SIZE + WRITE_SIZE, separate
 # passes) in profiles/r01_mlp_pmc_traffic.txt: 311.6 MB per 6,291,456-point launch (algorithmic: 306 MB).
+MEASURED_F16_MFMA_ONLY_TFLOPS = 1590.0      # dense f16, random operands, 170-340 ms runs (zero operands: 2470)
 PMC_HBM_BYTES_PER_POINT = {"f16x3": 55.9, "f32": 49.5}    # rocprofv3 PMC, profiles/r01_mlp_pmc_traffic.txt
 
 
@@ -230,7 +231,11 @@ def main():
                 "launches_timed": len(durs), "flop_per_launch": flop_per_launch,
                 "peak_basis": ("dense f16 MFMA 2500 TFLOP/s / 3 products per fp32 MAC" if f16
                                else "dense fp32 MFMA 157.3 TFLOP/s"),
-                "achieved_vs_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS}
+                "achieved_vs_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
+                # what the matrix pipe sustains on this board when it does nothing but MFMAs on random operands
+                # (scripts/microbench/mfma_peak.hip, profiles/r01_mfma_peak_microbench.txt): the power budget, not the name-plate
+                "measured_mfma_only_ceiling": (MEASURED_F16_MFMA_ONLY_TFLOPS / 3.0) if f16 else None,
+                "frac_of_measured_ceiling": (achieved / (MEASURED_F16_MFMA_ONLY_TFLOPS / 3.0)) if f16 else None}
 
     prec = _capi.default_precision()
     roofline = kernel_roofline(prec, max(1, args.steps))
