@@ -385,3 +385,42 @@ def test_training_step_is_deterministic():
     assert torch.equal(runs[0][0], runs[1][0])
     for a, b in zip(runs[0][1], runs[1][1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_short_training_run_matches_torch_layers(monkeypatch):
+    """End to end: fit a student network to maps rendered by a teacher, a few Adam steps through the front-end - once with the
+    HIP network backward, once with torch's layers (INERF_TRAIN_MLP=torch).  Same initial weights, same rays: the loss curves
+    must coincide to 1e-3 and go down."""
+    import warnings
+    from intrinsicnerf_amd import object_level as ol
+    dev = torch.device("cuda:0")
+    fx = load_golden("object_chair_det")
+    embed, ch = ol.get_embedder(10, 0); embed_d, ch_d = ol.get_embedder(4, 0)
+    mk = lambda: ol.NeRF(D=8, W=256, input_ch=ch, output_ch=5, skips=[4], input_ch_views=ch_d, use_viewdirs=True).to(dev)
+    teacher_c, teacher_f = mk(), mk()
+    sd_c, sd_f = case_weights(fx)
+    teacher_c.load_state_dict(sd_c); teacher_f.load_state_dict(sd_f)
+    rays = torch.from_numpy(fx["rays"]).to(dev)
+    query = ol.NetworkQuery(embed, embed_d)
+    with torch.no_grad():
+        want = ol.render_rays(rays, teacher_c, query, 64, N_importance=64, network_fine=teacher_f, white_bkgd=True)
+    start_c = {k: v + 0.02 * torch.randn(v.shape, generator=torch.Generator().manual_seed(1)) for k, v in sd_c.items()}
+    start_f = {k: v + 0.02 * torch.randn(v.shape, generator=torch.Generator().manual_seed(2)) for k, v in sd_f.items()}
+    curves = {}
+    for mode in ("hip", "torch"):
+        monkeypatch.setenv("INERF_TRAIN_MLP", mode)
+        net_c, net_f = mk(), mk()
+        net_c.load_state_dict(start_c); net_f.load_state_dict(start_f)
+        opt = torch.optim.Adam(list(net_c.parameters()) + list(net_f.parameters()), lr=2e-4)
+        losses = []
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for _ in range(12):
+                ret = ol.render_rays(rays, net_c, query, 64, N_importance=64, network_fine=net_f, white_bkgd=True)
+                loss = sum(((ret[k] - want[k]) ** 2).mean() for k in ("rgb_map", "albedo_map", "shading_map", "residual_map", "rgb0"))
+                opt.zero_grad(); loss.backward(); opt.step()
+                losses.append(float(loss))
+        curves[mode] = np.array(losses)
+    assert curves["hip"][-1] < 0.5 * curves["hip"][0], curves["hip"]
+    np.testing.assert_allclose(curves["hip"], curves["torch"], rtol=1e-3, atol=1e-7)
