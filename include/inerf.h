@@ -280,6 +280,26 @@ int inerf_render_rays(const inerf_render_args* args, void* stream);
 /* Raw channel counts for this network. */
 int inerf_raw_channels(const inerf_net_desc* net, uint32_t flags, int fine);
 
+/* Nearest-anchor lookup of the albedo clustering, every semantic class in one launch.  Replaces
+ * Cluster_Manager.dest_color / dest_class (SSR/training/cluster.py:73-98) and, underneath, Cluster.dest_color /
+ * dest_class (:275-297), mapping_color (:324-330), compute_dist (:299-305) and nearest_anchor (:307-310); called
+ * once per training step (trainer.py:913-920) and once per rendered frame (:1427-1430).
+ *   rgb[n,3]; label[n] (int64; ignored - may be NULL - with INERF_CLUSTER_IGNORE_LABEL, the reference's
+ *   class_num == 1 shortcut of dest_color, cluster.py:75-77);
+ *   anchors[A,4] = {a0, a1, a2, a0^2+a1^2+a2^2} in the mapped colour space, 16-byte aligned, the classes' anchors
+ *   back to back: class c owns rows anchor_begin[c] .. anchor_begin[c+1] (an empty range = the reference's
+ *   `clusters[c] is None`); links[A] = centre of each anchor, relative to its class (int32);
+ *   factor[K] = intensity_factor of each class's cluster; centers[Ctot,3] = rgb_centers back to back, class c
+ *   starting at row center_begin[c].  All device pointers.
+ * Outputs (either may be NULL): out_color[n,3] = rgb_centers[links[argmin]] of the pixel's class - the pixel itself
+ * where its label has no cluster or lies outside [0, K); out_class[n] (int64) = links[argmin], 0 for those pixels.
+ * argmin follows torch: the first minimal index wins, NaN distances (zero-intensity pixels) count as minimal. */
+#define INERF_CLUSTER_IGNORE_LABEL 1u
+int inerf_cluster_lookup(const float* rgb, const int64_t* label, int64_t n_pixels, const float* anchors,
+                         const int32_t* links, const int32_t* anchor_begin, const float* factor, const float* centers,
+                         const int32_t* center_begin, int n_classes, uint32_t flags, float* out_color,
+                         int64_t* out_class, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,7 @@ VARIANT_OBJECT, VARIANT_SSR = 0, 1
 PREC_F32, PREC_F16X3 = 0, 1
 STATUS_F16_RANGE = 1
 FLAG_WHITE_BKGD, FLAG_LINDISP, FLAG_ENDPOINT, FLAG_U_PER_RAY, FLAG_BINS_DIRECT = 1, 2, 4, 8, 16
+CLUSTER_IGNORE_LABEL = 1
 BASE_CHANNELS, ENDPOINT_DIM, RAY_FLOATS, MAX_CLASSES = 11, 128, 11, 240
 
 _ERR = {E_INVALID: "invalid argument", E_UNSUPPORTED: "unsupported configuration",
@@ -70,6 +71,7 @@ SYMBOLS = {
     "inerf_sample_pdf": (_I, [_P, _P, _P, _L, _I, _I, _U, _P, _P]),
     "inerf_workspace_bytes": (_L, [C.POINTER(NetDesc), _L, _I, _I, _U]),
     "inerf_render_rays": (_I, [C.POINTER(RenderArgs), _P]),
+    "inerf_cluster_lookup": (_I, [_P, _P, _L, _P, _P, _P, _P, _P, _P, _I, _U, _P, _P, _P]),
 }
 
 _lib = None

@@ -30,3 +30,4 @@ from .intrinsic_render import (  # noqa: F401
     lcg_state_dict,
 )
 from .conditioning import calibrated_lcg_weights, conditioning_scores  # noqa: F401
+from . import cluster  # noqa: F401,E402

@@ -1,0 +1,208 @@
+"""Albedo-cluster lookup: oracle vs the reference's golden vectors (CPU), HIP kernel vs both (GPU).
+
+An index result under fp32 arithmetic: the reference's distance `|a|^2 + |b|^2 - 2 a.b` carries a rounding error of a few
+ulps of `|a|^2 + |b|^2`, and its `a.b` comes from a library GEMM whose accumulation order is not specified (it differs
+between the reference's own CPU and GPU runs).  So the kernel must pick the reference's anchor wherever the choice is
+decided by more than that rounding, TIE_TOL * (|a|^2 + |b|^2) in exact (fp64) distance; where two anchors are closer than
+that it may pick either, and such pixels must be rare (< 0.5 %).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import load_golden
+
+TIE_TOL = 1e-6          # 8 ulps of fp32 on the distance's largest term
+TIE_FRACTION = 5e-3
+
+
+def fixture_clusters(fx, device="cpu"):
+    out = []
+    for i in range(int(fx["K"])):
+        if f"c{i}_anchors" not in fx:
+            out.append(None)
+            continue
+        out.append({"anchors": torch.from_numpy(fx[f"c{i}_anchors"]).to(device), "links": torch.from_numpy(fx[f"c{i}_links"]).to(device),
+                    "rgb_centers": torch.from_numpy(fx[f"c{i}_centers"]).to(device), "intensity_factor": float(fx[f"c{i}_factor"]),
+                    "batch_size": int(fx[f"c{i}_batch"])})
+    return out
+
+
+class Manager:
+    """Anything with the reference Cluster_Manager's attributes."""
+
+    def __init__(self, clusters):
+        self.class_num, self.clusters = len(clusters), clusters
+
+
+def test_oracle_reproduces_the_reference_lookup():
+    fx = load_golden("cluster_lookup")
+    clusters = fixture_clusters(fx)
+    rgb, label = torch.from_numpy(fx["rgb"]), torch.from_numpy(fx["label"])
+    assert np.array_equal(oracle.cluster.dest_color(clusters, rgb, label).numpy(), fx["dest_color"], equal_nan=True)
+    assert np.array_equal(oracle.cluster.dest_class(clusters, rgb, label).numpy(), fx["dest_class"])
+    assert np.array_equal(oracle.cluster.dest_color([clusters[4]], rgb, label).numpy(), fx["single_color"], equal_nan=True)
+    assert np.array_equal(oracle.cluster.dest_class([clusters[4]], rgb, label).numpy(), fx["single_class"])
+    assert oracle.cluster.dest_color([clusters[4]], rgb[:1], label[:1]).shape == fx["single_color_one_pixel"].shape == (3,)
+    # the fixture does exercise the corner cases
+    lab = fx["label"].reshape(-1)
+    assert (lab == 3).any() and (lab >= int(fx["K"])).any() and (lab < 0).any()
+    untouched = (lab == 3) | (lab >= int(fx["K"])) | (lab < 0)
+    assert np.array_equal(fx["dest_color"][untouched], fx["rgb"][untouched])
+    assert not np.array_equal(fx["dest_color"][~untouched], fx["rgb"][~untouched])
+
+
+def test_cluster_files_round_trip(tmp_path):
+    """clusters.json / c<i>/config.json as the reference writes them (cluster.py:35-50,122-129)."""
+    from intrinsicnerf_amd import cluster as ic
+    fx = load_golden("cluster_lookup")
+    mgr = ic.Cluster_Manager(class_num=int(fx["K"]), device="cpu")
+    for c in fixture_clusters(fx):
+        if c is None:
+            mgr.clusters.append(None)
+            continue
+        k = ic.Cluster(device="cpu", intensity_factor=c["intensity_factor"])
+        k.anchors, k.links, k.rgb_centers, k.batch_size = c["anchors"], c["links"], c["rgb_centers"], c["batch_size"]
+        mgr.clusters.append(k)
+    mgr.save(str(tmp_path))
+    with open(os.path.join(str(tmp_path), "clusters.json")) as f:
+        meta = json.load(f)
+    assert meta["class_num"] == 5 and meta["cluster_dirs"][3] is None
+    with open(os.path.join(str(tmp_path), "c0", "config.json")) as f:
+        assert set(json.load(f)) == {"batch_size", "intensity_factor", "rgb_centers", "anchors", "links"}
+    back = ic.Cluster_Manager(cluster_config_file=str(tmp_path), device="cpu")
+    assert back.class_num == 5 and back.clusters[3] is None
+    for a, b in zip(mgr.clusters, back.clusters):
+        if a is None:
+            continue
+        assert torch.equal(a.anchors, b.anchors) and torch.equal(a.links, b.links) and torch.equal(a.rgb_centers, b.rgb_centers)
+        assert a.intensity_factor == b.intensity_factor and a.batch_size == b.batch_size
+    with pytest.raises(RuntimeError, match="HIP device"):
+        back.dest_color(torch.from_numpy(fx["rgb"]), torch.from_numpy(fx["label"]))
+
+
+def check_against_oracle(clusters, rgb, label, got_color, got_class, ignore_label=False):
+    """Per class: the chosen anchor's cluster equals the oracle's, or the two anchors tie within fp32 rounding."""
+    rgb, label = rgb.cpu(), label.cpu().reshape(-1)
+    got_color, got_class = got_color.cpu(), got_class.cpu().reshape(-1)
+    ties = 0
+    for i, c in enumerate(clusters):
+        sel = torch.ones_like(label, dtype=torch.bool) if ignore_label else label == i
+        if c is None or not sel.any():
+            continue
+        want_idx = oracle.cluster.nearest_anchor(c, rgb[sel])
+        want_class = c["links"][want_idx].reshape(-1)
+        same = got_class[sel] == want_class
+        assert torch.equal(got_color[sel], c["rgb_centers"][got_class[sel]]), "colour is not the chosen cluster's centre"
+        if same.all():
+            continue
+        # differing cluster: some anchor of the chosen cluster must tie with the oracle's winner
+        d = oracle.cluster.mapping_color(rgb[sel][~same], c["intensity_factor"]).double()
+        a = c["anchors"].double()
+        dist = ((a[:, None, :] - d[None, :, :]) ** 2).sum(-1)
+        mine = torch.where(c["links"].reshape(-1, 1) == got_class[sel][~same][None, :], dist, torch.full_like(dist, float("inf"))).min(0).values
+        scale = (a ** 2).sum(1).max() + (d ** 2).sum(1)
+        finite = torch.isfinite(d).all(1)
+        assert finite.all(), "a zero-intensity pixel must take anchor 0 like the reference"
+        assert (mine - dist.min(0).values <= TIE_TOL * scale).all(), "a different anchor was chosen outside fp32 rounding"
+        ties += int((~same).sum())
+    assert ties <= max(2, TIE_FRACTION * rgb.shape[0]), f"{ties} of {rgb.shape[0]} pixels decided by rounding"
+    return ties
+
+
+@pytest.mark.gpu
+def test_lookup_matches_the_reference_vectors():
+    from intrinsicnerf_amd import cluster as ic
+    dev = torch.device("cuda:0")
+    fx = load_golden("cluster_lookup")
+    clusters = fixture_clusters(fx)
+    mgr = Manager(fixture_clusters(fx, dev))
+    rgb, label = torch.from_numpy(fx["rgb"]).to(dev), torch.from_numpy(fx["label"]).to(dev)
+    color, cls = ic.dest_color(mgr, rgb, label), ic.dest_class(mgr, rgb, label)
+    assert color.shape == (rgb.shape[0], 3) and cls.shape == (rgb.shape[0], 1) and cls.dtype == torch.int64
+    ties = check_against_oracle(clusters, rgb, label, color, cls)
+    diff = (color.cpu().numpy() != fx["dest_color"]).any(1)
+    assert diff.sum() <= ties and (cls.cpu().numpy() != fx["dest_class"]).sum() <= ties
+    lab = fx["label"].reshape(-1)
+    untouched = (lab == 3) | (lab >= int(fx["K"])) | (lab < 0)
+    assert np.array_equal(color.cpu().numpy()[untouched], fx["rgb"][untouched]) and (cls.cpu().numpy()[untouched] == 0).all()
+    # zero-intensity pixels: NaN distances -> the first anchor, like torch.argmin
+    for p in (7, 8):
+        assert np.array_equal(color.cpu().numpy()[p], fx["dest_color"][p]) and cls.cpu().numpy()[p] == fx["dest_class"][p]
+    # class_num == 1: labels ignored by dest_color, honoured by dest_class; one pixel squeezes to [3]
+    one = Manager([mgr.clusters[4]])
+    c1, k1 = ic.dest_color(one, rgb, label), ic.dest_class(one, rgb, label)
+    assert (c1.cpu().numpy() != fx["single_color"]).any(1).sum() <= 4
+    assert (k1.cpu().numpy() != fx["single_class"]).sum() <= 4
+    assert ic.dest_color(one, rgb[:1], label[:1]).shape == (3,)
+    # the reference-format classes give the same answers
+    k = ic.Cluster(device=dev)
+    k.anchors, k.links, k.rgb_centers = mgr.clusters[4]["anchors"], mgr.clusters[4]["links"], mgr.clusters[4]["rgb_centers"]
+    k.intensity_factor = mgr.clusters[4]["intensity_factor"]
+    assert torch.equal(k.dest_color(rgb), c1) and torch.equal(k.dest_class(rgb)[label.reshape(-1) == 0], k1[label.reshape(-1) == 0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_classes,n_pixels,coherent", [(28, 1024, False), (28, 76800, True), (3, 5, False), (101, 2048, False), (12, 20003, False)])
+def test_lookup_on_random_clusters(n_classes, n_pixels, coherent):
+    """Random anchors (voxel-grid spaced like the reference's, 0.01), random labels (training batch) or label runs (frame).
+    Up to 16 384 pixels the kernel gives every pixel a wave of its own, above that a wave takes 8 pixels: (12, 20003) puts
+    mixed classes into such tiles, the 631-pixel runs of the frame case put class boundaries inside them."""
+    from intrinsicnerf_amd import cluster as ic
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(n_classes * 1000 + n_pixels)
+    clusters = []
+    for i in range(n_classes):
+        if i % 7 == 5:
+            clusters.append(None)
+            continue
+        a = int(torch.randint(1, 3000, (1,), generator=g))
+        m = int(torch.randint(1, 9, (1,), generator=g))
+        cell = torch.randint(0, 100, (a, 3), generator=g)
+        anchors = ((cell + torch.rand(a, 3, generator=g)) * 0.01).float()
+        clusters.append({"anchors": anchors, "links": torch.randint(0, m, (a, 1), generator=g), "rgb_centers": torch.rand(m, 3, generator=g),
+                         "intensity_factor": 0.3 + 0.5 * float(torch.rand(1, generator=g)), "batch_size": 10240})
+    rgb = torch.rand(n_pixels, 3, generator=g) * 0.95 + 0.02
+    if coherent:
+        runs = torch.randint(0, n_classes, (n_pixels // 631 + 1,), generator=g)
+        label = runs.repeat_interleave(631)[:n_pixels, None]
+    else:
+        label = torch.randint(-1, n_classes + 1, (n_pixels, 1), generator=g)
+    mgr = Manager([None if c is None else {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in c.items()} for c in clusters])
+    color, cls = ic.dest_color(mgr, rgb.to(dev), label.to(dev)), ic.dest_class(mgr, rgb.to(dev), label.to(dev))
+    check_against_oracle(clusters, rgb, label, color, cls)
+    want_c, want_k = oracle.cluster.dest_color(clusters, rgb, label), oracle.cluster.dest_class(clusters, rgb, label)
+    assert (color.cpu() != want_c).any(1).float().mean() <= TIE_FRACTION
+    assert (cls.cpu() != want_k).float().mean() <= TIE_FRACTION
+    lab = label.reshape(-1)
+    none = torch.tensor([c is None for c in clusters] + [True])
+    untouched = (lab < 0) | (lab >= n_classes) | none[lab.clamp(0, n_classes)]
+    assert torch.equal(color.cpu()[untouched], rgb[untouched]) and (cls.cpu()[untouched] == 0).all()
+
+
+@pytest.mark.gpu
+def test_lookup_edge_cases():
+    from intrinsicnerf_amd import cluster as ic
+    dev = torch.device("cuda:0")
+    one_anchor = {"anchors": torch.tensor([[0.2, 0.3, 0.3]], device=dev), "links": torch.tensor([[0]], device=dev),
+                  "rgb_centers": torch.tensor([[0.1, 0.2, 0.3]], device=dev), "intensity_factor": 0.5}
+    mgr = Manager([None, one_anchor])
+    empty = ic.dest_color(mgr, torch.zeros(0, 3, device=dev), torch.zeros(0, 1, dtype=torch.long, device=dev))
+    assert empty.shape == (0, 3)
+    rgb = torch.rand(9, 3, device=dev)
+    label = torch.tensor([1, 0, 1, 1, 0, 1, 1, 1, 1], device=dev)[:, None]
+    out = ic.dest_color(mgr, rgb, label)
+    sel = label.reshape(-1) == 1
+    assert torch.equal(out[sel], one_anchor["rgb_centers"].expand(int(sel.sum()), 3)) and torch.equal(out[~sel], rgb[~sel])
+    assert torch.equal(ic.dest_color(Manager([None, None]), rgb, label), rgb)      # no cluster anywhere
+    # the tables follow the manager: replacing a cluster (update_center) must not serve stale anchors
+    mgr.clusters[1] = dict(one_anchor, rgb_centers=torch.tensor([[0.9, 0.8, 0.7]], device=dev))
+    assert torch.equal(ic.dest_color(mgr, rgb, label)[sel], mgr.clusters[1]["rgb_centers"].expand(int(sel.sum()), 3))
+    with pytest.raises(ValueError, match="links"):
+        ic.dest_color(Manager([dict(one_anchor, links=torch.tensor([[3]], device=dev))]), rgb, label)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        ic.dest_color(mgr, rgb.cpu(), label.cpu())
