@@ -15,6 +15,33 @@ OBJECT_MAP_LAYOUT = (("rgb_map", 3), ("disp_map", 1), ("acc_map", 1), ("albedo_m
                      ("residual_map", 3))
 
 
+def ssr_map_layout(n_classes, enable_semantic=True, n_importance=128, endpoint_feat=False):
+    """Layout of what ``SSRTrainer.render_rays`` returns per ray (trainer.py:776-797; ``raw_*`` never travels): the
+    coarse and fine maps, the semantic logits and ``z_std`` - 26 + 2C floats per ray with a fine pass (8.4 MB per
+    320x240 frame at C = 28)."""
+    base = (("rgb", 3), ("disp", 1), ("acc", 1), ("depth", 1), ("albedo", 3), ("shading", 1), ("residual", 3))
+    out = []
+    for level in ("coarse", "fine") if n_importance > 0 else ("coarse",):
+        out += [(k + "_" + level, w) for k, w in base]
+        if enable_semantic:
+            out.append(("sem_logits_" + level, int(n_classes)))
+    if n_importance > 0:
+        out.append(("z_std", 1))
+        if endpoint_feat:
+            out.append(("feat_map_fine", 128))
+    return tuple(out)
+
+
+def render_sharded(render_fn, rays, layout, group=None):
+    """Render this rank's band of ``rays`` ([N, 11], the same tensor on every rank) with ``render_fn(band) -> dict`` and
+    all-gather the maps named in ``layout``; every rank returns the full-frame dict."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    begin, end = shard_bounds(rays.shape[0], rank, world)
+    local = render_fn(rays[begin:end].contiguous())
+    return gather_maps(local, rays.shape[0], layout, group)
+
+
 def shard_bounds(n_rays, rank, world_size):
     """[begin, end) of this rank's contiguous band; bands differ in size by at most one ray."""
     base, extra = divmod(n_rays, world_size)

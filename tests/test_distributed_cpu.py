@@ -29,6 +29,42 @@ def _worker(rank, world, port, n_total, out_dir):
     dist.destroy_process_group()
 
 
+def _ssr_worker(rank, world, port, n_total, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from intrinsicnerf_amd import distributed as idist
+    layout = idist.ssr_map_layout(5, endpoint_feat=True)
+    rays = torch.arange(n_total * 11, dtype=torch.float32).reshape(n_total, 11)        # the same frame on every rank
+
+    def render(band):                        # a deterministic "render": every map a function of the ray's first float
+        t = band[:, 0]
+        return {k: (t[:, None] * (i + 1) + torch.arange(w)[None, :]).squeeze(-1) if w > 1 else t * (i + 1)
+                for i, (k, w) in enumerate(layout)} | {"raw_fine": band}                # raw_* is not in the layout: stays local
+
+    full = idist.render_sharded(render, rays, layout)
+    torch.save({k: v.clone() for k, v in full.items()}, os.path.join(out_dir, f"ssr{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [12, 13])
+def test_two_rank_ssr_frame(tmp_path, n_total):
+    """SSR frame (BASELINE configs[4]): coarse + fine maps, C logits, z_std and the endpoint feature in one all-gather."""
+    from intrinsicnerf_amd import distributed as idist
+    layout = idist.ssr_map_layout(5, endpoint_feat=True)
+    assert sum(w for _, w in layout) == 2 * (13 + 5) + 1 + 128 and "raw_fine" not in dict(layout)
+    assert [k for k, _ in idist.ssr_map_layout(3, n_importance=0)] == [
+        "rgb_coarse", "disp_coarse", "acc_coarse", "depth_coarse", "albedo_coarse", "shading_coarse", "residual_coarse", "sem_logits_coarse"]
+    world = 2
+    mp.spawn(_ssr_worker, args=(world, _free_port(), n_total, str(tmp_path)), nprocs=world, join=True)
+    t = torch.arange(n_total, dtype=torch.float32) * 11
+    for r in range(world):
+        full = torch.load(os.path.join(tmp_path, f"ssr{r}.pt"))
+        assert set(full) == {k for k, _ in layout}
+        for i, (k, w) in enumerate(layout):
+            want = (t[:, None] * (i + 1) + torch.arange(w)[None, :]) if w > 1 else t * (i + 1)
+            assert torch.equal(full[k], want), k
+
+
 @pytest.mark.parametrize("n_total", [10, 11])       # even and ragged bands
 def test_two_rank_gather(tmp_path, n_total):
     import __graft_entry__
