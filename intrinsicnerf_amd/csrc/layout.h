@@ -55,6 +55,10 @@ constexpr int kLdsBytes = kTilePoints * kLdsStride * 4;   // 156,672 B of the CU
 // stored as 32x16 A fragments whose k order follows the accumulator registers:
 //     [wave][q][hi|lo][lane][8 halfs],  row = lane & 31 (zero beyond the head's rows),
 //     hidden channel = wave * 16*Q + regop_chan(q, lane >> 5, c),  Q = k-blocks per wave (4: as2r, 2: resr).
+// The semantic head of that kernel works per wave on v_mfma_f32_16x16x32_f16 (16 points x 16 rows): sem1s is sem1 in the
+// skinny format with sem1's scale; its four-row accumulators (lane l: rows 4*(l>>4) .. +3 of a 16-row block) of two
+// neighbouring row blocks form one 32-deep B operand, so sem2r stores semantic_linear.1 as skinny fragments whose k order is
+//     hidden channel = 32*kb + regop16_chan(lane >> 4, c),   regop16_chan(g, c) = 16*(c >> 2) + 4*g + (c & 3).
 // Virtual k runs over the concatenation of the layer's LDS source segments (e.g. [enc64 | h256] for
 // pts_linears[5]); padded columns/rows hold zeros.  Biases are stored unpermuted (padded with zeros).
 constexpr float kActScale = 8.0f;   // INERF_PREC_F16X3: activations are split as f16 hi/lo of (8 * value)
@@ -76,6 +80,9 @@ struct NetLayout {
     GemmSlot res;             // residual head                         skinny, K=128
     GemmSlot as2r;            // as2 again, as register-operand fragments (w only; bias/scale are as2's)
     GemmSlot resr;            // res again, as register-operand fragments (w only; bias/scale are res's)
+    GemmSlot sem1s;           // sem1 again, in the skinny format (8 row blocks, K=256; w only): every wave of the two-workgroup
+                              //   kernel computes the whole semantic hidden layer for its own 16 points
+    GemmSlot sem2r;           // sem2 again, as 16-row register-operand fragments (w only)
     int32_t sem_rbs;          // ceil(C/16), 0 when the semantic head is absent
     int32_t total_floats;
 };
@@ -84,6 +91,8 @@ struct NetLayout {
 // 32x32 accumulator (register j: row (j&3) + 8*(j>>2) + 4*h) is reused as a B operand (registers 8*(q&1) .. +7
 // of row block q>>1)
 inline int regop_chan(int q, int h, int s) { return 32 * (q >> 1) + 8 * (2 * (q & 1) + (s >> 2)) + 4 * h + (s & 3); }
+
+inline int regop16_chan(int g, int c) { return 16 * (c >> 2) + 4 * g + (c & 3); }
 
 inline int trunk_k(int layer) { return layer == 0 ? kEncCols : (layer == kSkipInput ? kEncCols + kWidth : kWidth); }
 
@@ -109,6 +118,10 @@ inline NetLayout make_layout(const inerf_net_desc& net) {
     skinny(L.res, 1, kHalf);
     L.as2r.w = take(32 * kWidth);   L.as2r.b = L.as2.b;      // 4 waves x 4 k-blocks x (hi + lo) KiB
     L.resr.w = take(32 * kHalf);    L.resr.b = L.res.b;      // 4 waves x 2 k-blocks x (hi + lo) KiB
+    if (L.sem_rbs > 0) {
+        L.sem1s.w = take(kHalf * kWidth);           L.sem1s.b = L.sem1.b;
+        L.sem2r.w = take(L.sem_rbs * 16 * kHalf);   L.sem2r.b = L.sem2.b;
+    }
     L.total_floats = off;
     return L;
 }

@@ -19,8 +19,8 @@
 // ds_read_b128 lane group touches fall on 16 distinct bank slots.  Columns as in layout.h
 // (enc 64 | dir 32 | A 256 | B 256).  157,696 B per workgroup, one workgroup per CU.
 //
-// Two kernels: k_encode_mlp_f16x3 (the layout above; SSR network) and, further down,
-// k_encode_mlp_f16x3_dual (object-level network: half the LDS and registers, two workgroups per CU).
+// Two kernels: k_encode_mlp_f16x3 (the layout above; SSR network with the endpoint feature, A/B runs) and, further
+// down, k_encode_mlp_f16x3_dual (both networks: half the LDS and registers, two workgroups per CU).
 #include <stdlib.h>
 
 #include "mlp_f16_dev.h"
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
 }
 
 // ================================================================================================
-// Two workgroups per CU (object-level network).
+// Two workgroups per CU (object-level network; SSR network with its semantic head per wave, see sem_head).
 //
 // One wave per SIMD cannot hide anything: while it converts accumulators, waits on the weight stream or sits
 // at a barrier, the matrix pipe idles (measured: 57 % MFMA-busy in the kernel above).  This variant halves
@@ -335,7 +335,76 @@ __device__ __forceinline__ void regop_gemm(const WeightBuf& wb, int frag_bytes, 
     for (int pb = 0; pb < 2; ++pb) part[pb] = f32x4{acc[pb][0], acc[pb][1], acc[pb][2], acc[pb][3]};   // rows 0..3: lanes 0..31
 }
 
+// semantic head of the two-workgroup kernel (SSR): there is no room in LDS for the 128-channel hidden layer and no
+// registers to hold partial logits across the feature / view layers, so every wave does the whole head for ITS 16
+// points on v_mfma_f32_16x16x32_f16: hidden = relu(sem1 . h7) from the skinny-format copy of sem1 (streamed by all four
+// waves), converted in registers into the B operands of the logits GEMM (layout.h: sem2r) - no LDS, no exchange.
 template <bool kSave>
+__device__ __forceinline__ void sem_head(const WeightBuf& wb, const NetLayout& L, const _Float16* xs /* h7, this wave's points */,
+                                         int lane, f16x2& amax2, float* out_row, bool valid, int n_classes, const SaveDst* sv) {
+    constexpr int kRb = kHalf / 16, kKb = kWidth / 32;
+    f32x4 acc[kRb];
+#pragma unroll
+    for (int rb = 0; rb < kRb; ++rb) acc[rb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int kb = 0; kb < kKb; ++kb) {
+        const f16x8 xh = *reinterpret_cast<const f16x8*>(xs + 32 * kb);
+        const f16x8 xl = *reinterpret_cast<const f16x8*>(xs + kPlaneD + 32 * kb);
+#pragma unroll
+        for (int rb = 0; rb < kRb; ++rb) {
+            const int frag = (L.sem1s.w * 4) + ((rb * kKb + kb) * 2) * 1024;
+            const f16x8 wh = wb.frag(frag), wl = wb.frag(frag + 1024);
+            acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc[rb], 0, 0, 0);
+            acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, acc[rb], 0, 0, 0);
+            acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc[rb], 0, 0, 0);
+        }
+    }
+    // bias, ReLU, hi/lo split: accumulators of row blocks 2m, 2m+1 -> the 32-deep B operand m
+    const float inv = wb.scalar((L.sem1.b + kHalf) * 4);
+    f16x8 bh[kRb / 2], bl[kRb / 2];
+#pragma unroll
+    for (int rb = 0; rb < kRb; ++rb) {
+        const f32x4 bias = wb.vec4((L.sem1.b + 16 * rb) * 4, 16 * (lane >> 4));
+        f32x4 tv;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float t = fmaxf(__builtin_fmaf(acc[rb][i], inv, bias[i]), 0.0f);
+            const float th = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, t) & 0xFFFFE000u);
+            bh[rb >> 1][4 * (rb & 1) + i] = (_Float16)th;
+            bl[rb >> 1][4 * (rb & 1) + i] = (_Float16)(t - th);
+            tv[i] = t;
+        }
+        if constexpr (kSave)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, tv * (1.0f / kActScale)), sv->rsrc, sv->voff + 16 * rb * 4, 0, 0);
+    }
+#pragma unroll
+    for (int m = 0; m < kRb / 2; ++m) {
+        const f16x2 mx = __builtin_elementwise_max(__builtin_elementwise_max(f16x2{bh[m][0], bh[m][1]}, f16x2{bh[m][2], bh[m][3]}),
+                                                   __builtin_elementwise_max(f16x2{bh[m][4], bh[m][5]}, f16x2{bh[m][6], bh[m][7]}));
+        amax2 = __builtin_elementwise_max(amax2, mx);
+    }
+    const float inv2 = wb.scalar((L.sem2.b + 16 * L.sem_rbs) * 4);
+#pragma unroll 1
+    for (int rb = 0; rb < L.sem_rbs; ++rb) {
+        f32x4 a = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int m = 0; m < kRb / 2; ++m) {
+            const int frag = (L.sem2r.w * 4) + ((rb * (kRb / 2) + m) * 2) * 1024;
+            const f16x8 wh = wb.frag(frag), wl = wb.frag(frag + 1024);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh[m], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl[m], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh[m], a, 0, 0, 0);
+        }
+        const f32x4 bias = wb.vec4((L.sem2.b + 16 * rb) * 4, 16 * (lane >> 4));
+        const int ch0 = 16 * rb + 4 * (lane >> 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (valid && ch0 + i < n_classes)
+                __builtin_nontemporal_store(__builtin_fmaf(a[i], inv2, bias[i]), out_row + INERF_BASE_CHANNELS + ch0 + i);
+    }
+}
+
+template <bool kSave, bool kSsr>
 __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParams p) {
     constexpr int kPts = kTilePoints;
     constexpr int kParts = 256 / kPts;
@@ -377,7 +446,10 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
             float* const sv_dir = kSave ? p.save + p.save_off[SAVE_DIR] + (size_t)gp * kDirCols : nullptr;
             float x[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) x[c] = __fadd_rn(r[c], __fmul_rn(r[3 + c], zz));       // run_nerf.py:488
+            for (int c = 0; c < 3; ++c) {
+                x[c] = __fadd_rn(r[c], __fmul_rn(r[3 + c], zz));                                // run_nerf.py:488
+                if (kSsr && p.xyz_div != 1.0f) x[c] = __fdiv_rn(x[c], p.xyz_div);              // semantic_nerf.py:64
+            }
             for (int f = part; f < p.l_xyz; f += kParts) {
                 const float s = (float)(1 << f);
 #pragma unroll
@@ -493,6 +565,14 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
             to_operands<2, kSave>(am2, inv2, bias2, amax2, hi, lo, &sv);
             regop_gemm<4>(wb, (L.as2r.w + wave * 4 * 2 * 256) * 4, hi, lo, part_as);
         }
+        if (kSsr && L.sem_rbs > 0) {               // semantic logits straight to raw[11 .. 11+C) (semantic_nerf.py:150-152)
+            SaveDst sv;
+            sv.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save + (kSave ? p.save_off[SAVE_SEMH] : 0), 0, kSave ? p.n_points * kHalf * 4 : 0,
+                                                        0x00020000);
+            sv.voff = ((tile * kPts + 16 * wave + (lane & 15)) * kHalf + 4 * (lane >> 4)) * 4;
+            sv.stride = kHalf;
+            sem_head<kSave>(wb, L, xs, lane, amax2, out_row, my_valid, p.n_classes, &sv);
+        }
         // feature (no activation) in place of h7, then the view-dependent layer over [feature | dir] -> registers
         wide_gemm_h<2, 16, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.feat, 16), xr, 0, 0, lane, am2);
         store256(L.feat, false, SAVE_FEAT, pf128(L.views, 18));
@@ -555,26 +635,32 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
     }
 }
 
-static int launch_dual(MlpParams& p, int64_t n_points, hipStream_t stream) {
+static int launch_dual(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream) {
     p.n_tiles = (int)((n_points + kTilePoints - 1) / kTilePoints);
     const int max_grid = 2 * device_cus();
     const int grid = p.n_tiles < max_grid ? p.n_tiles : max_grid;
     const bool save = p.save != nullptr;
-    void (*kern)(const MlpParams) = save ? k_encode_mlp_f16x3_dual<true> : k_encode_mlp_f16x3_dual<false>;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[save]) {
+    void (*kern)(const MlpParams) = ssr ? (save ? k_encode_mlp_f16x3_dual<true, true> : k_encode_mlp_f16x3_dual<false, true>)
+                                        : (save ? k_encode_mlp_f16x3_dual<true, false> : k_encode_mlp_f16x3_dual<false, false>);
+    static bool attr_set[4] = {false, false, false, false};
+    const int variant = 2 * (int)ssr + (int)save;
+    if (!attr_set[variant]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesD);
         if (e != hipSuccess) return record(e);
-        attr_set[save] = true;
+        attr_set[variant] = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kLdsBytesD, stream, p);
     return record(hipGetLastError());
 }
 
 int launch_mlp_f16x3(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream) {
-    // object-level network: two workgroups per CU; INERF_F16_KERNEL=single keeps the one-workgroup kernel (A/B runs)
+    // Two workgroups per CU, except: the SSR network with its endpoint feature (the view layer's activation never
+    // reaches memory in that form) and the SSR training forward (measured: 10.3 vs 10.1 ms per step - the activation
+    // stores and the per-wave semantic head eat the overlap).  INERF_F16_KERNEL=single / dual overrides (A/B runs).
     const char* form = getenv("INERF_F16_KERNEL");
-    if (!ssr && !(form && form[0] == 's')) return launch_dual(p, n_points, stream);
+    const bool can_dual = !(ssr && p.endpoint);
+    const bool want_dual = form && form[0] == 'd' ? true : (form && form[0] == 's' ? false : !(ssr && p.save != nullptr));
+    if (can_dual && want_dual) return launch_dual(p, n_points, ssr, stream);
     p.n_tiles = (int)((n_points + kTilePoints - 1) / kTilePoints);
     const int grid = p.n_tiles < device_cus() ? p.n_tiles : device_cus();
     const bool save = p.save != nullptr;

@@ -165,10 +165,11 @@ float pack_wide_f16(float* dst_f, int n_out, int k_total, const Elem& w, float f
 }
 
 // skinny GEMM, A-operand fragments of v_mfma_f32_16x16x32_f16: [rb][kb32][hi|lo][lane][8 halfs]
-float pack_skinny_f16(float* dst_f, int rbs, int k_total, const Elem& w) {
+// forced_scale > 0: a second copy of a matrix packed just before - its scale and, in map mode, its scale group
+float pack_skinny_f16(float* dst_f, int rbs, int k_total, const Elem& w, float forced_scale = 0.0f) {
     _Float16* dst = reinterpret_cast<_Float16*>(dst_f);
-    if (g_map) map_new_group();
-    const float sc = g_map ? 1.0f : weight_scale(16 * rbs, k_total, w);
+    if (g_map && !(forced_scale > 0.0f)) map_new_group();
+    const float sc = g_map ? 1.0f : (forced_scale > 0.0f ? forced_scale : weight_scale(16 * rbs, k_total, w));
     const int kb_count = k_total / 32;
     for (int rb = 0; rb < rbs; ++rb)
         for (int kb = 0; kb < kb_count; ++kb)
@@ -203,6 +204,26 @@ void pack_regop_f16(float* dst_f, int q_per_wave, int rows, int k_total, const E
                         continue;
                     }
                     const HalfPair h = split_f16(row < rows ? w(row, kv) * sc : 0.0f);
+                    dst[(frag * 64 + lane) * 8 + c] = h.hi;
+                    dst[((frag + 1) * 64 + lane) * 8 + c] = h.lo;
+                }
+}
+
+// register-operand copy of a skinny head whose input is a 16x16x32 accumulator set (layout.h: sem2r); scale (and scale
+// group) of the skinny copy packed just before
+void pack_regop16_f16(float* dst_f, int rbs, int k_total, const Elem& w, float scale) {
+    _Float16* dst = reinterpret_cast<_Float16*>(dst_f);
+    const float sc = g_map ? 1.0f : scale;
+    const int kb_count = k_total / 32;
+    for (int rb = 0; rb < rbs; ++rb)
+        for (int kb = 0; kb < kb_count; ++kb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int c = 0; c < 8; ++c) {
+                    const int row = 16 * rb + (lane & 15);
+                    const int kv = 32 * kb + inerf::regop16_chan(lane >> 4, c);
+                    const int64_t frag = ((int64_t)rb * kb_count + kb) * 2;
+                    if (g_map) { map_pair(dst + (frag * 64 + lane) * 8 + c, dst + ((frag + 1) * 64 + lane) * 8 + c, w(row, kv)); continue; }
+                    const HalfPair h = split_f16(w(row, kv) * sc);
                     dst[(frag * 64 + lane) * 8 + c] = h.hi;
                     dst[((frag + 1) * 64 + lane) * 8 + c] = h.lo;
                 }
@@ -390,13 +411,16 @@ int inerf_pack_weights(const inerf_net_desc* net, const float* const* tensors, i
     // ---- semantic head (ssr) ----
     if (L.sem_rbs > 0) {
         const float* w1 = W("semantic_linear.0.0");
-        pack_wide(out + L.sem1.w, kHalf, kWidth, [=](int r, int kv) { return w1[(int64_t)r * kWidth + kv]; });
+        const Elem sem1 = [=](int r, int kv) { return w1[(int64_t)r * kWidth + kv]; };
+        pack_wide(out + L.sem1.w, kHalf, kWidth, sem1);
+        if (f16) pack_skinny_f16(out + L.sem1s.w, kHalf / 16, kWidth, sem1, g_map ? 1.0f : last_scale);
         copy_bias(L.sem1.b, B("semantic_linear.0.0"), kHalf);
         finish_wide(L.sem1, kHalf);
         const float* w2 = W("semantic_linear.1");
         const int c = net->n_classes;
-        pack_skinny(out + L.sem2.w, L.sem_rbs, kHalf,
-                    [=](int r, int kv) { return r < c ? w2[(int64_t)r * kHalf + kv] : 0.0f; });
+        const Elem sem2 = [=](int r, int kv) { return r < c ? w2[(int64_t)r * kHalf + kv] : 0.0f; };
+        pack_skinny(out + L.sem2.w, L.sem_rbs, kHalf, sem2);
+        if (f16) pack_regop16_f16(out + L.sem2r.w, L.sem_rbs, kHalf, sem2, last_scale);
         copy_bias(L.sem2.b, B("semantic_linear.1"), c);
         finish_skinny(L.sem2, L.sem_rbs);
     }

@@ -215,11 +215,19 @@ def _torch_reference_grads(module, embed, embed_d, rays, z, cot, endpoint=False)
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant,c,endpoint,n,s", [("object", 0, False, 37, 5), ("object", 0, False, 64, 64),
                                                     ("ssr", 5, True, 23, 11), ("ssr", 28, False, 16, 192), ("ssr", 0, False, 9, 7)])
-def test_network_backward_vs_torch_autograd(variant, c, endpoint, n, s):
+@pytest.mark.parametrize("form", ["default", "dual"])
+def test_network_backward_vs_torch_autograd(variant, c, endpoint, n, s, form, monkeypatch):
     """One network, arbitrary cotangent on raw (every channel: sigma, the sigmoid heads, logits, endpoint feature), ragged
     point counts: raw and every parameter gradient of kernels.mlp_train against torch autograd through the module's own
-    forward on the same GPU."""
+    forward on the same GPU.  `dual` forces the two-workgroup training forward where the default keeps the one-workgroup one
+    (the SSR network; with the endpoint feature there is only the latter)."""
     from intrinsicnerf_amd import kernels, object_level as ol, ssr
+    if form == "dual":
+        if variant == "object" or endpoint:
+            pytest.skip("same kernel as the default")
+        monkeypatch.setenv("INERF_F16_KERNEL", "dual")
+    else:
+        monkeypatch.delenv("INERF_F16_KERNEL", raising=False)
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(7 + n)
     sd = oracle.lcg_state_dict(variant, c, seed=21, sigma_gain_log2=3, freq_decay=True)

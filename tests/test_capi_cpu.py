@@ -124,6 +124,9 @@ def _layout(variant, c):
     # register-operand copies of the two output heads (f16 format only; zeros otherwise): weights only
     slots["as2r"] = ("regop", take(32 * 256), slots["as2"][2], 4, 256)
     slots["resr"] = ("regop", take(32 * 128), slots["res"][2], 2, 128)
+    if variant == "ssr" and c > 0:       # the two-workgroup kernel's semantic head: sem1 in the skinny format, sem2 as 16-row register operands
+        slots["sem1s"] = ("skinny", take(128 * 256), slots["sem1"][2], 8, 256)
+        slots["sem2r"] = ("regop16", take(((c + 15) // 16) * 16 * 128), slots["sem2"][2], (c + 15) // 16, 128)
     return slots, off
 
 
@@ -244,6 +247,26 @@ def test_packer_regop_heads(capi):
             hi_s, lo_s = _unpack_skinny_f16(blob, slots[skinny][1], 1, k)
             assert np.array_equal(hi_r[:16], hi_s) and np.array_equal(lo_r[:16], lo_s)
             assert not hi_r[16:].any() and not lo_r[16:].any() and hi_r[:3].any()
+        if variant == "ssr":
+            # sem1s: the semantic hidden layer again, skinny fragments, SAME split halves as the wide copy
+            hi_w, lo_w = _unpack_wide_f16(blob, slots["sem1"][1], 128, 256)
+            hi_s, lo_s = _unpack_skinny_f16(blob, slots["sem1s"][1], 8, 256)
+            assert np.array_equal(hi_w, hi_s) and np.array_equal(lo_w, lo_s) and hi_w.any()
+            # sem2r: semantic_linear.1 with k in the order of two stacked 16x16x32 accumulators (layout.h regop16_chan)
+            rbs = slots["sem2r"][3]
+            hi_s, lo_s = _unpack_skinny_f16(blob, slots["sem2"][1], rbs, 128)
+            halfs = blob[slots["sem2r"][1]: slots["sem2r"][1] + 16 * rbs * 128].view(np.float16).reshape(rbs, 4, 2, 64, 8)
+            hi_r = np.zeros((16 * rbs, 128), np.float32); lo_r = np.zeros_like(hi_r)
+            seen = np.zeros((16 * rbs, 128), np.int32)
+            for rb in range(rbs):
+                for kb in range(4):
+                    for lane in range(64):
+                        for cc in range(8):
+                            chan = 32 * kb + 16 * (cc >> 2) + 4 * (lane >> 4) + (cc & 3)
+                            hi_r[16 * rb + (lane & 15), chan] = halfs[rb, kb, 0, lane, cc]
+                            lo_r[16 * rb + (lane & 15), chan] = halfs[rb, kb, 1, lane, cc]
+                            seen[16 * rb + (lane & 15), chan] += 1
+            assert (seen == 1).all() and np.array_equal(hi_r, hi_s) and np.array_equal(lo_r, lo_s) and hi_r[:c].any()
         desc32 = capi.net_desc(capi.VARIANT_SSR if variant == "ssr" else capi.VARIANT_OBJECT, c, 10, 4, 1.0, precision=capi.PREC_F32)
         blob32 = packing.pack_state_dict(desc32, sd).numpy()
         assert not blob32[slots["as2r"][1]:].any()
