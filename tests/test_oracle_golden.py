@@ -5,6 +5,8 @@ outputs for small ray batches, reproduced by the oracle on whatever CPU runs the
 that generated the fixtures the match is bit-exact; another CPU may take different GEMM blocking,
 hence the small tolerance (rtol 2e-5, atol 2e-6; disp 2e-4 - see tests/_cases.py).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -82,3 +84,19 @@ def test_lcg_weights_are_exact_dyadics():
     n_params = sum(int(np.prod(s)) for _, s in spec)
     assert n_params == 698660                           # SURVEY.md 8a M2 @ C=28
     assert sum(int(np.prod(s)) for _, s in oracle.state_dict_spec("object")) == 662152   # M1
+
+
+def test_oracle_equals_the_live_reference_on_random_configurations():
+    """Where the reference is mounted (the build container), sweep random configurations the fixtures do not hold - ray /
+    sample / importance counts, flags, class counts, default-initialised networks, the cluster lookup - and require
+    oracle == reference on every returned tensor (tests/golden/check_reference_live.py; a subprocess, because the import
+    recipe patches torch.Tensor.cuda).  The GPU box has no reference: skipped there."""
+    import subprocess
+    import sys
+    if not os.path.isdir("/root/reference/object_level"):
+        pytest.skip("reference not mounted")
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "check_reference_live.py")
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    out = subprocess.run([sys.executable, script, "--cases", "6", "--seed", "1"], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "oracle == reference on 18 random configurations" in out.stdout
