@@ -221,7 +221,7 @@ def main():
         achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12
         f16 = prec == _capi.PREC_F16X3
         peak = PEAK_F16_MFMA_TFLOPS / 3.0 if f16 else PEAK_F32_MFMA_TFLOPS
-        return {"bound": "mfma", "kernel": "k_encode_mlp_f16x3_dual<false>" if f16 else "k_encode_mlp<false, 2>", "achieved": achieved,
+        return {"bound": "mfma", "kernel": "k_encode_mlp_f16x3_dual<false, false>" if f16 else "k_encode_mlp<false, 2>", "achieved": achieved,
                 "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "traffic": PMC_HBM_BYTES_PER_POINT["f16x3" if f16 else "f32"] * n_local * (N_SAMPLES + (N_SAMPLES + N_IMPORTANCE)) / 2.0,
                 "traffic_note": f"HBM bytes per launch = {PMC_HBM_BYTES_PER_POINT['f16x3' if f16 else 'f32']} B/point measured by "
