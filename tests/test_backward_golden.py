@@ -202,8 +202,20 @@ def test_ssr_training_step_gradients_vs_oracle():
 # network backward: fused training forward + MFMA input-gradient chain + weight-gradient GEMMs (kernels.mlp_train)
 # ---------------------------------------------------------------------------------------------------------------------
 def _torch_reference_grads(module, embed, embed_d, rays, z, cot, endpoint=False):
-    """raw and parameter gradients of the same network through torch autograd (the module's own forward)."""
+    """raw and parameter gradients of the same network through torch autograd (the module's own forward).  The sample
+    positions are always the fp32 ones (o + d z rounded like the reference and the kernels do): one ulp of position is 1e-4
+    rad in the 2^9 frequency band, so an fp64 run on fp64 positions would be a different function."""
+    dtype = cot.dtype
+    rays, z = rays.float(), z.float()
     pts = rays[:, None, 0:3] + rays[:, None, 3:6] * z[:, :, None]
+    sf = float(getattr(embed, "scalar_factor", 1.0))
+    if dtype != torch.float32 and sf != 1.0:
+        # the SSR encoding's x / 10 (semantic_nerf.py:64) belongs to the positions too: an fp32 true division (done on the
+        # CPU: torch's GPU kernel multiplies by the reciprocal), then an embedder without a divisor
+        from intrinsicnerf_amd import ssr
+        embed = ssr.get_embedder(10, 0, scalar_factor=1)[0]
+        pts = (pts.cpu() / sf).to(pts.device)
+    pts, rays = pts.to(dtype), rays.to(dtype)
     emb = torch.cat([embed(pts.reshape(-1, 3)), embed_d(rays[:, None, 8:11].expand(pts.shape).reshape(-1, 3))], -1)
     raw = module(emb, True) if endpoint else module(emb)
     raw = raw.reshape(z.shape[0], z.shape[1], -1)
@@ -214,18 +226,25 @@ def _torch_reference_grads(module, embed, embed_d, rays, z, cot, endpoint=False)
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant,c,endpoint,n,s", [("object", 0, False, 37, 5), ("object", 0, False, 64, 64),
-                                                    ("ssr", 5, True, 23, 11), ("ssr", 28, False, 16, 192), ("ssr", 0, False, 9, 7)])
-@pytest.mark.parametrize("form", ["default", "dual"])
+                                                    ("ssr", 5, True, 23, 11), ("ssr", 28, False, 16, 192), ("ssr", 0, False, 9, 7),
+                                                    # more 64-point tiles than workgroups: the kernels' tile loops go round
+                                                    ("ssr", 5, True, 350, 64), ("object", 0, False, 700, 64), ("ssr", 3, False, 700, 64)])
+@pytest.mark.parametrize("form", ["default", "single"])
 def test_network_backward_vs_torch_autograd(variant, c, endpoint, n, s, form, monkeypatch):
     """One network, arbitrary cotangent on raw (every channel: sigma, the sigmoid heads, logits, endpoint feature), ragged
     point counts: raw and every parameter gradient of kernels.mlp_train against torch autograd through the module's own
-    forward on the same GPU.  `dual` forces the two-workgroup training forward where the default keeps the one-workgroup one
-    (the SSR network; with the endpoint feature there is only the latter)."""
+    forward on the same GPU.  The default training forward is the two-workgroup kernel; `single` forces the one-workgroup
+    one, which SSR renders with the endpoint feature always use."""
     from intrinsicnerf_amd import kernels, object_level as ol, ssr
-    if form == "dual":
-        if variant == "object" or endpoint:
+    if form == "single":
+        if endpoint:
             pytest.skip("same kernel as the default")
-        monkeypatch.setenv("INERF_F16_KERNEL", "dual")
+        if variant == "ssr" and n * s > 30000:
+            # OPEN (DESIGN.md section 8): with three or more 64-point tiles per workgroup the one-workgroup SSR training forward
+            # leaves the gradients of pts_linears.0-5 6e-4 of their norm away from fp64 autograd (1e-6 above that layer, and
+            # everywhere through the two-workgroup forward); two tiles per workgroup - the endpoint case above - are fine
+            pytest.xfail("one-workgroup SSR training forward, >= 3 tiles per workgroup: lower trunk gradients 6e-4 off")
+        monkeypatch.setenv("INERF_F16_KERNEL", "single")
     else:
         monkeypatch.delenv("INERF_F16_KERNEL", raising=False)
     dev = torch.device("cuda:0")
@@ -245,6 +264,13 @@ def test_network_backward_vs_torch_autograd(variant, c, endpoint, n, s, form, mo
     chn = 11 + c + (128 if endpoint else 0)
     cot = (torch.randn(n, s, chn, generator=g) * torch.logspace(-3, 1, n, base=10.0)[:, None, None]).to(dev)   # 4 decades of scale
     want_raw, want = _torch_reference_grads(net, embed, embed_d, rays, z, cot, endpoint)
+    if n * s > 8192:      # tens of thousands of cancelling terms per gradient element: torch's fp32 autograd is 1e-3 off in
+        import copy       # the lower trunk layers at 44 800 points (scripts/diag_train_grads.py) - fp64 autograd is the judge
+        net64 = copy.deepcopy(net).double()
+        _, want64 = _torch_reference_grads(net64, embed, embed_d, rays.double(), z.double(), cot.double(), endpoint)
+        fp32_dev = max(float((want[k].double() - want64[k]).norm() / want64[k].norm().clamp_min(1e-30)) for k in want)
+        print(f"torch fp32 autograd vs fp64: {fp32_dev:.2e} of a tensor's norm at worst")
+        want = want64
     net.zero_grad()
     desc = net.fused_desc()
     desc.xyz_div = embed.scalar_factor
@@ -252,10 +278,12 @@ def test_network_backward_vs_torch_autograd(variant, c, endpoint, n, s, form, mo
     assert type(raw.grad_fn).__name__ == "_FusedMlpFnBackward"
     assert_maps_close(raw.detach().cpu().numpy(), want_raw.cpu().numpy(), 1e-4, 1e-5 * float(want_raw.abs().max()), "raw")
     (raw * cot).sum().backward()
-    for name, p in net.named_parameters():
-        w = want[name].double()
-        err = float((p.grad.double() - w).norm())
-        assert err <= 2e-4 * float(w.norm()) + 1e-10, (name, err, float(w.norm()))
+    errs = {name: (float((p.grad.double() - want[name].double()).norm()), float(want[name].double().norm()))
+            for name, p in net.named_parameters()}
+    bad = {k: f"{e / max(w, 1e-30):.1e}" for k, (e, w) in errs.items() if e > 2e-4 * w + 1e-10}
+    if n * s > 8192:
+        print("relative errors:", {k: f"{e / max(w, 1e-30):.1e}" for k, (e, w) in errs.items()})
+    assert not bad, bad
 
 
 @pytest.mark.gpu
@@ -312,7 +340,8 @@ def test_network_backward_splits_large_batches(monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("p,m,n", [(64, 256, 256), (1000, 256, 256), (12345, 256, 64), (777, 128, 256), (4097, 128, 32), (70001, 256, 256)])
+@pytest.mark.parametrize("p,m,n", [(64, 256, 256), (1000, 256, 256), (12345, 256, 64), (777, 128, 256), (4097, 128, 32), (70001, 256, 256),
+                                   (44800, 256, 64), (40001, 128, 32), (30000, 128, 256), (50000, 256, 128)])    # several tiles per workgroup, every shape
 def test_weight_gradient_kernel_vs_fp64(p, m, n):
     """G^T X and the column sums of G from the split-K MFMA kernel against an fp64 product: ragged point counts, gradients
     spanning four decades, every supported tile shape; also with operands that are column-aligned views of wider buffers."""
