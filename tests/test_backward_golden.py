@@ -201,7 +201,30 @@ def test_ssr_training_step_gradients_vs_oracle():
 # ---------------------------------------------------------------------------------------------------------------------
 # network backward: fused training forward + MFMA input-gradient chain + weight-gradient GEMMs (kernels.mlp_train)
 # ---------------------------------------------------------------------------------------------------------------------
-def _torch_reference_grads(module, embed, embed_d, rays, z, cot, endpoint=False):
+def _relu_tie_points(module, emb, endpoint, rel=1e-6):
+    """Sample points at which some pre-activation of ``module`` (every nn.Linear output) is within ``rel`` of its layer's
+    rms of zero.  There an fp32 evaluation lands on either side of the ReLU depending on its rounding, and the whole
+    downstream gradient of that channel switches on or off: with tens of thousands of points a few such ties always
+    exist, and one at a point with a large cotangent moves a tensor's gradient by 1e-3 (scripts/diag_train_grads.py:
+    pre-activation 2.4e-9 against an rms of 0.039 at the dominant point of the 44 800-point SSR case)."""
+    ties = torch.zeros(emb.shape[0], dtype=torch.bool, device=emb.device)
+    hooks = []
+
+    def watch(mod, inputs, out):
+        if out.dim() == 2 and out.shape[0] == emb.shape[0]:
+            ties.logical_or_((out.detach().abs() < rel * out.detach().pow(2).mean().sqrt()).any(1))
+
+    for m in module.modules():
+        if isinstance(m, torch.nn.Linear):
+            hooks.append(m.register_forward_hook(watch))
+    with torch.no_grad():
+        module(emb, True) if endpoint else module(emb)
+    for h in hooks:
+        h.remove()
+    return ties
+
+
+def _torch_reference_grads(module, embed, embed_d, rays, z, cot, endpoint=False, ties_out=None):
     """raw and parameter gradients of the same network through torch autograd (the module's own forward).  The sample
     positions are always the fp32 ones (o + d z rounded like the reference and the kernels do): one ulp of position is 1e-4
     rad in the 2^9 frequency band, so an fp64 run on fp64 positions would be a different function."""
@@ -217,6 +240,8 @@ def _torch_reference_grads(module, embed, embed_d, rays, z, cot, endpoint=False)
         pts = (pts.cpu() / sf).to(pts.device)
     pts, rays = pts.to(dtype), rays.to(dtype)
     emb = torch.cat([embed(pts.reshape(-1, 3)), embed_d(rays[:, None, 8:11].expand(pts.shape).reshape(-1, 3))], -1)
+    if ties_out is not None:
+        ties_out.append(_relu_tie_points(module, emb, endpoint).reshape(z.shape))
     raw = module(emb, True) if endpoint else module(emb)
     raw = raw.reshape(z.shape[0], z.shape[1], -1)
     module.zero_grad()
@@ -239,11 +264,6 @@ def test_network_backward_vs_torch_autograd(variant, c, endpoint, n, s, form, mo
     if form == "single":
         if endpoint:
             pytest.skip("same kernel as the default")
-        if variant == "ssr" and n * s > 30000:
-            # OPEN: with three or more 64-point tiles per workgroup the one-workgroup SSR training forward
-            # leaves the gradients of pts_linears.0-5 6e-4 of their norm away from fp64 autograd (1e-6 above that layer, and
-            # everywhere through the two-workgroup forward); two tiles per workgroup - the endpoint case above - are fine
-            pytest.xfail("one-workgroup SSR training forward, >= 3 tiles per workgroup: lower trunk gradients 6e-4 off")
         monkeypatch.setenv("INERF_F16_KERNEL", "single")
     else:
         monkeypatch.delenv("INERF_F16_KERNEL", raising=False)
@@ -263,10 +283,16 @@ def test_network_backward_vs_torch_autograd(variant, c, endpoint, n, s, form, mo
     z = torch.sort(torch.rand(n, s, generator=g) * 3 + 0.5, -1)[0].to(dev)
     chn = 11 + c + (128 if endpoint else 0)
     cot = (torch.randn(n, s, chn, generator=g) * torch.logspace(-3, 1, n, base=10.0)[:, None, None]).to(dev)   # 4 decades of scale
+    if n * s > 8192:      # a few ReLU ties always exist among tens of thousands of points: they get no cotangent
+        import copy
+        net64 = copy.deepcopy(net).double()
+        ties = []
+        _torch_reference_grads(net64, embed, embed_d, rays.double(), z.double(), cot.double(), endpoint, ties_out=ties)
+        assert 0 < int(ties[0].sum()) < n * s // 100, int(ties[0].sum())
+        cot = cot * (~ties[0])[:, :, None].to(cot.dtype)
     want_raw, want = _torch_reference_grads(net, embed, embed_d, rays, z, cot, endpoint)
     if n * s > 8192:      # tens of thousands of cancelling terms per gradient element: torch's fp32 autograd is 1e-3 off in
-        import copy       # the lower trunk layers at 44 800 points (scripts/diag_train_grads.py) - fp64 autograd is the judge
-        net64 = copy.deepcopy(net).double()
+                          # the lower trunk layers at 44 800 points (scripts/diag_train_grads.py) - fp64 autograd is the judge
         _, want64 = _torch_reference_grads(net64, embed, embed_d, rays.double(), z.double(), cot.double(), endpoint)
         fp32_dev = max(float((want[k].double() - want64[k]).norm() / want64[k].norm().clamp_min(1e-30)) for k in want)
         print(f"torch fp32 autograd vs fp64: {fp32_dev:.2e} of a tensor's norm at worst")
