@@ -337,7 +337,7 @@ def render_rays_fused(desc, packed_coarse, packed_fine, rays, n_samples, n_impor
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# training: fused forward that keeps the activations, MFMA input-gradient chain, weight gradients as library GEMMs
+# training: fused forward that keeps the activations, MFMA input-gradient chain, split-K MFMA weight gradients
 # ---------------------------------------------------------------------------------------------------------------------
 (SAVE_ENC, SAVE_DIR, SAVE_H0, SAVE_AS1H, SAVE_FEAT, SAVE_VH, SAVE_SEMH, SAVE_DPRE, SAVE_SLOTS) = (0, 1, 2, 10, 11, 12, 13, 14, 15)
 
@@ -488,7 +488,8 @@ def _colsum(g, nc):
 def mlp_weight_gradients(desc, names, save, dz, d_raw, n_points, endpoint=False, ranges=None, heads=None):
     """dW = dZ^T X and db = column sums of dZ for every layer.  The 128/256-row layers go through the HIP split-K kernel when
     ``ranges`` (float32[2] device tensor: max |dz|, max |activation|, as delivered by the two training kernels) is given, else
-    - and the 1-4-row heads always - through library GEMMs split over K.  Returns a dict name -> gradient with the
+    - and the 1-4-row heads, unless ``heads`` (their gradients as accumulated by the chain kernel) is given - through library
+    GEMMs split over K.  Returns a dict name -> gradient with the
     reference's parameter names and shapes."""
     X = save_slot_views(desc, save, n_points)
     G = save_slot_views(desc, dz, n_points)
@@ -558,7 +559,7 @@ def mlp_weight_gradients(desc, names, save, dz, d_raw, n_points, endpoint=False,
 
 class _FusedMlpFn(torch.autograd.Function):
     """raw = MLP(encode(o + d z), encode(viewdir)) with a HIP forward AND backward: fused split-f16 forward that keeps the
-    activations, MFMA input-gradient chain, weight gradients by library GEMMs.  Parameters are re-packed on the device
+    activations, MFMA input-gradient chain, split-K MFMA weight gradients (INERF_WGRAD=library: library GEMMs).  Parameters are re-packed on the device
     (packing.DevicePacker).  rays / z get no gradient (as in the reference: rays are data, resampled depths are detached)."""
 
     @staticmethod

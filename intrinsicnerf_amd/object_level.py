@@ -155,7 +155,7 @@ def _training_path_notice(what):
     """Training steps (run_nerf.py:942-1018, trainer.py:882-990) take the STAGED path: sampling and compositing run
     on the HIP kernels - compositing with its HIP backward (inerf_composite_backward) - and each network is one
     autograd node (kernels.mlp_train): fused HIP forward that keeps the activations, HIP input-gradient chain, weight
-    gradients as library GEMMs.  ``INERF_TRAIN_MLP=torch`` (or a precision other than f16x3, or a network outside the
+    gradients by the split-K MFMA kernel.  ``INERF_TRAIN_MLP=torch`` (or a precision other than f16x3, or a network outside the
     fused architecture) evaluates the layers with their torch ``forward`` instead.  Said once per process."""
     global _told_training_path
     if not _told_training_path:
