@@ -29,19 +29,31 @@ def _stale():
 
 
 def build_library(force=False, verbose=False):
-    """Compile ``libinerf.so`` in-tree if it is missing or older than its sources.  Returns its path."""
+    """Compile ``libinerf.so`` in-tree if it is missing or older than its sources.  Returns its path.
+
+    Safe under ``torch.distributed.run``: the ranks of one node serialise on a lock file, the first one builds (into a
+    private temporary name, then an atomic rename) and the others find the library up to date when they get the lock."""
     if not force and not _stale():
         return LIB_PATH
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        raise RuntimeError("hipcc not found: cannot build libinerf.so (ROCm toolchain required)")
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH + ".tmp"]
-    if verbose:
-        print(" ".join(cmd))
-    proc = subprocess.run(cmd, capture_output=True, text=True)
-    if proc.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + proc.stdout + proc.stderr)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    import fcntl
+    with open(LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():
+                return LIB_PATH
+            hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+            if not os.path.exists(hipcc):
+                raise RuntimeError("hipcc not found: cannot build libinerf.so (ROCm toolchain required)")
+            tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
+            cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
+            if verbose:
+                print(" ".join(cmd))
+            proc = subprocess.run(cmd, capture_output=True, text=True)
+            if proc.returncode != 0:
+                raise RuntimeError("hipcc failed:\n" + proc.stdout + proc.stderr)
+            os.replace(tmp, LIB_PATH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
