@@ -72,6 +72,32 @@ def test_argument_validation(capi):
     assert lib.inerf_packed_floats(capi.net_desc(capi.VARIANT_OBJECT, precision=7)) == capi.E_INVALID     # unknown precision
     with pytest.raises(RuntimeError):
         capi.check(capi.E_UNSUPPORTED, "x")
+    # every entry point rejects null pointers / impossible sizes before it touches the device, and accepts empty batches
+    import ctypes as C
+    ssr28 = capi.net_desc(capi.VARIANT_SSR, 28, 10, 4, 10.0)
+    assert lib.inerf_sample_coarse(None, None, None, 4, 64, 0, None, None) == capi.E_INVALID
+    assert lib.inerf_sample_pdf(None, None, None, 4, 63, 128, 0, None, None) == capi.E_INVALID
+    assert lib.inerf_composite(None, None, None, 3, None, 4, 64, 11, 0, 0, 0, C.byref(capi.CompositeOut()), None) == capi.E_INVALID
+    assert lib.inerf_composite_backward(None, None, None, 3, None, 4, 64, 11, 0, 0, 0, C.byref(capi.CompositeOut()), None, None) == capi.E_INVALID
+    assert lib.inerf_encode_mlp_train(good, None, None, None, 4, 64, 0, None, None, None, None, None) == capi.E_INVALID
+    assert lib.inerf_mlp_backward_inputs(good, None, None, None, None, 256, 0, None, None, None, None, None) == capi.E_INVALID
+    assert lib.inerf_mlp_weight_gradient(None, 256, None, 256, 1000, 256, 256, None, None, None, 65536, None) == capi.E_INVALID
+    assert lib.inerf_cluster_lookup(None, None, 10, None, None, None, None, None, None, 1, 0, None, None, None) == capi.E_INVALID
+    for rc in (lib.inerf_sample_coarse(None, None, None, 0, 64, 0, None, None),
+               lib.inerf_sample_pdf(None, None, None, 0, 63, 128, 0, None, None),
+               lib.inerf_encode_mlp(good, None, None, None, 0, 64, 0, None, None, None),
+               lib.inerf_encode_mlp_train(good, None, None, None, 0, 64, 0, None, None, None, None, None),
+               lib.inerf_mlp_backward_inputs(good, None, None, None, None, 0, 0, None, None, None, None, None),
+               lib.inerf_cluster_lookup(None, None, 0, None, None, None, None, None, None, 1, 0, None, None, None)):
+        assert rc == capi.OK
+    assert lib.inerf_mlp_save_floats(good, 64) == 64 * (64 + 32 + 8 * 256 + 256 + 256 + 128 + 8)
+    assert lib.inerf_mlp_save_floats(ssr28, 64) == 64 * (64 + 32 + 8 * 256 + 256 + 256 + 128 + 128 + 8)
+    off, width = C.c_int64(), C.c_int()
+    assert lib.inerf_mlp_save_slot(ssr28, 13, 100, C.byref(off), C.byref(width)) == capi.OK and width.value == 128
+    assert lib.inerf_mlp_save_slot(good, 13, 100, C.byref(off), C.byref(width)) == capi.OK and width.value == 0
+    assert lib.inerf_mlp_save_slot(good, 15, 100, C.byref(off), C.byref(width)) == capi.E_INVALID
+    assert lib.inerf_wgrad_grid(0) == 0 and lib.inerf_mlp_backward_grid(64 * 7) == 7
+    assert lib.inerf_mlp_head_partial_floats() == 1672
 
 
 # ---- packer: rebuild each layer's (virtual-k) weight matrix from the blob with the documented formula ----
