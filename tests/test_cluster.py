@@ -206,3 +206,32 @@ def test_lookup_edge_cases():
         ic.dest_color(Manager([dict(one_anchor, links=torch.tensor([[3]], device=dev))]), rgb, label)
     with pytest.raises(RuntimeError, match="HIP device"):
         ic.dest_color(mgr, rgb.cpu(), label.cpu())
+
+
+def test_cluster_tables_layout_on_cpu():
+    """Host logic of the lookup without a GPU: the concatenated tables reproduce every class's data, classes without a cluster
+    own an empty anchor range, |a|^2 is the reference's expression, and the table cache follows the manager's clusters."""
+    from intrinsicnerf_amd import cluster as ic
+    fx = load_golden("cluster_lookup")
+    clusters = fixture_clusters(fx)
+    t = ic.ClusterTables(clusters, "cpu")
+    ab, cb = t.anchor_begin.tolist(), t.center_begin.tolist()
+    assert t.n_classes == 5 and ab[0] == 0 and ab[3] == ab[4] and cb[3] == cb[4]          # class 3 has no cluster
+    for i, c in enumerate(clusters):
+        if c is None:
+            continue
+        rows = t.anchors[ab[i]:ab[i + 1]]
+        assert torch.equal(rows[:, :3], c["anchors"]) and torch.equal(rows[:, 3], torch.sum(c["anchors"] ** 2, dim=1))
+        assert torch.equal(t.links[ab[i]:ab[i + 1]].long(), c["links"].reshape(-1))
+        assert torch.equal(t.centers[cb[i]:cb[i + 1]], c["rgb_centers"]) and float(t.factor[i]) == np.float32(c["intensity_factor"])
+    assert t.anchors.data_ptr() % 16 == 0 and t.links.dtype == torch.int32
+    mgr = Manager(clusters)
+    first = ic.tables_for(mgr, mgr.clusters, "cpu")
+    assert ic.tables_for(mgr, mgr.clusters, "cpu") is first                              # cached
+    mgr.clusters = list(mgr.clusters)
+    mgr.clusters[0] = dict(clusters[0], rgb_centers=clusters[0]["rgb_centers"] + 0.5)      # what update_center does: new objects
+    assert ic.tables_for(mgr, mgr.clusters, "cpu") is not first
+    with pytest.raises(ValueError, match="links"):
+        ic.ClusterTables([dict(clusters[0], links=clusters[0]["links"] + 100)], "cpu")
+    empty = ic.ClusterTables([None, None], "cpu")
+    assert empty.anchor_begin.tolist() == [0, 0, 0] and empty.anchors.shape == (1, 4)
