@@ -27,7 +27,10 @@ extern "C" {
 #endif
 
 #define INERF_VERSION_MAJOR 0
-#define INERF_VERSION_MINOR 1
+#define INERF_VERSION_MINOR 2
+/* Bumped whenever a struct layout, an argument list or the packed-weight format of this header changes; bindings
+ * compare it with inerf_abi_version() of the library they loaded (a stale .so then fails loudly, not silently). */
+#define INERF_ABI_VERSION 20002
 
 /* error codes */
 #define INERF_OK              0
@@ -63,6 +66,7 @@ extern "C" {
 #define INERF_MAX_CLASSES     240  /* semantic classes supported by the packed layout                     */
 
 const char* inerf_version(void);
+int inerf_abi_version(void);          /* INERF_ABI_VERSION the library was built against */
 int inerf_last_hip_error(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -271,9 +275,14 @@ typedef struct inerf_render_args {
     int64_t workspace_bytes;
 } inerf_render_args;
 
-/* Bytes of workspace inerf_render_rays needs for these sizes (independent of which optional
- * outputs are requested). */
+/* Bytes of workspace inerf_render_rays needs for these sizes when the caller supplies none of the optional stage
+ * outputs (an upper bound for every call with these sizes). */
 int64_t inerf_workspace_bytes(const inerf_net_desc* net, int64_t n_rays, int n_samples, int n_importance, uint32_t flags);
+
+/* Bytes of workspace THIS call needs: stage tensors the caller supplies as outputs (raw_coarse, raw_fine, z_coarse,
+ * z_samples, z_fine, coarse.weights) are written in place and get no workspace region - raw alone is N x S x CH
+ * floats.  `workspace` / `workspace_bytes` of the argument are ignored.  May return 0 (workspace may then be NULL). */
+int64_t inerf_render_workspace_bytes(const inerf_render_args* args);
 
 int inerf_render_rays(const inerf_render_args* args, void* stream);
 

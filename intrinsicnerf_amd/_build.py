@@ -11,6 +11,7 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libinerf.so")
+OBJ_DIR = os.path.join(CSRC, "_obj")          # git-ignored and gpurun-ignored: only the linked library travels
 SOURCES = ["pack.cpp", "api.cpp", "mlp.hip", "mlp_f16.hip", "mlp_bwd.hip", "mlp_wgrad.hip", "ray_ops.hip", "cluster.hip"]
 HEADERS = [os.path.join(CSRC, "layout.h"), os.path.join(CSRC, "mlp_common.h"), os.path.join(CSRC, "mlp_f16_dev.h"), os.path.join(os.path.dirname(PKG_DIR), "include", "inerf.h")]
 # -ffp-contract=off: the reference rounds o + d*z, albedo*shading + residual, near*(1-t) + far*t ... as
@@ -26,6 +27,10 @@ def _stale():
     t = os.path.getmtime(LIB_PATH)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def have_hipcc():
+    return bool(shutil.which("hipcc")) or os.path.exists("/opt/rocm/bin/hipcc")
 
 
 def build_library(force=False, verbose=False):
@@ -44,13 +49,38 @@ def build_library(force=False, verbose=False):
             hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
             if not os.path.exists(hipcc):
                 raise RuntimeError("hipcc not found: cannot build libinerf.so (ROCm toolchain required)")
+            # one object per source, compiled in parallel and only when that source (or a header) changed: editing one
+            # kernel file costs one compile + the link instead of the whole 40 s
+            os.makedirs(OBJ_DIR, exist_ok=True)
+            newest_header = max(os.path.getmtime(h) for h in HEADERS)
+
+            def compile_one(src):
+                obj = os.path.join(OBJ_DIR, src + ".o")
+                path = os.path.join(CSRC, src)
+                if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), newest_header):
+                    return obj, None
+                cmd = [hipcc] + [f for f in FLAGS if f != "-shared"] + ["-c", path, "-o", obj + f".{os.getpid()}.tmp"]
+                if verbose:
+                    print(" ".join(cmd))
+                proc = subprocess.run(cmd, capture_output=True, text=True)
+                if proc.returncode != 0:
+                    return obj, proc.stdout + proc.stderr
+                os.replace(obj + f".{os.getpid()}.tmp", obj)
+                return obj, None
+
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+                results = list(pool.map(compile_one, SOURCES))
+            errors = [e for _, e in results if e]
+            if errors:
+                raise RuntimeError("hipcc failed:\n" + "\n".join(errors))
             tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
-            cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
+            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [o for o, _ in results] + ["-o", tmp]
             if verbose:
                 print(" ".join(cmd))
             proc = subprocess.run(cmd, capture_output=True, text=True)
             if proc.returncode != 0:
-                raise RuntimeError("hipcc failed:\n" + proc.stdout + proc.stderr)
+                raise RuntimeError("hipcc (link) failed:\n" + proc.stdout + proc.stderr)
             os.replace(tmp, LIB_PATH)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)

@@ -7,7 +7,10 @@ and the current HIP stream handle; torch only owns memory and streams.
 import ctypes as C
 import os
 
+from . import _build
 from ._build import LIB_PATH
+
+ABI_VERSION = 20002          # INERF_ABI_VERSION of include/inerf.h these ctypes declarations mirror
 
 OK, E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_HIP = 0, -1, -2, -3, -4
 VARIANT_OBJECT, VARIANT_SSR = 0, 1
@@ -46,6 +49,7 @@ class RenderArgs(C.Structure):
 _P, _I, _L, _U = C.c_void_p, C.c_int, C.c_int64, C.c_uint32
 SYMBOLS = {
     "inerf_version": (C.c_char_p, []),
+    "inerf_abi_version": (_I, []),
     "inerf_last_hip_error": (_I, []),
     "inerf_num_tensors": (_I, [C.POINTER(NetDesc)]),
     "inerf_tensor_info": (_I, [C.POINTER(NetDesc), _I, C.POINTER(C.c_char_p), C.POINTER(_L), C.POINTER(_L)]),
@@ -70,6 +74,7 @@ SYMBOLS = {
     "inerf_sample_fine": (_I, [_P, _P, _P, _L, _I, _I, _U, _P, _P, _P, _P]),
     "inerf_sample_pdf": (_I, [_P, _P, _P, _L, _I, _I, _U, _P, _P]),
     "inerf_workspace_bytes": (_L, [C.POINTER(NetDesc), _L, _I, _I, _U]),
+    "inerf_render_workspace_bytes": (_L, [C.POINTER(RenderArgs)]),
     "inerf_render_rays": (_I, [C.POINTER(RenderArgs), _P]),
     "inerf_cluster_lookup": (_I, [_P, _P, _L, _P, _P, _P, _P, _P, _P, _I, _U, _P, _P, _P]),
 }
@@ -85,10 +90,21 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is not built.  Run `python -c 'import __graft_entry__ as g; g.build()'` (or "
                 "`python -m intrinsicnerf_amd._build`).  intrinsicnerf_amd has no CPU or eager fallback.")
+        if _build._stale():
+            # sources or include/inerf.h are newer than the library: the hand-mirrored structs below may no longer
+            # match it.  Rebuild when the toolchain is here, refuse to load otherwise - never run a stale library.
+            if _build.have_hipcc():
+                _build.build_library()
+            else:
+                raise RuntimeError(f"{LIB_PATH} is older than its sources and hipcc is not available to rebuild it")
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)          # AttributeError here = header/library mismatch
             fn.restype, fn.argtypes = res, args
+        got = handle.inerf_abi_version()
+        if got != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} reports ABI {got}, this binding was written for {ABI_VERSION}: rebuild the "
+                               "library (python -m intrinsicnerf_amd._build) or update _capi.py")
         _lib = handle
     return _lib
 
@@ -102,12 +118,33 @@ def check(rc, what):
     raise RuntimeError(f"{what}: {msg}")
 
 
+_forced_precision = None
+
+
+class forced_precision:
+    """Context manager: every ``default_precision()`` inside answers ``prec`` (used to re-render a whole frame with the
+    exact fp32 kernel after the split-precision one reported an out-of-range activation)."""
+
+    def __init__(self, prec):
+        self.prec = prec
+
+    def __enter__(self):
+        global _forced_precision
+        self.saved, _forced_precision = _forced_precision, self.prec
+
+    def __exit__(self, *exc):
+        global _forced_precision
+        _forced_precision = self.saved
+
+
 def default_precision():
     """MLP arithmetic used when a caller does not choose: $INERF_PRECISION = f16x3 (default) | f32.
 
     f16x3 = fp32 operands split into f16 hi/lo pairs, three f16 MFMA products per MAC, fp32 accumulation:
     same accuracy against fp64 as the all-fp32 kernel, ~2.9x its speed.  The front-ends
     re-run a batch in f32 automatically if an activation leaves f16's range (never seen on real networks)."""
+    if _forced_precision is not None:
+        return _forced_precision
     name = os.environ.get("INERF_PRECISION", "f16x3").lower()
     if name not in ("f32", "f16x3"):
         raise ValueError(f"INERF_PRECISION={name!r}: expected 'f32' or 'f16x3'")

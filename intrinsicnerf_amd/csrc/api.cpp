@@ -16,20 +16,35 @@ struct Plan {
     int ch_c, ch_f, s_f;
 };
 
-Plan plan(const inerf_net_desc& net, int64_t n, int sc, int ni, uint32_t flags) {
+// which intermediate tensors the caller supplies as outputs (inerf_render_args): no workspace is reserved for those.
+// raw is by far the largest (N x S x CH floats: ~6 GB for 32768 rays x 192 samples x 240 channels), and the SSR
+// front-end asks for raw_coarse / raw_fine by default.
+enum : unsigned { kHaveZc = 1, kHaveWc = 2, kHaveRawC = 4, kHaveZs = 8, kHaveZf = 16, kHaveRawF = 32 };
+
+unsigned provided(const inerf_render_args& a) {
+    return (a.z_coarse ? kHaveZc : 0u) | (a.coarse.weights ? kHaveWc : 0u) | (a.raw_coarse ? kHaveRawC : 0u) |
+           (a.z_samples ? kHaveZs : 0u) | (a.z_fine ? kHaveZf : 0u) | (a.raw_fine ? kHaveRawF : 0u);
+}
+
+Plan plan(const inerf_net_desc& net, int64_t n, int sc, int ni, uint32_t flags, unsigned have = 0) {
     Plan p{};
     p.ch_c = inerf_raw_channels(&net, flags, 0);
     p.ch_f = inerf_raw_channels(&net, flags, 1);
     p.s_f = sc + ni;
     int64_t off = 0;
-    auto take = [&](int64_t floats) { int64_t o = off; off += up(floats * 4); return o; };
-    p.z_c = take(n * sc);
-    p.w_c = take(n * sc);
-    p.raw_c = take(n * sc * p.ch_c);
+    auto take = [&](int64_t floats, unsigned bit) {
+        if (have & bit) return (int64_t)-1;
+        int64_t o = off;
+        off += up(floats * 4);
+        return o;
+    };
+    p.z_c = take(n * sc, kHaveZc);
+    p.w_c = ni > 0 ? take(n * sc, kHaveWc) : (int64_t)-1;   // the coarse weights are only needed for resampling
+    p.raw_c = take(n * sc * p.ch_c, kHaveRawC);
     if (ni > 0) {
-        p.z_s = take(n * ni);
-        p.z_f = take(n * p.s_f);
-        p.raw_f = take(n * p.s_f * p.ch_f);
+        p.z_s = take(n * ni, kHaveZs);
+        p.z_f = take(n * p.s_f, kHaveZf);
+        p.raw_f = take(n * p.s_f * p.ch_f, kHaveRawF);
     }
     p.total = off;
     return p;
@@ -43,14 +58,19 @@ extern "C" int64_t inerf_workspace_bytes(const inerf_net_desc* net, int64_t n_ra
     return plan(*net, n_rays, n_samples, n_importance, flags).total;
 }
 
+extern "C" int64_t inerf_render_workspace_bytes(const inerf_render_args* a) {
+    if (!a || !inerf::net_supported(a->net) || a->n_rays < 0 || a->n_samples < 1 || a->n_importance < 0) return INERF_E_INVALID;
+    return plan(a->net, a->n_rays, a->n_samples, a->n_importance, a->flags, provided(*a)).total;
+}
+
 extern "C" int inerf_render_rays(const inerf_render_args* a, void* stream) {
     if (a && a->n_rays == 0) return inerf::net_supported(a->net) ? INERF_OK : INERF_E_UNSUPPORTED;   // empty batch: null pointers allowed
     if (!a || !a->packed_coarse || !a->rays || !a->t_vals || a->n_rays < 0 || a->n_samples < 1 || a->n_importance < 0)
         return INERF_E_INVALID;
     if (!inerf::net_supported(a->net)) return INERF_E_UNSUPPORTED;
     if (a->n_importance > 0 && !a->u) return INERF_E_INVALID;
-    const Plan p = plan(a->net, a->n_rays, a->n_samples, a->n_importance, a->flags);
-    if (!a->workspace || a->workspace_bytes < p.total) return INERF_E_WORKSPACE;
+    const Plan p = plan(a->net, a->n_rays, a->n_samples, a->n_importance, a->flags, provided(*a));
+    if (p.total > 0 && (!a->workspace || a->workspace_bytes < p.total)) return INERF_E_WORKSPACE;
     char* ws = static_cast<char*>(a->workspace);
     auto f = [&](int64_t off) { return reinterpret_cast<float*>(ws + off); };
     const bool ssr = a->net.variant == INERF_VARIANT_SSR;

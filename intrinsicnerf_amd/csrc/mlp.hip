@@ -341,17 +341,24 @@ __global__ __launch_bounds__(256, 3 - PB) void k_encode_mlp(const MlpParams p) {
     }
 }
 
-static int g_num_cus = 0;
+static int g_num_cus[256] = {0};          // per device id; 0 = not queried yet
 static int g_last_hip_error = 0;
 
+int current_device() {
+    int dev = 0;
+    return hipGetDevice(&dev) == hipSuccess && dev >= 0 ? dev : 0;
+}
+
 int device_cus() {
-    if (g_num_cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const int dev = current_device() & 255;
+    int n = __atomic_load_n(&g_num_cus[dev], __ATOMIC_RELAXED);
+    if (n == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 256;
+        n = cus;
+        __atomic_store_n(&g_num_cus[dev], n, __ATOMIC_RELAXED);
     }
-    return g_num_cus;
+    return n;
 }
 
 // Tile shape: 64-point tiles, one workgroup per CU (default; measured 129.2 TFLOP/s) or 32-point
@@ -388,12 +395,12 @@ int launch_mlp_f32(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream)
     const int grid = p.n_tiles < max_grid ? p.n_tiles : max_grid;
     void (*kern)(const MlpParams) = pb == 2 ? (ssr ? k_encode_mlp<true, 2> : k_encode_mlp<false, 2>)
                                             : (ssr ? k_encode_mlp<true, 1> : k_encode_mlp<false, 1>);
-    static bool attr_set[2][2] = {{false, false}, {false, false}};
-    if (!attr_set[ssr][pb - 1]) {
+    static PerDeviceOnce attr_set[2][2];
+    if (attr_set[ssr][pb - 1].first()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            lds_bytes);
         if (e != hipSuccess) return record(e);
-        attr_set[ssr][pb - 1] = true;
+        attr_set[ssr][pb - 1].mark();
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, stream, p);
     return record(hipGetLastError());

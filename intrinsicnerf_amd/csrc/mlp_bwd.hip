@@ -447,11 +447,11 @@ extern "C" int inerf_mlp_backward_inputs(const inerf_net_desc* net, const float*
     p.channels = INERF_BASE_CHANNELS + p.n_classes + (p.endpoint ? INERF_ENDPOINT_DIM : 0);
     const int grid = p.n_tiles < device_cus() ? p.n_tiles : device_cus();
     void (*kern)(const BwdParams) = ssr ? k_mlp_dgrad<true> : k_mlp_dgrad<false>;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[ssr]) {
+    static PerDeviceOnce attr_set[2];
+    if (attr_set[ssr].first()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesH);
         if (e != hipSuccess) return record(e);
-        attr_set[ssr] = true;
+        attr_set[ssr].mark();
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kLdsBytesH, (hipStream_t)stream, p);
     return record(hipGetLastError());

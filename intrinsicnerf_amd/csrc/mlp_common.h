@@ -27,8 +27,26 @@ struct MlpParams {
     float xyz_div;
 };
 
-int device_cus();
+int device_cus();                 // CU count of the CURRENT device (cached per device id)
+int current_device();             // hipGetDevice, 0 on error
 int tile_blocks();
+
+// "Has this been done for the current device?" - function attributes (dynamic LDS size) belong to the device a kernel
+// is loaded on, and a process may drive several (the Python launchers switch devices per call), so every launcher keeps
+// one of these per kernel variant instead of a process-wide bool.  Lock-free; a race only repeats an idempotent call.
+struct PerDeviceOnce {
+    unsigned long long done[4] = {0, 0, 0, 0};          // bit d of word d/64: devices 0..255
+    bool first() {
+        const int d = current_device() & 255;
+        const unsigned long long bit = 1ull << (d & 63);
+        if (__atomic_load_n(&done[d >> 6], __ATOMIC_ACQUIRE) & bit) return false;
+        return true;
+    }
+    void mark() {
+        const int d = current_device() & 255;
+        __atomic_fetch_or(&done[d >> 6], 1ull << (d & 63), __ATOMIC_RELEASE);
+    }
+};
 int record(hipError_t e);
 int launch_mlp_f32(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream);
 int launch_mlp_f16x3(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream);   // p.save != nullptr: saving variant

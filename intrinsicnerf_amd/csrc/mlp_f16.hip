@@ -131,9 +131,11 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
         // training forward: fp32 copy of a layer's output, this lane's first point / first channel of its wave
         auto save_dst = [&](int slot, int width, int chan0) {
             SaveDst d;
+            // sizes and offsets in unsigned 32-bit arithmetic: a 256-wide slot of 2^21+ points is beyond INT_MAX bytes
+            // (the host keeps n_points * 256 * 4 < 2^32, see inerf_encode_mlp_train)
             d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save + (kSave ? p.save_off[slot] : 0), 0,
-                                                       kSave ? p.n_points * width * 4 : 0, 0x00020000);
-            d.voff = (pt0 * width + chan0 + 4 * (lane >> 5)) * 4;
+                                                       kSave ? (int)((unsigned)p.n_points * (unsigned)width * 4u) : 0, 0x00020000);
+            d.voff = (int)(((unsigned)pt0 * (unsigned)width + (unsigned)(chan0 + 4 * (lane >> 5))) * 4u);
             d.stride = width;
             return d;
         };
@@ -504,9 +506,9 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
         const int pt0 = tile * kPts + (lane & 31);
         auto save_dst = [&](int slot, int width, int chan0) {
             SaveDst d;
-            d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save + (kSave ? p.save_off[slot] : 0), 0, kSave ? p.n_points * width * 4 : 0,
-                                                       0x00020000);
-            d.voff = (pt0 * width + chan0 + 4 * (lane >> 5)) * 4;
+            d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save + (kSave ? p.save_off[slot] : 0), 0,
+                                                       kSave ? (int)((unsigned)p.n_points * (unsigned)width * 4u) : 0, 0x00020000);
+            d.voff = (int)(((unsigned)pt0 * (unsigned)width + (unsigned)(chan0 + 4 * (lane >> 5))) * 4u);
             d.stride = width;
             return d;
         };
@@ -567,9 +569,9 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
         }
         if (kSsr && L.sem_rbs > 0) {               // semantic logits straight to raw[11 .. 11+C) (semantic_nerf.py:150-152)
             SaveDst sv;
-            sv.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save + (kSave ? p.save_off[SAVE_SEMH] : 0), 0, kSave ? p.n_points * kHalf * 4 : 0,
-                                                        0x00020000);
-            sv.voff = ((tile * kPts + 16 * wave + (lane & 15)) * kHalf + 4 * (lane >> 4)) * 4;
+            sv.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save + (kSave ? p.save_off[SAVE_SEMH] : 0), 0,
+                                                        kSave ? (int)((unsigned)p.n_points * (unsigned)kHalf * 4u) : 0, 0x00020000);
+            sv.voff = (int)(((unsigned)(tile * kPts + 16 * wave + (lane & 15)) * (unsigned)kHalf + (unsigned)(4 * (lane >> 4))) * 4u);
             sv.stride = kHalf;
             sem_head<kSave>(wb, L, xs, lane, amax2, out_row, my_valid, p.n_classes, &sv);
         }
@@ -642,12 +644,12 @@ static int launch_dual(MlpParams& p, int64_t n_points, bool ssr, hipStream_t str
     const bool save = p.save != nullptr;
     void (*kern)(const MlpParams) = ssr ? (save ? k_encode_mlp_f16x3_dual<true, true> : k_encode_mlp_f16x3_dual<false, true>)
                                         : (save ? k_encode_mlp_f16x3_dual<true, false> : k_encode_mlp_f16x3_dual<false, false>);
-    static bool attr_set[4] = {false, false, false, false};
+    static PerDeviceOnce attr_set[4];
     const int variant = 2 * (int)ssr + (int)save;
-    if (!attr_set[variant]) {
+    if (attr_set[variant].first()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesD);
         if (e != hipSuccess) return record(e);
-        attr_set[variant] = true;
+        attr_set[variant].mark();
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kLdsBytesD, stream, p);
     return record(hipGetLastError());
@@ -664,13 +666,13 @@ int launch_mlp_f16x3(MlpParams& p, int64_t n_points, bool ssr, hipStream_t strea
     const bool save = p.save != nullptr;
     void (*kern)(const MlpParams) = ssr ? (save ? k_encode_mlp_f16x3<true, true> : k_encode_mlp_f16x3<true, false>)
                                         : (save ? k_encode_mlp_f16x3<false, true> : k_encode_mlp_f16x3<false, false>);
-    static bool attr_set[4] = {false, false, false, false};
+    static PerDeviceOnce attr_set[4];
     const int variant = 2 * (int)ssr + (int)save;
-    if (!attr_set[variant]) {
+    if (attr_set[variant].first()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            kLdsBytesH);
         if (e != hipSuccess) return record(e);
-        attr_set[variant] = true;
+        attr_set[variant].mark();
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kLdsBytesH, stream, p);
     return record(hipGetLastError());

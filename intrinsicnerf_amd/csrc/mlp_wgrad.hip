@@ -239,11 +239,7 @@ extern "C" int inerf_mlp_weight_gradient(const float* G, int ldg, const float* X
     INERF_WG_CASE(8, 4) INERF_WG_CASE(4, 4)
 #undef INERF_WG_CASE
     if (!kern) return INERF_E_UNSUPPORTED;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return record(e);
-    }
-    if (lds > 64 * 1024) {
+    if (lds > 64 * 1024) {          // only <8, 8> and <4, 8>; set on every launch (a few microseconds): the attribute is per device
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return record(e);
     }

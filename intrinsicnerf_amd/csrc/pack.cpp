@@ -233,7 +233,8 @@ void pack_regop16_f16(float* dst_f, int rbs, int k_total, const Elem& w, float s
 
 extern "C" {
 
-const char* inerf_version(void) { return "inerf 0.1 (gfx950)"; }
+const char* inerf_version(void) { return "inerf 0.2 (gfx950)"; }
+int inerf_abi_version(void) { return INERF_ABI_VERSION; }
 
 int inerf_num_tensors(const inerf_net_desc* net) {
     if (!net || !inerf::net_supported(*net)) return INERF_E_INVALID;

@@ -68,15 +68,60 @@ def _new_status(like):
     return torch.zeros(1, dtype=torch.int32, device=like.device)
 
 
-def check_f16_range(status, what):
-    """Raise if a PREC_F16X3 launch met an activation outside f16's range (one device sync)."""
-    if status is not None and int(status.item()) & _capi.STATUS_F16_RANGE:
+_deferred = None          # list of status words collected by an open deferred_range_checks() block, else None
+
+
+class deferred_range_checks:
+    """Context manager for a multi-chunk frame rendered under no_grad: ``check_f16_range(..., deferrable=True)`` calls
+    inside only remember their status word, and ONE device->host read at the end of the block checks them all - a
+    frame costs one host synchronisation instead of one per chunk.  Raises FloatingPointError at exit if any chunk
+    left f16's range; the caller then re-renders the frame in exact fp32 (``_capi.forced_precision``)."""
+
+    def __init__(self, what):
+        self.what = what
+
+    def __enter__(self):
+        global _deferred
+        self.outer, _deferred = _deferred, []
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        global _deferred
+        mine, _deferred = _deferred, self.outer
+        if exc_type is not None or not mine:
+            return False
+        if self.outer is not None:                 # nested block: hand the words to the enclosing one
+            self.outer.extend(mine)
+            return False
+        word = mine[0] if len(mine) == 1 else torch.cat(mine).max()
+        check_f16_range(word, self.what)
+        return False
+
+
+def check_f16_range(status, what, deferrable=False):
+    """Raise if a PREC_F16X3 launch met an activation outside f16's range (one device sync) - or, inside a
+    ``deferred_range_checks`` block and with ``deferrable``, leave the word for the block's single check."""
+    if status is None:
+        return
+    if deferrable and _deferred is not None:
+        _deferred.append(status.reshape(1))
+        return
+    if int(status.item()) & _capi.STATUS_F16_RANGE:
         raise FloatingPointError(
             f"{what}: an activation exceeded the f16 range (|v| > 6e4) in the split-precision MLP kernel; "
             "results are invalid - re-run with precision f32 (INERF_PRECISION=f32)")
 
 
 _warned_fallback = False
+
+
+def warn_f32_fallback(e):
+    global _warned_fallback
+    if not _warned_fallback:
+        import warnings
+        warnings.warn(f"{e}  Re-running this batch with the exact fp32 MFMA kernel (set INERF_PRECISION=f32 to "
+                      "skip the attempt).")
+        _warned_fallback = True
 
 
 def with_f32_fallback(desc, run):
@@ -89,11 +134,7 @@ def with_f32_fallback(desc, run):
     except FloatingPointError as e:
         if desc.precision != _capi.PREC_F16X3:
             raise
-        if not _warned_fallback:
-            import warnings
-            warnings.warn(f"{e}  Re-running this batch with the exact fp32 MFMA kernel (set INERF_PRECISION=f32 to "
-                          "skip the attempt).")
-            _warned_fallback = True
+        warn_f32_fallback(e)
         d32 = _capi.NetDesc(desc.variant, desc.n_classes, desc.l_xyz, desc.l_dir, desc.xyz_div, _capi.PREC_F32)
         return run(d32)
 
@@ -320,9 +361,9 @@ def render_rays_fused(desc, packed_coarse, packed_fine, rays, n_samples, n_impor
         if n_importance > 0:
             out["z_samples"], out["z_fine"] = _new(rays, n, n_importance), _new(rays, n, s_f)
             args.z_samples, args.z_fine = out["z_samples"].data_ptr(), out["z_fine"].data_ptr()
-    ws_bytes = L.inerf_workspace_bytes(desc, n, n_samples, n_importance, flags)
+    ws_bytes = L.inerf_render_workspace_bytes(C.byref(args))       # nothing is reserved for stage tensors requested as outputs
     if ws_bytes < 0:
-        _capi.check(int(ws_bytes), "inerf_workspace_bytes")
+        _capi.check(int(ws_bytes), "inerf_render_workspace_bytes")
     ws = torch.empty(max(int(ws_bytes), 1), dtype=torch.uint8, device=rays.device)
     args.workspace, args.workspace_bytes = ws.data_ptr(), int(ws_bytes)
     if desc.precision == _capi.PREC_F16X3:

@@ -316,7 +316,8 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
                 packing.packed_for_module(fine_net, d, dev) if N_importance > 0 else None,
                 ray_batch, N_samples, N_importance, t_vals, u, t_rand, noise_c, noise_f, white_bkgd, lindisp,
                 want_raw_coarse=retraw and N_importance == 0, want_raw_fine=retraw)
-            kernels.check_f16_range(res.pop("status", None), "render_rays")
+            # eval-mode chunks of a frame (no RNG draws to repeat) leave the check to batchify_rays' end-of-frame one
+            kernels.check_f16_range(res.pop("status", None), "render_rays", deferrable=t_rand is None and noise_c is None)
             return res
 
         o = kernels.with_f32_fallback(desc, run)
@@ -363,13 +364,28 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
 
 
 def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
-    """Render rays in chunks - run_nerf.py:59-71.  Results do not depend on ``chunk``."""
-    all_ret = {}
-    for i in range(0, rays_flat.shape[0], chunk):
-        ret = render_rays(rays_flat[i:i + chunk], **kwargs)
-        for k in ret:
-            all_ret.setdefault(k, []).append(ret[k])
-    return {k: torch.cat(all_ret[k], 0) for k in all_ret}
+    """Render rays in chunks - run_nerf.py:59-71.  Results do not depend on ``chunk``.
+
+    The split-precision kernel's range word is read ONCE per call, after the last chunk (kernels.deferred_range_checks):
+    a frame is one host synchronisation, not one per chunk.  If it reports an out-of-range activation the whole call is
+    repeated with the exact fp32 kernel (only eval-mode chunks defer, so no random draw is repeated)."""
+    def run():
+        all_ret = {}
+        for i in range(0, rays_flat.shape[0], chunk):
+            ret = render_rays(rays_flat[i:i + chunk], **kwargs)
+            for k in ret:
+                all_ret.setdefault(k, []).append(ret[k])
+        return {k: (all_ret[k][0] if len(all_ret[k]) == 1 else torch.cat(all_ret[k], 0)) for k in all_ret}
+
+    try:
+        with kernels.deferred_range_checks("render"):
+            return run()
+    except FloatingPointError as e:
+        if _capi.default_precision() != _capi.PREC_F16X3:
+            raise
+        kernels.warn_f32_fallback(e)
+        with _capi.forced_precision(_capi.PREC_F32):
+            return run()
 
 
 def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,

@@ -243,7 +243,15 @@ class SSRRenderMixin:
 
     def render_rays(self, flat_rays):
         ray_shape = flat_rays.shape
-        all_ret = batchify_rays(self.volumetric_rendering, flat_rays, self.chunk)
+        try:      # one host synchronisation per frame: the chunks' f16 range words are read together at the end
+            with kernels.deferred_range_checks("render_rays"):
+                all_ret = batchify_rays(self.volumetric_rendering, flat_rays, self.chunk)
+        except FloatingPointError as e:
+            if _capi.default_precision() != _capi.PREC_F16X3:
+                raise
+            kernels.warn_f32_fallback(e)
+            with _capi.forced_precision(_capi.PREC_F32):
+                all_ret = batchify_rays(self.volumetric_rendering, flat_rays, self.chunk)
         for k in all_ret:
             all_ret[k] = torch.reshape(all_ret[k], list(ray_shape[:-1]) + list(all_ret[k].shape[1:]))
         return all_ret
@@ -278,7 +286,7 @@ class SSRRenderMixin:
                 ray_batch, self.N_samples, self.N_importance, t_vals, u, t_rand, noise_c, noise_f,
                 white_bkgd=self.white_bkgd, endpoint=ep, want_raw_coarse=self.return_raw, want_raw_fine=self.return_raw,
                 want_sem=bool(self.enable_semantic))
-            kernels.check_f16_range(res.pop("status", None), "volumetric_rendering")
+            kernels.check_f16_range(res.pop("status", None), "volumetric_rendering", deferrable=t_rand is None and noise_c is None)
             return res
 
         if _wants_grad(self.ssr_net_coarse, self.ssr_net_fine):

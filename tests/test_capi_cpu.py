@@ -399,3 +399,47 @@ def test_device_packer_is_bit_identical_to_host_packer(capi, variant, c):
             host = packing.pack_state_dict_bwd(desc, sd) if backward else packing.pack_state_dict(desc, sd)
             dev = packing.device_packer(desc, backward, "cpu")(sd)
             assert torch.equal(host.view(torch.int32), dev.view(torch.int32)), (variant, c, seed, backward)
+
+
+def test_abi_version_and_stale_library_guard(capi, monkeypatch):
+    """The binding refuses a library whose ABI number differs from the one its ctypes mirrors were written for, and a
+    library older than its sources is rebuilt (or refused when there is no hipcc) instead of being loaded silently."""
+    text = open(os.path.join(REPO, "include", "inerf.h")).read()
+    assert int(re.search(r"#define INERF_ABI_VERSION (\d+)", text).group(1)) == capi.ABI_VERSION
+    assert capi.lib().inerf_abi_version() == capi.ABI_VERSION
+    from intrinsicnerf_amd import _build
+    monkeypatch.setattr(capi, "_lib", None)
+    monkeypatch.setattr(capi, "ABI_VERSION", capi.ABI_VERSION + 1)
+    with pytest.raises(RuntimeError, match="ABI"):
+        capi.lib()
+    monkeypatch.setattr(capi, "ABI_VERSION", capi.ABI_VERSION - 1)
+    monkeypatch.setattr(_build, "_stale", lambda: True)
+    monkeypatch.setattr(_build, "have_hipcc", lambda: False)
+    with pytest.raises(RuntimeError, match="older than its sources"):
+        capi.lib()
+    monkeypatch.undo()
+    assert capi.lib().inerf_abi_version() == capi.ABI_VERSION
+
+
+def test_workspace_skips_caller_provided_stage_tensors(capi):
+    """inerf_render_workspace_bytes: stage tensors the caller supplies as outputs get no workspace region (raw was
+    held twice - ~6 GB per chunk at C = 101 with the endpoint feature)."""
+    lib = capi.lib()
+    c, n, sc, ni = 101, 32768, 64, 128
+    desc = capi.net_desc(capi.VARIANT_SSR, c, 10, 4, 10.0)
+    full = lib.inerf_workspace_bytes(desc, n, sc, ni, capi.FLAG_ENDPOINT)
+    a = capi.RenderArgs()
+    a.net, a.n_rays, a.n_samples, a.n_importance, a.flags = desc, n, sc, ni, capi.FLAG_ENDPOINT
+    assert lib.inerf_render_workspace_bytes(C.byref(a)) == full
+    up = lambda floats: (floats * 4 + 255) // 256 * 256
+    raw_c, raw_f = up(n * sc * (11 + c)), up(n * (sc + ni) * (11 + c + 128))
+    a.raw_coarse, a.raw_fine = 0x1000, 0x2000                       # "provided" (never dereferenced here)
+    assert lib.inerf_render_workspace_bytes(C.byref(a)) == full - raw_c - raw_f
+    a.z_coarse, a.z_samples, a.z_fine = 0x10, 0x20, 0x30
+    a.coarse.weights = 0x40
+    assert lib.inerf_render_workspace_bytes(C.byref(a)) == 0
+    # coarse-only: no resampling, no weights region
+    b = capi.RenderArgs()
+    b.net, b.n_rays, b.n_samples, b.n_importance = desc, n, sc, 0
+    assert lib.inerf_render_workspace_bytes(C.byref(b)) == up(n * sc) + up(n * sc * (11 + c))
+    assert lib.inerf_render_workspace_bytes(None) == capi.E_INVALID

@@ -192,3 +192,53 @@ def test_ray_generators_match_the_reference_bit_for_bit():
             assert np.array_equal(got.numpy(), fx[f"ssr_rays_{conv}_{dt}"]), (conv, dt)
     got = ssr.create_rays(2, T, Hs, Ws, 5.5, 6.5, 9.5, 9.5, 0.1, 10.0, c2w_staticcam=T.flip(0))
     assert np.array_equal(got.numpy(), fx["ssr_rays_static"])
+
+
+def test_deferred_range_checks_read_the_status_words_once():
+    """kernels.deferred_range_checks: deferrable checks inside the block only collect their status word; the block's exit
+    raises if any of them carried the range bit; non-deferrable checks (training path) still raise immediately."""
+    from intrinsicnerf_amd import _capi, kernels
+    ok, bad = torch.zeros(1, dtype=torch.int32), torch.full((1,), _capi.STATUS_F16_RANGE, dtype=torch.int32)
+    with kernels.deferred_range_checks("frame"):
+        kernels.check_f16_range(ok, "chunk 0", deferrable=True)
+        kernels.check_f16_range(ok, "chunk 1", deferrable=True)
+    with pytest.raises(FloatingPointError, match="frame"):
+        with kernels.deferred_range_checks("frame"):
+            kernels.check_f16_range(ok, "chunk 0", deferrable=True)
+            kernels.check_f16_range(bad, "chunk 1", deferrable=True)          # no raise here ...
+            reached = True
+    assert reached                                                            # ... only at the end of the frame
+    with pytest.raises(FloatingPointError, match="training"):
+        with kernels.deferred_range_checks("frame"):
+            kernels.check_f16_range(bad, "training forward")                  # not deferrable: immediately
+    assert kernels._deferred is None
+    kernels.check_f16_range(None, "fp32 kernel has no status word")
+    with kernels.deferred_range_checks("outer"):                              # nested blocks hand their words outwards
+        with kernels.deferred_range_checks("inner"):
+            kernels.check_f16_range(ok, "x", deferrable=True)
+        assert len(kernels._deferred) == 1
+    # the whole-frame retry switches the default precision for its duration only
+    before = _capi.default_precision()
+    with _capi.forced_precision(_capi.PREC_F32):
+        assert _capi.default_precision() == _capi.PREC_F32
+        assert _capi.net_desc(_capi.VARIANT_OBJECT).precision == _capi.PREC_F32
+    assert _capi.default_precision() == before
+
+
+def test_packed_cache_invalidate():
+    """The packed-weight cache follows autograd's version counters; writes through ``.data`` bypass them and need
+    packing.invalidate."""
+    from intrinsicnerf_amd import _capi, object_level as ol, packing
+    net = ol.NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+    desc = _capi.net_desc(_capi.VARIANT_OBJECT, 0, 10, 4, 1.0, _capi.PREC_F16X3)
+    a = packing.packed_for_module(net, desc, "cpu")
+    assert packing.packed_for_module(net, desc, "cpu") is a                   # cached
+    with torch.no_grad():
+        net.alpha_linear.bias.add_(1.0)                                       # bumps _version
+    b = packing.packed_for_module(net, desc, "cpu")
+    assert b is not a and not torch.equal(a, b)
+    net.alpha_linear.bias.data.add_(1.0)                                      # does not
+    assert packing.packed_for_module(net, desc, "cpu") is b
+    packing.invalidate(net)
+    c = packing.packed_for_module(net, desc, "cpu")
+    assert c is not b and not torch.equal(b, c)

@@ -1,0 +1,129 @@
+"""GPU parity on UN-CURATED inputs: unfiltered rays of the benchmark frames, default-``nn.Linear``-init networks whose
+density head is calibrated so that acc spans (0, 1] (oracle/calibration.py), every ray judged.
+
+With white-spectrum random weights many rays are ill-conditioned for any fp32 evaluation of the two-pass path (the
+reference's own fp32 result is far from the same arithmetic in fp64 on them), so a per-ray 1e-4 assertion cannot hold
+for ANY implementation.  Instead of discarding those rays the test compares distributions, per output map:
+
+  e_hip[r] = |HIP - oracle_fp32| in units of the tolerance (1e-5 + 1e-4 |want|; disp: 5e-4)
+  e_ref[r] = |oracle_fp32 - oracle_fp64| in the same units
+
+and requires (oracle.calibration.rank_report) every quantile (50 ... 99 %) of e_hip <= max(0.5, 3 x the same quantile
+of e_ref) and, for the tails, #(e_hip > T) <= 3 x #(e_ref > T) + 3 for T in {1, 10, 100} tolerances.  On top of that the
+plain tolerance must hold on EVERY ray whose fp32-vs-fp64 score (max over all maps and stage tensors) is <= 0.2 -
+and on every ray for the coarse maps, which do not sit behind sample_pdf.
+"""
+import functools
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import calibration as cal
+
+pytestmark = pytest.mark.gpu
+
+N_RAYS = 1024
+RTOL, ATOL, RTOL_DISP = 1e-4, 1e-5, 5e-4
+
+
+@pytest.fixture(autouse=True, params=["f32", "f16x3", "f16x3-1wg"])
+def precision(request, monkeypatch):
+    monkeypatch.setenv("INERF_PRECISION", request.param.split("-")[0])
+    if request.param.endswith("-1wg"):
+        monkeypatch.setenv("INERF_F16_KERNEL", "single")
+    else:
+        monkeypatch.delenv("INERF_F16_KERNEL", raising=False)
+    return request.param
+
+
+def chair_rays(n=N_RAYS, side=800):
+    """Every (side*side // n)-th ray of the benchmark's 800x800 chair frame (bench.py), unfiltered."""
+    import bench
+    from intrinsicnerf_amd import object_level as ol
+    focal = 0.5 * side / np.tan(0.5 * bench.CAMERA_ANGLE_X)
+    K = np.array([[focal, 0, 0.5 * side], [0, focal, 0.5 * side], [0, 0, 1]])
+    ro, rd = ol.get_rays(side, side, K, bench.chair_pose())
+    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    sel = torch.arange(0, side * side, side * side // n + 1)[:n]           # odd stride: walks over rows and columns
+    ro, rd = ro[sel], rd[sel]
+    return torch.cat([ro, rd, 2.0 * torch.ones_like(rd[:, :1]), 6.0 * torch.ones_like(rd[:, :1]),
+                      rd / rd.norm(dim=-1, keepdim=True)], -1).contiguous()
+
+
+def room_rays(n=N_RAYS):
+    """Every k-th ray of the 320x240 Replica-like frame of scripts/bench_ssr_frame.py, unfiltered."""
+    from intrinsicnerf_amd import ssr
+    H, W = 240, 320
+    fx = fy = W / 2.0 / np.tan(np.deg2rad(45.0))
+    rays = ssr.create_rays(1, torch.eye(4)[None], H, W, fx, fy, (W - 1) / 2.0, (H - 1) / 2.0, 0.1, 10.0).reshape(-1, 11)
+    return rays[torch.arange(0, H * W, H * W // n + 1)[:n]].contiguous()
+
+
+@functools.lru_cache(maxsize=None)
+def workload(variant):
+    """(rays, cfg, sd_c, sd_f, oracle fp32 outputs, oracle fp64 outputs) - computed once per session."""
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    if variant == "object":
+        rays, c = chair_rays(), 0
+        cfg = oracle.RenderConfig(variant="object", white_bkgd=True)
+    else:
+        rays, c = room_rays(), 28
+        cfg = oracle.RenderConfig(variant="ssr", white_bkgd=False, n_classes=c, netchunk=32768)
+    sd_c = cal.calibrated_default_init(variant, c, 0, rays)
+    sd_f = cal.calibrated_default_init(variant, c, 1, rays)
+    to64 = lambda sd: {k: v.double() for k, v in sd.items()}
+    with torch.no_grad():
+        o32 = oracle.render_rays(rays, sd_c, sd_f, cfg, stages=True)
+        o64 = oracle.render_rays(rays.double(), to64(sd_c), to64(sd_f), cfg, stages=True)
+    return rays, cfg, sd_c, sd_f, o32, o64
+
+
+def _keys(out):
+    maps = [f"{k}_{lvl}" for lvl in ("coarse", "fine") for k in cal.MAP_KEYS if f"{k}_{lvl}" in out]
+    return maps + ["z_std"]
+
+
+def _tol(key):
+    return RTOL_DISP if key.startswith("disp") else RTOL
+
+
+@pytest.mark.parametrize("variant", ["object", "ssr"])
+def test_unfiltered_rays_rank_statistics(variant, precision):
+    from intrinsicnerf_amd import _capi, kernels, packing
+    rays, cfg, sd_c, sd_f, o32, o64 = workload(variant)
+    acc = o32["acc_fine"].numpy()
+    assert acc.min() < 0.9 and (acc > 0.999).mean() > 0.02 and (acc > 0.999).mean() < 0.98, "workload is degenerate"
+    dev = torch.device("cuda:0")
+    ssr = variant == "ssr"
+    desc = _capi.net_desc(_capi.VARIANT_SSR if ssr else _capi.VARIANT_OBJECT, cfg.n_classes if ssr else 0, 10, 4, cfg.xyz_div)
+    got = kernels.render_rays_fused(desc, packing.pack_state_dict(desc, sd_c).to(dev), packing.pack_state_dict(desc, sd_f).to(dev),
+                                    rays.to(dev), 64, 128, torch.linspace(0., 1., 64).to(dev), torch.linspace(0., 1., 128).to(dev),
+                                    white_bkgd=cfg.white_bkgd, want_stages=True)
+    kernels.check_f16_range(got.pop("status", None), "test")
+    keys = _keys(o32)
+    e_ref = {k: cal.scaled_errors(o32[k].numpy(), o64[k].numpy(), _tol(k), ATOL) for k in keys}
+    e_hip = {k: cal.scaled_errors(got[k].cpu().numpy(), o32[k].numpy(), _tol(k), ATOL) for k in keys}
+    # the reference arithmetic's own reproducibility per ray: max over maps AND the stage tensors behind them
+    stage = ("z_samples", "weights_coarse", "weights_fine", "z_fine")
+    score = np.maximum.reduce([e_ref[k] for k in keys] + [cal.scaled_errors(o32[k].numpy(), o64[k].numpy(), RTOL, ATOL) for k in stage])
+    well = score <= 0.2
+    problems = []
+    for k in keys:
+        for v in cal.rank_report(e_hip[k], e_ref[k]):
+            problems.append(f"{k}: {v}   [hip: {cal.summarize(e_hip[k])} | ref: {cal.summarize(e_ref[k])}]")
+        strict = np.ones_like(well) if k.endswith("_coarse") else well
+        worst = float(np.max(e_hip[k][strict], initial=0.0))
+        if worst > 1.0:
+            problems.append(f"{k}: {int((e_hip[k][strict] > 1).sum())} of {int(strict.sum())} reproducible rays beyond the "
+                            f"plain tolerance (worst {worst:.3g})")
+    assert not problems, f"{variant}/{precision}: {len(problems)} violations\n" + "\n".join(problems)
+    # the run must have had something to say.  (On the chair frame almost no ray of a white-spectrum network is
+    # reproducible once the 128 resampled depths count - the rank statistics and the coarse maps carry that case;
+    # about half of the room frame's rays are.)
+    if variant == "ssr":
+        assert well.sum() >= 50, f"only {int(well.sum())} reproducible rays"
+    print(f"\n[{variant}/{precision}] {len(rays)} unfiltered rays, {int(well.sum())} reproducible (score <= 0.2)")
+    for k in keys:
+        print(f"  {k:16s} hip-vs-fp32: {cal.summarize(e_hip[k])}\n  {'':16s} fp32-vs-fp64: {cal.summarize(e_ref[k])}")
