@@ -9,6 +9,13 @@ through the product front-end ``intrinsicnerf_amd.object_level.render``.  With N
 are split into N row bands (one process per GPU) and the rendered maps are all-gathered over RCCL, so
 the total work is fixed: "scaling": "strong".  Inputs are resident in HBM before the timed region.
 
+Networks: default-``nn.Linear``-init weights (seeds 0 / 1) whose density head ``alpha_linear`` is rescaled so that
+acc spans (0, 1] on this frame (oracle/calibration.py) - with the plain seeds every density is negative and the
+frame is all background, so neither sample_pdf nor compositing would see a non-trivial input.  After the timed
+region a strided sample of the TIMED frame is compared with the CPU oracle (== reference): rank statistics against
+the oracle's own fp32-vs-fp64 distance on every sampled ray plus the plain 1e-4 tolerance on the reproducible ones;
+the run fails if that does not hold ("parity" in the JSON line).
+
 The MLP GEMMs run in the package's default arithmetic (INERF_PRECISION, default "f16x3": fp32 operands
 split into f16 hi/lo pairs, 3 f16 MFMA products per MAC, fp32 accumulation - same error against fp64
 as the exact-fp32 MFMA kernel); "dtype" says which one ran.
@@ -20,7 +27,11 @@ Prints ONE JSON line (rank 0) with the bench contract's fields plus
                    (2500 / 3 = 833 TFLOP/s); for the exact-fp32 kernel it is the 157.3 TFLOP/s fp32 MFMA
                    peak.  "roofline_f32_kernel" always carries the exact-fp32 kernel's figures too;
   "cpu_baseline" : the CPU oracle (PyTorch-CPU restatement == reference, see oracle/) timed on this
-                   box's host cores on a bounded sample of the same workload.
+                   box's host cores on a bounded sample of the same workload (best thread count and 1 thread);
+  "parity"       : the check described above;
+  "configs"      : BASELINE.json configs[1] (coarse-only 800x800) and configs[3] (320x240 SSR room frame, C = 28)
+                   through their front-ends: rays/s and the MLP kernel's roofline fraction at their launch shapes;
+  "frame_costs"  : where a frame's wall time goes besides the kernels (host, packing, gather, status read).
 """
 import argparse
 import json
@@ -39,12 +50,16 @@ N_SAMPLES, N_IMPORTANCE = 64, 128
 CAMERA_ANGLE_X = 0.6911112070083618          # NeRF-synthetic transforms_*.json
 NEAR, FAR = 2.0, 6.0                         # run_nerf.py:705-706
 FLOP_PER_POINT = 2 * 659456                  # BASELINE.md section 2 (GEMM MACs of one NeRF evaluation)
+SSR_CLASSES = 28
+FLOP_PER_POINT_SSR = 2 * (659456 + 32768 + 128 * SSR_CLASSES)
 PEAK_F32_MFMA_TFLOPS = 157.3                 # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_F16_MFMA_TFLOPS = 2500.0                # MI355X_MICROARCH.md: dense f16/bf16 matrix peak
+MEASURED_F16_MFMA_ONLY_TFLOPS = 1590.0       # dense f16, random operands, 170-340 ms runs (zero operands: 2470)
 # HBM bytes per sample point of the encode+MLP kernels from the PMC passes (FETCH_SIZE + WRITE_SIZE, separate
 # passes) in profiles/r01_mlp_pmc_traffic.txt: 311.6 MB per 6,291,456-point launch (algorithmic: 306 MB).
-MEASURED_F16_MFMA_ONLY_TFLOPS = 1590.0      # dense f16, random operands, 170-340 ms runs (zero operands: 2470)
-PMC_HBM_BYTES_PER_POINT = {"f16x3": 55.9, "f32": 49.5}    # rocprofv3 PMC, profiles/r01_mlp_pmc_traffic.txt
+PMC_HBM_BYTES_PER_POINT = {"f16x3": 55.9, "f32": 49.5}
+PARITY_RAYS = 4096
+RTOL, ATOL, RTOL_DISP = 1e-4, 1e-5, 5e-4
 
 
 def chair_pose(theta_deg=40.0, phi_deg=-30.0, radius=4.0):
@@ -57,59 +72,135 @@ def chair_pose(theta_deg=40.0, phi_deg=-30.0, radius=4.0):
     return torch.tensor((flip @ rt @ rp @ t)[:3, :4], dtype=torch.float32)
 
 
-def cpu_baseline(budget_s=10.0):
-    """Time the CPU oracle on rays of the same frame with the same networks.
+def chair_intrinsics():
+    focal = 0.5 * W / np.tan(0.5 * CAMERA_ANGLE_X)
+    return np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
 
-    torch's intra-op pool is not monotone in thread count on many-core hosts (256 threads on a 512-ray
-    chunk is ~60x slower than 32), so the thread count is probed first and the remaining budget is
-    spent at the best one; "cores" reports the threads actually used.
-    """
-    import oracle
-    from intrinsicnerf_amd import object_level as ol
+
+def host_description():
+    """CPU model string, physical cores, logical CPUs available to this process."""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    focal = 0.5 * W / np.tan(0.5 * CAMERA_ANGLE_X)
-    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
-    ro, rd = ol.get_rays(H, W, K, chair_pose())
-    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
-    sel = torch.arange(0, H * W, 39)[:16384]                   # rays spread over the frame
-    ro, rd = ro[sel], rd[sel]
-    rays = torch.cat([ro, rd, NEAR * torch.ones_like(rd[:, :1]), FAR * torch.ones_like(rd[:, :1]),
-                      rd / rd.norm(dim=-1, keepdim=True)], -1)
-    sd_c, sd_f = oracle.make_state_dict("object", seed=0), oracle.make_state_dict("object", seed=1)
+    return model, (len(cores) or avail), avail
+
+
+def cpu_oracle_run(rays, sd_c, sd_f, full_spec=False):
+    """Time the CPU oracle (== reference arithmetic) on ``rays`` as ONE chunk and return its outputs.
+
+    torch's intra-op pool is not monotone in thread count on many-core hosts (the reference's netchunk = 65536 rows
+    per op bounds what more threads can do, and 256 threads on a small chunk are ~60x slower than 32), so the thread
+    count is probed first - up to all physical cores - and the chunk is timed at the best one, then a small sample at
+    1 thread (the reference script itself pins OMP_NUM_THREADS=1, object_level/run_nerf.py:2-3).  ``full_spec``
+    (--cpu-baseline-full): SURVEY.md section 8d's procedure - median of 3 repeats of a 32768-ray chunk.
+    """
+    import oracle
+    model, physical, avail = host_description()
     cfg = oracle.RenderConfig(variant="object", n_samples=N_SAMPLES, n_importance=N_IMPORTANCE, white_bkgd=True)
-    chunk = 1024
 
-    def run(lo, m=chunk):
+    def run(r):
         with torch.no_grad():
-            oracle.render_rays(rays[lo:lo + m], sd_c, sd_f, cfg)
+            return oracle.render_rays(r, sd_c, sd_f, cfg, stages=True)
 
-    best_t, best_rate = 1, 0.0
-    for t in sorted({min(avail, c) for c in (8, 16, 32, 64, 128, 256)}):    # short probe: 256 rays per width
+    probe_n = min(512, rays.shape[0])
+    widths = sorted({min(avail, c) for c in (8, 16, 32, 64, 128, physical, avail)})
+    best_t, best_rate, probe = 1, 0.0, {}
+    for t in widths:
         torch.set_num_threads(t)
-        run(0, 256)                                             # warm the pool at this width
+        run(rays[:64])                                           # warm the pool at this width
         t0 = time.perf_counter()
-        run(256, 256)
-        rate = 256 / (time.perf_counter() - t0)
+        run(rays[:probe_n])
+        rate = probe_n / (time.perf_counter() - t0)
+        probe[t] = round(rate, 1)
         if rate > best_rate:
             best_t, best_rate = t, rate
         elif rate < 0.5 * best_rate:
-            break                                               # past the knee: wider only gets slower
+            break                                                # past the knee: wider only gets slower
     torch.set_num_threads(best_t)
-    run(0)
-    done, t0 = 0, time.perf_counter()
-    while True:
-        run((done + 2 * chunk) % (rays.shape[0] - chunk))
-        done += chunk
-        dt = time.perf_counter() - t0
-        if dt >= budget_s:
-            break
-    return {"value": done / dt, "unit": "rays/s", "cores": int(best_t), "kind": "port",
-            "sample": f"{done} rays of the same 800x800 frame, 64+128 samples, PyTorch-CPU oracle "
-                      f"(oracle/intrinsic_render.py == reference, see tests/golden) in {dt:.1f} s at {best_t} threads "
-                      f"(best of a thread-count probe; host exposes {avail} logical CPUs)"}
+    times = []
+    for _ in range(3 if full_spec else 1):
+        t0 = time.perf_counter()
+        out = run(rays)
+        times.append(time.perf_counter() - t0)
+    dt = float(np.median(times))
+    torch.set_num_threads(1)
+    n1 = min(2048 if full_spec else 256, rays.shape[0])
+    t0 = time.perf_counter()
+    run(rays[:n1])
+    dt1 = time.perf_counter() - t0
+    torch.set_num_threads(best_t)
+    base = {"value": rays.shape[0] / dt, "unit": "rays/s", "cores": int(best_t), "kind": "port",
+            "single_thread_rays_per_s": n1 / dt1, "cpu_model": model, "physical_cores": physical, "logical_cpus": avail,
+            "thread_probe_rays_per_s": probe, "torch": torch.__version__,
+            "sample": f"{rays.shape[0]} rays of the same 800x800 frame (every {H * W // rays.shape[0]}-th ray) as ONE chunk, "
+                      f"64+128 samples, netchunk 65536, PyTorch-CPU oracle (oracle/intrinsic_render.py == reference, see "
+                      f"tests/golden) in {dt:.1f} s at {best_t} threads ({'median of 3' if full_spec else 'one run'}; best of a "
+                      f"thread-count probe over {list(probe)}); 1 thread: {n1} rays in {dt1:.1f} s"}
+    return out, base
+
+
+def parity_report(frame, sel, o32, o64):
+    """The timed frame's maps at rays ``sel`` against the oracle: (dict for the JSON line, list of violations)."""
+    from oracle import calibration as cal
+    pairs = (("rgb_map", "rgb_fine"), ("disp_map", "disp_fine"), ("acc_map", "acc_fine"), ("albedo_map", "albedo_fine"),
+             ("shading_map", "shading_fine"), ("residual_map", "residual_fine"))
+    tol = lambda k: RTOL_DISP if k.startswith("disp") else RTOL
+    e_ref = {ok: cal.scaled_errors(o32[ok].numpy(), o64[ok].numpy(), tol(ok), ATOL) for _, ok in pairs}
+    stage = ("z_samples", "weights_coarse", "weights_fine", "z_fine", "rgb_coarse", "acc_coarse", "z_std")
+    score = np.maximum.reduce(list(e_ref.values()) + [cal.scaled_errors(o32[k].numpy(), o64[k].numpy(), RTOL, ATOL) for k in stage])
+    well = score <= 0.2
+    problems, per_map = [], {}
+    for fk, ok in pairs:
+        got = frame[fk].reshape(H * W, -1)[sel].cpu().numpy()
+        e = cal.scaled_errors(got, o32[ok].numpy(), tol(ok), ATOL)
+        problems += [f"{fk}: {v}" for v in cal.rank_report(e, e_ref[ok])]
+        worst = float(np.max(e[well], initial=0.0))
+        if worst > 1.0:
+            problems.append(f"{fk}: reproducible rays beyond the plain tolerance (worst {worst:.3g} x tol)")
+        fin = np.where(np.isfinite(e), e, 1e30)
+        fin_r = np.where(np.isfinite(e_ref[ok]), e_ref[ok], 1e30)
+        per_map[fk] = {"q50": float(np.quantile(fin, .5)), "q99": float(np.quantile(fin, .99)), "beyond_tol": int((fin > 1).sum()),
+                       "ref_q50": float(np.quantile(fin_r, .5)), "ref_q99": float(np.quantile(fin_r, .99)),
+                       "ref_beyond_tol": int((fin_r > 1).sum()), "worst_on_reproducible": worst}
+    acc = o32["acc_fine"].numpy()
+    rep = {"rays": int(len(sel)), "reproducible_rays": int(well.sum()), "violations": problems,
+           "acc_quantiles_10_50_90": [float(np.quantile(acc, q)) for q in (.1, .5, .9)],
+           "unit": "tolerances (|got - want| / (1e-5 + 1e-4 |want|); disp: 5e-4)",
+           "criterion": "per map: quantiles 50..99 % of |HIP - oracle_fp32| <= max(0.5, 3 x those of |oracle_fp32 - oracle_fp64|); "
+                        "#(> T) <= 3 x ref + 3 for T in 1, 10, 100; plain tolerance on every ray whose fp32-vs-fp64 score <= 0.2",
+           "maps": per_map}
+    return rep, problems
+
+
+def events_ms(fn, reps=1):
+    """Average GPU time of ``fn()`` in ms by HIP events on the current stream (torch's current stream IS the stream the
+    launchers enqueue on)."""
+    durs = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        b.synchronize()
+        durs.append(a.elapsed_time(b))
+    return sum(durs) / len(durs), durs
 
 
 def main():
@@ -117,7 +208,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle: no cpu_baseline and no parity check")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="SURVEY.md 8d: one 32768-ray chunk x 3 (takes minutes)")
+    ap.add_argument("--no-extras", action="store_true", help="skip configs / train_step / exact-fp32 extras")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -139,33 +232,46 @@ def main():
 
     import __graft_entry__
     __graft_entry__.build()
-    import oracle                                      # only for make_state_dict (seeded default init) + cpu_baseline
+    import oracle                                      # calibrated seeded weights, the parity checker, cpu_baseline
+    from oracle import calibration as cal
     from intrinsicnerf_amd import _capi, distributed as idist, kernels, object_level as ol, packing
 
     # ---- synthetic workload: configs[2], resident in HBM ----
-    focal = 0.5 * W / np.tan(0.5 * CAMERA_ANGLE_X)
-    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+    K = chair_intrinsics()
     ro, rd = ol.get_rays(H, W, K, chair_pose().to(dev))
     ro, rd = ro.reshape(-1, 3).contiguous(), rd.reshape(-1, 3).contiguous()
     n_total = H * W
     b, e = idist.shard_bounds(n_total, rank, world)
     ro_l, rd_l = ro[b:e].contiguous(), rd[b:e].contiguous()
     n_local = e - b
+    # strided sample of the WHOLE frame (identical on every rank): calibrates the density head, and is what the oracle
+    # renders for the parity check and the CPU baseline
+    sel = torch.arange(0, n_total, n_total // PARITY_RAYS + 1, device=dev)[:PARITY_RAYS]
+    vd_s = rd[sel] / rd[sel].norm(dim=-1, keepdim=True)
+    rays_s = torch.cat([ro[sel], rd[sel], NEAR * torch.ones_like(vd_s[:, :1]), FAR * torch.ones_like(vd_s[:, :1]), vd_s], -1).cpu()
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    sd_c = cal.calibrated_default_init("object", 0, 0, rays_s)      # default init, seeds 0 / 1, calibrated density head
+    sd_f = cal.calibrated_default_init("object", 0, 1, rays_s)
     embed, ch = ol.get_embedder(10, 0)
     embed_d, ch_d = ol.get_embedder(4, 0)
     mk = lambda: ol.NeRF(D=8, W=256, input_ch=ch, output_ch=5, skips=[4], input_ch_views=ch_d, use_viewdirs=True).to(dev)
     net_c, net_f = mk(), mk()
-    net_c.load_state_dict(oracle.make_state_dict("object", seed=0))      # random-init weights, seeds 0 / 1
-    net_f.load_state_dict(oracle.make_state_dict("object", seed=1))
-    kw = dict(network_fn=net_c, network_fine=net_f, network_query_fn=ol.NetworkQuery(embed, embed_d), N_samples=N_SAMPLES,
+    net_c.load_state_dict(sd_c)
+    net_f.load_state_dict(sd_f)
+    query = ol.NetworkQuery(embed, embed_d)
+    kw = dict(network_fn=net_c, network_fine=net_f, network_query_fn=query, N_samples=N_SAMPLES,
               N_importance=N_IMPORTANCE, white_bkgd=True, perturb=False, raw_noise_std=0., use_viewdirs=True, ndc=False,
               lindisp=False)
+    map_keys = ("rgb_map", "disp_map", "acc_map", "albedo_map", "shading_map", "residual_map")
+
+    def render_band(o, d, **over):
+        with torch.no_grad():
+            r = ol.render(H, W, K, chunk=max(1, o.shape[0]), rays=(o, d), near=NEAR, far=FAR, **{**kw, **over})
+        return dict(zip(map_keys, r[:6])), r[6]
 
     def step():
-        with torch.no_grad():
-            r = ol.render(H, W, K, chunk=n_local, rays=(ro_l, rd_l), near=NEAR, far=FAR, **kw)
-            maps = dict(zip(("rgb_map", "disp_map", "acc_map", "albedo_map", "shading_map", "residual_map"), r[:6]))
-            return idist.gather_maps(maps, n_total) if world > 1 else maps
+        maps, _ = render_band(ro_l, rd_l)
+        return idist.gather_maps(maps, n_total) if world > 1 else maps
 
     def fence():
         if world > 1:
@@ -193,6 +299,52 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         assert torch.equal(lo, hi), "ranks disagree on the gathered frame"
     rays_per_s = n_total * args.steps / dt
+    ms_per_step = dt / args.steps * 1e3
+
+    # ---- where a frame's wall time goes besides the kernels (untimed relative to `value`) ----
+    def wall_and_gpu(fn, reps):
+        fence()
+        t1 = time.perf_counter()
+        gpu_ms, _ = events_ms(fn, reps)          # each repetition ends with an event synchronise, like a frame's consumer
+        return (time.perf_counter() - t1) / reps * 1e3, gpu_ms
+
+    reps = max(1, min(args.steps, 3))
+    wall_ms, gpu_ms = wall_and_gpu(lambda: render_band(ro_l, rd_l), reps)
+    band = 80000                                    # what one of 8 GPUs renders of this frame
+    band_wall, band_gpu = wall_and_gpu(lambda: render_band(ro_l[:band], rd_l[:band]), 3)
+    maps_l, _ = render_band(ro_l, rd_l)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    if world > 1:
+        idist.gather_maps(maps_l, n_total)
+    else:
+        idist.unpack_maps(idist.pack_maps(maps_l))   # N = 1: the local part of the gather (pack into the [n, 12] block)
+    fence()
+    gather_ms = (time.perf_counter() - t1) * 1e3
+    packing.invalidate(net_c)
+    packing.invalidate(net_f)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    d0 = net_c.fused_desc()
+    packing.packed_for_module(net_c, d0, dev)
+    packing.packed_for_module(net_f, d0, dev)
+    torch.cuda.synchronize()
+    pack_ms = (time.perf_counter() - t1) * 1e3
+    st = torch.zeros(1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(20):
+        st.item()
+    sync_ms = (time.perf_counter() - t1) / 20 * 1e3
+    frame_costs = {
+        "render_wall_ms": wall_ms, "render_gpu_ms": gpu_ms, "non_kernel_ms": wall_ms - gpu_ms,
+        "non_kernel_frac": (wall_ms - gpu_ms) / wall_ms,
+        "band_80000_rays": {"wall_ms": band_wall, "gpu_ms": band_gpu, "non_kernel_frac": (band_wall - band_gpu) / band_wall},
+        "gather_ms": gather_ms, "gather_note": ("all_gather_into_tensor of 12 floats/ray straight into the final layout"
+                                                if world > 1 else "N = 1: pack into the [n, 12] gather block + views (no collective)"),
+        "repack_after_weight_update_ms": pack_ms, "status_read_ms": sync_ms,
+        "note": "render_gpu_ms: HIP events around one frame's launches; non_kernel = wall - that (host launch path, the one "
+                "end-of-frame read of the f16 range word, allocator); packing only after a weight update (cached otherwise)"}
 
     # ---- roofline of the dominant kernel: HIP events around its launches, same sizes as the timed region ----
     vd = rd_l / rd_l.norm(dim=-1, keepdim=True)
@@ -200,6 +352,21 @@ def main():
     t_vals = torch.linspace(0., 1., N_SAMPLES, device=dev)
     u = torch.linspace(0., 1., N_IMPORTANCE, device=dev)
     flop_per_launch = FLOP_PER_POINT * n_local * (N_SAMPLES + (N_SAMPLES + N_IMPORTANCE)) / 2.0   # mean of the two launches
+
+    def roofline_entry(f16, kernel, achieved, avg_ms, n_launches, flop, traffic_pts):
+        peak = PEAK_F16_MFMA_TFLOPS / 3.0 if f16 else PEAK_F32_MFMA_TFLOPS
+        bpp = PMC_HBM_BYTES_PER_POINT["f16x3" if f16 else "f32"]
+        return {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                "traffic": bpp * traffic_pts,
+                "traffic_note": f"HBM bytes per launch = {bpp} B/point measured by rocprofv3 PMC (FETCH_SIZE, WRITE_SIZE in separate "
+                                f"passes, profiles/r01_mlp_pmc_traffic.txt) x this launch's points; {'1.15' if f16 else '1.02'}x algorithmic",
+                "avg_launch_ms": avg_ms, "launches_timed": n_launches, "flop_per_launch": flop,
+                "peak_basis": ("dense f16 MFMA 2500 TFLOP/s / 3 products per fp32 MAC" if f16 else "dense fp32 MFMA 157.3 TFLOP/s"),
+                "achieved_vs_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
+                # what the matrix pipe sustains on this board when it does nothing but MFMAs on random operands
+                # (scripts/microbench/mfma_peak.hip, profiles/r01_mfma_peak_microbench.txt): the power budget, not the name-plate
+                "measured_mfma_only_ceiling": (MEASURED_F16_MFMA_ONLY_TFLOPS / 3.0) if f16 else None,
+                "frac_of_measured_ceiling": (achieved / (MEASURED_F16_MFMA_ONLY_TFLOPS / 3.0)) if f16 else None}
 
     def kernel_roofline(prec, reps):
         desc = _capi.net_desc(_capi.VARIANT_OBJECT, 0, 10, 4, 1.0, prec)
@@ -211,45 +378,29 @@ def main():
         durs = []                                              # one entry per launch [ms]
         for _ in range(reps):
             for packed, z in ((pc, z_c), (pf, z_f)):
-                a, bb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record()
-                kernels.encode_mlp(desc, packed, rays_l, z)
-                bb.record()
-                bb.synchronize()
-                durs.append(a.elapsed_time(bb))
+                durs += events_ms(lambda: kernels.encode_mlp(desc, packed, rays_l, z))[1]
         avg_ms = sum(durs) / len(durs)
-        achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12
         f16 = prec == _capi.PREC_F16X3
-        peak = PEAK_F16_MFMA_TFLOPS / 3.0 if f16 else PEAK_F32_MFMA_TFLOPS
-        return {"bound": "mfma", "kernel": "k_encode_mlp_f16x3_dual<false, false>" if f16 else "k_encode_mlp<false, 2>", "achieved": achieved,
-                "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                "traffic": PMC_HBM_BYTES_PER_POINT["f16x3" if f16 else "f32"] * n_local * (N_SAMPLES + (N_SAMPLES + N_IMPORTANCE)) / 2.0,
-                "traffic_note": f"HBM bytes per launch = {PMC_HBM_BYTES_PER_POINT['f16x3' if f16 else 'f32']} B/point measured by "
-                                "rocprofv3 PMC (FETCH_SIZE, WRITE_SIZE in separate passes, profiles/r01_mlp_pmc_traffic.txt) x this "
-                                f"launch's points; {'1.15' if f16 else '1.02'}x algorithmic",
-                "avg_launch_ms": avg_ms,
-                "launches_timed": len(durs), "flop_per_launch": flop_per_launch,
-                "peak_basis": ("dense f16 MFMA 2500 TFLOP/s / 3 products per fp32 MAC" if f16
-                               else "dense fp32 MFMA 157.3 TFLOP/s"),
-                "achieved_vs_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
-                # what the matrix pipe sustains on this board when it does nothing but MFMAs on random operands
-                # (scripts/microbench/mfma_peak.hip, profiles/r01_mfma_peak_microbench.txt): the power budget, not the name-plate
-                "measured_mfma_only_ceiling": (MEASURED_F16_MFMA_ONLY_TFLOPS / 3.0) if f16 else None,
-                "frac_of_measured_ceiling": (achieved / (MEASURED_F16_MFMA_ONLY_TFLOPS / 3.0)) if f16 else None}
+        out = roofline_entry(f16, "k_encode_mlp_f16x3_dual<false, false>" if f16 else "k_encode_mlp<false, 2>",
+                             flop_per_launch / (avg_ms * 1e-3) / 1e12, avg_ms, len(durs), flop_per_launch,
+                             n_local * (N_SAMPLES + (N_SAMPLES + N_IMPORTANCE)) / 2.0)
+        coarse_ms = sum(durs[0::2]) / len(durs[0::2])          # the coarse-shaped launches alone = configs[1]'s kernel
+        return out, (z_c, coarse_ms)
 
     prec = _capi.default_precision()
-    roofline = kernel_roofline(prec, max(1, args.steps))
-    roofline_f32 = roofline if prec == _capi.PREC_F32 else kernel_roofline(_capi.PREC_F32, 1)
+    f16 = prec == _capi.PREC_F16X3
+    roofline, (z_coarse, coarse_launch_ms) = kernel_roofline(prec, max(1, args.steps))
+    roofline_f32 = roofline if prec == _capi.PREC_F32 else kernel_roofline(_capi.PREC_F32, 1)[0]
 
+    extras = rank == 0 and world == 1 and not args.no_extras
     # the same frame through the product front-end with the exact-fp32 MFMA kernel, for reference (one timed step)
     exact = None
-    if prec != _capi.PREC_F32:
-        os.environ["INERF_PRECISION"] = "f32"
-        step(); fence()
-        t1 = time.perf_counter()
-        step(); fence()
-        dt32 = time.perf_counter() - t1
-        os.environ["INERF_PRECISION"] = "f16x3"
+    if prec != _capi.PREC_F32 and not args.no_extras:
+        with _capi.forced_precision(_capi.PREC_F32):
+            step(); fence()
+            t1 = time.perf_counter()
+            step(); fence()
+            dt32 = time.perf_counter() - t1
         if world > 1:
             t = torch.tensor([dt32], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -257,13 +408,68 @@ def main():
         exact = {"value": n_total / dt32, "unit": "rays/s", "ms_per_step": dt32 * 1e3, "steps": 1,
                  "note": "whole path with INERF_PRECISION=f32 (v_mfma_f32_32x32x2_f32 everywhere)"}
 
+    # ---- BASELINE.json configs[1] and configs[3] through their front-ends (rank 0, N = 1 only; not part of `value`) ----
+    configs = None
+    if extras:
+        configs = {}
+        # configs[1]: the same 800x800 frame, 64 coarse samples only (run_nerf.py:492-493 without the fine pass), white bkgd
+        co = dict(N_importance=0, network_fine=None)
+        render_band(ro_l, rd_l, **co); fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            cmaps, _ = render_band(ro_l, rd_l, **co)
+        fence()
+        dtc = (time.perf_counter() - t1) / args.steps
+        assert torch.isfinite(cmaps["rgb_map"]).all()
+        flop_c = FLOP_PER_POINT * n_local * N_SAMPLES
+        configs["coarse_only_800x800"] = {
+            "workload": "Blender chair 800x800, 64 coarse samples, coarse network only, white_bkgd, eval (BASELINE configs[1])",
+            "value": n_total / dtc, "unit": "rays/s", "ms_per_step": dtc * 1e3, "steps": args.steps,
+            "roofline": roofline_entry(f16, roofline["kernel"], flop_c / (coarse_launch_ms * 1e-3) / 1e12, coarse_launch_ms,
+                                       max(1, args.steps), flop_c, n_local * N_SAMPLES)}
+        # configs[3]: Replica room_0-like 320x240 frame through ssr.SSRRenderer.render_rays (C = 28, 64+128, chunk 32768)
+        from intrinsicnerf_amd import ssr
+        SH, SW = 240, 320
+        fx = SW / 2.0 / np.tan(np.deg2rad(45.0))
+        srays = ssr.create_rays(1, torch.eye(4)[None], SH, SW, fx, fx, (SW - 1) / 2.0, (SH - 1) / 2.0, 0.1, 10.0).reshape(-1, 11).contiguous()
+        r = ssr.SSRRenderer(SSR_CLASSES, white_bkgd=False, endpoint_feat=False, device=dev)
+        ssel = srays[::srays.shape[0] // 1024]
+        r.ssr_net_coarse.load_state_dict(cal.calibrated_default_init("ssr", SSR_CLASSES, 0, ssel))
+        r.ssr_net_fine.load_state_dict(cal.calibrated_default_init("ssr", SSR_CLASSES, 1, ssel))
+        r.return_raw = False
+        r.check_numerics = False
+        srays = srays.to(dev)
+        with torch.no_grad():
+            sret = r.render_rays(srays); fence()
+            t1 = time.perf_counter()
+            for _ in range(max(3, args.steps)):
+                sret = r.render_rays(srays)
+            fence()
+        dts = (time.perf_counter() - t1) / max(3, args.steps)
+        assert torch.isfinite(sret["rgb_fine"]).all() and float(sret["acc_fine"].min()) < 0.999
+        sdesc = r.ssr_net_fine.fused_desc()
+        sdesc.xyz_div = 10.0
+        spk = packing.packed_for_module(r.ssr_net_fine, sdesc, dev)
+        chunk = srays[:32768].contiguous()
+        sz = torch.sort(torch.rand(chunk.shape[0], N_SAMPLES + N_IMPORTANCE, device=dev) * 9.9 + 0.1, -1)[0]
+        kernels.encode_mlp(sdesc, spk, chunk, sz)
+        s_ms, s_durs = events_ms(lambda: kernels.encode_mlp(sdesc, spk, chunk, sz), 3)
+        flop_s = FLOP_PER_POINT_SSR * chunk.shape[0] * (N_SAMPLES + N_IMPORTANCE)
+        configs["ssr_room0_320x240"] = {
+            "workload": f"Replica room_0-like 320x240 frame (76800 rays), Semantic_NeRF C = {SSR_CLASSES}, 64+128 samples, depth "
+                        "[0.1, 10], xyz/10, eval, 3 chunks of <= 32768 rays (BASELINE configs[3])",
+            "value": srays.shape[0] / dts, "unit": "rays/s", "ms_per_step": dts * 1e3, "steps": max(3, args.steps),
+            "frame_tflops_algorithmic": FLOP_PER_POINT_SSR * srays.shape[0] * (2 * N_SAMPLES + N_IMPORTANCE) / dts / 1e12,
+            "roofline": roofline_entry(f16, "k_encode_mlp_f16x3_dual<false, true>" if f16 else "k_encode_mlp<true, 2>",
+                                       flop_s / (s_ms * 1e-3) / 1e12, s_ms, len(s_durs), flop_s, chunk.shape[0] * (N_SAMPLES + N_IMPORTANCE))}
+        del r, sret, srays, spk, sz
+
     # the reference's training step through the same front-end (rank 0, N = 1 only; untimed
     # relative to `value`): 1024 rays + one neighbour each (run_nerf.py:918-929), 64 + 128 samples, forward + backward + Adam
     train = None
-    if rank == 0 and world == 1 and prec == _capi.PREC_F16X3:
+    if extras and prec == _capi.PREC_F16X3:
         import warnings
         tnet_c, tnet_f = mk(), mk()
-        query = ol.NetworkQuery(embed, embed_d)
         opt = torch.optim.Adam(list(tnet_c.parameters()) + list(tnet_f.parameters()), lr=5e-4)
         tr = rays_l[torch.randperm(rays_l.shape[0], device=dev)[:2048]].contiguous()
         target = torch.rand(tr.shape[0], 3, device=dev)
@@ -290,25 +496,44 @@ def main():
                  "note": "the reference's training batch (2048 rays x (64+128) samples) through object_level.render_rays under "
                          "autograd: HIP forward + backward (networks, compositing) + torch Adam; not part of `value`"}
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
+    # ---- CPU oracle on the sampled rays of the timed frame: cpu_baseline (its fp32 run, timed) + parity (fp32 and fp64) ----
+    cpu = parity = None
+    problems = []
+    if rank == 0 and not args.no_cpu_baseline:
+        if args.cpu_baseline_full:
+            sel_full = torch.arange(0, n_total, n_total // 32768 + 1, device=dev)[:32768]
+            vdf = rd[sel_full] / rd[sel_full].norm(dim=-1, keepdim=True)
+            rays_full = torch.cat([ro[sel_full], rd[sel_full], NEAR * torch.ones_like(vdf[:, :1]), FAR * torch.ones_like(vdf[:, :1]), vdf], -1).cpu()
+            _, cpu = cpu_oracle_run(rays_full, sd_c, sd_f, full_spec=True)
+            o32, _ = cpu_oracle_run(rays_s, sd_c, sd_f)
+        else:
+            o32, cpu = cpu_oracle_run(rays_s, sd_c, sd_f)
+        to64 = lambda sd: {k: v.double() for k, v in sd.items()}
+        with torch.no_grad():
+            o64 = oracle.render_rays(rays_s.double(), to64(sd_c), to64(sd_f),
+                                     oracle.RenderConfig(variant="object", n_samples=N_SAMPLES, n_importance=N_IMPORTANCE, white_bkgd=True),
+                                     stages=True)
+        parity, problems = parity_report(frame, sel, o32, o64)
 
     if rank == 0:
         print(json.dumps({
             "metric": "rays/sec (64+128 samples/ray)", "value": rays_per_s, "unit": "rays/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32 (operands split into f16 hi+lo, 3 f16 MFMA products per MAC, fp32 accumulate)"
-                     if prec == _capi.PREC_F16X3 else "f32", "data": "synthetic",
+            "dtype": "f32 (operands split into f16 hi+lo, 3 f16 MFMA products per MAC, fp32 accumulate)" if f16 else "f32",
+            "data": "synthetic",
             "config": {"workload": "Blender chair 800x800 frame (640000 rays), 64 coarse + 128 importance samples, "
-                                   "coarse+fine intrinsic NeRF (D=8, W=256), white_bkgd, eval mode, random-init weights "
-                                   "(seeds 0/1)", "rays_per_step": n_total, "parallelism": f"ray-sharded x{world}",
+                                   "coarse+fine intrinsic NeRF (D=8, W=256), white_bkgd, eval mode, default-init weights "
+                                   "(seeds 0/1) with the density head calibrated so that acc spans (0, 1]",
+                       "rays_per_step": n_total, "parallelism": f"ray-sharded x{world}",
                        "gather": "all_gather of 12 floats/ray" if world > 1 else "none"},
-            "roofline": roofline, "roofline_f32_kernel": roofline_f32, "exact_f32_path": exact, "train_step": train,
-            "cpu_baseline": cpu}))
+            "roofline": roofline, "roofline_f32_kernel": roofline_f32, "exact_f32_path": exact, "parity": parity,
+            "configs": configs, "frame_costs": frame_costs, "train_step": train, "cpu_baseline": cpu}))
+        sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
+    if problems:
+        raise SystemExit("bench.py: the timed frame does NOT match the oracle:\n" + "\n".join(problems))
 
 
 if __name__ == "__main__":

@@ -102,3 +102,49 @@ class injected_np_rand:
     def __exit__(self, *exc):
         np.random.rand = self.saved
         assert exc[0] is not None or not self.q, "front-end made fewer RNG draws than the reference"
+
+
+# ------------------------------------------------------------------------------------------------
+# un-curated fixtures (tests/golden/make_golden_uncurated.py): default-init networks, unfiltered rays
+# ------------------------------------------------------------------------------------------------
+def uncurated_weights(fx):
+    """The two default-init state dicts of an ``uncurated_*`` fixture: seeded ``make_state_dict`` plus the stored
+    calibration of the density head (a power-of-two gain on alpha_linear.weight, the bias as stored)."""
+    variant, c = str(fx["variant"]), int(fx["n_classes"])
+    out = []
+    for lvl in ("coarse", "fine"):
+        sd = oracle.make_state_dict(variant, c, seed=int(fx["seed_" + lvl]))
+        sd["alpha_linear.weight"] = sd["alpha_linear.weight"] * float(fx["alpha_gain_" + lvl])
+        sd["alpha_linear.bias"] = torch.full_like(sd["alpha_linear.bias"], float(fx["alpha_bias_" + lvl]))
+        out.append(sd)
+    return out
+
+
+def uncurated_config(fx):
+    variant = str(fx["variant"])
+    return oracle.RenderConfig(variant=variant, n_samples=64, n_importance=int(fx["n_importance"]), white_bkgd=bool(fx["white_bkgd"]),
+                               n_classes=int(fx["n_classes"]), netchunk=32768 if variant == "ssr" else 65536)
+
+
+def uncurated_judge(fx, got, tag, rtol=1e-4, atol=1e-5, rtol_disp=5e-4):
+    """Judge ``got`` (dict of arrays under the oracle's key names) against an un-curated fixture: every output map on
+    EVERY ray by rank statistics against the reference's own fp32-vs-fp64 distance, and the plain tolerance on every ray
+    the reference arithmetic reproduces (score over maps and stage tensors <= 0.2; for coarse maps: every ray).
+    Returns (list of violations, one-line-per-map summary)."""
+    from oracle import calibration as cal
+    keys = [k[4:] for k in fx if k.startswith("ref_")]
+    tol = lambda k: rtol_disp if k.startswith("disp") else rtol
+    e_ref = {k: cal.scaled_errors(fx["ref_" + k], fx["f64_" + k], tol(k), atol) for k in keys}
+    score = np.maximum.reduce(list(e_ref.values()) + [fx[k] for k in fx if k.startswith("stage_score_")])
+    well = score <= 0.2
+    problems, lines = [], [f"{tag}: {len(well)} unfiltered rays, {int(well.sum())} reproducible"]
+    for k in keys:
+        e = cal.scaled_errors(np.asarray(got[k]), fx["ref_" + k], tol(k), atol)
+        problems += [f"{tag}:{k}: {v}" for v in cal.rank_report(e, e_ref[k])]
+        strict = np.ones_like(well) if k.endswith("_coarse") else well
+        worst = float(np.max(e[strict], initial=0.0))
+        if worst > 1.0:
+            problems.append(f"{tag}:{k}: {int((e[strict] > 1).sum())} of {int(strict.sum())} reproducible rays beyond the plain "
+                            f"tolerance (worst {worst:.3g})")
+        lines.append(f"  {k:16s} vs reference: {cal.summarize(e)} | reference vs fp64: {cal.summarize(e_ref[k])}")
+    return problems, "\n".join(lines)

@@ -87,3 +87,78 @@ def test_psnr_delta_within_budget(monkeypatch):
     spec.loader.exec_module(mod)
     monkeypatch.setattr(sys, "argv", ["psnr_delta.py", "--side", "16"])
     assert mod.main() <= 1e-4
+
+
+def test_full_ssr_frame_properties(precision):
+    """BASELINE configs[3] at full size: the 320x240 Replica-like frame (76 800 rays, C = 28, 64+128 samples) through
+    ``SSRRenderer.render_rays`` exactly as the reference's trainer calls it (chunk = 32768 -> three chunks, raw_coarse /
+    raw_fine returned: ~3 GB).  Size-independent properties on every ray, chunk invariance bit for bit, and a 256-ray
+    strided spot check against the oracle judged like tests/test_unfiltered_parity.py (default-init network, nothing
+    filtered)."""
+    import numpy as np
+    from intrinsicnerf_amd import ssr
+    from oracle import calibration as cal
+    dev = torch.device("cuda:0")
+    H, W, C = 240, 320, 28
+    fx = W / 2.0 / np.tan(np.deg2rad(45.0))
+    rays = ssr.create_rays(1, torch.eye(4)[None], H, W, fx, fx, (W - 1) / 2.0, (H - 1) / 2.0, 0.1, 10.0).reshape(-1, 11).contiguous()
+    idx = torch.arange(0, H * W, H * W // 256 + 1)[:256]
+    sd_c = cal.calibrated_default_init("ssr", C, 0, rays[idx])
+    sd_f = cal.calibrated_default_init("ssr", C, 1, rays[idx])
+    r = ssr.SSRRenderer(C, white_bkgd=False, endpoint_feat=False, chunk=1024 * 32, device=dev)
+    r.ssr_net_coarse.load_state_dict(sd_c); r.ssr_net_fine.load_state_dict(sd_f)
+    r.check_numerics = False
+    with torch.no_grad():
+        ret = r.render_rays(rays.to(dev))
+    torch.cuda.synchronize()
+    n = H * W
+    assert tuple(ret["raw_coarse"].shape) == (n, 64, 11 + C) and tuple(ret["raw_fine"].shape) == (n, 192, 11 + C)
+    assert tuple(ret["sem_logits_fine"].shape) == (n, C) and tuple(ret["z_std"].shape) == (n,)
+    for k, v in ret.items():
+        if not k.startswith("disp"):
+            assert torch.isfinite(v).all(), k
+    for lvl in ("coarse", "fine"):
+        acc = ret["acc_" + lvl]
+        assert (acc >= 0).all() and (acc <= 1 + 1e-5).all()
+        assert torch.equal(torch.isnan(ret["disp_" + lvl]), acc == 0)
+        hit = acc > 1e-3
+        ratio = ret["depth_" + lvl][hit] / acc[hit]
+        assert (ratio >= 0.1 - 1e-3).all() and (ratio <= 10.0 + 1e-2).all()
+        # rgb = albedo*shading + residual per sample, composited with the same weights (no white background here)
+        assert ret["rgb_" + lvl].min() >= 0 and ret["rgb_" + lvl].max() <= 2.0 + 1e-4
+    assert float(ret["acc_fine"].min()) < 0.9 and float((ret["acc_fine"] > 0.999).float().mean()) > 0.05      # non-degenerate frame
+    # chunking is invisible: one 76 800-ray chunk and 7 ragged ones give the same bits
+    raw_f = ret.pop("raw_fine"); ret.pop("raw_coarse")
+    r.return_raw = False
+    for chunk in (n, 12345):
+        r.chunk = chunk
+        with torch.no_grad():
+            again = r.render_rays(rays.to(dev))
+        for k in ret:
+            assert torch.equal(torch.nan_to_num(again[k]), torch.nan_to_num(ret[k])), (chunk, k)
+    # the returned raw is what the maps were composited from: no density above zero <=> nothing accumulated
+    assert bool(((raw_f[..., 3].amax(1) <= 0) <= (ret["acc_fine"] == 0)).all())
+    del raw_f
+    # spot check against the oracle
+    cfg = oracle.RenderConfig(variant="ssr", white_bkgd=False, n_classes=C, netchunk=32768)
+    sub = rays[idx]
+    to64 = lambda sd: {k: v.double() for k, v in sd.items()}
+    with torch.no_grad():
+        o32 = oracle.render_rays(sub, sd_c, sd_f, cfg, stages=True)
+        o64 = oracle.render_rays(sub.double(), to64(sd_c), to64(sd_f), cfg, stages=True)
+    ren = {"sem_logits_coarse": "sem_coarse", "sem_logits_fine": "sem_fine"}
+    keys = [k for k in ret if not k.startswith("raw")]
+    tol = lambda k: 5e-4 if k.startswith("disp") else 1e-4
+    e_ref = {k: cal.scaled_errors(o32[ren.get(k, k)].numpy(), o64[ren.get(k, k)].numpy(), tol(k)) for k in keys}
+    score = np.maximum.reduce(list(e_ref.values()) + [cal.scaled_errors(o32[k].numpy(), o64[k].numpy())
+                                                     for k in ("z_samples", "weights_coarse", "weights_fine", "z_fine")])
+    well = score <= 0.2
+    assert well.sum() >= 30
+    problems = []
+    for k in keys:
+        e = cal.scaled_errors(ret[k][idx.to(dev)].cpu().numpy(), o32[ren.get(k, k)].numpy(), tol(k))
+        problems += [f"{k}: {v}" for v in cal.rank_report(e, e_ref[k])]
+        strict = np.ones_like(well) if k.endswith("_coarse") else well
+        if float(np.max(e[strict], initial=0.0)) > 1.0:
+            problems.append(f"{k}: reproducible rays beyond the plain tolerance (worst {float(e[strict].max()):.3g})")
+    assert not problems, "\n".join(problems)

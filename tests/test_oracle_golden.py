@@ -100,3 +100,21 @@ def test_oracle_equals_the_live_reference_on_random_configurations():
     out = subprocess.run([sys.executable, script, "--cases", "6", "--seed", "1"], capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "oracle == reference on 18 random configurations" in out.stdout
+
+
+@pytest.mark.parametrize("name", golden_names("uncurated_"))
+def test_uncurated_fixtures_replay(name, torch_threads):
+    """Un-curated fixtures (default-init networks, unfiltered rays of the benchmark frames, outputs of the REAL reference -
+    tests/golden/make_golden_uncurated.py): the oracle reproduces the reference (bit for bit on the CPU that wrote them;
+    on another CPU within what the reference's own fp32-vs-fp64 distance allows, ray ranks compared)."""
+    from _cases import uncurated_config, uncurated_judge, uncurated_weights
+    fx = load_golden(name)
+    sd_c, sd_f = uncurated_weights(fx)
+    cfg = uncurated_config(fx)
+    with torch.no_grad():
+        out = oracle.render_rays(torch.from_numpy(fx["rays"]), sd_c, sd_f if cfg.n_importance > 0 else None, cfg)
+    problems, summary = uncurated_judge(fx, {k: v.numpy() for k, v in out.items()}, name)
+    assert not problems, "\n".join(problems) + "\n" + summary
+    assert "ref_rgb_coarse" in fx and (cfg.n_importance == 0 or "ref_z_std" in fx)
+    acc = fx["ref_acc_fine" if cfg.n_importance > 0 else "ref_acc_coarse"]
+    assert acc.min() < 0.9 and acc.max() > 0.999              # not the all-background frame

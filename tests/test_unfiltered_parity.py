@@ -20,6 +20,8 @@ import pytest
 import torch
 
 import oracle
+from _cases import uncurated_config, uncurated_judge, uncurated_weights
+from conftest import golden_names, load_golden
 from oracle import calibration as cal
 
 pytestmark = pytest.mark.gpu
@@ -127,3 +129,26 @@ def test_unfiltered_rays_rank_statistics(variant, precision):
     print(f"\n[{variant}/{precision}] {len(rays)} unfiltered rays, {int(well.sum())} reproducible (score <= 0.2)")
     for k in keys:
         print(f"  {k:16s} hip-vs-fp32: {cal.summarize(e_hip[k])}\n  {'':16s} fp32-vs-fp64: {cal.summarize(e_ref[k])}")
+
+
+@pytest.mark.parametrize("name", golden_names("uncurated_"))
+def test_uncurated_reference_fixtures(name, precision):
+    """The same judgement against outputs of the REAL reference (tests/golden/make_golden_uncurated.py): default-init
+    networks, every k-th ray of the benchmark frames, nothing selected.  ``uncurated_object_coarse_only_wb`` is BASELINE
+    configs[1] in miniature (64 coarse samples, coarse network only, white background): every ray at the plain tolerance."""
+    from intrinsicnerf_amd import _capi, kernels, packing
+    fx = load_golden(name)
+    cfg = uncurated_config(fx)
+    sd_c, sd_f = uncurated_weights(fx)
+    dev = torch.device("cuda:0")
+    ssr = cfg.variant == "ssr"
+    desc = _capi.net_desc(_capi.VARIANT_SSR if ssr else _capi.VARIANT_OBJECT, cfg.n_classes if ssr else 0, 10, 4, cfg.xyz_div)
+    ni = cfg.n_importance
+    got = kernels.render_rays_fused(desc, packing.pack_state_dict(desc, sd_c).to(dev),
+                                    packing.pack_state_dict(desc, sd_f).to(dev) if ni > 0 else None,
+                                    torch.from_numpy(fx["rays"]).to(dev), 64, ni, torch.linspace(0., 1., 64).to(dev),
+                                    torch.linspace(0., 1., ni).to(dev) if ni > 0 else None, white_bkgd=cfg.white_bkgd)
+    kernels.check_f16_range(got.pop("status", None), "test")
+    problems, summary = uncurated_judge(fx, {k: v.cpu().numpy() for k, v in got.items()}, f"{name}/{precision}")
+    print("\n" + summary)
+    assert not problems, "\n".join(problems) + "\n" + summary
