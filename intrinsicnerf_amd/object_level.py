@@ -130,6 +130,36 @@ class NetworkQuery:
         return run_network(inputs, viewdirs, network_fn, self.embed_fn, self.embeddirs_fn, self.netchunk)
 
 
+def _as_network_query(q):
+    """``q`` as a NetworkQuery if it is one - or if it is, structurally, the closure the reference's create_nerf builds
+    (run_nerf.py:298-301):
+
+        lambda inputs, viewdirs, network_fn: run_network(inputs, viewdirs, network_fn, embed_fn=embed_fn,
+                                                         embeddirs_fn=embeddirs_fn, netchunk=args.netchunk)
+
+    i.e. a 3-argument function whose only global is THIS package's ``run_network`` and whose closure holds ``embed_fn``
+    and ``embeddirs_fn``.  A run_nerf.py that merely imports this module's symbols therefore takes the fused path with
+    its create_nerf untouched.  Anything else returns None and is called as given (the staged path)."""
+    if isinstance(q, NetworkQuery):
+        return q
+    code, cells, glob = getattr(q, "__code__", None), getattr(q, "__closure__", None), getattr(q, "__globals__", None)
+    if code is None or cells is None or glob is None or code.co_argcount != 3 or code.co_kwonlyargcount:
+        return None
+    if not set(code.co_names) <= {"run_network", "netchunk"} or "run_network" not in code.co_names:
+        return None
+    target = glob.get("run_network")
+    if target is None or getattr(target, "__module__", "").split(".")[0] != __name__.split(".")[0] or target.__name__ != "run_network":
+        return None
+    free = dict(zip(code.co_freevars, cells))
+    try:
+        embed_fn, embeddirs_fn = free["embed_fn"].cell_contents, free["embeddirs_fn"].cell_contents
+    except (KeyError, ValueError):
+        return None
+    if not isinstance(embed_fn, Embedder) or not isinstance(embeddirs_fn, Embedder):
+        return None
+    return NetworkQuery(embed_fn, embeddirs_fn)
+
+
 def _fusable(network_fn, embed_fn, embeddirs_fn):
     """Descriptor if (network, encoders) is a combination the fused kernel implements, else None."""
     if not hasattr(network_fn, "fused_desc"):
@@ -277,10 +307,10 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
         raise NotImplementedError("render_rays without view directions: the 11-channel intrinsic network needs "
                                   "use_viewdirs=True (run_nerf_helpers.py:281-282 is unused by every config)")
     desc = None
-    if isinstance(network_query_fn, NetworkQuery):
-        desc = _fusable(network_fn, network_query_fn.embed_fn, network_query_fn.embeddirs_fn)
-        if desc is not None and network_fine is not None and _fusable(
-                network_fine, network_query_fn.embed_fn, network_query_fn.embeddirs_fn) is None:
+    nq = _as_network_query(network_query_fn)
+    if nq is not None:
+        desc = _fusable(network_fn, nq.embed_fn, nq.embeddirs_fn)
+        if desc is not None and network_fine is not None and _fusable(network_fine, nq.embed_fn, nq.embeddirs_fn) is None:
             desc = None
     # random inputs, drawn in the reference's order: t_rand (:478), coarse noise (:387), u (helpers:414), fine noise
     t_vals = torch.linspace(0., 1., steps=N_samples, device=dev)
@@ -334,7 +364,7 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
         # the network is called as given / through its torch forward
         rays_o, rays_d, viewdirs = ray_batch[:, 0:3], ray_batch[:, 3:6].contiguous(), ray_batch[:, -3:]
         def query(z, fn):
-            raw = _train_query(train_desc, fn, ray_batch, z) if train_desc is not None else None
+            raw = _train_query(train_desc, fn, ray_batch, z) if train_desc is not None else None        # nq's encoders
             if raw is None:
                 pts = rays_o[..., None, :] + rays_d[..., None, :] * z[..., :, None]
                 raw = network_query_fn(pts, viewdirs, fn)

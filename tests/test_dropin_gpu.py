@@ -1,0 +1,236 @@
+"""GPU: the reference's own call sites, replayed.  A maintainer switches to this package by importing its symbols into
+run_nerf.py / trainer.py; these tests do what those scripts then do, in their words:
+
+* ``create_nerf(args)`` with the chair config's values, the ``network_query_fn`` LAMBDA of run_nerf.py:298-301 (not the
+  package's NetworkQuery), ``render(H, W, K, chunk=args.chunk, c2w=pose, **render_kwargs_test)`` (run_nerf.py:167-170);
+* a ``.tar`` checkpoint with the reference's top-level keys, reloaded the way run_nerf.py:313-330 reloads it;
+* an ``SSRTrainer``-like object configured from the SSR_room0_config.yaml-shaped dict through the reference's
+  ``set_params`` attribute names, ``create_ssr()``, a ``.ckpt`` reload (trainer.py:1042-1047) and ``render_rays``.
+"""
+import types
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from _cases import assert_maps_close
+from oracle import calibration as cal
+
+# INTEGRATION.md, variant A: the reference's scripts import the package's symbols over their own definitions
+from intrinsicnerf_amd.object_level import NeRF, get_embedder, run_network      # noqa: E402
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 1e-4, 1e-5
+
+
+def chair_args(**over):
+    """object_level/configs/chair.txt + the config_parser defaults it leaves alone (run_nerf.py:532-640)."""
+    a = dict(expname="blender_paper_chair", basedir="./logs", dataset_type="blender", no_batching=True, use_viewdirs=True,
+             white_bkgd=True, lrate_decay=500, N_samples=64, N_importance=128, N_rand=1024, half_res=True, netdepth=8, netwidth=256,
+             netdepth_fine=8, netwidth_fine=256, lrate=5e-4, chunk=1024 * 32, netchunk=1024 * 64, no_reload=False, ft_path=None,
+             perturb=1., i_embed=0, multires=10, multires_views=4, raw_noise_std=0., lindisp=False, no_ndc=False)
+    a.update(over)
+    return types.SimpleNamespace(**a)
+
+
+def reference_style_create_nerf(args, dev):
+    """run_nerf.py:275-356 with this package's symbols imported over the reference's (module globals above, as in
+    run_nerf.py) - the body is the reference's control flow (embedders, two NeRFs, the query LAMBDA, the kwargs dicts);
+    nothing here knows about the fused path."""
+    embed_fn, input_ch = get_embedder(args.multires, args.i_embed)
+    embeddirs_fn, input_ch_views = get_embedder(args.multires_views, args.i_embed)
+    output_ch = 5 if args.N_importance > 0 else 4
+    model = NeRF(D=args.netdepth, W=args.netwidth, input_ch=input_ch, output_ch=output_ch, skips=[4],
+                 input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs).to(dev)
+    model_fine = NeRF(D=args.netdepth_fine, W=args.netwidth_fine, input_ch=input_ch, output_ch=output_ch, skips=[4],
+                      input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs).to(dev)
+    network_query_fn = lambda inputs, viewdirs, network_fn: run_network(inputs, viewdirs, network_fn,      # noqa: E731
+                                                                        embed_fn=embed_fn,
+                                                                        embeddirs_fn=embeddirs_fn,
+                                                                        netchunk=args.netchunk)
+    train = {"network_query_fn": network_query_fn, "perturb": args.perturb, "N_importance": args.N_importance,
+             "network_fine": model_fine, "N_samples": args.N_samples, "network_fn": model, "use_viewdirs": args.use_viewdirs,
+             "white_bkgd": args.white_bkgd, "raw_noise_std": args.raw_noise_std, "ndc": False, "lindisp": args.lindisp}
+    test = {k: train[k] for k in train}
+    test["perturb"] = False
+    test["raw_noise_std"] = 0.
+    return train, test, model, model_fine
+
+
+@pytest.fixture(scope="module")
+def chair_scene():
+    import bench
+    H = W = 40
+    focal = 0.5 * W / np.tan(0.5 * bench.CAMERA_ANGLE_X)
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+    pose = bench.chair_pose()
+    from intrinsicnerf_amd import object_level as ol
+    ro, rd = ol.get_rays(H, W, K, pose)
+    vd = rd / rd.norm(dim=-1, keepdim=True)
+    rays = torch.cat([ro, rd, 2 * torch.ones_like(rd[..., :1]), 6 * torch.ones_like(rd[..., :1]), vd], -1).reshape(-1, 11)
+    sd_c, _ = oracle.calibrated_lcg_weights("object", 0, 40, rays)
+    sd_f, _ = oracle.calibrated_lcg_weights("object", 0, 41, rays)
+    cfg = oracle.RenderConfig(variant="object", white_bkgd=True)
+    with torch.no_grad():
+        want = oracle.render_rays(rays, sd_c, sd_f, cfg)
+    ok = (oracle.conditioning_scores(rays, sd_c, sd_f, cfg, torch.linspace(0., 1., 64)) <= 0.2).numpy()
+    return dict(H=H, W=W, K=K, pose=pose, rays=rays, sd_c=sd_c, sd_f=sd_f, want=want, ok=ok)
+
+
+def test_run_nerf_call_sites_with_the_reference_lambda(chair_scene, tmp_path):
+    from intrinsicnerf_amd import object_level as ol
+    dev = torch.device("cuda:0")
+    s = chair_scene
+    args = chair_args()
+    train_kw, test_kw, model, model_fine = reference_style_create_nerf(args, dev)
+    # ---- run_nerf.py:1035-1043 writes, :313-330 reloads: the reference's top-level keys
+    path = tmp_path / "200000.tar"
+    opt = torch.optim.Adam(list(model.parameters()) + list(model_fine.parameters()), lr=args.lrate)
+    torch.save({"global_step": 200000, "network_fn_state_dict": s["sd_c"], "network_fine_state_dict": s["sd_f"],
+                "optimizer_state_dict": opt.state_dict()}, path)
+    ckpt = torch.load(path)
+    assert ckpt["global_step"] == 200000
+    opt.load_state_dict(ckpt["optimizer_state_dict"])
+    model.load_state_dict(ckpt["network_fn_state_dict"])
+    model_fine.load_state_dict(ckpt["network_fine_state_dict"])
+    # ---- run_nerf.py:167-170 (render_path): render(H, W, K, chunk=chunk, c2w=c2w[:3,:4], **render_kwargs)
+    assert ol._as_network_query(test_kw["network_query_fn"]) is not None          # the lambda is recognised: fused path
+    with torch.no_grad():
+        rgb, disp, acc, albedo, shading, residual, extras = ol.render(s["H"], s["W"], s["K"], chunk=args.chunk,
+                                                                      c2w=s["pose"].to(dev)[:3, :4], near=2., far=6., **test_kw)
+    assert tuple(rgb.shape) == (s["H"], s["W"], 3) and tuple(shading.shape) == (s["H"], s["W"])
+    assert set(extras) == {"rgb0", "disp0", "acc0", "albedo0", "shading0", "residual0", "z_std"}         # run_nerf.py:512-522
+    ok, want = s["ok"], s["want"]
+    assert ok.mean() > 0.5
+    n = s["H"] * s["W"]
+    for got, key in ((rgb, "rgb_fine"), (acc, "acc_fine"), (albedo, "albedo_fine"), (shading, "shading_fine"),
+                     (residual, "residual_fine"), (extras["rgb0"], "rgb_coarse"), (extras["z_std"], "z_std")):
+        assert_maps_close(got.reshape(n, -1).cpu().numpy()[ok], want[key].reshape(n, -1).numpy()[ok], RTOL, ATOL, key)
+    # rgb0 etc. do not sit behind sample_pdf: every ray, not only the reproducible ones
+    assert_maps_close(extras["rgb0"].reshape(n, 3).cpu().numpy(), want["rgb_coarse"].numpy(), RTOL, ATOL, "rgb0 (all rays)")
+    # ---- the same call with an OPAQUE query function (a plain def that hides the encoders): the staged path - the
+    # function is called as given - must agree with the fused one
+    q = test_kw["network_query_fn"]
+    opaque = dict(test_kw, network_query_fn=lambda i, v, f, _q=q: _q(i, v, f))
+    assert ol._as_network_query(opaque["network_query_fn"]) is None
+    with torch.no_grad():
+        staged = ol.render(s["H"], s["W"], s["K"], chunk=args.chunk, c2w=s["pose"].to(dev)[:3, :4], near=2., far=6., **opaque)
+    same = all(torch.equal(torch.nan_to_num(a), torch.nan_to_num(b)) for a, b in zip(staged[:6], (rgb, disp, acc, albedo, shading, residual)))
+    print(f"\nstaged (opaque query function) vs fused: {'bit-identical' if same else 'within tolerance'}")
+    for a, b, key in zip(staged[:6], (rgb, disp, acc, albedo, shading, residual), ("rgb", "disp", "acc", "albedo", "shading", "residual")):
+        assert_maps_close(a.reshape(n, -1).cpu().numpy()[ok], b.reshape(n, -1).cpu().numpy()[ok], 5e-4 if key == "disp" else RTOL, ATOL,
+                          f"staged vs fused {key}")
+    # ---- a training-step call, as run_nerf.py:942-946 makes it: render(..., rays=batch_rays, retraw=True, **train)
+    batch = (s["rays"][:64, 0:3].to(dev), s["rays"][:64, 3:6].to(dev))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = ol.render(s["H"], s["W"], s["K"], chunk=args.chunk, rays=batch, verbose=False, retraw=True, near=2., far=6., **train_kw)
+    assert out[0].grad_fn is not None and "raw" in out[6] and tuple(out[6]["raw"].shape) == (64, 192, 11)
+    img_loss = ((out[0] - 0.5) ** 2).mean() + ((out[6]["rgb0"] - 0.5) ** 2).mean()
+    opt.zero_grad()
+    img_loss.backward()
+    opt.step()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model_fine.parameters())
+
+
+def room_config(c=28):
+    """SSR/configs/SSR_room0_config.yaml as the dict yaml.load gives train_SSR_main.py (paths shortened)."""
+    return {"experiment": {"scene_file": "/data/room_0", "save_dir": "logs/room_0/", "dataset_dir": "/data/room_0/Sequence_2",
+                           "convention": "opencv", "width": 320, "height": 240, "gpu": "0", "enable_semantic": True,
+                           "enable_depth": True, "endpoint_feat": False},
+            "model": {"netdepth": 8, "netwidth": 256, "netdepth_fine": 8, "netwidth_fine": 256, "chunk": "1024*32", "netchunk": "1024*32"},
+            "render": {"N_rays": "32*16", "N_samples": 64, "N_importance": 128, "perturb": 1, "use_viewdirs": True, "i_embed": 0,
+                       "multires": 10, "multires_views": 4, "raw_noise_std": 1, "test_viz_factor": 1, "no_batching": True,
+                       "depth_range": [0.1, 10.0], "white_bkgd": False},
+            "train": {"lrate": "5e-4", "lrate_decay": "250e3", "N_iters": 200000},
+            "logging": {"step_log_print": 1000}}
+
+
+def test_ssr_trainer_call_sites_from_the_yaml_dict(tmp_path):
+    from intrinsicnerf_amd import ssr
+
+    class Trainer(ssr.SSRRenderMixin):
+        """What is left of SSRTrainer (trainer.py:37) around the render path: __init__, set_params (:116-147) verbatim in
+        attribute names, and the mixin's render_rays / volumetric_rendering / create_ssr."""
+
+        def __init__(self, config):
+            self.config = config
+            self.set_params()
+            self.training = True
+
+        def set_params(self):
+            c = self.config
+            ev = lambda v: eval(v) if isinstance(v, str) else v
+            self.enable_semantic = c["experiment"]["enable_semantic"]
+            self.n_rays = ev(c["render"]["N_rays"])
+            self.N_samples = c["render"]["N_samples"]
+            self.netchunk = ev(c["model"]["netchunk"])
+            self.chunk = ev(c["model"]["chunk"])
+            self.use_viewdir = c["render"]["use_viewdirs"]
+            self.convention = c["experiment"]["convention"]
+            self.endpoint_feat = c["experiment"].get("endpoint_feat", False)
+            self.N_importance = c["render"]["N_importance"]
+            self.raw_noise_std = c["render"]["raw_noise_std"]
+            self.white_bkgd = c["render"]["white_bkgd"]
+            self.perturb = c["render"]["perturb"]
+            self.no_batching = c["render"]["no_batching"]
+            self.lrate = float(c["train"]["lrate"])
+            self.lrate_decay = float(c["train"]["lrate_decay"])
+            self.save_dir = c["experiment"]["save_dir"]
+
+    C = 28
+    dev = torch.device("cuda:0")
+    t = Trainer(room_config(C))
+    t.num_valid_semantic_class = C                     # trainer.py:166 (from the dataset)
+    t.create_ssr()                                      # trainer.py:811-846
+    assert isinstance(t.optimizer, torch.optim.Adam) and t.chunk == 32768 and t.netchunk == 32768
+    # rays as trainer.py:608-624 builds them for a test frame; a strided subset keeps the oracle quick
+    H, W = t.config["experiment"]["height"], t.config["experiment"]["width"]
+    fx = W / 2.0 / np.tan(np.deg2rad(45.0))
+    near, far = t.config["render"]["depth_range"]
+    rays = ssr.create_rays(1, torch.eye(4)[None], H, W, fx, fx, (W - 1.0) / 2.0, (H - 1.0) / 2.0, near, far, use_viewdirs=t.use_viewdir,
+                           convention=t.convention).reshape(-1, 11)
+    sub = rays[torch.arange(0, H * W, 151)].contiguous()
+    sd_c = cal.calibrated_default_init("ssr", C, 0, sub)
+    sd_f = cal.calibrated_default_init("ssr", C, 1, sub)
+    # ---- trainer.py:1042-1047 writes, :1049-1060 style reload
+    ck = tmp_path / "200000.ckpt"
+    torch.save({"global_step": 200000, "network_coarse_state_dict": sd_c, "network_fine_state_dict": sd_f,
+                "optimizer_state_dict": t.optimizer.state_dict()}, ck)
+    ckpt = torch.load(ck)
+    t.ssr_net_coarse.load_state_dict(ckpt["network_coarse_state_dict"])
+    t.ssr_net_fine.load_state_dict(ckpt["network_fine_state_dict"])
+    t.optimizer.load_state_dict(ckpt["optimizer_state_dict"])
+    # ---- eval render (trainer.py:1251: self.training = False; render_rays(rays) under no_grad)
+    t.training = False
+    t.ssr_net_coarse.eval(); t.ssr_net_fine.eval()
+    with torch.no_grad():
+        out = t.render_rays(sub.to(dev))
+    keys = {f"{k}_{l}" for l in ("coarse", "fine") for k in ("rgb", "disp", "acc", "depth", "albedo", "shading", "residual")}
+    assert set(out) == keys | {"raw_coarse", "raw_fine", "z_std", "sem_logits_coarse", "sem_logits_fine"}          # trainer.py:776-802
+    cfg = oracle.RenderConfig(variant="ssr", white_bkgd=False, n_classes=C, netchunk=32768)
+    to64 = lambda sd: {k: v.double() for k, v in sd.items()}
+    with torch.no_grad():
+        o32 = oracle.render_rays(sub, sd_c, sd_f, cfg, stages=True)
+        o64 = oracle.render_rays(sub.double(), to64(sd_c), to64(sd_f), cfg, stages=True)
+    ren = {"sem_logits_coarse": "sem_coarse", "sem_logits_fine": "sem_fine"}
+    score = np.maximum.reduce([cal.scaled_errors(o32[k].numpy(), o64[k].numpy(), 5e-4 if k.startswith("disp") else 1e-4)
+                               for k in o32 if not k.startswith("raw")])
+    well = score <= 0.2
+    assert well.sum() >= 100
+    for k in sorted(keys | {"z_std", "sem_logits_coarse", "sem_logits_fine"}):
+        assert_maps_close(out[k].cpu().numpy()[well], o32[ren.get(k, k)].numpy()[well], 5e-4 if k.startswith("disp") else RTOL, ATOL, k)
+    # ---- a training step as trainer.py:882-990 drives the same methods (perturb = 1, raw_noise_std = 1, autograd on)
+    t.training = True
+    t.ssr_net_coarse.train(); t.ssr_net_fine.train()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        o = t.render_rays(sub[:t.n_rays].to(dev))
+    loss = ((o["rgb_fine"] - 0.5) ** 2).mean() + ((o["rgb_coarse"] - 0.5) ** 2).mean() + \
+        torch.nn.functional.cross_entropy(o["sem_logits_fine"], torch.zeros(o["sem_logits_fine"].shape[0], dtype=torch.long, device=dev))
+    t.optimizer.zero_grad()
+    loss.backward()
+    t.optimizer.step()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in t.ssr_net_fine.parameters())

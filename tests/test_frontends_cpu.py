@@ -242,3 +242,47 @@ def test_packed_cache_invalidate():
     packing.invalidate(net)
     c = packing.packed_for_module(net, desc, "cpu")
     assert c is not b and not torch.equal(b, c)
+
+
+def test_reference_query_lambda_is_recognised():
+    """The closure the reference's create_nerf builds (run_nerf.py:298-301) around THIS package's run_network is taken
+    apart into its encoders, so an unpatched create_nerf still reaches the fused kernel; anything else is left alone."""
+    from intrinsicnerf_amd import object_level as ol
+    run_network = ol.run_network                                    # `from intrinsicnerf_amd.object_level import run_network`
+    embed_fn, _ = ol.get_embedder(10, 0)
+    embeddirs_fn, _ = ol.get_embedder(4, 0)
+    import types
+    args = types.SimpleNamespace(netchunk=65536)
+
+    def make(run_network, embed_fn, embeddirs_fn):
+        return lambda inputs, viewdirs, network_fn: run_network(inputs, viewdirs, network_fn,        # noqa: E731
+                                                                embed_fn=embed_fn, embeddirs_fn=embeddirs_fn, netchunk=args.netchunk)
+
+    # run_network as a module global (the reference's situation) ...
+    g = {"run_network": run_network, "args": args}
+    exec("def build(embed_fn, embeddirs_fn):\n"
+         "    return lambda inputs, viewdirs, network_fn : run_network(inputs, viewdirs, network_fn,\n"
+         "                                                embed_fn=embed_fn,\n"
+         "                                                embeddirs_fn=embeddirs_fn,\n"
+         "                                                netchunk=args.netchunk)\n", g)
+    # (args is a global of this synthetic module rather than a closure cell; co_names then holds 'args' too - not the reference's shape)
+    assert ol._as_network_query(g["build"](embed_fn, embeddirs_fn)) is None
+    exec("def build2(embed_fn, embeddirs_fn, args):\n"
+         "    return lambda inputs, viewdirs, network_fn : run_network(inputs, viewdirs, network_fn,\n"
+         "                                                embed_fn=embed_fn,\n"
+         "                                                embeddirs_fn=embeddirs_fn,\n"
+         "                                                netchunk=args.netchunk)\n", g)
+    q = ol._as_network_query(g["build2"](embed_fn, embeddirs_fn, args))
+    assert isinstance(q, ol.NetworkQuery) and q.embed_fn is embed_fn and q.embeddirs_fn is embeddirs_fn
+    nq = ol.NetworkQuery(embed_fn, embeddirs_fn)
+    assert ol._as_network_query(nq) is nq
+    # ... but not: a foreign run_network, foreign encoders, a wrapper that does more, a callable object
+    g2 = dict(g, run_network=lambda *a, **k: None)
+    exec("def build3(embed_fn, embeddirs_fn, args):\n"
+         "    return lambda inputs, viewdirs, network_fn : run_network(inputs, viewdirs, network_fn,\n"
+         "                                                embed_fn=embed_fn, embeddirs_fn=embeddirs_fn, netchunk=args.netchunk)\n", g2)
+    assert ol._as_network_query(g2["build3"](embed_fn, embeddirs_fn, args)) is None
+    assert ol._as_network_query(g["build2"](torch.nn.Identity(), embeddirs_fn, args)) is None
+    assert ol._as_network_query(make(run_network, embed_fn, embeddirs_fn)) is None      # run_network itself is a closure cell here
+    assert ol._as_network_query(lambda i, v, f: None) is None
+    assert ol._as_network_query(print) is None
