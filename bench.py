@@ -164,7 +164,8 @@ def parity_report(frame, sel, o32, o64):
     tol = lambda k: RTOL_DISP if k.startswith("disp") else RTOL
     e_ref = {ok: cal.scaled_errors(o32[ok].numpy(), o64[ok].numpy(), tol(ok), ATOL) for _, ok in pairs}
     stage = ("z_samples", "weights_coarse", "weights_fine", "z_fine", "rgb_coarse", "acc_coarse", "z_std")
-    score = np.maximum.reduce(list(e_ref.values()) + [cal.scaled_errors(o32[k].numpy(), o64[k].numpy(), RTOL, ATOL) for k in stage])
+    score = np.maximum.reduce(list(e_ref.values()) + [cal.scaled_errors(o32[k].numpy(), o64[k].numpy(), RTOL, ATOL) for k in stage]
+                              + [cal.resampling_hazard(o64["z_coarse"], o64["weights_coarse"], o32["weights_coarse"])])
     well = score <= 0.2
     problems, per_map = [], {}
     for fk, ok in pairs:

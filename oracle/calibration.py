@@ -76,3 +76,35 @@ def summarize(e):
     fin = np.where(np.isfinite(e), e, 1e30)
     qs = " ".join(f"q{int(q * 100)} {float(np.quantile(fin, q)):.3g}" for q in QUANTILES)
     return f"{qs} max {float(fin.max()):.3g} #>1 {int((fin > 1).sum())}/{len(fin)}"
+
+
+def resampling_hazard(z_coarse, weights64, weights32, u=None, n_importance=128, trials=4, rtol=1e-4, atol=1e-5, seed=0):
+    """Per-ray stability of ``sample_pdf`` under weight noise of the size fp32 arithmetic actually produces on that ray.
+
+    ``sample_pdf`` is discontinuous: a bin whose cdf difference falls below 1e-5 switches from ``t = (u - cdf_lo) / denom``
+    to ``t = u - cdf_lo`` (run_nerf_helpers.py:440-443) - and on an opaque ray the empty bins' pdf, 1e-5 / (sum(w) + 62e-5),
+    sits right AT that threshold - so a 1e-7 change of the coarse weights can move an importance sample by a whole bin.
+    One fp32-vs-fp64 comparison samples that hazard once; this probes it several more times: the fp64 weights are
+    perturbed by +-2 x |fp32 - fp64| (uniformly up, uniformly down, and ``trials`` random sign patterns) and the largest
+    move of any importance sample, in tolerances, is returned per ray.  Rays with a large value cannot pin ANY fp32
+    implementation's fine pass to the plain tolerance; tests leave them to the rank statistics."""
+    from .intrinsic_render import inverse_cdf_sample
+    z = torch.as_tensor(z_coarse).double()
+    w64 = torch.as_tensor(weights64).double()[:, 1:-1]
+    delta = 2.0 * (torch.as_tensor(weights32).double()[:, 1:-1] - w64).abs() + 1e-9
+    n = z.shape[0]
+    if u is None:
+        u = torch.linspace(0.0, 1.0, n_importance, dtype=torch.float64)
+    u = torch.as_tensor(u).double()
+    if u.dim() == 1:
+        u = u.expand(n, u.shape[0])
+    bins = 0.5 * (z[:, 1:] + z[:, :-1])
+    base = inverse_cdf_sample(bins, w64, u)
+    g = torch.Generator().manual_seed(seed)
+    signs = [torch.ones_like(w64), -torch.ones_like(w64)]
+    signs += [torch.randint(0, 2, w64.shape, generator=g).double() * 2 - 1 for _ in range(trials)]
+    worst = torch.zeros(n, dtype=torch.float64)
+    for s in signs:
+        moved = inverse_cdf_sample(bins, (w64 + s * delta).clamp_min(0.0), u)
+        worst = torch.maximum(worst, ((moved - base).abs() / (atol + rtol * base.abs())).amax(1))
+    return worst.numpy()

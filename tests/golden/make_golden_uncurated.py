@@ -104,6 +104,8 @@ def object_case(run_nerf, H_ref, name, n, n_importance):
     for k in ("z_samples", "weights_coarse", "weights_fine", "z_fine"):
         if k in mine:                      # per-ray fp32-vs-fp64 distance of the stage tensors (the conditioning score's other half)
             fx["stage_score_" + k] = cal.scaled_errors(mine[k].numpy(), m64[k].numpy())
+    if n_importance > 0:
+        fx["stage_score_resampling_hazard"] = cal.resampling_hazard(m64["z_coarse"], m64["weights_coarse"], mine["weights_coarse"])
     mg.save(name, **fx)
 
 
@@ -135,6 +137,7 @@ def ssr_case(SSRTrainer, ssr_rays, name, n, n_classes):
         fx["f64_" + ok] = m64[ok]
     for k in ("z_samples", "weights_coarse", "weights_fine", "z_fine"):
         fx["stage_score_" + k] = cal.scaled_errors(mine[k].numpy(), m64[k].numpy())
+    fx["stage_score_resampling_hazard"] = cal.resampling_hazard(m64["z_coarse"], m64["weights_coarse"], mine["weights_coarse"])
     mg.save(name, **fx)
 
 

@@ -217,7 +217,8 @@ def test_ssr_trainer_call_sites_from_the_yaml_dict(tmp_path):
         o64 = oracle.render_rays(sub.double(), to64(sd_c), to64(sd_f), cfg, stages=True)
     ren = {"sem_logits_coarse": "sem_coarse", "sem_logits_fine": "sem_fine"}
     score = np.maximum.reduce([cal.scaled_errors(o32[k].numpy(), o64[k].numpy(), 5e-4 if k.startswith("disp") else 1e-4)
-                               for k in o32 if not k.startswith("raw")])
+                               for k in o32 if not k.startswith("raw")]
+                              + [cal.resampling_hazard(o64["z_coarse"], o64["weights_coarse"], o32["weights_coarse"])])
     well = score <= 0.2
     assert well.sum() >= 100
     for k in sorted(keys | {"z_std", "sem_logits_coarse", "sem_logits_fine"}):

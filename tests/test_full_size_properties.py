@@ -151,7 +151,8 @@ def test_full_ssr_frame_properties(precision):
     tol = lambda k: 5e-4 if k.startswith("disp") else 1e-4
     e_ref = {k: cal.scaled_errors(o32[ren.get(k, k)].numpy(), o64[ren.get(k, k)].numpy(), tol(k)) for k in keys}
     score = np.maximum.reduce(list(e_ref.values()) + [cal.scaled_errors(o32[k].numpy(), o64[k].numpy())
-                                                     for k in ("z_samples", "weights_coarse", "weights_fine", "z_fine")])
+                                                     for k in ("z_samples", "weights_coarse", "weights_fine", "z_fine")]
+                              + [cal.resampling_hazard(o64["z_coarse"], o64["weights_coarse"], o32["weights_coarse"])])
     well = score <= 0.2
     assert well.sum() >= 30
     problems = []

@@ -109,7 +109,8 @@ def test_unfiltered_rays_rank_statistics(variant, precision):
     e_hip = {k: cal.scaled_errors(got[k].cpu().numpy(), o32[k].numpy(), _tol(k), ATOL) for k in keys}
     # the reference arithmetic's own reproducibility per ray: max over maps AND the stage tensors behind them
     stage = ("z_samples", "weights_coarse", "weights_fine", "z_fine")
-    score = np.maximum.reduce([e_ref[k] for k in keys] + [cal.scaled_errors(o32[k].numpy(), o64[k].numpy(), RTOL, ATOL) for k in stage])
+    score = np.maximum.reduce([e_ref[k] for k in keys] + [cal.scaled_errors(o32[k].numpy(), o64[k].numpy(), RTOL, ATOL) for k in stage]
+                              + [cal.resampling_hazard(o64["z_coarse"], o64["weights_coarse"], o32["weights_coarse"])])
     well = score <= 0.2
     problems = []
     for k in keys:
