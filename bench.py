@@ -156,7 +156,7 @@ def cpu_oracle_run(rays, sd_c, sd_f, full_spec=False):
     return out, base
 
 
-def parity_report(frame, sel, o32, o64):
+def parity_report(frame, sel, o32, o64, rays_s, sd_f):
     """The timed frame's maps at rays ``sel`` against the oracle: (dict for the JSON line, list of violations)."""
     from oracle import calibration as cal
     pairs = (("rgb_map", "rgb_fine"), ("disp_map", "disp_fine"), ("acc_map", "acc_fine"), ("albedo_map", "albedo_fine"),
@@ -164,8 +164,11 @@ def parity_report(frame, sel, o32, o64):
     tol = lambda k: RTOL_DISP if k.startswith("disp") else RTOL
     e_ref = {ok: cal.scaled_errors(o32[ok].numpy(), o64[ok].numpy(), tol(ok), ATOL) for _, ok in pairs}
     stage = ("z_samples", "weights_coarse", "weights_fine", "z_fine", "rgb_coarse", "acc_coarse", "z_std")
-    score = np.maximum.reduce(list(e_ref.values()) + [cal.scaled_errors(o32[k].numpy(), o64[k].numpy(), RTOL, ATOL) for k in stage]
-                              + [cal.resampling_hazard(o64["z_coarse"], o64["weights_coarse"], o32["weights_coarse"])])
+    score = np.maximum.reduce(list(e_ref.values()) + [cal.scaled_errors(o32[k].numpy(), o64[k].numpy(), RTOL, ATOL) for k in stage])
+    if (score <= 0.2).any():       # probe the fine pass's conditioning on the rays that passed so far (oracle.calibration.fine_pass_hazard)
+        import oracle
+        cfg = oracle.RenderConfig(variant="object", n_samples=N_SAMPLES, n_importance=N_IMPORTANCE, white_bkgd=True)
+        score = np.maximum(score, cal.fine_pass_hazard(rays_s, sd_f, cfg, o32, o64, subset=score <= 0.2))
     well = score <= 0.2
     problems, per_map = [], {}
     for fk, ok in pairs:
@@ -514,7 +517,7 @@ def main():
             o64 = oracle.render_rays(rays_s.double(), to64(sd_c), to64(sd_f),
                                      oracle.RenderConfig(variant="object", n_samples=N_SAMPLES, n_importance=N_IMPORTANCE, white_bkgd=True),
                                      stages=True)
-        parity, problems = parity_report(frame, sel, o32, o64)
+        parity, problems = parity_report(frame, sel, o32, o64, rays_s, sd_f)
 
     if rank == 0:
         print(json.dumps({

@@ -30,7 +30,7 @@ extern "C" {
 #define INERF_VERSION_MINOR 2
 /* Bumped whenever a struct layout, an argument list or the packed-weight format of this header changes; bindings
  * compare it with inerf_abi_version() of the library they loaded (a stale .so then fails loudly, not silently). */
-#define INERF_ABI_VERSION 20002
+#define INERF_ABI_VERSION 20003
 
 /* error codes */
 #define INERF_OK              0
@@ -288,6 +288,28 @@ int inerf_render_rays(const inerf_render_args* args, void* stream);
 
 /* Raw channel counts for this network. */
 int inerf_raw_channels(const inerf_net_desc* net, uint32_t flags, int fine);
+
+/* ---------------------------------------------------------------------------------------------
+ * Image-level neighbours of the path.
+ * ------------------------------------------------------------------------------------------- */
+
+/* Ray generation: the [n_poses * height * width, 11] ray batch [o3, d3, near, far, viewdir3] of a pinhole camera.
+ * Replaces get_rays (run_nerf_helpers.py:359-368) + the view-direction normalisation and concatenation inside
+ * render() (run_nerf.py:99-128), and get_rays_camera / get_rays_world / create_rays (SSR/models/rays.py:27-67,
+ * 223-256, depth_type "z").  poses: device, camera-to-world matrices as rows of 4 floats ([3,4] or [4,4] row-major),
+ * consecutive poses `pose_stride` (>= 12) floats apart; static_poses: NULL, or the c2w_staticcam of the reference
+ * (origins and directions from it, view directions from `poses`).  Pixel (i = column, j = row) of pose b is ray
+ * b*H*W + j*W + i.  INERF_CAM_OPENGL: dirs = ((i-cx)/fx, -(j-cy)/fy, -1) (object-level, SSR convention "opengl");
+ * otherwise ((i-cx)/fx, (j-cy)/fy, 1) (SSR "opencv").  Bit-identical to the reference's CPU evaluation
+ * (tests/golden/rays_generators.npz): every fp32 operation is issued in ATen's order (see csrc/frame_ops.hip). */
+#define INERF_CAM_OPENGL 1u
+int inerf_gen_rays(const float* poses, int pose_stride, const float* static_poses, int n_poses, int height, int width,
+                   float fx, float fy, float cx, float cy, float near, float far, uint32_t flags, float* rays_out,
+                   void* stream);
+
+/* to8b on the device: out[i] = (uint8)(255 * clip(values[i], 0, 1)) (run_nerf_helpers.py:13 / trainer.py:1242), so an
+ * image loop (run_nerf.py:142-212, trainer.py:1221-1389) copies a quarter of the bytes to the host.  NaN -> 0. */
+int inerf_frame_to_u8(const float* values, int64_t n, unsigned char* out, void* stream);
 
 /* Nearest-anchor lookup of the albedo clustering, every semantic class in one launch.  Replaces
  * Cluster_Manager.dest_color / dest_class (SSR/training/cluster.py:73-98) and, underneath, Cluster.dest_color /

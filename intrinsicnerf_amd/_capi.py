@@ -10,7 +10,7 @@ import os
 from . import _build
 from ._build import LIB_PATH
 
-ABI_VERSION = 20002          # INERF_ABI_VERSION of include/inerf.h these ctypes declarations mirror
+ABI_VERSION = 20003          # INERF_ABI_VERSION of include/inerf.h these ctypes declarations mirror
 
 OK, E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_HIP = 0, -1, -2, -3, -4
 VARIANT_OBJECT, VARIANT_SSR = 0, 1
@@ -18,6 +18,7 @@ PREC_F32, PREC_F16X3 = 0, 1
 STATUS_F16_RANGE = 1
 FLAG_WHITE_BKGD, FLAG_LINDISP, FLAG_ENDPOINT, FLAG_U_PER_RAY, FLAG_BINS_DIRECT = 1, 2, 4, 8, 16
 CLUSTER_IGNORE_LABEL = 1
+CAM_OPENGL = 1
 BASE_CHANNELS, ENDPOINT_DIM, RAY_FLOATS, MAX_CLASSES = 11, 128, 11, 240
 
 _ERR = {E_INVALID: "invalid argument", E_UNSUPPORTED: "unsupported configuration",
@@ -76,6 +77,8 @@ SYMBOLS = {
     "inerf_workspace_bytes": (_L, [C.POINTER(NetDesc), _L, _I, _I, _U]),
     "inerf_render_workspace_bytes": (_L, [C.POINTER(RenderArgs)]),
     "inerf_render_rays": (_I, [C.POINTER(RenderArgs), _P]),
+    "inerf_gen_rays": (_I, [_P, _I, _P, _I, _I, _I, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _U, _P, _P]),
+    "inerf_frame_to_u8": (_I, [_P, _L, _P, _P]),
     "inerf_cluster_lookup": (_I, [_P, _P, _L, _P, _P, _P, _P, _P, _P, _I, _U, _P, _P, _P]),
 }
 

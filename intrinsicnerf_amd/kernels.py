@@ -64,6 +64,42 @@ def sample_coarse(rays, t_vals, t_rand=None, lindisp=False):
     return z
 
 
+def gen_rays(poses, height, width, fx, fy, cx, cy, near, far, opengl, static_poses=None):
+    """[B * H * W, 11] ray batch ``[o3, d3, near, far, viewdir3]`` of B pinhole cameras through ``inerf_gen_rays``
+    (get_rays + render()'s assembly, run_nerf_helpers.py:359-368 + run_nerf.py:99-128 | create_rays, rays.py:223-256).
+    ``poses``: [B, 3, 4] / [B, 4, 4] / [3, 4] / [4, 4] float32 device tensor; bit-identical to the reference's CPU rays."""
+    def prep(t, name):
+        t = _dev(t, name)
+        if t.dim() == 2:
+            t = t[None]
+        if t.dim() != 3 or t.shape[1] not in (3, 4) or t.shape[2] != 4:
+            raise ValueError(f"{name} has shape {tuple(t.shape)}, expected [B, 3|4, 4]")
+        return t.contiguous()
+    poses = prep(poses, "poses")
+    b = poses.shape[0]
+    if static_poses is not None:
+        static_poses = prep(static_poses, "static_poses")
+        if static_poses.shape != poses.shape:
+            raise ValueError("static_poses must have the shape of poses")
+    out = _new(poses, b * int(height) * int(width), RAY_FLOATS)
+    with torch.cuda.device(poses.device):
+        rc = _capi.lib().inerf_gen_rays(_ptr(poses), poses.shape[1] * 4, _ptr(static_poses), b, int(height), int(width),
+                                        float(fx), float(fy), float(cx), float(cy), float(near), float(far),
+                                        _capi.CAM_OPENGL if opengl else 0, _ptr(out), _stream(poses))
+    _capi.check(rc, "inerf_gen_rays")
+    return out
+
+
+def frame_to_u8(values):
+    """``(255 * clip(x, 0, 1)).astype(uint8)`` (to8b, run_nerf_helpers.py:13) on the device; same shape, dtype uint8."""
+    values = _dev(values, "values")
+    out = torch.empty(values.shape, dtype=torch.uint8, device=values.device)
+    with torch.cuda.device(values.device):
+        rc = _capi.lib().inerf_frame_to_u8(_ptr(values), values.numel(), C.c_void_p(out.data_ptr()), _stream(values))
+    _capi.check(rc, "inerf_frame_to_u8")
+    return out
+
+
 def _new_status(like):
     return torch.zeros(1, dtype=torch.int32, device=like.device)
 

@@ -20,7 +20,7 @@ import torch.nn.functional as F
 from . import _capi, kernels, packing
 
 __all__ = ["Embedder", "get_embedder", "NeRF", "NetworkQuery", "run_network", "raw2outputs", "sample_pdf",
-           "render_rays", "batchify_rays", "render", "get_rays", "get_rays_np", "ndc_rays", "create_nerf"]
+           "render_rays", "batchify_rays", "render", "render_path", "get_rays", "get_rays_np", "ndc_rays", "create_nerf", "to8b"]
 
 
 # ----------------------------------------------------------------------------------------------
@@ -424,6 +424,17 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far
 
     Returns ``[rgb_map, disp_map, acc_map, albedo_map, shading_map, residual_map, extras]``.
     """
+    if (c2w is not None and use_viewdirs and not ndc and isinstance(c2w, torch.Tensor) and c2w.is_cuda
+            and (c2w_staticcam is None or (isinstance(c2w_staticcam, torch.Tensor) and c2w_staticcam.is_cuda))):
+        # pose -> [H*W, 11] ray batch in one launch (inerf_gen_rays): the same bits as the lines below give on the
+        # reference's CPU path, on every device (torch's own reductions carry no such promise across devices)
+        rays = kernels.gen_rays(c2w.float(), H, W, K[0][0], K[1][1], K[0][2], K[1][2], near, far, True,
+                                None if c2w_staticcam is None else c2w_staticcam.float())
+        all_ret = batchify_rays(rays, chunk, **kwargs)
+        for k in all_ret:
+            all_ret[k] = torch.reshape(all_ret[k], [H, W] + list(all_ret[k].shape[1:]))
+        k_extract = ["rgb_map", "disp_map", "acc_map", "albedo_map", "shading_map", "residual_map"]
+        return [all_ret[k] for k in k_extract] + [{k: all_ret[k] for k in all_ret if k not in k_extract}]
     if c2w is not None:
         rays_o, rays_d = get_rays(H, W, K, c2w)
     else:
@@ -450,6 +461,85 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far
     return [all_ret[k] for k in k_extract] + [{k: all_ret[k] for k in all_ret if k not in k_extract}]
 
 
+def to8b(x):
+    """run_nerf_helpers.py:13 - numpy arrays as there; device tensors are quantised on the device."""
+    from . import frames
+    return frames.to8b(x)
+
+
+def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedir=None, render_factor=0, update_cluster=False,
+                b_f=0.5, cluster_manager_factory=None):
+    """Render every pose of ``render_poses`` - run_nerf.py:142-272; returns ``(rgbs, disps, cluster_manager)``.
+
+    Same arguments, same returned stacks (``[N, H, W, 3]`` / ``[N, H, W]`` float32 numpy), same files in ``savedir``
+    (``{:03d}.png``, ``a*``, ``s*``, ``res*``, ``acc*``).  What differs is the plumbing: a pose becomes its ray batch
+    in one launch (``inerf_gen_rays``), a frame's six maps travel to the host as ONE pinned, asynchronous copy that
+    overlaps the next frame's kernels (frames.FrameStreamer) instead of six blocking ``.cpu()`` calls, and the host
+    looks at a frame only after the next one is enqueued.  ``update_cluster`` needs the mean-shift fitting of the
+    reference's ``Cluster_Manager.update_center`` (sklearn; training control plane, not rebuilt here): pass the
+    reference's class as ``cluster_manager_factory``."""
+    import os
+    from . import frames
+    H, W, focal = hwf
+    if render_factor != 0:       # render downsampled for speed (run_nerf.py:146-150)
+        H = H // render_factor
+        W = W // render_factor
+        focal = focal / render_factor
+    H, W = int(H), int(W)
+    keys = ("rgb_map", "disp_map", "acc_map", "albedo_map", "shading_map", "residual_map")
+    rgbs, disps, albedos, shadings, residuals, accs, labels, sample_pixels, sample_labels = ([] for _ in range(9))
+    frames.ensure_dir(savedir)
+    widths = None
+
+    def finish(i, frame):
+        m = frames.unpack_frame(frame, widths, keys, (H, W))
+        rgbs.append(m["rgb_map"]); disps.append(m["disp_map"]); albedos.append(m["albedo_map"])
+        shadings.append(m["shading_map"]); residuals.append(m["residual_map"])
+        label = (m["acc_map"] > 10).astype(int)              # run_nerf.py:173 as written there
+        labels.append(label)
+        accs.append(label.astype(np.float32))
+        if update_cluster:
+            sample_pixels.append(albedos[-1][::2, ::2, :].reshape(-1, 3))
+            sample_labels.append(label[::2, ::2].reshape(-1, 1))
+        if savedir is not None:
+            for prefix, img in (("", rgbs[-1]), ("a", albedos[-1]), ("s", shadings[-1]), ("res", residuals[-1]), ("acc", accs[-1])):
+                frames.write_png(os.path.join(savedir, "{}{:03d}.png".format(prefix, i)), frames.to8b(img))
+
+    streamer, in_flight = None, []
+    for i, c2w in enumerate(render_poses):
+        out = render(H, W, K, chunk=chunk, c2w=c2w[:3, :4], **render_kwargs)
+        pack, widths = frames.pack_maps({k: v.detach().reshape(H * W, -1) for k, v in zip(keys, out[:6])}, keys)
+        if pack.is_cuda:
+            if streamer is None:
+                streamer = frames.FrameStreamer(pack.device)
+            done = streamer.push(pack)
+            in_flight.append(i)
+            if done is not None:
+                finish(in_flight.pop(0), done)
+        else:
+            finish(i, pack.numpy())
+    if streamer is not None:
+        for frame in streamer.drain():
+            finish(in_flight.pop(0), frame)
+    cluster_manager = None
+    if update_cluster:
+        if cluster_manager_factory is None:
+            raise NotImplementedError("render_path(update_cluster=True) fits mean-shift clusters (Cluster_Manager.update_center, "
+                                      "object_level cluster code of the reference); pass that class as cluster_manager_factory")
+        cluster_manager = cluster_manager_factory(class_num=1)
+        cluster_manager.update_center(np.concatenate(sample_labels, 0), np.concatenate(sample_pixels, 0), band_factor=b_f)
+        dev = render_poses[0].device if isinstance(render_poses[0], torch.Tensor) else "cpu"
+        for i, albedo in enumerate(albedos):           # run_nerf.py:226-241
+            pixel = torch.from_numpy(albedo).reshape(-1, 3).to(dev)
+            label = torch.from_numpy(labels[i]).reshape(-1, 1).to(dev)
+            result = cluster_manager.dest_color(pixel, label).reshape(albedo.shape).cpu().numpy()
+            if savedir is not None:
+                frames.write_png(os.path.join(savedir, "c{:03d}.png".format(i)), frames.to8b(result))
+                edit = (result.reshape(-1, 3) * shadings[i].reshape(-1, 1) + residuals[i].reshape(-1, 3)).reshape(result.shape)
+                frames.write_png(os.path.join(savedir, "edit{:03d}.png".format(i)), frames.to8b(edit))
+    return np.stack(rgbs, 0), np.stack(disps, 0), cluster_manager
+
+
 # ----------------------------------------------------------------------------------------------
 # ray generation (input producers of the path)
 # ----------------------------------------------------------------------------------------------
@@ -457,6 +547,9 @@ def get_rays(H, W, K, c2w):
     """Pinhole rays in the OpenGL (-z forward) convention - run_nerf_helpers.py:359-368."""
     dev = c2w.device if isinstance(c2w, torch.Tensor) else None
     c2w = torch.as_tensor(c2w, dtype=torch.float32, device=dev)
+    if c2w.is_cuda:       # one HIP launch, the reference's CPU bits on every device (csrc/frame_ops.hip)
+        rays = kernels.gen_rays(c2w, H, W, K[0][0], K[1][1], K[0][2], K[1][2], 0., 1., True).reshape(H, W, -1)
+        return rays[..., 0:3], rays[..., 3:6]
     j, i = torch.meshgrid(torch.linspace(0, H - 1, H, device=c2w.device), torch.linspace(0, W - 1, W, device=c2w.device),
                           indexing="ij")
     dirs = torch.stack([(i - K[0][2]) / K[0][0], -(j - K[1][2]) / K[1][1], -torch.ones_like(i)], -1)

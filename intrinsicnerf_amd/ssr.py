@@ -198,7 +198,18 @@ def get_rays_world(T_WC, dirs_C):
 
 def create_rays(num_rays, Ts_c2w, height, width, fx, fy, cx, cy, near, far, c2w_staticcam=None, depth_type="z",
                 use_viewdirs=True, convention="opencv"):
-    """[num_images, H*W, 11] ray batch ``[o3, d3, near, far, viewdir3]`` - rays.py:223-256."""
+    """[num_images, H*W, 11] ray batch ``[o3, d3, near, far, viewdir3]`` - rays.py:223-256.
+
+    Poses on a HIP device (and depth_type "z", view directions on - every shipped config): one ``inerf_gen_rays`` launch
+    that reproduces the reference's CPU bits; CPU poses (what trainer.py:608-624 passes) take the torch expressions below,
+    which ARE the reference's."""
+    if (isinstance(Ts_c2w, torch.Tensor) and Ts_c2w.is_cuda and depth_type == "z" and use_viewdirs
+            and (c2w_staticcam is None or (isinstance(c2w_staticcam, torch.Tensor) and c2w_staticcam.is_cuda))):
+        if Ts_c2w.shape[0] != num_rays:
+            raise ValueError(f"create_rays: {num_rays} images but {Ts_c2w.shape[0]} poses")
+        rays = kernels.gen_rays(Ts_c2w.float(), height, width, fx, fy, cx, cy, near, far, convention == "opengl",
+                                None if c2w_staticcam is None else c2w_staticcam.float())
+        return rays.reshape(num_rays, height * width, -1)
     dirs_C = get_rays_camera(num_rays, height, width, fx, fy, cx, cy, depth_type=depth_type,
                              convention=convention).view(num_rays, -1, 3)
     rays_o, rays_d = get_rays_world(Ts_c2w, dirs_C)
@@ -255,6 +266,101 @@ class SSRRenderMixin:
         for k in all_ret:
             all_ret[k] = torch.reshape(all_ret[k], list(ray_shape[:-1]) + list(all_ret[k].shape[1:]))
         return all_ret
+
+    def render_path(self, rays, save_dir=None, update_cluster=False, b_f=0.5):
+        """Render the frames ``rays[i]`` ([n_images, H*W, 11]) - trainer.py:1221-1456; returns the reference's 12-tuple
+        ``(rgbs, disps, deps, vis_deps, sems, vis_sems, entropys, vis_entropys, albedos, shadings, residuals,
+        cluster_manager)``.
+
+        Per frame the label map (argmax of the softmax, :1244) and the entropy map (:1245) are computed on the device, all
+        maps travel to the host as one pinned asynchronous copy that overlaps the next frame's kernels
+        (frames.FrameStreamer) - the reference issues ~10 blocking ``.cpu()`` calls per frame.  The visualisations are
+        the trainer's own business: ``vis_deps`` / ``vis_entropys`` need ``imgviz.depth2rgb`` (None when imgviz is not
+        importable), ``vis_sems`` reads ``self.valid_colour_map`` (None without it).  Reads ``H_scaled, W_scaled, near,
+        far`` like the reference.  ``update_cluster`` needs ``self.cluster_manager_factory`` (the reference's
+        ``Cluster_Manager``: its mean-shift fitting is training control plane, not rebuilt here)."""
+        import os
+        import numpy as np
+        from . import frames
+        H, W = int(self.H_scaled), int(self.W_scaled)
+        try:
+            from imgviz import depth2rgb
+        except ImportError:
+            depth2rgb = None
+        lvl = "fine" if self.N_importance > 0 else "coarse"
+        keys = [f"{k}_{lvl}" for k in ("rgb", "disp", "depth", "albedo", "shading", "residual")]
+        if self.enable_semantic:
+            keys += ["sem_label", "sem_entropy"]
+        cmap = getattr(self, "valid_colour_map", None)
+        if save_dir is not None:
+            assert os.path.exists(save_dir)
+        acc = {k: [] for k in ("rgb", "disp", "dep", "vis_dep", "albedo", "shading", "residual", "sem", "vis_sem", "ent", "vis_ent")}
+        sample_pixels, sample_labels = [], []
+        widths = None
+
+        def finish(i, frame):
+            m = frames.unpack_frame(frame, widths, keys, (H, W))
+            acc["rgb"].append(m[f"rgb_{lvl}"]); acc["disp"].append(m[f"disp_{lvl}"]); acc["albedo"].append(m[f"albedo_{lvl}"])
+            acc["shading"].append(m[f"shading_{lvl}"]); acc["residual"].append(m[f"residual_{lvl}"]); acc["dep"].append(m[f"depth_{lvl}"])
+            if depth2rgb is not None:
+                acc["vis_dep"].append(depth2rgb(acc["dep"][-1], min_value=self.near, max_value=self.far))
+            if self.enable_semantic:
+                label = m["sem_label"].astype(np.uint8)
+                acc["sem"].append(label); acc["ent"].append(m["sem_entropy"])
+                if cmap is not None:
+                    acc["vis_sem"].append(np.asarray(cmap)[label.astype(np.int64)].astype(np.uint8))
+                if depth2rgb is not None:
+                    acc["vis_ent"].append(depth2rgb(acc["ent"][-1]))
+            if update_cluster:
+                sample_pixels.append(acc["albedo"][-1][::2, ::2, :].reshape(-1, 3))
+                sample_labels.append(acc["sem"][-1][::2, ::2].reshape(-1, 1))
+            if save_dir is not None:
+                w = lambda name, img: frames.write_png(os.path.join(save_dir, name.format(i)), img)
+                w("rgb_{:03d}.png", frames.to8b(acc["rgb"][-1])); w("albedo_{:03d}.png", frames.to8b(acc["albedo"][-1]))
+                w("shading_{:03d}.png", frames.to8b(acc["shading"][-1])); w("residual_{:03d}.png", frames.to8b(acc["residual"][-1]))
+                w("disp_{:03d}.png", acc["disp"][-1].astype(np.uint16)); w("depth_{:03d}.png", (acc["dep"][-1] * 1000).astype(np.uint16))
+                if acc["vis_dep"]:
+                    w("vis_depth_{:03d}.png", acc["vis_dep"][-1])
+                if self.enable_semantic:
+                    w("label_{:03d}.png", acc["sem"][-1]); w("entropy_{:03d}.png", frames.to8b(acc["ent"][-1]))
+                    if acc["vis_sem"]:
+                        w("vis_label_{:03d}.png", acc["vis_sem"][-1])
+                    if acc["vis_ent"]:
+                        w("vis_entropy_{:03d}.png", acc["vis_ent"][-1])
+
+        streamer, in_flight = None, []
+        for i in range(len(rays)):
+            out = self.render_rays(rays[i])
+            maps = {k: out[k].detach() for k in keys if k in out}
+            if self.enable_semantic:
+                logits = out[f"sem_logits_{lvl}"].detach()
+                logp = F.log_softmax(logits, dim=-1)
+                maps["sem_label"] = torch.argmax(F.softmax(logits, dim=-1), dim=-1).float()         # < 2^24: exact in fp32
+                maps["sem_entropy"] = torch.sum(-logp * F.softmax(logits, dim=-1), dim=-1)
+            pack, widths = frames.pack_maps(maps, keys)
+            if pack.is_cuda:
+                if streamer is None:
+                    streamer = frames.FrameStreamer(pack.device)
+                done = streamer.push(pack)
+                in_flight.append(i)
+                if done is not None:
+                    finish(in_flight.pop(0), done)
+            else:
+                finish(i, pack.numpy())
+        if streamer is not None:
+            for frame in streamer.drain():
+                finish(in_flight.pop(0), frame)
+        st = lambda name: np.stack(acc[name], 0) if acc[name] else None
+        cluster_manager = None
+        if update_cluster:
+            factory = getattr(self, "cluster_manager_factory", None)
+            if factory is None:
+                raise NotImplementedError("render_path(update_cluster=True) fits mean-shift clusters (Cluster_Manager.update_center, "
+                                          "SSR/training/cluster.py:101-182); set self.cluster_manager_factory to that class")
+            cluster_manager = factory(class_num=1 if getattr(self, "no_semantic_tree", False) else self.num_valid_semantic_class)
+            cluster_manager.update_center(np.stack(sample_labels, 0), np.stack(sample_pixels, 0), band_factor=b_f)
+        return (st("rgb"), st("disp"), st("dep"), st("vis_dep"), st("sem"), st("vis_sem"), st("ent"), st("vis_ent"),
+                st("albedo"), st("shading"), st("residual"), cluster_manager)
 
     def volumetric_rendering(self, ray_batch):
         ray_batch = ray_batch.float()

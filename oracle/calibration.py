@@ -78,33 +78,89 @@ def summarize(e):
     return f"{qs} max {float(fin.max()):.3g} #>1 {int((fin > 1).sum())}/{len(fin)}"
 
 
-def resampling_hazard(z_coarse, weights64, weights32, u=None, n_importance=128, trials=4, rtol=1e-4, atol=1e-5, seed=0):
-    """Per-ray stability of ``sample_pdf`` under weight noise of the size fp32 arithmetic actually produces on that ray.
-
-    ``sample_pdf`` is discontinuous: a bin whose cdf difference falls below 1e-5 switches from ``t = (u - cdf_lo) / denom``
-    to ``t = u - cdf_lo`` (run_nerf_helpers.py:440-443) - and on an opaque ray the empty bins' pdf, 1e-5 / (sum(w) + 62e-5),
-    sits right AT that threshold - so a 1e-7 change of the coarse weights can move an importance sample by a whole bin.
-    One fp32-vs-fp64 comparison samples that hazard once; this probes it several more times: the fp64 weights are
-    perturbed by +-2 x |fp32 - fp64| (uniformly up, uniformly down, and ``trials`` random sign patterns) and the largest
-    move of any importance sample, in tolerances, is returned per ray.  Rays with a large value cannot pin ANY fp32
-    implementation's fine pass to the plain tolerance; tests leave them to the rank statistics."""
-    from .intrinsic_render import inverse_cdf_sample
+def _perturbed_samples(z_coarse, weights64, weights32, u, trials, seed, cdf_noise):
+    """Importance samples (fp64) of ``sample_pdf`` on the fp64 coarse weights, unperturbed (first entry) and under
+    ``trials + 2`` perturbations of the size fp32 arithmetic produces on each ray: weights moved by
+    +-2 x max(|fp32 - fp64| of the element, rms of the ray's differences) (uniformly up, uniformly down, then random
+    sign patterns), cdf entries by uniform noise of +-``cdf_noise`` (a 62-term fp32 cumulative sum rounds differently
+    in every summation order; a few ulps of a value <= 1)."""
     z = torch.as_tensor(z_coarse).double()
     w64 = torch.as_tensor(weights64).double()[:, 1:-1]
-    delta = 2.0 * (torch.as_tensor(weights32).double()[:, 1:-1] - w64).abs() + 1e-9
+    d = (torch.as_tensor(weights32).double()[:, 1:-1] - w64).abs()
+    delta = 2.0 * torch.maximum(d, d.square().mean(1, keepdim=True).sqrt()) + 1e-9
     n = z.shape[0]
-    if u is None:
-        u = torch.linspace(0.0, 1.0, n_importance, dtype=torch.float64)
     u = torch.as_tensor(u).double()
     if u.dim() == 1:
         u = u.expand(n, u.shape[0])
+    u = u.contiguous()
     bins = 0.5 * (z[:, 1:] + z[:, :-1])
-    base = inverse_cdf_sample(bins, w64, u)
+
+    def sample(w, noise):
+        w = w + 1e-5                                                   # run_nerf_helpers.py:404-409
+        cdf = torch.cumsum(w / w.sum(-1, keepdim=True), -1)
+        cdf = torch.cat([torch.zeros_like(cdf[:, :1]), cdf], -1) + noise
+        idx = torch.searchsorted(cdf, u, right=True)
+        lo, hi = (idx - 1).clamp_min(0), idx.clamp_max(cdf.shape[-1] - 1)
+        denom = torch.gather(cdf, 1, hi) - torch.gather(cdf, 1, lo)
+        denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+        t = (u - torch.gather(cdf, 1, lo)) / denom
+        return torch.gather(bins, 1, lo) + t * (torch.gather(bins, 1, hi) - torch.gather(bins, 1, lo))
+
+    zero = torch.zeros(n, w64.shape[1] + 1, dtype=torch.float64)
+    out = [sample(w64, zero)]
     g = torch.Generator().manual_seed(seed)
-    signs = [torch.ones_like(w64), -torch.ones_like(w64)]
-    signs += [torch.randint(0, 2, w64.shape, generator=g).double() * 2 - 1 for _ in range(trials)]
-    worst = torch.zeros(n, dtype=torch.float64)
-    for s in signs:
-        moved = inverse_cdf_sample(bins, (w64 + s * delta).clamp_min(0.0), u)
-        worst = torch.maximum(worst, ((moved - base).abs() / (atol + rtol * base.abs())).amax(1))
-    return worst.numpy()
+    for trial in range(trials + 2):
+        if trial < 2:
+            s, noise = torch.full_like(w64, 1.0 - 2.0 * trial), zero
+        else:
+            s = torch.randint(0, 2, w64.shape, generator=g).double() * 2 - 1
+            noise = (torch.rand(zero.shape, generator=g, dtype=torch.float64) * 2 - 1) * cdf_noise
+        out.append(sample((w64 + s * delta).clamp_min(0.0), noise))
+    return out
+
+
+def fine_pass_hazard(rays, sd_fine, cfg, o32, o64, subset=None, trials=6, seed=0, cdf_noise=2e-7, rtol=1e-4, atol=1e-5,
+                     rtol_disp=5e-4):
+    """Per-ray conditioning of the FINE pass behind ``sample_pdf``: how far (in tolerances) the fine maps and ``z_std`` move
+    when the importance samples are drawn from coarse weights / cdf entries perturbed by what fp32 arithmetic produces on
+    that ray (``_perturbed_samples``).
+
+    ``sample_pdf`` is discontinuous: a bin whose cdf difference falls below 1e-5 switches from ``t = (u - cdf_lo) / denom``
+    to ``t = u - cdf_lo`` (run_nerf_helpers.py:440-443) - and on an opaque ray the empty bins' pdf, 1e-5 / (sum(w) + 62e-5),
+    sits right AT that threshold - so a 1e-7 change of a coarse weight or of a cdf entry can move an importance sample
+    by a whole bin, and ``1 / denom`` amplifies cdf round-off by up to 1e5.  Whether that matters depends on what the
+    fine network returns where the sample lands, so the probe re-runs the fine pass (fp32, on the fp32 oracle's own
+    coarse depths) for every perturbation and compares its maps with the unperturbed run's.  One fp32-vs-fp64 comparison
+    samples this hazard once; the probe samples it ``trials + 2`` more times.  Rays with a large value cannot pin ANY
+    fp32 implementation to the plain tolerance; tests leave those to the rank statistics.  ``subset`` (bool mask) limits
+    the work to the rays of interest; the others get +inf."""
+    from .intrinsic_render import composite, query_network
+    n = rays.shape[0]
+    mask = np.ones(n, bool) if subset is None else np.asarray(subset, bool)
+    out = np.full(n, np.inf)
+    if not mask.any():
+        return out
+    sel = torch.from_numpy(np.nonzero(mask)[0])
+    r = rays[sel].float()
+    z_c = torch.as_tensor(o32["z_coarse"])[sel].float()
+    u = torch.linspace(0.0, 1.0, cfg.n_importance, dtype=torch.float64)
+    draws = _perturbed_samples(torch.as_tensor(o64["z_coarse"])[sel], torch.as_tensor(o64["weights_coarse"])[sel],
+                               torch.as_tensor(o32["weights_coarse"])[sel], u, trials, seed, cdf_noise)
+
+    def fine(z_new):
+        z_new = z_new.float()
+        z_all, _ = torch.sort(torch.cat([z_c, z_new], -1), -1)
+        with torch.no_grad():
+            pts = r[:, None, 0:3] + r[:, None, 3:6] * z_all[:, :, None]
+            c = composite(query_network(sd_fine, pts, r[:, 8:11], cfg), z_all, r[:, 3:6], cfg)
+        c["z_std"] = torch.std(z_new, dim=-1, unbiased=False)
+        return {k: v.numpy() for k, v in c.items() if v is not None and k != "weights"}
+
+    base = fine(draws[0])
+    worst = np.zeros(len(sel))
+    for z_new in draws[1:]:
+        got = fine(z_new)
+        for k in base:
+            worst = np.maximum(worst, scaled_errors(got[k], base[k], rtol_disp if k == "disp" else rtol, atol))
+    out[mask] = worst
+    return out

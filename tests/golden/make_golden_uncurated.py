@@ -70,6 +70,14 @@ def to64(sd):
     return {k: v.double() for k, v in sd.items()}
 
 
+def fine_hazard(fx, rays, sd_f, cfg, mine, m64, pairs):
+    """oracle.calibration.fine_pass_hazard on the rays whose fp32-vs-fp64 score (maps and stage tensors) is <= 0.2; +inf elsewhere."""
+    tol = lambda k: 5e-4 if k.startswith("disp") else 1e-4
+    score = np.maximum.reduce([cal.scaled_errors(fx["ref_" + ok], fx["f64_" + ok], tol(ok)) for _, ok in pairs]
+                              + [fx[k] for k in fx if k.startswith("stage_score_")])
+    return cal.fine_pass_hazard(rays, sd_f, cfg, mine, m64, subset=score <= 0.2)
+
+
 def object_case(run_nerf, H_ref, name, n, n_importance):
     rays = frame_rays_object(H_ref, n)
     cfg = oracle.RenderConfig(variant="object", n_samples=64, n_importance=n_importance, white_bkgd=True)
@@ -105,7 +113,7 @@ def object_case(run_nerf, H_ref, name, n, n_importance):
         if k in mine:                      # per-ray fp32-vs-fp64 distance of the stage tensors (the conditioning score's other half)
             fx["stage_score_" + k] = cal.scaled_errors(mine[k].numpy(), m64[k].numpy())
     if n_importance > 0:
-        fx["stage_score_resampling_hazard"] = cal.resampling_hazard(m64["z_coarse"], m64["weights_coarse"], mine["weights_coarse"])
+        fx["stage_score_fine_pass_hazard"] = fine_hazard(fx, rays, sd_f, cfg, mine, m64, pairs)
     mg.save(name, **fx)
 
 
@@ -137,7 +145,7 @@ def ssr_case(SSRTrainer, ssr_rays, name, n, n_classes):
         fx["f64_" + ok] = m64[ok]
     for k in ("z_samples", "weights_coarse", "weights_fine", "z_fine"):
         fx["stage_score_" + k] = cal.scaled_errors(mine[k].numpy(), m64[k].numpy())
-    fx["stage_score_resampling_hazard"] = cal.resampling_hazard(m64["z_coarse"], m64["weights_coarse"], mine["weights_coarse"])
+    fx["stage_score_fine_pass_hazard"] = fine_hazard(fx, rays, sd_f, cfg, mine, m64, pairs)
     mg.save(name, **fx)
 
 

@@ -83,6 +83,9 @@ def test_argument_validation(capi):
     assert lib.inerf_mlp_backward_inputs(good, None, None, None, None, 256, 0, None, None, None, None, None) == capi.E_INVALID
     assert lib.inerf_mlp_weight_gradient(None, 256, None, 256, 1000, 256, 256, None, None, None, 65536, None) == capi.E_INVALID
     assert lib.inerf_cluster_lookup(None, None, 10, None, None, None, None, None, None, 1, 0, None, None, None) == capi.E_INVALID
+    assert lib.inerf_gen_rays(None, 12, None, 1, 4, 4, 1., 1., 2., 2., 0., 1., 0, None, None) == capi.E_INVALID
+    assert lib.inerf_gen_rays(None, 12, None, 0, 4, 4, 1., 1., 2., 2., 0., 1., 0, None, None) == capi.OK            # no poses
+    assert lib.inerf_frame_to_u8(None, 16, None, None) == capi.E_INVALID and lib.inerf_frame_to_u8(None, 0, None, None) == capi.OK
     for rc in (lib.inerf_sample_coarse(None, None, None, 0, 64, 0, None, None),
                lib.inerf_sample_pdf(None, None, None, 0, 63, 128, 0, None, None),
                lib.inerf_encode_mlp(good, None, None, None, 0, 64, 0, None, None, None),

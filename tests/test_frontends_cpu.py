@@ -286,3 +286,32 @@ def test_reference_query_lambda_is_recognised():
     assert ol._as_network_query(make(run_network, embed_fn, embeddirs_fn)) is None      # run_network itself is a closure cell here
     assert ol._as_network_query(lambda i, v, f: None) is None
     assert ol._as_network_query(print) is None
+
+
+def test_png_writer_and_host_to8b(tmp_path):
+    """frames.write_png (used when imageio is absent) writes decodable 8-bit RGB / grey and 16-bit grey PNGs; frames.to8b on
+    numpy arrays is the reference's lambda (run_nerf_helpers.py:13)."""
+    import struct
+    import zlib
+    from intrinsicnerf_amd import frames
+    rng = np.random.RandomState(0)
+    for img in ((rng.rand(5, 7, 3) * 255).astype(np.uint8), (rng.rand(4, 9) * 255).astype(np.uint8), (rng.rand(3, 5) * 65535).astype(np.uint16)):
+        path = tmp_path / "x.png"
+        frames.write_png(str(path), img)
+        data = open(path, "rb").read()
+        assert data[:8] == b"\x89PNG\r\n\x1a\n"
+        pos, chunks = 8, {}
+        while pos < len(data):
+            n, tag = struct.unpack(">I4s", data[pos:pos + 8])
+            body = data[pos + 8:pos + 8 + n]
+            assert struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(tag + body) & 0xffffffff
+            chunks[tag] = chunks.get(tag, b"") + body
+            pos += 12 + n
+        w, h, depth, colour = struct.unpack(">IIBB", chunks[b"IHDR"][:10])
+        assert (h, w) == img.shape[:2] and depth == 8 * img.dtype.itemsize and colour == (2 if img.ndim == 3 else 0)
+        raw = zlib.decompress(chunks[b"IDAT"])
+        row = len(raw) // h
+        pix = np.frombuffer(b"".join(raw[r * row + 1:(r + 1) * row] for r in range(h)), dtype=">u2" if depth == 16 else np.uint8)
+        assert np.array_equal(pix.reshape(img.shape), img)
+    x = rng.rand(50).astype(np.float32) * 1.5 - 0.25
+    assert np.array_equal(frames.to8b(x), (255 * np.clip(x, 0, 1)).astype(np.uint8))
