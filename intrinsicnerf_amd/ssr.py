@@ -211,7 +211,7 @@ def create_rays(num_rays, Ts_c2w, height, width, fx, fy, cx, cy, near, far, c2w_
                                 None if c2w_staticcam is None else c2w_staticcam.float())
         return rays.reshape(num_rays, height * width, -1)
     dirs_C = get_rays_camera(num_rays, height, width, fx, fy, cx, cy, depth_type=depth_type,
-                             convention=convention).view(num_rays, -1, 3)
+                             convention=convention).view(num_rays, -1, 3).to(Ts_c2w.device)
     rays_o, rays_d = get_rays_world(Ts_c2w, dirs_C)
     if use_viewdirs:
         viewdirs = rays_d
