@@ -289,11 +289,14 @@ __device__ __forceinline__ void to_operands(const f32x16 (&am)[RB][2], float inv
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int j = 8 * q2 + i;
-                    float t = fmaxf(__builtin_fmaf(am[rb][pb][j], inv, bias[rb][j >> 2][j & 3]), 0.0f);
-                    const float th = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, t) & 0xFFFFE000u);
-                    fh[i] = (_Float16)th;
-                    fl[i] = (_Float16)(t - th);
-                    tv[i] = t;
+                    tv[i] = fmaxf(__builtin_fmaf(am[rb][pb][j], inv, bias[rb][j >> 2][j & 3]), 0.0f);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) {
+                    f16x2 h2, l2;
+                    split_pair(tv[i], tv[i + 1], h2, l2);
+                    fh[i] = h2[0]; fh[i + 1] = h2[1];
+                    fl[i] = l2[0]; fl[i + 1] = l2[1];
                 }
                 if constexpr (SAVE) {          // registers 8*q2 .. +7 are channels 32*rb + 8*(2*q2) + 4h .. +3 and + 8*(2*q2 + 1) + 4h .. +3
 #pragma unroll
@@ -734,16 +737,15 @@ __device__ __forceinline__ void store_q(const f32x16 (&am)[PB], float inv, const
     for (int pb = 0; pb < PB; ++pb) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            float t[4], th[4];
+            float t[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 t[i] = __builtin_fmaf(am[pb][4 * g + i], inv, bias[g][i]);
                 if (relu) t[i] = fmaxf(t[i], 0.0f);
-                th[i] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, t[i]) & 0xFFFFE000u);
             }
-            const f16x2 h01 = {(_Float16)th[0], (_Float16)th[1]}, h23 = {(_Float16)th[2], (_Float16)th[3]};
-            const f16x2 l01 = {(_Float16)(t[0] - th[0]), (_Float16)(t[1] - th[1])};
-            const f16x2 l23 = {(_Float16)(t[2] - th[2]), (_Float16)(t[3] - th[3])};
+            f16x2 h01, h23, l01, l23;
+            split_pair(t[0], t[1], h01, l01);
+            split_pair(t[2], t[3], h23, l23);
             f16x2 a01 = h01, a23 = h23;
             if (!relu) {
                 a01 = __builtin_bit_cast(f16x2, __builtin_bit_cast(unsigned, h01) & 0x7FFF7FFFu);
@@ -770,12 +772,14 @@ __device__ __forceinline__ void to_operands_q(const f32x16 (&am)[PB], float inv,
         for (int q2 = 0; q2 < 2; ++q2) {
             f16x8 fh, fl;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < 8; i += 2) {
                 const int j = 8 * q2 + i;
-                const float t = fmaxf(__builtin_fmaf(am[pb][j], inv, bias[j >> 2][j & 3]), 0.0f);
-                const float th = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, t) & 0xFFFFE000u);
-                fh[i] = (_Float16)th;
-                fl[i] = (_Float16)(t - th);
+                const float t0 = fmaxf(__builtin_fmaf(am[pb][j], inv, bias[j >> 2][j & 3]), 0.0f);
+                const float t1 = fmaxf(__builtin_fmaf(am[pb][j + 1], inv, bias[(j + 1) >> 2][(j + 1) & 3]), 0.0f);
+                f16x2 h2, l2;
+                split_pair(t0, t1, h2, l2);
+                fh[i] = h2[0]; fh[i + 1] = h2[1];
+                fl[i] = l2[0]; fl[i + 1] = l2[1];
             }
             const f16x2 m = __builtin_elementwise_max(__builtin_elementwise_max(f16x2{fh[0], fh[1]}, f16x2{fh[2], fh[3]}),
                                                       __builtin_elementwise_max(f16x2{fh[4], fh[5]}, f16x2{fh[6], fh[7]}));

@@ -167,6 +167,20 @@ __device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const Weigh
 // Range check: packed f16 max over the |hi| pairs (inf when |t| > 65504).
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
+// hi = (t0, t1) rounded toward zero to f16 (= the 13 low mantissa bits cleared, for |t| in f16's normal range; the
+// conversion saturates at 65504 instead of overflowing), lo = f16(t - hi): the difference is exact in fp32, so lo is the
+// remainder rounded once.  Three instructions per pair: v_cvt_pkrtz_f16_f32 and two v_fma_mix{lo,hi}_f16, which read hi
+// as an f16 source, subtract it from the fp32 value and write the f16 result into one half of the destination - the
+// compiler does not form them from C (it emits two ANDs, a packed fp32 subtract and two packed conversions).
+__device__ __forceinline__ void split_pair(float t0, float t1, f16x2& hi, f16x2& lo) {
+    const unsigned h = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(t0, t1));
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(t0));
+    asm("v_fma_mixhi_f16 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(t1));
+    hi = __builtin_bit_cast(f16x2, h);
+    lo = __builtin_bit_cast(f16x2, l);
+}
+
 // The optional training copy goes through a buffer descriptor (one per activation slot, wave-uniform) and ONE per-lane
 // byte offset shared by all slots: with 64-bit global addresses the compiler kept an address pair per layer alive across
 // the tile loop and spilled ~300 registers.  Points beyond the end of the slot are dropped by the descriptor's range check.
@@ -187,12 +201,11 @@ __device__ __forceinline__ void wide_store_h(const f32x16 (&am)[RB][2], float in
         for (int pb = 0; pb < 2; ++pb) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                float t[4], th[4];
+                float t[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     t[i] = __builtin_fmaf(am[rb][pb][4 * g + i], inv, bias[rb][g][i]);
                     if (relu) t[i] = fmaxf(t[i], 0.0f);
-                    th[i] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, t[i]) & 0xFFFFE000u);
                     if (gout && (pb == 0 ? valid0 : valid1))
                         gout[(size_t)pb * 32 * gstride + 32 * rb + 8 * g + i] = t[i] * (1.0f / kActScale);
                 }
@@ -201,9 +214,9 @@ __device__ __forceinline__ void wide_store_h(const f32x16 (&am)[RB][2], float in
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), sv->rsrc,
                                                            sv->voff + (pb * 32 * sv->stride + 32 * rb + 8 * g) * 4, 0, 0);
                 }
-                const f16x2 h01 = {(_Float16)th[0], (_Float16)th[1]}, h23 = {(_Float16)th[2], (_Float16)th[3]};
-                const f16x2 l01 = {(_Float16)(t[0] - th[0]), (_Float16)(t[1] - th[1])};
-                const f16x2 l23 = {(_Float16)(t[2] - th[2]), (_Float16)(t[3] - th[3])};
+                f16x2 h01, h23, l01, l23;
+                split_pair(t[0], t[1], h01, l01);
+                split_pair(t[2], t[3], h23, l23);
                 f16x2 a01 = h01, a23 = h23;
                 if (!relu) {     // ReLU outputs are non-negative already
                     a01 = __builtin_bit_cast(f16x2, __builtin_bit_cast(unsigned, h01) & 0x7FFF7FFFu);
