@@ -12,13 +12,19 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libinerf.so")
 OBJ_DIR = os.path.join(CSRC, "_obj")          # git-ignored and gpurun-ignored: only the linked library travels
-SOURCES = ["pack.cpp", "api.cpp", "mlp.hip", "mlp_f16.hip", "mlp_bwd.hip", "mlp_wgrad.hip", "ray_ops.hip", "frame_ops.hip", "cluster.hip"]
-HEADERS = [os.path.join(CSRC, "layout.h"), os.path.join(CSRC, "mlp_common.h"), os.path.join(CSRC, "mlp_f16_dev.h"), os.path.join(os.path.dirname(PKG_DIR), "include", "inerf.h")]
+SOURCES = ["pack.cpp", "api.cpp", "mlp.hip", "mlp_f16.hip", "mlp_f16_pipe.hip", "mlp_bwd.hip", "mlp_wgrad.hip", "ray_ops.hip", "frame_ops.hip", "cluster.hip"]
+HEADERS = [os.path.join(CSRC, "layout.h"), os.path.join(CSRC, "mlp_common.h"), os.path.join(CSRC, "mlp_f16_dev.h"), os.path.join(CSRC, "mlp_f16_heads.h"), os.path.join(os.path.dirname(PKG_DIR), "include", "inerf.h")]
 # -ffp-contract=off: the reference rounds o + d*z, albedo*shading + residual, near*(1-t) + far*t ... as
 # separate multiplies and adds; fused multiply-adds would move sample positions by an ulp, which the
 # 2^9 frequency encoding amplifies.  MFMA accumulation is unaffected (it is an explicit builtin).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-Wno-comment", "-Wno-unused-result"]
+
+
+# mlp_f16_pipe.hip: MFMA results in ordinary VGPRs (its epilogue reads them with VALU instructions while the next MFMAs run);
+# the 256 registers of resident weights then take the AGPR half of the unified file.  Without the option the allocator puts
+# the accumulators there and copies 64-128 registers back per phase.
+EXTRA_FLAGS = {"mlp_f16_pipe.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _stale():
@@ -59,7 +65,7 @@ def build_library(force=False, verbose=False):
                 path = os.path.join(CSRC, src)
                 if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), newest_header):
                     return obj, None
-                cmd = [hipcc] + [f for f in FLAGS if f != "-shared"] + ["-c", path, "-o", obj + f".{os.getpid()}.tmp"]
+                cmd = [hipcc] + [f for f in FLAGS if f != "-shared"] + EXTRA_FLAGS.get(src, []) + ["-c", path, "-o", obj + f".{os.getpid()}.tmp"]
                 if verbose:
                     print(" ".join(cmd))
                 proc = subprocess.run(cmd, capture_output=True, text=True)

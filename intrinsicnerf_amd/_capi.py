@@ -10,7 +10,7 @@ import os
 from . import _build
 from ._build import LIB_PATH
 
-ABI_VERSION = 20003          # INERF_ABI_VERSION of include/inerf.h these ctypes declarations mirror
+ABI_VERSION = 20004          # INERF_ABI_VERSION of include/inerf.h these ctypes declarations mirror
 
 OK, E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_HIP = 0, -1, -2, -3, -4
 VARIANT_OBJECT, VARIANT_SSR = 0, 1
@@ -59,6 +59,7 @@ SYMBOLS = {
     "inerf_pack_weights": (_I, [C.POINTER(NetDesc), C.POINTER(_P), _I, _P, _L]),
     "inerf_sample_coarse": (_I, [_P, _P, _P, _L, _I, _U, _P, _P]),
     "inerf_encode_mlp": (_I, [C.POINTER(NetDesc), _P, _P, _P, _L, _I, _U, _P, _P, _P]),
+    "inerf_debug_encode_mlp": (_I, [C.POINTER(NetDesc), _P, _P, _P, _L, _I, _U, _P, _P, _P]),
     "inerf_mlp_save_floats": (_L, [C.POINTER(NetDesc), _L]),
     "inerf_mlp_save_slot": (_I, [C.POINTER(NetDesc), _I, _L, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "inerf_encode_mlp_train": (_I, [C.POINTER(NetDesc), _P, _P, _P, _L, _I, _U, _P, _P, _P, _P, _P]),
@@ -100,7 +101,7 @@ def lib():
                 _build.build_library()
             else:
                 raise RuntimeError(f"{LIB_PATH} is older than its sources and hipcc is not available to rebuild it")
-        handle = C.CDLL(LIB_PATH)
+        handle = C.CDLL(os.environ.get("INERF_LIB_OVERRIDE", LIB_PATH))      # kernel-tuning experiments load variant builds
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)          # AttributeError here = header/library mismatch
             fn.restype, fn.argtypes = res, args

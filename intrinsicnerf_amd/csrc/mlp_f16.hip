@@ -24,6 +24,7 @@
 #include <stdlib.h>
 
 #include "mlp_f16_dev.h"
+#include "mlp_f16_heads.h"
 
 namespace inerf {
 
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     float sn, cs;
-                    sincosf(x[c] * s, &sn, &cs);
+                    fast_sincosf(x[c] * s, &sn, &cs);
                     split_store(row + kColEnc + 3 + 6 * f + c, sn, amax);
                     split_store(row + kColEnc + 6 + 6 * f + c, cs, amax);
                     if (kSave && sv_ok) { sv_enc[3 + 6 * f + c] = sn; sv_enc[6 + 6 * f + c] = cs; }
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     float sn, cs;
-                    sincosf(v[c] * s, &sn, &cs);
+                    fast_sincosf(v[c] * s, &sn, &cs);
                     split_store(row + kColDir + 3 + 6 * fd + c, sn, amax);
                     split_store(row + kColDir + 6 + 6 * fd + c, cs, amax);
                     if (kSave && sv_ok) { sv_dir[3 + 6 * fd + c] = sn; sv_dir[6 + 6 * fd + c] = cs; }
@@ -267,148 +268,6 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
 // LDS per workgroup: two planes (hi, lo) of X[64 points][296 halfs] = [h 256 | dir 32 | pad 8]; 592-byte rows
 // put the 16 rows of a ds_read_b128 lane group on 16 distinct bank slots.
 // ================================================================================================
-constexpr int kRowD = kWidth + kDirCols + 8;      // 296
-constexpr int kPlaneD = kTilePoints * kRowD;
-constexpr int kLdsBytesD = 2 * kPlaneD * 2;       // 75,776
-constexpr int kColDirD = kWidth;                  // direction encoding right behind h: views reads [feature | dir] in one sweep
-constexpr int kColExD = 64;                       // exchange area: floats [wave][8] per point in columns 64..127 of the hi plane
-
-// accumulators of this wave's 32*RB channels x 64 points -> (bias, ReLU, hi/lo split) -> B operands, one per
-// 16-channel k-block q (accumulator registers 8*(q&1) .. +7 of row block q>>1) and point block
-template <int RB, bool SAVE = false>
-__device__ __forceinline__ void to_operands(const f32x16 (&am)[RB][2], float inv, const f32x4 (&bias)[RB][4], f16x2& amax2,
-                                            f16x8 (&hi)[2 * RB][2], f16x8 (&lo)[2 * RB][2], const SaveDst* sv = nullptr) {
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-        for (int pb = 0; pb < 2; ++pb) {
-#pragma unroll
-            for (int q2 = 0; q2 < 2; ++q2) {
-                f16x8 fh, fl;
-                float tv[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int j = 8 * q2 + i;
-                    tv[i] = fmaxf(__builtin_fmaf(am[rb][pb][j], inv, bias[rb][j >> 2][j & 3]), 0.0f);
-                }
-#pragma unroll
-                for (int i = 0; i < 8; i += 2) {
-                    f16x2 h2, l2;
-                    split_pair(tv[i], tv[i + 1], h2, l2);
-                    fh[i] = h2[0]; fh[i + 1] = h2[1];
-                    fl[i] = l2[0]; fl[i + 1] = l2[1];
-                }
-                if constexpr (SAVE) {          // registers 8*q2 .. +7 are channels 32*rb + 8*(2*q2) + 4h .. +3 and + 8*(2*q2 + 1) + 4h .. +3
-#pragma unroll
-                    for (int gg = 0; gg < 2; ++gg) {
-                        const f32x4 v = f32x4{tv[4 * gg], tv[4 * gg + 1], tv[4 * gg + 2], tv[4 * gg + 3]} * (1.0f / kActScale);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), sv->rsrc,
-                                                               sv->voff + (pb * 32 * sv->stride + 32 * rb + 8 * (2 * q2 + gg)) * 4, 0, 0);
-                    }
-                }
-                const f16x2 m = __builtin_elementwise_max(__builtin_elementwise_max(f16x2{fh[0], fh[1]}, f16x2{fh[2], fh[3]}),
-                                                          __builtin_elementwise_max(f16x2{fh[4], fh[5]}, f16x2{fh[6], fh[7]}));
-                amax2 = __builtin_elementwise_max(amax2, m);
-                hi[2 * rb + q2][pb] = fh;
-                lo[2 * rb + q2][pb] = fl;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-}
-
-// an output head straight from register operands: rows 0..3 of the 32-row result are the head's outputs, summed over
-// this wave's Q k-blocks only (partial sums; the caller adds the four waves')
-template <int Q>
-__device__ __forceinline__ void regop_gemm(const WeightBuf& wb, int frag_bytes, const f16x8 (&hi)[Q][2], const f16x8 (&lo)[Q][2],
-                                           f32x4 (&part)[2]) {
-    f32x16 acc[2];
-#pragma unroll
-    for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[pb][r] = 0.0f;
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        const f16x8 wh = wb.frag(frag_bytes + (2 * q) * 1024), wl = wb.frag(frag_bytes + (2 * q + 1) * 1024);
-#pragma unroll
-        for (int pb = 0; pb < 2; ++pb) {
-            acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hi[q][pb], acc[pb], 0, 0, 0);
-            acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, lo[q][pb], acc[pb], 0, 0, 0);
-            acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, hi[q][pb], acc[pb], 0, 0, 0);
-        }
-    }
-#pragma unroll
-    for (int pb = 0; pb < 2; ++pb) part[pb] = f32x4{acc[pb][0], acc[pb][1], acc[pb][2], acc[pb][3]};   // rows 0..3: lanes 0..31
-}
-
-// semantic head of the two-workgroup kernel (SSR): there is no room in LDS for the 128-channel hidden layer and no
-// registers to hold partial logits across the feature / view layers, so every wave does the whole head for ITS 16
-// points on v_mfma_f32_16x16x32_f16: hidden = relu(sem1 . h7) from the skinny-format copy of sem1 (streamed by all four
-// waves), converted in registers into the B operands of the logits GEMM (layout.h: sem2r) - no LDS, no exchange.
-template <bool kSave, int PLANE = kPlaneD>
-__device__ __forceinline__ void sem_head(const WeightBuf& wb, const NetLayout& L, const _Float16* xs /* h7, this wave's points */,
-                                         int lane, f16x2& amax2, float* out_row, bool valid, int n_classes, const SaveDst* sv) {
-    constexpr int kRb = kHalf / 16, kKb = kWidth / 32;
-    f32x4 acc[kRb];
-#pragma unroll
-    for (int rb = 0; rb < kRb; ++rb) acc[rb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int kb = 0; kb < kKb; ++kb) {
-        const f16x8 xh = *reinterpret_cast<const f16x8*>(xs + 32 * kb);
-        const f16x8 xl = *reinterpret_cast<const f16x8*>(xs + PLANE + 32 * kb);
-#pragma unroll
-        for (int rb = 0; rb < kRb; ++rb) {
-            const int frag = (L.sem1s.w * 4) + ((rb * kKb + kb) * 2) * 1024;
-            const f16x8 wh = wb.frag(frag), wl = wb.frag(frag + 1024);
-            acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc[rb], 0, 0, 0);
-            acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, acc[rb], 0, 0, 0);
-            acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc[rb], 0, 0, 0);
-        }
-    }
-    // bias, ReLU, hi/lo split: accumulators of row blocks 2m, 2m+1 -> the 32-deep B operand m
-    const float inv = wb.scalar((L.sem1.b + kHalf) * 4);
-    f16x8 bh[kRb / 2], bl[kRb / 2];
-#pragma unroll
-    for (int rb = 0; rb < kRb; ++rb) {
-        const f32x4 bias = wb.vec4((L.sem1.b + 16 * rb) * 4, 16 * (lane >> 4));
-        f32x4 tv;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float t = fmaxf(__builtin_fmaf(acc[rb][i], inv, bias[i]), 0.0f);
-            const float th = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, t) & 0xFFFFE000u);
-            bh[rb >> 1][4 * (rb & 1) + i] = (_Float16)th;
-            bl[rb >> 1][4 * (rb & 1) + i] = (_Float16)(t - th);
-            tv[i] = t;
-        }
-        if constexpr (kSave)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, tv * (1.0f / kActScale)), sv->rsrc, sv->voff + 16 * rb * 4, 0, 0);
-    }
-#pragma unroll
-    for (int m = 0; m < kRb / 2; ++m) {
-        const f16x2 mx = __builtin_elementwise_max(__builtin_elementwise_max(f16x2{bh[m][0], bh[m][1]}, f16x2{bh[m][2], bh[m][3]}),
-                                                   __builtin_elementwise_max(f16x2{bh[m][4], bh[m][5]}, f16x2{bh[m][6], bh[m][7]}));
-        amax2 = __builtin_elementwise_max(amax2, mx);
-    }
-    const float inv2 = wb.scalar((L.sem2.b + 16 * L.sem_rbs) * 4);
-#pragma unroll 1
-    for (int rb = 0; rb < L.sem_rbs; ++rb) {
-        f32x4 a = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int m = 0; m < kRb / 2; ++m) {
-            const int frag = (L.sem2r.w * 4) + ((rb * (kRb / 2) + m) * 2) * 1024;
-            const f16x8 wh = wb.frag(frag), wl = wb.frag(frag + 1024);
-            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh[m], a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl[m], a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh[m], a, 0, 0, 0);
-        }
-        const f32x4 bias = wb.vec4((L.sem2.b + 16 * rb) * 4, 16 * (lane >> 4));
-        const int ch0 = 16 * rb + 4 * (lane >> 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (valid && ch0 + i < n_classes)
-                __builtin_nontemporal_store(__builtin_fmaf(a[i], inv2, bias[i]), out_row + INERF_BASE_CHANNELS + ch0 + i);
-    }
-}
-
 template <bool kSave, bool kSsr>
 __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParams p) {
     constexpr int kPts = kTilePoints;
@@ -460,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     float sn, cs;
-                    sincosf(x[c] * s, &sn, &cs);
+                    fast_sincosf(x[c] * s, &sn, &cs);
                     split_store<kPlaneD>(row + 3 + 6 * f + c, sn, amax);
                     split_store<kPlaneD>(row + 6 + 6 * f + c, cs, amax);
                     if (sv_ok) { sv_enc[3 + 6 * f + c] = sn; sv_enc[6 + 6 * f + c] = cs; }
@@ -482,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         float sn, cs;
-                        sincosf(r[8 + c] * s, &sn, &cs);
+                        fast_sincosf(r[8 + c] * s, &sn, &cs);
                         split_store<kPlaneD>(row + kColDirD + 3 + 6 * fd + c, sn, amax);
                         split_store<kPlaneD>(row + kColDirD + 6 + 6 * fd + c, cs, amax);
                         if (sv_ok) { sv_dir[3 + 6 * fd + c] = sn; sv_dir[6 + 6 * fd + c] = cs; }
@@ -872,7 +731,7 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_quad(const MlpParam
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     float sn, cs;
-                    sincosf(x[c] * s, &sn, &cs);
+                    fast_sincosf(x[c] * s, &sn, &cs);
                     split_store<kPlaneQ>(row + 3 + 6 * f + c, sn, amax);
                     split_store<kPlaneQ>(row + 6 + 6 * f + c, cs, amax);
                 }
@@ -889,7 +748,7 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_quad(const MlpParam
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         float sn, cs;
-                        sincosf(r[8 + c] * s, &sn, &cs);
+                        fast_sincosf(r[8 + c] * s, &sn, &cs);
                         split_store<kPlaneQ>(row + kColDirD + 3 + 6 * fd + c, sn, amax);
                         split_store<kPlaneQ>(row + kColDirD + 6 + 6 * fd + c, cs, amax);
                     }
@@ -1065,6 +924,7 @@ int launch_mlp_f16x3(MlpParams& p, int64_t n_points, bool ssr, hipStream_t strea
     // (The SSR training forward takes 10.1-10.3 ms per step in either form.)
     const char* form = getenv("INERF_F16_KERNEL");
     if (form && form[0] == 'q' && !p.save && !(ssr && p.endpoint)) return launch_quad(p, n_points, ssr, stream);   // 128-point tiles, 8 waves
+    if (form && form[0] == 'p' && !p.save && !(ssr && p.endpoint)) return launch_pipe(p, n_points, ssr, stream);   // resident weights, pipelined epilogue
     if (!(ssr && p.endpoint) && !(form && form[0] == 's')) return launch_dual(p, n_points, ssr, stream);
     p.n_tiles = (int)((n_points + kTilePoints - 1) / kTilePoints);
     const int grid = p.n_tiles < device_cus() ? p.n_tiles : device_cus();

@@ -51,6 +51,31 @@ __device__ __forceinline__ void split_store(_Float16* hi_ptr, float v, float& am
     amax = fmaxf(amax, fabsf(t));
 }
 
+// sin and cos of an encoding argument a = x * 2^f (|a| up to 6 * 2^9 on the chair scene, 2^9 on the room's x / 10).
+// ocml's sincosf spends ~100 instructions (and diverges into its large-argument path) per call; the encodings are 24
+// calls per sample point.  This is the classic three-constant Cody-Waite reduction, exact to ~6e-8 in the reduced
+// argument for |a| < 2^15 thanks to the fused multiply-adds (pi/2 = c1 + c2 + c3 to 2^-72), followed by the cephes
+// single-precision minimax polynomials on [-pi/4, pi/4]: max |error| 9.2e-8 against a double-precision evaluation for
+// |a| <= 3e4 (libm's own float sin: 7e-8; measured over 1e7 arguments).  Larger arguments take ocml's path.
+__device__ __forceinline__ void fast_sincosf(float a, float* sn, float* cs) {
+    if (__builtin_expect(!(fabsf(a) < 32768.0f), 0)) { sincosf(a, sn, cs); return; }
+    const float j = __builtin_rintf(a * 0.636619772367581343f);
+    float r = __builtin_fmaf(-j, 1.5707963705062866f, a);
+    r = __builtin_fmaf(-j, -4.371138828673793e-08f, r);
+    r = __builtin_fmaf(-j, -1.7763568394002505e-15f, r);
+    const float z = r * r;
+    float sp = __builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    sp = __builtin_fmaf(sp, z, -1.6666654611e-1f);
+    const float s = __builtin_fmaf(sp * z, r, r);
+    float cp = __builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    cp = __builtin_fmaf(cp, z, 4.166664568298827e-2f);
+    const float c = __builtin_fmaf(cp * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
+    const int q = (int)j;
+    const float ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
+    *sn = (q & 2) ? -ss : ss;
+    *cs = ((q + 1) & 2) ? -cc : cc;
+}
+
 // ------------------------------------------------------------------------------------------------
 // wide GEMM: RB blocks of 32 channels per wave x 2 blocks of 32 points, K = 16 * (KB0 + KB1)
 // ------------------------------------------------------------------------------------------------
