@@ -509,9 +509,10 @@ class _WgradBatch:
         self.p, self.ranges, self.like = n_points, ranges, like
         self.jobs, self.total = [], 0
 
-    def add(self, g, x, m, n, want_bias=False):
-        """Schedules g[:, :m]^T @ x[:, :n]; returns a key for ``result`` (and ``bias`` if want_bias)."""
-        job = dict(g=g, x=x, m=m, n=n, off=self.total, boff=None)
+    def add(self, g, x, m, n, want_bias=False, ranges=None):
+        """Schedules g[:, :m]^T @ x[:, :n]; returns a key for ``result`` (and ``bias`` if want_bias).  ``ranges``: this
+        product's own operand bounds (default: the batch's)."""
+        job = dict(g=g, x=x, m=m, n=n, off=self.total, boff=None, ranges=ranges)
         self.total += m * n
         if want_bias:
             job["boff"] = self.total
@@ -531,7 +532,8 @@ class _WgradBatch:
                 g, x = j["g"], j["x"]
                 base = buf.data_ptr()
                 rc = lib.inerf_mlp_weight_gradient(C.c_void_p(g.data_ptr()), g.stride(0), C.c_void_p(x.data_ptr()), x.stride(0), self.p,
-                                                   j["m"], j["n"], _ptr(self.ranges), C.c_void_p(base + 4 * j["off"]),
+                                                   j["m"], j["n"], _ptr(self.ranges if j["ranges"] is None else j["ranges"]),
+                                                   C.c_void_p(base + 4 * j["off"]),
                                                    None if j["boff"] is None else C.c_void_p(base + 4 * j["boff"]), self.total,
                                                    _stream(self.like))
                 _capi.check(rc, "inerf_mlp_weight_gradient")
@@ -583,11 +585,22 @@ def mlp_weight_gradients(desc, names, save, dz, d_raw, n_points, endpoint=False,
     if sem:
         big["sem1"] = (SAVE_SEMH, SAVE_H0 + 7, 128, 256)
     W, B = {}, {}
+    sem2_key = None
     if ranges is not None:
         batch, keys, seen = _WgradBatch(n_points, ranges, save), {}, set()
         for k, (gs, xs, m, n) in big.items():
             keys[k] = batch.add(G[gs], X[xs], m, n, want_bias=gs not in seen)
             seen.add(gs)
+        if sem:
+            # semantic_linear.1 (semantic_nerf.py:110): dW[C,128] = d_logits^T . hidden, db = column sums.  d_logits is the
+            # slice d_raw[:, 11:11+C] - neither 16-byte aligned nor 32 columns wide - so it is copied once into a zero-padded
+            # [P, 128 | 256] matrix the split-K kernel can stream; its operand bound is its own (it is not part of dz).
+            c = desc.n_classes
+            mp = 128 if c <= 128 else 256
+            g_sem = d_raw.new_zeros(n_points, mp)
+            g_sem[:, :c] = d_raw[:, BASE_CHANNELS:BASE_CHANNELS + c]
+            r_sem = torch.stack([g_sem.abs().amax().clamp_min(1e-30), ranges[1]])
+            sem2_key = batch.add(g_sem, X[SAVE_SEMH], mp, 128, want_bias=True, ranges=r_sem)
         batch.run()
         for k, (gs, xs, m, n) in big.items():
             W[k] = batch.result(keys[k])
@@ -619,7 +632,10 @@ def mlp_weight_gradients(desc, names, save, dz, d_raw, n_points, endpoint=False,
     if sem:
         out["semantic_linear.0.0.weight"], out["semantic_linear.0.0.bias"] = W["sem1"], B[SAVE_SEMH]
         c = desc.n_classes
-        lin("semantic_linear.1", d_raw[:, BASE_CHANNELS:BASE_CHANNELS + c], X[SAVE_SEMH])
+        if sem2_key is not None:
+            out["semantic_linear.1.weight"], out["semantic_linear.1.bias"] = batch.result(sem2_key)[:c], batch.bias(sem2_key)[:c]
+        else:
+            lin("semantic_linear.1", d_raw[:, BASE_CHANNELS:BASE_CHANNELS + c], X[SAVE_SEMH])
     if heads is None:
         as1h = X[SAVE_AS1H]
         lin("albedo_linear2", dpre[:, 0:3], as1h[:, :128])

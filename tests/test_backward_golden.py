@@ -253,7 +253,9 @@ def _torch_reference_grads(module, embed, embed_d, rays, z, cot, endpoint=False,
 @pytest.mark.parametrize("variant,c,endpoint,n,s", [("object", 0, False, 37, 5), ("object", 0, False, 64, 64),
                                                     ("ssr", 5, True, 23, 11), ("ssr", 28, False, 16, 192), ("ssr", 0, False, 9, 7),
                                                     # more 64-point tiles than workgroups: the kernels' tile loops go round
-                                                    ("ssr", 5, True, 350, 64), ("object", 0, False, 700, 64), ("ssr", 3, False, 700, 64)])
+                                                    ("ssr", 5, True, 350, 64), ("object", 0, False, 700, 64), ("ssr", 3, False, 700, 64),
+                                                    # C > 128: semantic_linear.1's weight gradient takes the 256-row tile of the split-K kernel
+                                                    ("ssr", 150, False, 40, 16)])
 @pytest.mark.parametrize("form", ["default", "single"])
 def test_network_backward_vs_torch_autograd(variant, c, endpoint, n, s, form, monkeypatch):
     """One network, arbitrary cotangent on raw (every channel: sigma, the sigmoid heads, logits, endpoint feature), ragged
@@ -336,6 +338,37 @@ def test_training_step_uses_the_hip_network_backward(monkeypatch):
     for k in grads["hip"]:
         w = grads["torch"][k].double()
         assert float((grads["hip"][k].double() - w).norm()) <= 2e-4 * float(w.norm()) + 1e-10, k
+
+
+@pytest.mark.gpu
+def test_exact_fp32_precision_trains_through_torch_layers(monkeypatch):
+    """INERF_PRECISION=f32 has no HIP training kernels (the exact-fp32 MFMA runs at 1/16 of the f16 rate: a split-K weight
+    gradient on it would be slower than the library GEMM, and the f16x3 training path already matches fp64 autograd to 1e-5
+    of a tensor's norm).  What it does instead is explicit and checked here: sampling and compositing stay
+    on the HIP kernels (with the HIP compositing backward), each network is evaluated by its torch layers under autograd,
+    and the parameter gradients agree with the f16x3 HIP training path."""
+    import warnings
+    from intrinsicnerf_amd import object_level as ol
+    dev = torch.device("cuda:0")
+    fx = load_golden("object_chair_det")
+    embed, ch = ol.get_embedder(10, 0); embed_d, ch_d = ol.get_embedder(4, 0)
+    net = ol.NeRF(D=8, W=256, input_ch=ch, output_ch=5, skips=[4], input_ch_views=ch_d, use_viewdirs=True).to(dev)
+    net.load_state_dict(case_weights(fx)[0])
+    rays = torch.from_numpy(fx["rays"][:6]).to(dev)
+    grads = {}
+    for prec in ("f16x3", "f32"):
+        monkeypatch.setenv("INERF_PRECISION", prec)
+        net.zero_grad()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ret = ol.render_rays(rays, net, ol.NetworkQuery(embed, embed_d), 64, retraw=True, N_importance=16, white_bkgd=True)
+        assert (type(ret["raw"].grad_fn).__name__ == "_FusedMlpFnBackward") == (prec == "f16x3")
+        assert type(ret["rgb_map"].grad_fn).__name__ == "_CompositeFnBackward"          # compositing: HIP forward + HIP backward in both
+        (ret["rgb_map"].square().sum() + ret["albedo_map"].sum() + ret["rgb0"].sum()).backward()
+        grads[prec] = {k: p.grad.clone() for k, p in net.named_parameters()}
+    for k in grads["f32"]:
+        w = grads["f32"][k].double()
+        assert float((grads["f16x3"][k].double() - w).norm()) <= 2e-4 * float(w.norm()) + 1e-10, k
 
 
 @pytest.mark.gpu
