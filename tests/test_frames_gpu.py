@@ -107,8 +107,9 @@ def _chair_nets(dev, side):
     ro, rd = ol.get_rays(side, side, K, bench.chair_pose())
     vd = rd / rd.norm(dim=-1, keepdim=True)
     rays = torch.cat([ro, rd, 2 * torch.ones_like(rd[..., :1]), 6 * torch.ones_like(rd[..., :1]), vd], -1).reshape(-1, 11)
-    sd_c, _ = oracle.calibrated_lcg_weights("object", 0, 50, rays[::7])
-    sd_f, _ = oracle.calibrated_lcg_weights("object", 0, 51, rays[::7])
+    probe = rays[::max(1, rays.shape[0] // 384)]                    # a few hundred rays for the CPU-side calibration probe
+    sd_c, _ = oracle.calibrated_lcg_weights("object", 0, 50, probe)
+    sd_f, _ = oracle.calibrated_lcg_weights("object", 0, 51, probe)
     embed, ch = ol.get_embedder(10, 0); embed_d, ch_d = ol.get_embedder(4, 0)
     mk = lambda: ol.NeRF(D=8, W=256, input_ch=ch, output_ch=5, skips=[4], input_ch_views=ch_d, use_viewdirs=True).to(dev)
     net_c, net_f = mk(), mk()
