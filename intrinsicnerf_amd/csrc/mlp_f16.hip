@@ -680,7 +680,96 @@ __device__ __forceinline__ void load_bias_q(f32x4 (&bias)[4], float& inv, const 
     inv = wb.scalar(scale_bytes);
 }
 
-template <bool kSsr>
+// The quad layout worked as two 64-point halves with a software-pipelined epilogue (kernel form "halves"): one phase is the
+// GEMM of ONE half - this wave's 32 channels x 64 points, am[2H], am[2H+1], weights streamed two k-blocks ahead exactly as in
+// gemm_q - while, one chunk every second step, the OTHER half's accumulators (the previous phase's result) are retired:
+// bias, ReLU, hi/lo split, two ds_write_b64 into that half's rows.  A half's rows are rewritten only a barrier after their
+// last reader, so a 256-wide layer costs two barriers as before, but no wave ever converts accumulators without issuing
+// MFMAs - and the second wave of its SIMD fills the gaps its VALU instructions leave (measured on the one-wave-per-SIMD
+// form of the same idea, mlp_f16_pipe.hip: there every filler instruction delays the wave's own next MFMA by ~3 cycles).
+// x_hi / x_lo, d_hi / d_lo: opaque element offsets (the planes exceed the DS instructions' 16-bit offset field).
+template <int H, int KBT, bool EPI, bool ZERO = true>
+__device__ __forceinline__ void gemm_half_epi(const f16x8 (&pre)[4][2], const WeightBuf& wb, int frag_bytes, int kb_stride, _Float16* lds,
+                                              int x_hi, int x_lo, f32x16 (&am)[4], int d_hi, int d_lo, const f32x4 (&ebias)[4], float einv,
+                                              f16x2& amax2) {
+    static_assert(KBT == 16, "pipelined phases are the 256-wide layers");
+    constexpr int O = 2 * (1 - H);                 // the half being retired
+    if constexpr (ZERO) {
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) am[2 * H + pb][r] = 0.0f;
+    }
+    // a step is only 6 MFMAs (~200 cycles) here, so operands are requested further ahead than in gemm_q: weights FOUR k-blocks
+    // (ring of 6; the first four arrive in `pre`, requested by the previous phase), activations two (ring of 3)
+    f16x8 w[6][2], x[3][2][2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int part = 0; part < 2; ++part) w[k][part] = pre[k][part];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+            for (int part = 0; part < 2; ++part) x[k][pb][part] = *reinterpret_cast<const f16x8*>(lds + (part ? x_lo : x_hi) + 16 * k + pb * 32 * kRowD);
+#pragma unroll
+    for (int s = 0; s < KBT; ++s) {
+        const int s2 = s + 2 < KBT ? s + 2 : KBT - 1, s4 = s + 4 < KBT ? s + 4 : KBT - 1;
+#pragma unroll
+        for (int part = 0; part < 2; ++part) w[(s + 4) % 6][part] = wb.frag(frag_bytes + s4 * kb_stride + part * 1024);
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+            for (int part = 0; part < 2; ++part)
+                x[(s + 2) % 3][pb][part] = *reinterpret_cast<const f16x8*>(lds + (part ? x_lo : x_hi) + 16 * s2 + pb * 32 * kRowD);
+#pragma unroll
+        for (int combo = 0; combo < 3; ++combo)
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+                am[2 * H + pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[s % 6][combo == 2 ? 1 : 0], x[s % 3][pb][combo == 1 ? 1 : 0],
+                                                                          am[2 * H + pb], 0, 0, 0);
+        if constexpr (EPI) {
+            if ((s & 1) == 0) {
+                const int c = s >> 1, pb = c >> 2, g = c & 3;              // 8 chunks: (point block, 8-channel group)
+                float t[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t[i] = fmaxf(__builtin_fmaf(am[O + pb][4 * g + i], einv, ebias[g][i]), 0.0f);
+                f16x2 h01, h23, l01, l23;
+                split_pair(t[0], t[1], h01, l01);
+                split_pair(t[2], t[3], h23, l23);
+                amax2 = __builtin_elementwise_max(amax2, __builtin_elementwise_max(h01, h23));
+                const int doff = pb * 32 * kRowD + 8 * g;
+                *reinterpret_cast<f16x4*>(lds + d_hi + doff) = f16x4{h01[0], h01[1], h23[0], h23[1]};
+                *reinterpret_cast<f16x4*>(lds + d_lo + doff) = f16x4{l01[0], l01[1], l23[0], l23[1]};
+            }
+        }
+        // issue order: MFMA, weight load, MFMA, LDS reads, (epilogue VALU), MFMA ...
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            if (EPI) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (EPI) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            if (EPI && q == 1) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__device__ __forceinline__ int opaque_off(int v) { asm volatile("" : "+v"(v)); return v; }
+
+__device__ __forceinline__ void prefetch_q4(f16x8 (&pre)[4][2], const WeightBuf& wb, int frag_bytes, int kb_stride) {
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int part = 0; part < 2; ++part) pre[kb][part] = wb.frag(frag_bytes + kb * kb_stride + part * 1024);
+}
+
+template <bool kSsr, bool kHalves>
 __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_quad(const MlpParams p) {
     constexpr int kPts = kPtsQ;
     constexpr int kParts = 512 / kPts;          // 4
@@ -696,6 +785,12 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_quad(const MlpParam
     const _Float16* const xr = xw + 8 * (lane >> 5);                       // wide GEMM operand reads (+ column)
     _Float16* const xd = xw + 4 * (lane >> 5) + 32 * wave;                 // wide stores: this wave's 32 channels
     const _Float16* const xs = ldsq + (16 * wave + (lane & 15)) * kRowD + 8 * (lane >> 4);   // skinny operand reads: this wave's 16 points
+    // halves form: one opaque element offset per (half, plane) for operand reads and for this wave's stores
+    const int xbase = (lane & 31) * kRowD + 8 * (lane >> 5), dbase = (lane & 31) * kRowD + 4 * (lane >> 5) + 32 * wave;
+    const int xoff[2][2] = {{kHalves ? opaque_off(xbase) : 0, kHalves ? opaque_off(xbase + kPlaneQ) : 0},
+                            {kHalves ? opaque_off(xbase + 64 * kRowD) : 0, kHalves ? opaque_off(xbase + 64 * kRowD + kPlaneQ) : 0}};
+    const int doff[2][2] = {{kHalves ? opaque_off(dbase) : 0, kHalves ? opaque_off(dbase + kPlaneQ) : 0},
+                            {kHalves ? opaque_off(dbase + 64 * kRowD) : 0, kHalves ? opaque_off(dbase + 64 * kRowD + kPlaneQ) : 0}};
 
     WeightBuf wb;
     wb.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wts), 0, L.total_floats * 4, 0x00020000);
@@ -780,27 +875,100 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_quad(const MlpParam
 
         // ---------------- trunk ----------------
         gemm_q<4, 4>(pre, wb, frag256(L.trunk[0], 4), kStride256, xr, am);
-        store256(L.trunk[0], true, pf256(L.trunk[1], 16));
+        if constexpr (!kHalves) store256(L.trunk[0], true, pf256(L.trunk[1], 16));
+        if constexpr (!kHalves) {
 #pragma unroll 1
-        for (int layer = 1; layer < kSkipInput; ++layer) {
-            gemm_q<4, 16>(pre, wb, frag256(L.trunk[layer], 16), kStride256, xr, am);
-            if (layer + 1 < kSkipInput) store256(L.trunk[layer], true, pf256(L.trunk[layer + 1], 16));
-            else                        store256(L.trunk[layer], true, pf256(L.trunk[kSkipInput], 20, 4));
-        }
-        {   // pts_linears[5] over cat([pts, h]): h-part (k-blocks 4..19 of the stream), then the encoding again
-            const GemmSlot& s = L.trunk[kSkipInput];
-            gemm_q<4, 16>(pre, wb, frag256(s, 20) + 4 * kStride256, kStride256, xr, am);
-            prefetch_q(pre, wb, frag256(s, 20), kStride256);
+            for (int layer = 1; layer < kSkipInput; ++layer) {
+                gemm_q<4, 16>(pre, wb, frag256(L.trunk[layer], 16), kStride256, xr, am);
+                if (layer + 1 < kSkipInput) store256(L.trunk[layer], true, pf256(L.trunk[layer + 1], 16));
+                else                        store256(L.trunk[layer], true, pf256(L.trunk[kSkipInput], 20, 4));
+            }
+            {   // pts_linears[5] over cat([pts, h]): h-part (k-blocks 4..19 of the stream), then the encoding again
+                const GemmSlot& s = L.trunk[kSkipInput];
+                gemm_q<4, 16>(pre, wb, frag256(s, 20) + 4 * kStride256, kStride256, xr, am);
+                prefetch_q(pre, wb, frag256(s, 20), kStride256);
+                __syncthreads();
+                encode(false);
+                __syncthreads();
+                gemm_q<4, 4, false>(pre, wb, frag256(s, 20), kStride256, xr, am);
+                store256(s, true, pf256(L.trunk[6], 16));
+            }
+            gemm_q<4, 16>(pre, wb, frag256(L.trunk[6], 16), kStride256, xr, am);
+            store256(L.trunk[6], true, pf256(L.trunk[7], 16));
+            gemm_q<4, 16>(pre, wb, frag256(L.trunk[7], 16), kStride256, xr, am);
+            store256(L.trunk[7], true, pf256(L.as1, 16));
+        } else {
+            // Two 64-point halves, epilogues pipelined (gemm_half_epi).  am[0..1] = half A, am[2..3] = half B.  Phase (L, A) retires
+            // layer L-1 of half B, phase (L, B) layer L of half A; one barrier per phase.  Bias / output factor of the layer being
+            // retired are requested a phase before their first use (two register sets, alternating per layer).
+            f32x4 bset[2][4];
+            float iset[2];
+            f16x8 pre4[4][2];
+            auto want_bias = [&](int set, const GemmSlot& s) { load_bias_q(bset[set], iset[set], wb, (s.b + 32 * wave) * 4, (s.b + kWidth) * 4, lane); };
+            auto phase = [&](auto hc, auto epic, int frag, int eset, int next_frag) {
+                constexpr int Hh = decltype(hc)::value;
+                constexpr bool kEpi = decltype(epic)::value;
+                gemm_half_epi<Hh, 16, kEpi>(pre4, wb, frag, kStride256, ldsq, xoff[Hh][0], xoff[Hh][1], am,
+                                            doff[1 - Hh][0], doff[1 - Hh][1], bset[eset], iset[eset], amax2);
+                prefetch_q4(pre4, wb, next_frag, kStride256);
+                __syncthreads();
+            };
+            using std::integral_constant;
+            constexpr integral_constant<int, 0> HA{};
+            constexpr integral_constant<int, 1> HB{};
+            constexpr integral_constant<bool, true> EPI{};
+            constexpr integral_constant<bool, false> NOEPI{};
+            // layer 0: half A stored now (exposed), half B left pending with its bias in set 1 - the pipeline's entry state
+            want_bias(1, L.trunk[0]);
+            prefetch_q4(pre4, wb, frag256(L.trunk[1], 16), kStride256);
+            __syncthreads();                                                              // every wave has read the encodings
+            store_q<2>(reinterpret_cast<const f32x16(&)[2]>(am[0]), iset[1], bset[1], xd, true, amax2);
             __syncthreads();
-            encode(false);
+            // a pair of layers (l, l + 1): on entry half B of layer l - 1 is pending with its bias in set 1 and pre4 holds W(l)[0..3];
+            // on exit half B of layer l + 1 is pending with its bias in set 1 and pre4 holds the first fragments at next_frag
+            auto layer_pair = [&](int l, int next_frag) {
+                const GemmSlot& s0 = L.trunk[l];
+                const GemmSlot& s1 = L.trunk[l + 1];
+                const int f0 = frag256(s0, 16), f1 = frag256(s1, 16);
+                want_bias(0, s0);                                                         // first used in phase (l, B)
+                phase(HA, EPI, f0, 1, f0);                                                // retires (l - 1, B) with set 1
+                phase(HB, EPI, f0, 0, f1);                                                // retires (l, A)
+                phase(HA, EPI, f1, 0, f1);                                                // retires (l, B); set 1 is free from here on ...
+                want_bias(1, s1);                                                         // ... but requested only now: first used in the next phase
+                phase(HB, EPI, f1, 1, next_frag);                                         // retires (l + 1, A)
+            };
+#pragma unroll 1
+            for (int l = 1; l < kSkipInput; l += 2)
+                layer_pair(l, l + 2 < kSkipInput ? frag256(L.trunk[l + 2], 16) : frag256(L.trunk[kSkipInput], 20) + 4 * kStride256);
+            {   // pts_linears[5] over cat([pts, h]): h-parts of both halves, the encoding again, then its part for all 128 rows at once
+                const GemmSlot& s = L.trunk[kSkipInput];
+                const int fh = frag256(s, 20) + 4 * kStride256;
+                want_bias(0, s);
+                phase(HA, EPI, fh, 1, fh);                                                // retires (4, B)
+                gemm_half_epi<1, 16, false>(pre4, wb, fh, kStride256, ldsq, xoff[1][0], xoff[1][1], am, 0, 0, bset[0], iset[0], amax2);
+                prefetch_q(pre, wb, frag256(s, 20), kStride256);
+                __syncthreads();                                                          // every wave has read h4
+                encode(false);
+                __syncthreads();
+                gemm_q<4, 4, false>(pre, wb, frag256(s, 20), kStride256, xr, am);
+                prefetch_q4(pre4, wb, frag256(L.trunk[6], 16), kStride256);
+                __syncthreads();                                                          // every wave has read the encodings
+                store_q<2>(reinterpret_cast<const f32x16(&)[2]>(am[0]), iset[0], bset[0], xd, true, amax2);   // half A, exposed
+                __syncthreads();
+                // set 1 must hold layer 5's bias for the pending half B: copy (a few moves, once per tile)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bset[1][g] = bset[0][g];
+                iset[1] = iset[0];
+            }
+            layer_pair(6, frag256(L.as1, 16));                                            // leaves W(as1)[0..3] in pre4 ...
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int part = 0; part < 2; ++part) pre[k][part] = pre4[k][part];        // ... of which the heads' gemm_q wants two
+            // drain: half B of layer 7
+            store_q<2>(reinterpret_cast<const f32x16(&)[2]>(am[2]), iset[1], bset[1], xd + 64 * kRowD, true, amax2);
             __syncthreads();
-            gemm_q<4, 4, false>(pre, wb, frag256(s, 20), kStride256, xr, am);
-            store256(s, true, pf256(L.trunk[6], 16));
         }
-        gemm_q<4, 16>(pre, wb, frag256(L.trunk[6], 16), kStride256, xr, am);
-        store256(L.trunk[6], true, pf256(L.trunk[7], 16));
-        gemm_q<4, 16>(pre, wb, frag256(L.trunk[7], 16), kStride256, xr, am);
-        store256(L.trunk[7], true, pf256(L.as1, 16));
 
         // ---------------- heads ----------------
         const int my_pt = tile * kPts + 16 * wave + (lane & 15);
@@ -886,11 +1054,13 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_quad(const MlpParam
     if (p.status && __any(!(amax_all <= kF16Safe)) && lane == 0) atomicOr(p.status, INERF_STATUS_F16_RANGE);
 }
 
-static int launch_quad(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream) {
+static int launch_quad(MlpParams& p, int64_t n_points, bool ssr, bool halves, hipStream_t stream) {
     p.n_tiles = (int)((n_points + kPtsQ - 1) / kPtsQ);
     const int grid = p.n_tiles < device_cus() ? p.n_tiles : device_cus();
-    void (*kern)(const MlpParams) = ssr ? k_encode_mlp_f16x3_quad<true> : k_encode_mlp_f16x3_quad<false>;
-    static PerDeviceOnce attr_set[2];
+    void (*kern)(const MlpParams) = halves ? (ssr ? k_encode_mlp_f16x3_quad<true, true> : k_encode_mlp_f16x3_quad<false, true>)
+                                           : (ssr ? k_encode_mlp_f16x3_quad<true, false> : k_encode_mlp_f16x3_quad<false, false>);
+    static PerDeviceOnce attr_set4[4];
+    PerDeviceOnce* attr_set = attr_set4 + 2 * (int)halves;
     if (attr_set[ssr].first()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesQ);
         if (e != hipSuccess) return record(e);
@@ -923,7 +1093,8 @@ int launch_mlp_f16x3(MlpParams& p, int64_t n_points, bool ssr, hipStream_t strea
     // reaches memory in that form).  INERF_F16_KERNEL=single keeps the one-workgroup kernel everywhere (A/B runs).
     // (The SSR training forward takes 10.1-10.3 ms per step in either form.)
     const char* form = getenv("INERF_F16_KERNEL");
-    if (form && form[0] == 'q' && !p.save && !(ssr && p.endpoint)) return launch_quad(p, n_points, ssr, stream);   // 128-point tiles, 8 waves
+    if (form && form[0] == 'q' && !p.save && !(ssr && p.endpoint)) return launch_quad(p, n_points, ssr, false, stream);   // 128-point tiles, 8 waves
+    if (form && form[0] == 'h' && !p.save && !(ssr && p.endpoint)) return launch_quad(p, n_points, ssr, true, stream);    // ... as two pipelined halves
     if (form && form[0] == 'p' && !p.save && !(ssr && p.endpoint)) return launch_pipe(p, n_points, ssr, stream);   // resident weights, pipelined epilogue
     if (!(ssr && p.endpoint) && !(form && form[0] == 's')) return launch_dual(p, n_points, ssr, stream);
     p.n_tiles = (int)((n_points + kTilePoints - 1) / kTilePoints);
