@@ -1,0 +1,30 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence a round commits under profiles/ (run on the GPU box through gpurun; ~6 minutes):
+#   scripts/collect_profiles.sh r02
+# Writes gpurun_out/<tag>_*; copy what is to be kept into profiles/.
+tag=${1:-rXX}
+REPO=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$REPO/gpurun_out
+export TMPDIR=/tmp
+mkdir -p $OUT/prof
+cd $REPO
+# 1. the benchmark as the driver runs it (with the CPU oracle: parity + cpu_baseline)
+python bench.py --steps 5 --warmup 1 > $OUT/${tag}_bench.json 2> $OUT/${tag}_bench.err
+# 2. the same under rocprofv3 --kernel-trace --stats (no CPU legs: the profiler only sees the GPU)
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof/${tag}_bench -o bench -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/${tag}_bench_under_rocprof.json 2> $OUT/${tag}_bench_under_rocprof.err )
+find $OUT/prof/${tag}_bench -name "*kernel_stats.csv" -exec cp {} $OUT/${tag}_bench_kernel_stats.csv \;
+# 3. PMC passes on the dominant kernel at the benchmark's launch shape (640 000 rays x 192 samples), one counter group per pass
+export BENCH_SIZE="--rays 640000 --iters 2" BENCH_ARGS="--precision f16x3"
+bash scripts/pmc_pass.sh ${tag}_dual_A GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU
+bash scripts/pmc_pass.sh ${tag}_dual_fetch FETCH_SIZE
+bash scripts/pmc_pass.sh ${tag}_dual_write WRITE_SIZE
+bash scripts/pmc_pass.sh ${tag}_dual_cache TCC_HIT_sum TCC_MISS_sum
+python scripts/pmc_report.py $OUT/prof/${tag}_dual_A $OUT/prof/${tag}_dual_fetch $OUT/prof/${tag}_dual_write $OUT/prof/${tag}_dual_cache > $OUT/${tag}_mlp_pmc_summary.txt 2>&1
+for p in A fetch write cache; do find $OUT/prof/${tag}_dual_$p -name "*counter_collection.csv" -exec cp {} $OUT/${tag}_mlp_pmc_dual_$p.csv \; ; done
+# 4. the other kernel forms on the same box (same launch shape)
+for f in dual quad halves pipe single; do echo "$f: $(INERF_F16_KERNEL=$f python scripts/bench_mlp.py --rays 640000 --iters 3 2>&1 | tail -1)"; done > $OUT/${tag}_kernel_forms.txt
+# 5. SSR frame and the training step
+python scripts/bench_ssr_frame.py --frames 5 > $OUT/${tag}_ssr_frame.txt 2>&1
+python scripts/bench_train_step.py --iters 8 > $OUT/${tag}_train_step.txt 2>&1
+python scripts/bench_train_step.py --iters 8 --ssr 28 >> $OUT/${tag}_train_step.txt 2>&1
+tail -c 600 $OUT/${tag}_bench.err; tail -3 $OUT/${tag}_kernel_forms.txt; tail -2 $OUT/${tag}_ssr_frame.txt; tail -2 $OUT/${tag}_train_step.txt
