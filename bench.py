@@ -55,9 +55,11 @@ FLOP_PER_POINT_SSR = 2 * (659456 + 32768 + 128 * SSR_CLASSES)
 PEAK_F32_MFMA_TFLOPS = 157.3                 # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_F16_MFMA_TFLOPS = 2500.0                # MI355X_MICROARCH.md: dense f16/bf16 matrix peak
 MEASURED_F16_MFMA_ONLY_TFLOPS = 1590.0       # dense f16, random operands, 170-340 ms runs (zero operands: 2470)
-# HBM bytes per sample point of the encode+MLP kernels from the PMC passes (FETCH_SIZE + WRITE_SIZE, separate
-# passes) in profiles/r01_mlp_pmc_traffic.txt: 311.6 MB per 6,291,456-point launch (algorithmic: 306 MB).
-PMC_HBM_BYTES_PER_POINT = {"f16x3": 55.9, "f32": 49.5}
+# HBM bytes per sample point of the encode+MLP kernels from the PMC passes (FETCH_SIZE + WRITE_SIZE, separate passes).
+# f16x3: profiles/r02_mlp_pmc_traffic.txt, measured on the bench frame's own fine launch (640,000 rays x 192 samples):
+# 6461.6 MB per 122,880,000-point launch (algorithmic 5929.1 MB).  f32: profiles/r01_mlp_pmc_traffic.txt (kernel unchanged).
+PMC_HBM_BYTES_PER_POINT = {"f16x3": 52.6, "f32": 49.5}
+PMC_SOURCE = {"f16x3": ("profiles/r02_mlp_pmc_traffic.txt", "1.09"), "f32": ("profiles/r01_mlp_pmc_traffic.txt", "1.02")}
 PARITY_RAYS = 4096
 RTOL, ATOL, RTOL_DISP = 1e-4, 1e-5, 5e-4
 
@@ -360,10 +362,11 @@ def main():
     def roofline_entry(f16, kernel, achieved, avg_ms, n_launches, flop, traffic_pts):
         peak = PEAK_F16_MFMA_TFLOPS / 3.0 if f16 else PEAK_F32_MFMA_TFLOPS
         bpp = PMC_HBM_BYTES_PER_POINT["f16x3" if f16 else "f32"]
+        pmc_file, pmc_ratio = PMC_SOURCE["f16x3" if f16 else "f32"]
         return {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "traffic": bpp * traffic_pts,
                 "traffic_note": f"HBM bytes per launch = {bpp} B/point measured by rocprofv3 PMC (FETCH_SIZE, WRITE_SIZE in separate "
-                                f"passes, profiles/r01_mlp_pmc_traffic.txt) x this launch's points; {'1.15' if f16 else '1.02'}x algorithmic",
+                                f"passes, {pmc_file}) x this launch's points; {pmc_ratio}x algorithmic",
                 "avg_launch_ms": avg_ms, "launches_timed": n_launches, "flop_per_launch": flop,
                 "peak_basis": ("dense f16 MFMA 2500 TFLOP/s / 3 products per fp32 MAC" if f16 else "dense fp32 MFMA 157.3 TFLOP/s"),
                 "achieved_vs_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
