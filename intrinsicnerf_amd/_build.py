@@ -24,7 +24,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
 # mlp_f16_pipe.hip: MFMA results in ordinary VGPRs (its epilogue reads them with VALU instructions while the next MFMAs run);
 # the 256 registers of resident weights then take the AGPR half of the unified file.  Without the option the allocator puts
 # the accumulators there and copies 64-128 registers back per phase.
-EXTRA_FLAGS = {"mlp_f16_pipe.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+# mlp_bwd.hip: the chain kernel also runs one wave per SIMD; the option cuts its accumulator<->VGPR copies from ~580 to ~200.
+EXTRA_FLAGS = {"mlp_f16_pipe.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "mlp_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _stale():

@@ -426,7 +426,7 @@ extern "C" int inerf_debug_encode_mlp(const inerf_net_desc* net, const float* pa
 
 extern "C" int64_t inerf_mlp_save_floats(const inerf_net_desc* net, int64_t n_points) {
     if (!net || !inerf::net_supported(*net) || n_points < 0) return INERF_E_INVALID;
-    return inerf::save_offset(*net, inerf::SAVE_SLOTS, n_points);
+    return inerf::save_total_floats(*net, n_points);
 }
 
 extern "C" int inerf_mlp_save_slot(const inerf_net_desc* net, int slot, int64_t n_points, int64_t* offset_floats, int* width) {
@@ -461,6 +461,7 @@ static int encode_mlp_impl(const inerf_net_desc* net, const float* packed, const
     p.save = save;
     p.act_max = act_max;
     for (int s = 0; s < SAVE_SLOTS; ++s) p.save_off[s] = save_offset(*net, s, n_points);
+    p.bits_off = relu_bits_offset(*net, n_points);
     p.L = make_layout(*net);
     p.n_points = (int)n_points;
     p.n_samples = n_samples;

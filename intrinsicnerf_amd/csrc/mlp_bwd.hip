@@ -13,9 +13,13 @@
 // Differences:
 //   * gradients have no natural scale, so every point's chain is normalised by a power of two s_p >= its largest head
 //     gradient (exact; columns of a GEMM scale independently) and scaled back when dZ is written;
-//   * the ReLU masks come from the saved activations (h > 0), read where the epilogue needs them;
+//   * the ReLU masks of the trunk (h0..h6) are the bit words the training forward left behind the activation slots
+//     (layout.h relu_bits_offset: one 8-byte load per lane and layer instead of 64 floats); the stages that need the
+//     activations' VALUES anyway (h7 for the alpha_linear weight gradient, the three head hidden layers) read those;
 //   * the heads with 1-4 outputs (sigma, albedo/shading outputs, residual) are outer products: VALU, not MFMA;
 //   * the three matrices that feed d h7 (feature_linear^T, as1^T, sem1^T) share a weight scale and one accumulator.
+#include <type_traits>
+
 #include "mlp_f16_dev.h"
 
 namespace inerf {
@@ -30,6 +34,7 @@ struct BwdParams {
     float* head_partial;    // out, optional: [grid][kHeadFloats] weight / bias gradients of the 1-4-row heads, per workgroup
     int32_t* status;
     int64_t off[SAVE_SLOTS];
+    int64_t bits_off;       // ReLU masks of h0..h6 inside `save` (layout.h relu_bits_offset)
     BwdLayout L;
     int n_points, n_tiles, channels, n_classes, endpoint;
 };
@@ -45,18 +50,24 @@ constexpr int kHeadRes = 0, kHeadAs2 = 384, kHeadAlpha = 1408, kHeadBias = 1664,
 
 // epilogue of one transposed layer: t = acc * inv (+ per-channel vector x per-point scalar), ReLU mask from the saved
 // activation, hi/lo split into LDS (normalised, kActScale domain) and the true gradient to global memory
-template <int RB>
+struct NoAlpha {};
+template <int RB, bool BITS = false, typename AlphaAcc = NoAlpha>
 __device__ __forceinline__ void bwd_store(const f32x16 (&am)[RB][2], float inv, const float* mask_src /* + pt0*mstride + chan0 + 4h */,
                                           int mstride, const f32x4 (*extra)[4] /* [RB][4] or nullptr */, float ex0, float ex1,
                                           _Float16* dl /* plane_hi + (lane&31)*kRowH + 4h + dcol + chan0 */, f16x2& amax2,
                                           float* gout /* + pt0*gstride + chan0 + 4h */, int gstride, float s0, float s1,
                                           bool valid0, bool valid1, float& gmax,
-                                          f32x4 (*alpha_acc)[4] = nullptr /* [RB][4]: += (true d sigma of the point) * saved activation */) {
+                                          u32x2 mask_bits /* BITS: this lane's words of the layer (layout.h) */,
+                                          AlphaAcc& alpha_acc /* f32x4[RB][4]: += (true d sigma of the point) * saved activation; by
+                                                                 reference and selected at compile time - through a pointer-or-null
+                                                                 argument the accumulators lived in scratch memory */) {
+    constexpr bool kAlpha = !std::is_same<AlphaAcc, NoAlpha>::value;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
 #pragma unroll
         for (int pb = 0; pb < 2; ++pb) {
             const bool valid = pb == 0 ? valid0 : valid1;
+            const int bits16 = valid ? (int)(mask_bits[rb] >> (16 * (1 - pb))) : 0;     // points beyond the end carry no gradient
             const float ex = pb == 0 ? ex0 : ex1;
             const float back = (pb == 0 ? s0 : s1) * (1.0f / kActScale);
 #pragma unroll
@@ -65,12 +76,15 @@ __device__ __forceinline__ void bwd_store(const f32x16 (&am)[RB][2], float inv, 
                 f32x4 m4 = {1.0f, 1.0f, 1.0f, 1.0f};
                 if (mask_src) m4 = valid ? *reinterpret_cast<const f32x4*>(mask_src + (size_t)pb * 32 * mstride + 32 * rb + 8 * g)
                                          : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                if (alpha_acc) alpha_acc[rb][g] += m4 * (ex * (pb == 0 ? s0 : s1));      // m4 = h7 itself (zero for invalid points)
+                if constexpr (kAlpha) alpha_acc[rb][g] += m4 * (ex * (pb == 0 ? s0 : s1));      // m4 = h7 itself (zero for invalid points)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     t[i] = am[rb][pb][4 * g + i] * inv;
                     if (extra) t[i] = __builtin_fmaf(extra[rb][g][i], ex, t[i]);
-                    t[i] = m4[i] > 0.0f ? t[i] : 0.0f;
+                    if constexpr (BITS)    // v_bfe_i32: the bit, sign-extended, is the AND mask
+                        t[i] = __builtin_bit_cast(float, __builtin_bit_cast(int, t[i]) & __builtin_amdgcn_sbfe(bits16, 15 - (4 * g + i), 1));
+                    else
+                        t[i] = m4[i] > 0.0f ? t[i] : 0.0f;
                     th[i] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, t[i]) & 0xFFFFE000u);
                 }
                 const f16x2 h01 = {(_Float16)th[0], (_Float16)th[1]}, h23 = {(_Float16)th[2], (_Float16)th[3]};
@@ -136,6 +150,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
 
     WidePreH<2> preA, preB;
     prefetch_w<2>(preA, wb, frag(L.views_t, 8));
+    const __amdgpu_buffer_rsrc_t bits_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.save) + p.bits_off, 0, (int)((unsigned)p.n_tiles * (unsigned)kReluBitTileBytes), 0x00020000);
 
     // head weight gradients, accumulated over this workgroup's tiles (see kHead*)
     const bool heads = p.head_partial != nullptr;
@@ -245,8 +261,9 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
             const float inv = wb.scalar(L.views_t.b * 4);
             prefetch_w<2>(preA, wb, frag(L.feat_t, 16));
             prefetch_w<2>(preB, wb, frag(L.as1_t, 16));
+            NoAlpha none;
             bwd_store<2>(am, inv, nullptr, 0, nullptr, 0.0f, 0.0f, xd + kColB, amax2, const_cast<float*>(gptr(p.dz, SAVE_FEAT)), kWidth,
-                         s0, s1, valid0, valid1, gmax);
+                         s0, s1, valid0, valid1, gmax, u32x2{0u, 0u}, none);
         }
         __syncthreads();                     // A (dZ_vh) has been read by every wave, B (d feature) is complete
 
@@ -336,7 +353,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
             const float e0 = ptf(lane & 31)[7], e1 = ptf((lane & 31) + 32)[7];
             __syncthreads();                 // every wave is done reading A and B
             bwd_store<2>(am, inv, gptr(p.save, SAVE_H7), kWidth, aw, e0, e1, xd + kColA, amax2, const_cast<float*>(gptr(p.dz, SAVE_H7)),
-                         kWidth, s0, s1, valid0, valid1, gmax, heads ? halpha : nullptr);
+                         kWidth, s0, s1, valid0, valid1, gmax, u32x2{0u, 0u}, halpha);       // (accumulated whether or not `heads`)
         }
         __syncthreads();
 
@@ -345,12 +362,15 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
         for (int l = kDepth - 1; l >= 1; --l) {
             const int src = ((kDepth - 1 - l) & 1) ? kColB : kColA;
             const int dst = ((kDepth - 1 - l) & 1) ? kColA : kColB;
+            const u32x2 mbits = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
+                bits_rsrc, lane * 8, (((tile * kReluBitLayers + (l - 1)) * 4 + wave) * 64) * 8, 0));
             wide_gemm_h<2, 16, 0>(preA, wb, frag(L.trunk_t[l], 16), xr, src, 0, lane, am);
             const float inv = wb.scalar(L.trunk_t[l].b * 4);
             if (l > 1) prefetch_w<2>(preA, wb, frag(L.trunk_t[l - 1], 16));
             else       prefetch_w<2>(preA, wb, frag(L.views_t, 8));
-            bwd_store<2>(am, inv, gptr(p.save, SAVE_H0 + l - 1), kWidth, nullptr, 0.0f, 0.0f, xd + dst, amax2,
-                         const_cast<float*>(gptr(p.dz, SAVE_H0 + l - 1)), kWidth, s0, s1, valid0, valid1, gmax);
+            NoAlpha none;
+            bwd_store<2, true>(am, inv, nullptr, 0, nullptr, 0.0f, 0.0f, xd + dst, amax2,
+                               const_cast<float*>(gptr(p.dz, SAVE_H0 + l - 1)), kWidth, s0, s1, valid0, valid1, gmax, mbits, none);
             __syncthreads();
         }
     }
@@ -439,6 +459,7 @@ extern "C" int inerf_mlp_backward_inputs(const inerf_net_desc* net, const float*
     BwdParams p;
     p.wts = packed_bwd; p.raw = raw; p.d_raw = d_raw; p.save = save; p.dz = dz_out; p.dz_max = dz_max; p.head_partial = head_partial; p.status = status;
     for (int s = 0; s < SAVE_SLOTS; ++s) p.off[s] = save_offset(*net, s, n_points);
+    p.bits_off = relu_bits_offset(*net, n_points);
     p.L = make_bwd_layout(*net);
     p.n_points = (int)n_points;
     p.n_tiles = (int)((n_points + kTilePoints - 1) / kTilePoints);

@@ -16,6 +16,7 @@ struct MlpParams {
     float* save;            // training forward: activation buffer (layout.h SaveSlot), else nullptr
     float* act_max;         // training forward, optional: device float that receives max |activation| (caller zeroes it)
     int64_t save_off[SAVE_SLOTS];   // float offsets of the slots for this launch's n_points
+    int64_t bits_off;       // float offset of the ReLU-mask area (layout.h relu_bits_offset)
     NetLayout L;
     int n_points;           // N*S  (< 2^31, checked on the host)
     int n_samples;

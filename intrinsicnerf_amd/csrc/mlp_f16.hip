@@ -63,6 +63,13 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
     WidePreH<2> pre2;
     WidePreH<1> pre1;
     wide_prefetch_h<2>(pre2, wb, frag256(L.trunk[0], 4), bias256(L.trunk[0]), scale256(L.trunk[0]), lane);
+    auto enc_save = [&](int slot, int cols, int gp, bool ok) {          // training copy of a point's encoding row (EncSave)
+        EncSave e;
+        e.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save + (kSave ? p.save_off[slot] : 0), 0,
+                                                   kSave ? (int)((unsigned)p.n_points * (unsigned)cols * 4u) : 0, 0x00020000);
+        e.voff = ok ? gp * cols * 4 : EncSave::kDropOffset;
+        return e;
+    };
 
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         // ---------------- encode -> hi/lo planes ----------------
@@ -75,8 +82,7 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
             const float zz = __builtin_nontemporal_load(p.z + gp);     // streamed once: keep it out of the L2 the weights live in
             _Float16* row = ldsh + pt * kRowH;
             const bool sv_ok = kSave && tile * kPts + pt < p.n_points;
-            float* const sv_enc = kSave ? p.save + p.save_off[SAVE_ENC] + (size_t)gp * kEncCols : nullptr;
-            float* const sv_dir = kSave ? p.save + p.save_off[SAVE_DIR] + (size_t)gp * kDirCols : nullptr;
+            const EncSave sv_enc = enc_save(SAVE_ENC, kEncCols, gp, sv_ok), sv_dir = enc_save(SAVE_DIR, kDirCols, gp, sv_ok);
             float x[3], v[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -92,7 +98,7 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
                     fast_sincosf(x[c] * s, &sn, &cs);
                     split_store(row + kColEnc + 3 + 6 * f + c, sn, amax);
                     split_store(row + kColEnc + 6 + 6 * f + c, cs, amax);
-                    if (kSave && sv_ok) { sv_enc[3 + 6 * f + c] = sn; sv_enc[6 + 6 * f + c] = cs; }
+                    if (kSave) { sv_enc.put(3 + 6 * f + c, sn); sv_enc.put(6 + 6 * f + c, cs); }
                 }
             }
             const int fd = kParts - 1 - part;
@@ -104,25 +110,25 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
                     fast_sincosf(v[c] * s, &sn, &cs);
                     split_store(row + kColDir + 3 + 6 * fd + c, sn, amax);
                     split_store(row + kColDir + 6 + 6 * fd + c, cs, amax);
-                    if (kSave && sv_ok) { sv_dir[3 + 6 * fd + c] = sn; sv_dir[6 + 6 * fd + c] = cs; }
+                    if (kSave) { sv_dir.put(3 + 6 * fd + c, sn); sv_dir.put(6 + 6 * fd + c, cs); }
                 }
             }
             if (part == 2) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) split_store(row + kColEnc + c, x[c], amax);
                 for (int c = 3 + 6 * p.l_xyz; c < kEncCols; ++c) { row[kColEnc + c] = (_Float16)0.0f; row[kPlaneH + kColEnc + c] = (_Float16)0.0f; }
-                if (kSave && sv_ok) {
-                    for (int c = 0; c < 3; ++c) sv_enc[c] = x[c];
-                    for (int c = 3 + 6 * p.l_xyz; c < kEncCols; ++c) sv_enc[c] = 0.0f;
+                if (kSave) {
+                    for (int c = 0; c < 3; ++c) sv_enc.put(c, x[c]);
+                    for (int c = 3 + 6 * p.l_xyz; c < kEncCols; ++c) sv_enc.put(c, 0.0f);
                 }
             }
             if (part == 3) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) split_store(row + kColDir + c, v[c], amax);
                 for (int c = 3 + 6 * p.l_dir; c < kDirCols; ++c) { row[kColDir + c] = (_Float16)0.0f; row[kPlaneH + kColDir + c] = (_Float16)0.0f; }
-                if (kSave && sv_ok) {
-                    for (int c = 0; c < 3; ++c) sv_dir[c] = v[c];
-                    for (int c = 3 + 6 * p.l_dir; c < kDirCols; ++c) sv_dir[c] = 0.0f;
+                if (kSave) {
+                    for (int c = 0; c < 3; ++c) sv_dir.put(c, v[c]);
+                    for (int c = 3 + 6 * p.l_dir; c < kDirCols; ++c) sv_dir.put(c, 0.0f);
                 }
             }
         }
@@ -140,6 +146,9 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
             d.stride = width;
             return d;
         };
+        // ReLU masks of h0..h6 for the input-gradient chain (layout.h relu_bits_offset): one descriptor for the area
+        const __amdgpu_buffer_rsrc_t bits_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            p.save + (kSave ? p.bits_off : 0), 0, kSave ? (int)((unsigned)p.n_tiles * (unsigned)kReluBitTileBytes) : 0, 0x00020000);
         auto step256 = [&](const GemmSlot& s, auto kb0c, auto kb1c, int c0, int c1, int dcol, bool relu, int slot,
                            auto&& prefetch_next) {
             constexpr int KB0 = decltype(kb0c)::value, KB1 = decltype(kb1c)::value;
@@ -153,7 +162,12 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
             wide_gemm_h<2, KB0, KB1>(pre2, wb, frag256(s, KB0 + KB1), xr, c0, c1, lane, am);
             prefetch_next();
             const SaveDst sv = save_dst(slot, kWidth, 64 * wave);
-            wide_store_h<2, kRowH, kPlaneH, kSave>(am, inv, bias, xd + dcol + 64 * wave, relu, amax2, nullptr, 0, 0, 0, &sv);
+            if (kSave && slot < SAVE_H7) {          // (a compile-time constant at every call site)
+                const BitsDst bd = {bits_rsrc, (((tile * kReluBitLayers + (slot - SAVE_H0)) * 4 + wave) * 64 + lane) * 8};
+                wide_store_h<2, kRowH, kPlaneH, kSave, kSave>(am, inv, bias, xd + dcol + 64 * wave, relu, amax2, nullptr, 0, 0, 0, &sv, &bd);
+            } else {
+                wide_store_h<2, kRowH, kPlaneH, kSave>(am, inv, bias, xd + dcol + 64 * wave, relu, amax2, nullptr, 0, 0, 0, &sv);
+            }
             __syncthreads();
         };
         auto step128 = [&](const GemmSlot& s, auto kb0c, auto kb1c, int c0, int c1, int dcol, bool relu, float* gout, int slot,
@@ -294,6 +308,13 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
     WidePreH<2> pre2;
     WidePreH<1> pre1;
     prefetch_w<2>(pre2, wb, frag256(L.trunk[0], 4));
+    auto enc_save = [&](int slot, int cols, int gp, bool ok) {          // training copy of a point's encoding row (EncSave)
+        EncSave e;
+        e.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save + (kSave ? p.save_off[slot] : 0), 0,
+                                                   kSave ? (int)((unsigned)p.n_points * (unsigned)cols * 4u) : 0, 0x00020000);
+        e.voff = ok ? gp * cols * 4 : EncSave::kDropOffset;
+        return e;
+    };
 
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         // ---------------- encode -> hi/lo planes (xyz: columns 0..63, dir: columns 256..287) ----------------
@@ -306,8 +327,7 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
             const float zz = __builtin_nontemporal_load(p.z + gp);
             _Float16* row = ldsd + pt * kRowD;
             const bool sv_ok = kSave && with_dir && tile * kPts + pt < p.n_points;       // the skip layer's second pass re-computes only
-            float* const sv_enc = kSave ? p.save + p.save_off[SAVE_ENC] + (size_t)gp * kEncCols : nullptr;
-            float* const sv_dir = kSave ? p.save + p.save_off[SAVE_DIR] + (size_t)gp * kDirCols : nullptr;
+            const EncSave sv_enc = enc_save(SAVE_ENC, kEncCols, gp, sv_ok), sv_dir = enc_save(SAVE_DIR, kDirCols, gp, sv_ok);
             float x[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -322,16 +342,16 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
                     fast_sincosf(x[c] * s, &sn, &cs);
                     split_store<kPlaneD>(row + 3 + 6 * f + c, sn, amax);
                     split_store<kPlaneD>(row + 6 + 6 * f + c, cs, amax);
-                    if (sv_ok) { sv_enc[3 + 6 * f + c] = sn; sv_enc[6 + 6 * f + c] = cs; }
+                    if (kSave) { sv_enc.put(3 + 6 * f + c, sn); sv_enc.put(6 + 6 * f + c, cs); }
                 }
             }
             if (part == 2) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) split_store<kPlaneD>(row + c, x[c], amax);
                 for (int c = 3 + 6 * p.l_xyz; c < kEncCols; ++c) { row[c] = (_Float16)0.0f; row[kPlaneD + c] = (_Float16)0.0f; }
-                if (sv_ok) {
-                    for (int c = 0; c < 3; ++c) sv_enc[c] = x[c];
-                    for (int c = 3 + 6 * p.l_xyz; c < kEncCols; ++c) sv_enc[c] = 0.0f;
+                if (kSave) {
+                    for (int c = 0; c < 3; ++c) sv_enc.put(c, x[c]);
+                    for (int c = 3 + 6 * p.l_xyz; c < kEncCols; ++c) sv_enc.put(c, 0.0f);
                 }
             }
             if (with_dir) {
@@ -344,16 +364,16 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
                         fast_sincosf(r[8 + c] * s, &sn, &cs);
                         split_store<kPlaneD>(row + kColDirD + 3 + 6 * fd + c, sn, amax);
                         split_store<kPlaneD>(row + kColDirD + 6 + 6 * fd + c, cs, amax);
-                        if (sv_ok) { sv_dir[3 + 6 * fd + c] = sn; sv_dir[6 + 6 * fd + c] = cs; }
+                        if (kSave) { sv_dir.put(3 + 6 * fd + c, sn); sv_dir.put(6 + 6 * fd + c, cs); }
                     }
                 }
                 if (part == 3) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) split_store<kPlaneD>(row + kColDirD + c, r[8 + c], amax);
                     for (int c = 3 + 6 * p.l_dir; c < kDirCols; ++c) { row[kColDirD + c] = (_Float16)0.0f; row[kPlaneD + kColDirD + c] = (_Float16)0.0f; }
-                    if (sv_ok) {
-                        for (int c = 0; c < 3; ++c) sv_dir[c] = r[8 + c];
-                        for (int c = 3 + 6 * p.l_dir; c < kDirCols; ++c) sv_dir[c] = 0.0f;
+                    if (kSave) {
+                        for (int c = 0; c < 3; ++c) sv_dir.put(c, r[8 + c]);
+                        for (int c = 3 + 6 * p.l_dir; c < kDirCols; ++c) sv_dir.put(c, 0.0f);
                     }
                 }
             }
@@ -374,14 +394,21 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
             d.stride = width;
             return d;
         };
-        auto store256 = [&](const GemmSlot& s, bool relu, int slot, auto&& prefetch_next) {
+        // ReLU masks of h0..h6 for the input-gradient chain (layout.h relu_bits_offset)
+        const __amdgpu_buffer_rsrc_t bits_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            p.save + (kSave ? p.bits_off : 0), 0, kSave ? (int)((unsigned)p.n_tiles * (unsigned)kReluBitTileBytes) : 0, 0x00020000);
+        auto store256 = [&](const GemmSlot& s, bool relu, int slot, auto&& prefetch_next, auto bits_tag) {
             load_bias<2>(bias2, inv2, wb, (s.b + 64 * wave) * 4, (s.b + kWidth) * 4, lane);
             prefetch_next();
             const SaveDst sv = save_dst(slot, kWidth, 64 * wave);
+            constexpr bool kBits = kSave && decltype(bits_tag)::value;
+            const BitsDst bd = {bits_rsrc, kBits ? (((tile * kReluBitLayers + (slot - SAVE_H0)) * 4 + wave) * 64 + lane) * 8 : 0};
             __syncthreads();                       // every wave has read the layer's input
-            wide_store_h<2, kRowD, kPlaneD, kSave>(am2, inv2, bias2, xd, relu, amax2, nullptr, 0, 0, 0, &sv);
+            wide_store_h<2, kRowD, kPlaneD, kSave, kBits>(am2, inv2, bias2, xd, relu, amax2, nullptr, 0, 0, 0, &sv, &bd);
             __syncthreads();
         };
+        constexpr std::true_type kWithBits{};
+        constexpr std::false_type kNoBits{};
         auto pf256 = [&](const GemmSlot& s, int kbt) { return [&, kbt]() { prefetch_w<2>(pre2, wb, frag256(s, kbt)); }; };
         auto pf256_at = [&](const GemmSlot& s, int kbt, int kb_first) {
             return [&, kbt, kb_first]() { prefetch_w<2>(pre2, wb, frag256(s, kbt) + kb_first * 2 * 2 * 1024); };
@@ -390,12 +417,12 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
 
         // ---------------- trunk ----------------
         wide_gemm_h<2, 4, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.trunk[0], 4), xr, 0, 0, lane, am2);
-        store256(L.trunk[0], true, SAVE_H0, pf256(L.trunk[1], 16));
+        store256(L.trunk[0], true, SAVE_H0, pf256(L.trunk[1], 16), kWithBits);
 #pragma unroll 1
         for (int layer = 1; layer < kSkipInput; ++layer) {
             wide_gemm_h<2, 16, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.trunk[layer], 16), xr, 0, 0, lane, am2);
-            if (layer + 1 < kSkipInput) store256(L.trunk[layer], true, SAVE_H0 + layer, pf256(L.trunk[layer + 1], 16));
-            else                        store256(L.trunk[layer], true, SAVE_H0 + layer, pf256_at(L.trunk[kSkipInput], 20, 4));
+            if (layer + 1 < kSkipInput) store256(L.trunk[layer], true, SAVE_H0 + layer, pf256(L.trunk[layer + 1], 16), kWithBits);
+            else                        store256(L.trunk[layer], true, SAVE_H0 + layer, pf256_at(L.trunk[kSkipInput], 20, 4), kWithBits);
         }
         {   // pts_linears[5] over cat([pts, h]): h-part (k-blocks 4..19 of the stream), then the encoding again
             const GemmSlot& s = L.trunk[kSkipInput];
@@ -405,12 +432,12 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
             encode(false);
             __syncthreads();
             wide_gemm_h<2, 4, 0, kRowD, kPlaneD, false>(pre2, wb, frag256(s, 20), xr, 0, 0, lane, am2);
-            store256(s, true, SAVE_H0 + kSkipInput, pf256(L.trunk[6], 16));
+            store256(s, true, SAVE_H0 + kSkipInput, pf256(L.trunk[6], 16), kWithBits);
         }
         wide_gemm_h<2, 16, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.trunk[6], 16), xr, 0, 0, lane, am2);
-        store256(L.trunk[6], true, SAVE_H0 + 6, pf256(L.trunk[7], 16));
+        store256(L.trunk[6], true, SAVE_H0 + 6, pf256(L.trunk[7], 16), kWithBits);
         wide_gemm_h<2, 16, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.trunk[7], 16), xr, 0, 0, lane, am2);
-        store256(L.trunk[7], true, SAVE_H7, pf256(L.as1, 16));
+        store256(L.trunk[7], true, SAVE_H7, pf256(L.as1, 16), kNoBits);
 
         // ---------------- heads ----------------
         const int my_pt = tile * kPts + 16 * wave + (lane & 15);
@@ -439,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
         }
         // feature (no activation) in place of h7, then the view-dependent layer over [feature | dir] -> registers
         wide_gemm_h<2, 16, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.feat, 16), xr, 0, 0, lane, am2);
-        store256(L.feat, false, SAVE_FEAT, pf128(L.views, 18));
+        store256(L.feat, false, SAVE_FEAT, pf128(L.views, 18), kNoBits);
         {
             f32x16 am1[1][2];
             f32x4 bias1[1][4];

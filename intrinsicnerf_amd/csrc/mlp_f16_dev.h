@@ -14,6 +14,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 // Weight / bias fetches go through ONE buffer descriptor over the packed blob: the per-lane part of the
 // address (lane * 16 B) is a single VGPR shared by every layer and the layer / wave / k-block part is a
@@ -215,13 +216,45 @@ struct SaveDst {
     int stride;        // floats per point
 };
 
-template <int RB, int ROW = kRowH, int PLANE = kPlaneH, bool SAVE = false>
+// Training copy of one point's encoding row (SAVE_ENC / SAVE_DIR): descriptor + 32-bit byte offset, like SaveDst.  With
+// 64-bit per-lane pointers here the two-workgroup training kernel faulted on address 0 as soon as its spill pattern
+// changed (the pointer pairs were spilled and reloaded across the encoder's divergent branches); a descriptor cannot
+// fault, and a point beyond the end gets an offset outside the slot, which the range check drops - no branch either.
+struct EncSave {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff;                         // bytes of the point's row, or kDropOffset
+    static constexpr int kDropOffset = 0x7FFF0000;
+    __device__ __forceinline__ void put(int col, float v) const {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, voff + 4 * col, 0, 0);
+    }
+};
+
+// word = (word << 1) | (v > 0) in two instructions.  v > 0 <=> its bit pattern, read as a signed integer, is > 0 (-0.0 is
+// INT_MIN); the median of (pattern, 0, 1) is that bit.  (From C the compiler builds compare + select + or.)
+__device__ __forceinline__ unsigned push_positive_bit(unsigned word, float v) {
+    int b;
+    asm("v_med3_i32 %0, %1, 0, 1" : "=v"(b) : "v"(v));
+    asm("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(word) : "v"(b));
+    return word;
+}
+
+// ReLU masks of a trunk layer (layout.h relu_bits_offset): where this lane's two words of the layer go
+struct BitsDst {
+    __amdgpu_buffer_rsrc_t rsrc;      // the whole mask area
+    int off;                          // bytes: (((tile * kReluBitLayers + layer) * 4 + wave) * 64 + lane) * 8
+};
+
+template <int RB, int ROW = kRowH, int PLANE = kPlaneH, bool SAVE = false, bool BITS = false>
 __device__ __forceinline__ void wide_store_h(const f32x16 (&am)[RB][2], float inv, const f32x4 (&bias)[RB][4],
                                              _Float16* dl,   // plane_hi + (lane&31)*kRowH + 4*(lane>>5) + dcol + chan0
                                              bool relu, f16x2& amax2, float* gout /* or nullptr: + chan0 + 4*(lane>>5) */,
-                                             int gstride, int valid0, int valid1, const SaveDst* sv = nullptr) {
+                                             int gstride, int valid0, int valid1, const SaveDst* sv = nullptr,
+                                             const BitsDst* bd = nullptr) {
+    static_assert(!BITS || RB == 2, "mask words are defined for the 64-channel wave tile");
+    unsigned mask[RB];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
+        mask[rb] = 0u;
 #pragma unroll
         for (int pb = 0; pb < 2; ++pb) {
 #pragma unroll
@@ -231,6 +264,7 @@ __device__ __forceinline__ void wide_store_h(const f32x16 (&am)[RB][2], float in
                 for (int i = 0; i < 4; ++i) {
                     t[i] = __builtin_fmaf(am[rb][pb][4 * g + i], inv, bias[rb][g][i]);
                     if (relu) t[i] = fmaxf(t[i], 0.0f);
+                    if constexpr (BITS) mask[rb] = push_positive_bit(mask[rb], t[i]);
                     if (gout && (pb == 0 ? valid0 : valid1))
                         gout[(size_t)pb * 32 * gstride + 32 * rb + 8 * g + i] = t[i] * (1.0f / kActScale);
                 }
@@ -256,6 +290,10 @@ __device__ __forceinline__ void wide_store_h(const f32x16 (&am)[RB][2], float in
             // keep the scheduler from converting all 8 blocks at once (it would need >256 live VGPRs and spill)
             __builtin_amdgcn_sched_barrier(0);
         }
+    }
+    if constexpr (BITS) {
+        const u32x2 w = {mask[0], mask[RB - 1]};
+        __builtin_amdgcn_raw_buffer_store_b64(w, bd->rsrc, bd->off, 0, 0);
     }
 }
 

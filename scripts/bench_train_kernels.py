@@ -53,7 +53,7 @@ t_wg, _ = timed(lambda: kernels.mlp_weight_gradients(desc, names, save, dz, d_ra
 gb = save.numel() * 4 / 1e9
 print(f"{n} rays x {s} samples = {n * s} points; activation buffer {gb:.2f} GB")
 print(f"inference forward        {t_inf:7.3f} ms  {flop / t_inf / 1e9:6.1f} TFLOP/s")
-print(f"training forward (save)  {t_fwd:7.3f} ms  {flop / t_fwd / 1e9:6.1f} TFLOP/s   writes {gb / t_fwd * 1e3:5.2f} TB/s")
-print(f"input-gradient chain (+ head gradients) {t_bwd:7.3f} ms  {0.89 * flop / t_bwd / 1e9:6.1f} TFLOP/s   reads+writes {2 * gb / t_bwd * 1e3:5.2f} TB/s")
+print(f"training forward (save)  {t_fwd:7.3f} ms  {flop / t_fwd / 1e9:6.1f} TFLOP/s   writes {gb / t_fwd:5.2f} TB/s")
+print(f"input-gradient chain (+ head gradients) {t_bwd:7.3f} ms  {0.89 * flop / t_bwd / 1e9:6.1f} TFLOP/s   reads+writes {2 * gb / t_bwd:5.2f} TB/s (round-1 accounting: activations read + dZ written in full)")
 print(f"weight gradients, library GEMMs {t_wl:7.3f} ms  {flop / t_wl / 1e9:6.1f} TFLOP/s")
 print(f"weight gradients, HIP kernel    {t_wg:7.3f} ms  {flop / t_wg / 1e9:6.1f} TFLOP/s")

@@ -93,8 +93,10 @@ def test_argument_validation(capi):
                lib.inerf_mlp_backward_inputs(good, None, None, None, None, 0, 0, None, None, None, None, None),
                lib.inerf_cluster_lookup(None, None, 0, None, None, None, None, None, None, 1, 0, None, None, None)):
         assert rc == capi.OK
-    assert lib.inerf_mlp_save_floats(good, 64) == 64 * (64 + 32 + 8 * 256 + 256 + 256 + 128 + 8)
-    assert lib.inerf_mlp_save_floats(ssr28, 64) == 64 * (64 + 32 + 8 * 256 + 256 + 256 + 128 + 128 + 8)
+    bits = 7 * 4 * 64 * 2                          # ReLU-mask words per 64-point tile (h0..h6, 4 waves, 64 lanes, 2 words)
+    assert lib.inerf_mlp_save_floats(good, 64) == 64 * (64 + 32 + 8 * 256 + 256 + 256 + 128 + 8) + bits
+    assert lib.inerf_mlp_save_floats(ssr28, 64) == 64 * (64 + 32 + 8 * 256 + 256 + 256 + 128 + 128 + 8) + bits
+    assert lib.inerf_mlp_save_floats(good, 65) == 65 * (64 + 32 + 8 * 256 + 256 + 256 + 128 + 8) + 2 * bits      # whole tiles
     off, width = C.c_int64(), C.c_int()
     assert lib.inerf_mlp_save_slot(ssr28, 13, 100, C.byref(off), C.byref(width)) == capi.OK and width.value == 128
     assert lib.inerf_mlp_save_slot(good, 13, 100, C.byref(off), C.byref(width)) == capi.OK and width.value == 0
