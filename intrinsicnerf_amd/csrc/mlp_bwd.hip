@@ -51,11 +51,29 @@ constexpr int kHeadRes = 0, kHeadAs2 = 384, kHeadAlpha = 1408, kHeadBias = 1664,
 // epilogue of one transposed layer: t = acc * inv (+ per-channel vector x per-point scalar), ReLU mask from the saved
 // activation, hi/lo split into LDS (normalised, kActScale domain) and the true gradient to global memory
 struct NoAlpha {};
+
+// Where a layer's dZ goes.  The accumulator layout (lane = point, 16 registers = 4 + 4 + 4 + 4 channels) stores badly: a 16-byte
+// piece per lane is 32 bytes per point and instruction, every 128-byte line is assembled in L2 from four instructions
+// (measured: 1.2-1.5 x write amplification, and the 512 partial-line transactions per wave and layer were most of an
+// epilogue's 10 000 cycles).  So the block is transposed by the matrix core first: with the block's f16 hi / lo halves -
+// which the epilogue has anyway - as the A operand (row = point, k = the lane's channels) and a 0/1 selection matrix as B
+// (B[k][j] = 1/kActScale where channel(k) == j), D'[point][channel] comes back with lane = CHANNEL, registers = points: one
+// dword store per register then writes two complete 128-byte lines.  hi + lo carry 22 bits - exactly what the weight-
+// gradient kernel keeps of a dZ value when it splits it.  4 MFMAs per 32 x 32 block, +8 % of a layer's matrix work.
+struct DzDst {
+    __amdgpu_buffer_rsrc_t rsrc;      // the layer's dZ slot: [n_points][width] fp32 (points beyond the end are dropped by the range check)
+    int voff;                         // bytes: ((tile * 64 + 4 * (lane >> 5)) * width + chan0 + (lane & 31)) * 4
+    int width;                        // floats per point
+    const float* srow;                // LDS: per-point scale s_p of point 4 * (lane >> 5), row stride kRowH / 2 floats
+};
+struct Selector { f16x8 k[2]; };      // B operand of the transposing MFMAs (see DzDst), per lane: built once per kernel
 template <int RB, bool BITS = false, typename AlphaAcc = NoAlpha>
-__device__ __forceinline__ void bwd_store(const f32x16 (&am)[RB][2], float inv, const float* mask_src /* + pt0*mstride + chan0 + 4h */,
-                                          int mstride, const f32x4 (*extra)[4] /* [RB][4] or nullptr */, float ex0, float ex1,
+__device__ __forceinline__ void bwd_store(const f32x16 (&am)[RB][2], float inv,
+                                          const f32x4 (*acts)[2][4] /* [RB][2][4] saved activations of this lane's values (requested
+                                                                       before the GEMM; zero for points beyond the end), or nullptr */,
+                                          const f32x4 (*extra)[4] /* [RB][4] or nullptr */, float ex0, float ex1,
                                           _Float16* dl /* plane_hi + (lane&31)*kRowH + 4h + dcol + chan0 */, f16x2& amax2,
-                                          float* gout /* + pt0*gstride + chan0 + 4h */, int gstride, float s0, float s1,
+                                          const DzDst& dst, const Selector& sel, float s0, float s1,
                                           bool valid0, bool valid1, float& gmax,
                                           u32x2 mask_bits /* BITS: this lane's words of the layer (layout.h) */,
                                           AlphaAcc& alpha_acc /* f32x4[RB][4]: += (true d sigma of the point) * saved activation; by
@@ -70,12 +88,12 @@ __device__ __forceinline__ void bwd_store(const f32x16 (&am)[RB][2], float inv, 
             const int bits16 = valid ? (int)(mask_bits[rb] >> (16 * (1 - pb))) : 0;     // points beyond the end carry no gradient
             const float ex = pb == 0 ? ex0 : ex1;
             const float back = (pb == 0 ? s0 : s1) * (1.0f / kActScale);
+            f16x4 hi_g[4], lo_g[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                float t[4], th[4];
+                float t[4];
                 f32x4 m4 = {1.0f, 1.0f, 1.0f, 1.0f};
-                if (mask_src) m4 = valid ? *reinterpret_cast<const f32x4*>(mask_src + (size_t)pb * 32 * mstride + 32 * rb + 8 * g)
-                                         : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                if (acts) m4 = acts[rb][pb][g];
                 if constexpr (kAlpha) alpha_acc[rb][g] += m4 * (ex * (pb == 0 ? s0 : s1));      // m4 = h7 itself (zero for invalid points)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -85,22 +103,39 @@ __device__ __forceinline__ void bwd_store(const f32x16 (&am)[RB][2], float inv, 
                         t[i] = __builtin_bit_cast(float, __builtin_bit_cast(int, t[i]) & __builtin_amdgcn_sbfe(bits16, 15 - (4 * g + i), 1));
                     else
                         t[i] = m4[i] > 0.0f ? t[i] : 0.0f;
-                    th[i] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, t[i]) & 0xFFFFE000u);
                 }
-                const f16x2 h01 = {(_Float16)th[0], (_Float16)th[1]}, h23 = {(_Float16)th[2], (_Float16)th[3]};
-                const f16x2 l01 = {(_Float16)(t[0] - th[0]), (_Float16)(t[1] - th[1])};
-                const f16x2 l23 = {(_Float16)(t[2] - th[2]), (_Float16)(t[3] - th[3])};
+                f16x2 h01, h23, l01, l23;
+                split_pair(t[0], t[1], h01, l01);
+                split_pair(t[2], t[3], h23, l23);
                 const f16x2 a01 = __builtin_bit_cast(f16x2, __builtin_bit_cast(unsigned, h01) & 0x7FFF7FFFu);
                 const f16x2 a23 = __builtin_bit_cast(f16x2, __builtin_bit_cast(unsigned, h23) & 0x7FFF7FFFu);
                 amax2 = __builtin_elementwise_max(amax2, __builtin_elementwise_max(a01, a23));
-                const f16x4 hi4 = {h01[0], h01[1], h23[0], h23[1]}, lo4 = {l01[0], l01[1], l23[0], l23[1]};
+                hi_g[g] = f16x4{h01[0], h01[1], h23[0], h23[1]};
+                lo_g[g] = f16x4{l01[0], l01[1], l23[0], l23[1]};
                 _Float16* d = dl + pb * 32 * kRowH + 32 * rb + 8 * g;
-                *reinterpret_cast<f16x4*>(d) = hi4;
-                *reinterpret_cast<f16x4*>(d + kPlaneH) = lo4;
-                if (valid)
-                    *reinterpret_cast<f32x4*>(gout + (size_t)pb * 32 * gstride + 32 * rb + 8 * g) = f32x4{t[0], t[1], t[2], t[3]} * back;
+                *reinterpret_cast<f16x4*>(d) = hi_g[g];
+                *reinterpret_cast<f16x4*>(d + kPlaneH) = lo_g[g];
                 // invalid points carry zeros: no need to exclude them from the running maximum
                 gmax = fmaxf(gmax, fmaxf(fmaxf(fabsf(t[0]), fabsf(t[1])), fmaxf(fabsf(t[2]), fabsf(t[3]))) * back);
+            }
+            // transpose (see DzDst): D'[point][channel] = sum_k A[point][k] Sel[k][channel], hi then lo, two k-blocks of 16 channels
+            f32x16 tr = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const f16x8 ah = {hi_g[2 * kb][0], hi_g[2 * kb][1], hi_g[2 * kb][2], hi_g[2 * kb][3],
+                                  hi_g[2 * kb + 1][0], hi_g[2 * kb + 1][1], hi_g[2 * kb + 1][2], hi_g[2 * kb + 1][3]};
+                const f16x8 al = {lo_g[2 * kb][0], lo_g[2 * kb][1], lo_g[2 * kb][2], lo_g[2 * kb][3],
+                                  lo_g[2 * kb + 1][0], lo_g[2 * kb + 1][1], lo_g[2 * kb + 1][2], lo_g[2 * kb + 1][3]};
+                tr = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, sel.k[kb], tr, 0, 0, 0);
+                tr = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, sel.k[kb], tr, 0, 0, 0);
+            }
+            const float* sr = dst.srow + pb * 32 * (kRowH / 2);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int prow = (r & 3) + 8 * (r >> 2);                 // + 4 * (lane >> 5): in voff / srow
+                const float v = tr[r] * sr[prow * (kRowH / 2)];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), dst.rsrc,
+                                                      dst.voff + ((32 * pb + prow) * dst.width + 32 * rb) * 4, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -108,22 +143,36 @@ __device__ __forceinline__ void bwd_store(const f32x16 (&am)[RB][2], float inv, 
 }
 
 // four consecutive channels of one point -> hi/lo planes (normalised value v, stored as kActScale * v)
-__device__ __forceinline__ void split_store4(_Float16* hi_ptr, const float (&v)[4], f16x2& amax2) {
-    float t[4], th[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        t[i] = v[i] * kActScale;
-        th[i] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, t[i]) & 0xFFFFE000u);
-    }
-    const f16x2 h01 = {(_Float16)th[0], (_Float16)th[1]}, h23 = {(_Float16)th[2], (_Float16)th[3]};
-    const f16x4 hi4 = {h01[0], h01[1], h23[0], h23[1]};
-    const f16x4 lo4 = {(_Float16)(t[0] - th[0]), (_Float16)(t[1] - th[1]), (_Float16)(t[2] - th[2]), (_Float16)(t[3] - th[3])};
+__device__ __forceinline__ void split_store4(_Float16* hi_ptr, _Float16* lo_ptr, const float (&v)[4], f16x2& amax2) {
+    f16x2 h01, h23, l01, l23;
+    split_pair(v[0] * kActScale, v[1] * kActScale, h01, l01);
+    split_pair(v[2] * kActScale, v[3] * kActScale, h23, l23);
+    const f16x4 hi4 = {h01[0], h01[1], h23[0], h23[1]}, lo4 = {l01[0], l01[1], l23[0], l23[1]};
     const f16x2 a01 = __builtin_bit_cast(f16x2, __builtin_bit_cast(unsigned, h01) & 0x7FFF7FFFu);
     const f16x2 a23 = __builtin_bit_cast(f16x2, __builtin_bit_cast(unsigned, h23) & 0x7FFF7FFFu);
     amax2 = __builtin_elementwise_max(amax2, __builtin_elementwise_max(a01, a23));
     *reinterpret_cast<f16x4*>(hi_ptr) = hi4;
-    *reinterpret_cast<f16x4*>(hi_ptr + kPlaneH) = lo4;
+    *reinterpret_cast<f16x4*>(lo_ptr) = lo4;
 }
+
+// The VALU stages walk 8 / 16 / 8 rows of the planes per thread.  Written as `ldsb + pt * kRowH + ...` the unrolled loops need one
+// address register per (row, plane) - offsets beyond the 16-bit DS immediate - which the compiler computes once, hoists out
+// of the tile loop (40 registers) and spills; their reloads then queue behind the stage's prefetched global loads.  Instead:
+// four bases per stage, opaque to the optimiser and made inside the tile loop: [rows 0..31 | rows 32..63] x [hi | lo plane],
+// every access = base + an immediate below 64 KB.
+__device__ __forceinline__ int opaque_off(int v) { asm volatile("" : "+v"(v)); return v; }
+struct StageRows {
+    int st[2][2];      // element offsets of this thread's first row of each half, at its destination columns, [half][plane]
+    int f[2];          // ... of the per-point scratch floats (column 0 of the hi plane), [half]
+    __device__ __forceinline__ StageRows(int row0, int col) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            st[h][0] = opaque_off((row0 + 32 * h) * kRowH + col);
+            st[h][1] = opaque_off((row0 + 32 * h) * kRowH + col + kPlaneH);
+            f[h] = opaque_off((row0 + 32 * h) * kRowH);
+        }
+    }
+};
 
 template <bool kSsr>
 __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
@@ -150,6 +199,12 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
 
     WidePreH<2> preA, preB;
     prefetch_w<2>(preA, wb, frag(L.views_t, 8));
+    Selector sel;                          // see DzDst: lane (j = lane & 31, kg = lane >> 5) holds Sel[8 kg + m][j], m = 0..7, per k-block
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+            sel.k[kb][m] = (16 * kb + 8 * (m >> 2) + 4 * (lane >> 5) + (m & 3)) == (lane & 31) ? (_Float16)(1.0f / kActScale) : (_Float16)0.0f;
     const __amdgpu_buffer_rsrc_t bits_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.save) + p.bits_off, 0, (int)((unsigned)p.n_tiles * (unsigned)kReluBitTileBytes), 0x00020000);
 
@@ -166,7 +221,28 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) halpha[rb][g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
+#ifdef INERF_DGRAD_STAMPS   // development build (scripts/build_variant.sh): dz_max points at 2 + 64 x uint64; cycle stamps of
+    // workgroup 0 / thread 0 at the phase boundaries of its SECOND tile (steady state)
+    unsigned long long* const dbg = (p.dz_max && blockIdx.x == 0 && tid == 0) ? reinterpret_cast<unsigned long long*>(p.dz_max) + 1 : nullptr;
+    int dbg_n = 0;
+#define STAMP() do { if (dbg && tile == (int)gridDim.x && dbg_n < 62) { dbg[1 + dbg_n] = __builtin_readcyclecounter(); ++dbg_n; dbg[0] = dbg_n; } } while (0)
+#else
+#define STAMP() do { } while (0)
+#endif
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+        STAMP();
+        // The saved activations the three VALU stages need are requested a stage ahead (with one wave per SIMD a load issued
+        // inside the stage that uses it is 2 000 exposed cycles per loop iteration: the two stages took 60 k of a tile's 235 k).
+        f32x4 act_vh[8];
+        {
+            const int c4 = (tid & 31) * 4;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int gp = tile * kPts + (tid >> 5) + 8 * i;
+                act_vh[i] = gp < p.n_points ? *reinterpret_cast<const f32x4*>(p.save + p.off[SAVE_VH] + (size_t)gp * kHalf + c4)
+                                            : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+        }
         // ---------------- heads: pre-activation gradients of the output heads, per-point scale ----------------
         if (tid < kPts) {
             const int gp = tile * kPts + tid;
@@ -205,27 +281,29 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
             f[8] = s;
             f[9] = is;
         }
+        STAMP();
         __syncthreads();
+        STAMP();
 
         // ---------------- dZ of the view-dependent layer: relu'(vh) * (W_res^T d_res [+ d endpoint feature]) -> A ----------------
         {
             const int c4 = (tid & 31) * 4;
+            const StageRows rows(tid >> 5, kColA + c4);
             f32x4 w4[4];
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) w4[cc] = *reinterpret_cast<const f32x4*>(p.wts + L.res_w + 4 * (c4 + cc));
-#pragma unroll 2
+#pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int pt = (tid >> 5) + 8 * i;
                 const int gp = tile * kPts + pt;
                 const bool valid = gp < p.n_points;
-                const float* f = ptf(pt);
+                const float* f = reinterpret_cast<const float*>(ldsb + rows.f[i >> 2] + (i & 3) * 8 * kRowH);
                 const float d0 = f[4], d1 = f[5], d2 = f[6];
                 float v[4];
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) v[cc] = w4[cc][0] * d0 + w4[cc][1] * d1 + w4[cc][2] * d2;
-                f32x4 act = {0.0f, 0.0f, 0.0f, 0.0f};
+                const f32x4 act = act_vh[i];
                 if (valid) {
-                    act = *reinterpret_cast<const f32x4*>(p.save + p.off[SAVE_VH] + (size_t)gp * kHalf + c4);
                     if (kSsr && p.endpoint) {       // raw[..., -128:] is this layer's output itself (semantic_nerf.py:163-164)
                         const float* ge = p.d_raw + (size_t)gp * ch + ch - INERF_ENDPOINT_DIM + c4;
 #pragma unroll
@@ -239,21 +317,42 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
                 }
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) v[cc] = act[cc] > 0.0f ? v[cc] : 0.0f;
-                split_store4(ldsb + pt * kRowH + kColA + c4, v, amax2);
+                split_store4(ldsb + rows.st[i >> 2][0] + (i & 3) * 8 * kRowH, ldsb + rows.st[i >> 2][1] + (i & 3) * 8 * kRowH, v, amax2);
                 if (valid) {
                     const f32x4 o = f32x4{v[0], v[1], v[2], v[3]} * f[8];
                     *reinterpret_cast<f32x4*>(p.dz + p.off[SAVE_VH] + (size_t)gp * kHalf + c4) = o;
                     gmax = fmaxf(gmax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
                 }
+                if (i & 1) __builtin_amdgcn_sched_barrier(0);      // two points at a time: unfenced, the scheduler interleaves all of them and spills
             }
         }
+        STAMP();
         __syncthreads();
+        STAMP();
 
         const int pt0 = tile * kPts + (lane & 31);
         const bool valid0 = pt0 < p.n_points, valid1 = pt0 + 32 < p.n_points;
         const float s0 = ptf(lane & 31)[8], s1 = ptf((lane & 31) + 32)[8];
         auto gptr = [&](const float* base, int slot) { return base + p.off[slot] + (size_t)pt0 * kWidth + 64 * wave + 4 * (lane >> 5); };
+        auto dz_dst = [&](int slot) {                 // 256-wide slots only (every layer this kernel runs on the matrix core)
+            DzDst d;
+            d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dz + p.off[slot], 0, (int)((unsigned)p.n_points * (unsigned)kWidth * 4u), 0x00020000);
+            d.voff = (int)((((unsigned)tile * kPts + 4u * (unsigned)(lane >> 5)) * (unsigned)kWidth + 64u * (unsigned)wave + (unsigned)(lane & 31)) * 4u);
+            d.width = kWidth;
+            d.srow = reinterpret_cast<const float*>(ldsb) + 8 + 4 * (lane >> 5) * (kRowH / 2);
+            return d;
+        };
         f32x16 am[2][2];
+        f32x4 act_as1[16];
+        {
+            const int c4 = (tid & 63) * 4;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int gp = tile * kPts + (tid >> 6) + 4 * i;
+                act_as1[i] = gp < p.n_points ? *reinterpret_cast<const f32x4*>(p.save + p.off[SAVE_AS1H] + (size_t)gp * kWidth + c4)
+                                             : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+        }
 
         // ---------------- d feature = W_views^T[:256] dZ_vh -> B (feature_linear has no activation: this is its dZ) ----------------
         wide_gemm_h<2, 8, 0>(preA, wb, frag(L.views_t, 8), xr, kColA, 0, lane, am);
@@ -262,29 +361,31 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
             prefetch_w<2>(preA, wb, frag(L.feat_t, 16));
             prefetch_w<2>(preB, wb, frag(L.as1_t, 16));
             NoAlpha none;
-            bwd_store<2>(am, inv, nullptr, 0, nullptr, 0.0f, 0.0f, xd + kColB, amax2, const_cast<float*>(gptr(p.dz, SAVE_FEAT)), kWidth,
-                         s0, s1, valid0, valid1, gmax, u32x2{0u, 0u}, none);
+            bwd_store<2>(am, inv, nullptr, nullptr, 0.0f, 0.0f, xd + kColB, amax2, dz_dst(SAVE_FEAT), sel, s0, s1, valid0, valid1, gmax,
+                         u32x2{0u, 0u}, none);
         }
+        STAMP();
         __syncthreads();                     // A (dZ_vh) has been read by every wave, B (d feature) is complete
+        STAMP();
 
         // ---------------- dZ of the albedo | shading hidden layer: relu'(as1h) * (W_as2^T [d_albedo, d_shading]) -> A ----------------
         {
             const int c4 = (tid & 63) * 4;
+            const StageRows rows(tid >> 6, kColA + c4);
             f32x4 w4[4];
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) w4[cc] = *reinterpret_cast<const f32x4*>(p.wts + L.as2_w + 4 * (c4 + cc));
-#pragma unroll 2
+#pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int pt = (tid >> 6) + 4 * i;
                 const int gp = tile * kPts + pt;
                 const bool valid = gp < p.n_points;
-                const float* f = ptf(pt);
+                const float* f = reinterpret_cast<const float*>(ldsb + rows.f[i >> 3] + (i & 7) * 4 * kRowH);
                 const float d0 = f[0], d1 = f[1], d2 = f[2], d3 = f[3];
                 float v[4];
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) v[cc] = w4[cc][0] * d0 + w4[cc][1] * d1 + w4[cc][2] * d2 + w4[cc][3] * d3;
-                const f32x4 act = valid ? *reinterpret_cast<const f32x4*>(p.save + p.off[SAVE_AS1H] + (size_t)gp * kWidth + c4)
-                                        : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                const f32x4 act = act_as1[i];
                 if (heads) {
                     has2[0] += act * (d0 * f[8]);
                     has2[1] += act * (d1 * f[8]);
@@ -293,17 +394,32 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
                 }
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) v[cc] = act[cc] > 0.0f ? v[cc] : 0.0f;
-                split_store4(ldsb + pt * kRowH + kColA + c4, v, amax2);
+                split_store4(ldsb + rows.st[i >> 3][0] + (i & 7) * 4 * kRowH, ldsb + rows.st[i >> 3][1] + (i & 7) * 4 * kRowH, v, amax2);
                 if (valid) {
                     const f32x4 o = f32x4{v[0], v[1], v[2], v[3]} * f[8];
                     *reinterpret_cast<f32x4*>(p.dz + p.off[SAVE_AS1H] + (size_t)gp * kWidth + c4) = o;
                     gmax = fmaxf(gmax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
                 }
+                if (i & 1) __builtin_amdgcn_sched_barrier(0);
             }
         }
+        STAMP();
         __syncthreads();
+        STAMP();
 
         // ---------------- d h7 = W_feat^T d feature + W_as1^T dZ_as1 (+ W_sem1^T dZ_semh) + w_alpha d sigma ----------------
+        f32x4 h7v[2][2][4];                  // h7 of this lane's values: ReLU mask AND operand of the alpha_linear weight gradient
+        {
+            const float* src = gptr(p.save, SAVE_H7);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        h7v[rb][pb][g] = (pb == 0 ? valid0 : valid1) ? *reinterpret_cast<const f32x4*>(src + (size_t)pb * 32 * kWidth + 32 * rb + 8 * g)
+                                                                     : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
         wide_gemm_h<2, 16, 0>(preA, wb, frag(L.feat_t, 16), xr, kColB, 0, lane, am);
         if (sem) prefetch_w<2>(preA, wb, frag(L.sem1_t, 8));
         else     prefetch_w<2>(preA, wb, frag(L.trunk_t[7], 16));
@@ -331,7 +447,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
                 }
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) v[cc] = act[cc] > 0.0f ? v[cc] : 0.0f;
-                split_store4(ldsb + pt * kRowH + kColA + c4, v, amax2);
+                split_store4(ldsb + pt * kRowH + kColA + c4, ldsb + pt * kRowH + kColA + c4 + kPlaneH, v, amax2);
                 if (valid) {
                     const f32x4 o = f32x4{v[0], v[1], v[2], v[3]} * f[8];
                     *reinterpret_cast<f32x4*>(p.dz + p.off[SAVE_SEMH] + (size_t)gp * kHalf + c4) = o;
@@ -351,11 +467,15 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
                 for (int g = 0; g < 4; ++g)
                     aw[rb][g] = wb.vec4((L.alpha_w + 64 * wave + 32 * rb + 8 * g) * 4, 16 * (lane >> 5)) * kActScale;
             const float e0 = ptf(lane & 31)[7], e1 = ptf((lane & 31) + 32)[7];
+            STAMP();
             __syncthreads();                 // every wave is done reading A and B
-            bwd_store<2>(am, inv, gptr(p.save, SAVE_H7), kWidth, aw, e0, e1, xd + kColA, amax2, const_cast<float*>(gptr(p.dz, SAVE_H7)),
-                         kWidth, s0, s1, valid0, valid1, gmax, u32x2{0u, 0u}, halpha);       // (accumulated whether or not `heads`)
+            STAMP();
+            bwd_store<2>(am, inv, h7v, aw, e0, e1, xd + kColA, amax2, dz_dst(SAVE_H7), sel, s0, s1, valid0, valid1, gmax,
+                         u32x2{0u, 0u}, halpha);       // (accumulated whether or not `heads`)
         }
+        STAMP();
         __syncthreads();
+        STAMP();
 
         // ---------------- trunk, layers 7..1: dZ_{l-1} = relu'(h_{l-1}) * W_l^T dZ_l, ping-pong A <-> B ----------------
 #pragma unroll 1
@@ -369,9 +489,11 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
             if (l > 1) prefetch_w<2>(preA, wb, frag(L.trunk_t[l - 1], 16));
             else       prefetch_w<2>(preA, wb, frag(L.views_t, 8));
             NoAlpha none;
-            bwd_store<2, true>(am, inv, nullptr, 0, nullptr, 0.0f, 0.0f, xd + dst, amax2,
-                               const_cast<float*>(gptr(p.dz, SAVE_H0 + l - 1)), kWidth, s0, s1, valid0, valid1, gmax, mbits, none);
+            bwd_store<2, true>(am, inv, nullptr, nullptr, 0.0f, 0.0f, xd + dst, amax2, dz_dst(SAVE_H0 + l - 1), sel, s0, s1, valid0, valid1,
+                               gmax, mbits, none);
+            STAMP();
             __syncthreads();
+            STAMP();
         }
     }
     if (heads) {                          // reduce over the threads / lanes that shared a channel group, through LDS
