@@ -18,6 +18,7 @@
 //     activations' VALUES anyway (h7 for the alpha_linear weight gradient, the three head hidden layers) read those;
 //   * the heads with 1-4 outputs (sigma, albedo/shading outputs, residual) are outer products: VALU, not MFMA;
 //   * the three matrices that feed d h7 (feature_linear^T, as1^T, sem1^T) share a weight scale and one accumulator.
+#include <cstdlib>
 #include <type_traits>
 
 #include "mlp_f16_dev.h"
@@ -174,9 +175,18 @@ struct StageRows {
     }
 };
 
-template <bool kSsr>
-__global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
+// NW waves per workgroup: 4 (each wave 64 channels = RB 2 row blocks; one wave per SIMD) or 8 (32 channels each; TWO waves per
+// SIMD, so one wave's epilogue / VALU stage / memory wait runs under the other's MFMAs - with one wave per SIMD a tile was
+// 63 k cycles of MFMA in 192 k).  Same tile, same LDS, same packed weights (an 8-wave wave takes one of the two row blocks of
+// the 4-wave packing), same results.
+template <bool kSsr, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
     constexpr int kPts = kTilePoints;
+    constexpr int RB = 8 / NW;                 // 32-channel row blocks per wave
+    constexpr int NT = 64 * NW;                // threads
+    constexpr int WCH = 32 * RB;               // channels per wave
+    constexpr int KS = 4096;                   // bytes between k-blocks of the 4-wave packing
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
     extern __shared__ __attribute__((aligned(16))) _Float16 ldsb[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -187,37 +197,53 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
 
     _Float16* const xw = ldsb + (lane & 31) * kRowH;
     const _Float16* const xr = xw + 8 * (lane >> 5);              // wide GEMM operand reads (+ column)
-    _Float16* const xd = xw + 4 * (lane >> 5) + 64 * wave;        // wide stores: this wave's 64 channels (+ column)
+    _Float16* const xd = xw + 4 * (lane >> 5) + WCH * wave;       // wide stores: this wave's channels (+ column)
     auto ptf = [&](int pt) { return reinterpret_cast<float*>(ldsb + pt * kRowH); };   // per-point scratch in the enc columns:
                                                                                       // [0..7] head gradients / s, [8] s, [9] 1/s
     WeightBuf wb;
     wb.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wts), 0, L.total_floats * 4, 0x00020000);
     wb.voff = lane * 16;
-    auto frag = [&](const GemmSlot& s, int kbt) { return (s.w + wave * kbt * 2 * 2 * 256) * 4; };
+    const int wave4 = NW == 4 ? wave : wave >> 1, rbsel = NW == 4 ? 0 : wave & 1;      // position in the 4-wave packing
+    auto frag = [&](const GemmSlot& s, int kbt) { return (s.w + wave4 * kbt * 2 * 2 * 256) * 4 + rbsel * 2048; };
     const bool sem = kSsr && L.has_sem;
     const int ch = p.channels;
 
-    WidePreH<2> preA, preB;
-    prefetch_w<2>(preA, wb, frag(L.views_t, 8));
+    WidePreH<RB> preA, preB;
+    prefetch_w<RB, KS>(preA, wb, frag(L.views_t, 8));
     Selector sel;                          // see DzDst: lane (j = lane & 31, kg = lane >> 5) holds Sel[8 kg + m][j], m = 0..7, per k-block
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int m = 0; m < 8; ++m)
             sel.k[kb][m] = (16 * kb + 8 * (m >> 2) + 4 * (lane >> 5) + (m & 3)) == (lane & 31) ? (_Float16)(1.0f / kActScale) : (_Float16)0.0f;
+    // Rows of the activation / gradient slots are reached through buffer descriptors (wave-uniform, in SGPRs) + ONE 32-bit
+    // per-thread offset per stage + a wave-uniform tile offset: with 64-bit per-thread pointers every stage kept four address
+    // registers alive across the tile loop (spilled in the eight-wave form).  The range check also replaces the `valid` tests:
+    // rows beyond n_points read as zeros and are not written.
+    auto slot_rsrc = [&](const float* base, int slot, int width) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base) + p.off[slot], 0, (int)((unsigned)p.n_points * (unsigned)width * 4u), 0x00020000);
+    };
+    auto load4 = [](__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    };
+    auto store4 = [](__amdgpu_buffer_rsrc_t r, int voff, int soff, f32x4 v) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+    };
+    const int vh_voff = ((tid >> 5) * kHalf + (tid & 31) * 4) * 4;        // 128-wide stages: this thread's first row / channels, bytes
+    const int as_voff = ((tid >> 6) * kWidth + (tid & 63) * 4) * 4;       // 256-wide stage
     const __amdgpu_buffer_rsrc_t bits_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.save) + p.bits_off, 0, (int)((unsigned)p.n_tiles * (unsigned)kReluBitTileBytes), 0x00020000);
 
     // head weight gradients, accumulated over this workgroup's tiles (see kHead*)
     const bool heads = p.head_partial != nullptr;
     float hb[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};     // threads 0..63: sums of the head gradients
-    f32x4 hres[3], has2[4], halpha[2][4];                                  // [row][4 channels]; alpha: [rb][g]
+    f32x4 hres[3], has2[4], halpha[RB][4];                                 // [row][4 channels]; alpha: [rb][g]
 #pragma unroll
     for (int j = 0; j < 3; ++j) hres[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) has2[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int g = 0; g < 4; ++g) halpha[rb][g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
@@ -233,15 +259,13 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
         STAMP();
         // The saved activations the three VALU stages need are requested a stage ahead (with one wave per SIMD a load issued
         // inside the stage that uses it is 2 000 exposed cycles per loop iteration: the two stages took 60 k of a tile's 235 k).
-        f32x4 act_vh[8];
+        constexpr int VH_STEP = NT / 32, VH_IT = kPts / VH_STEP;        // rows per pass of the 128-wide stages, passes
+        constexpr int AS_STEP = NT / 64, AS_IT = kPts / AS_STEP;        // ... of the 256-wide stage
+        f32x4 act_vh[VH_IT];
         {
-            const int c4 = (tid & 31) * 4;
+            const __amdgpu_buffer_rsrc_t r = slot_rsrc(p.save, SAVE_VH, kHalf);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int gp = tile * kPts + (tid >> 5) + 8 * i;
-                act_vh[i] = gp < p.n_points ? *reinterpret_cast<const f32x4*>(p.save + p.off[SAVE_VH] + (size_t)gp * kHalf + c4)
-                                            : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            }
+            for (int i = 0; i < VH_IT; ++i) act_vh[i] = load4(r, vh_voff, (tile * kPts + VH_STEP * i) * kHalf * 4);
         }
         // ---------------- heads: pre-activation gradients of the output heads, per-point scale ----------------
         if (tid < kPts) {
@@ -289,15 +313,17 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
         {
             const int c4 = (tid & 31) * 4;
             const StageRows rows(tid >> 5, kColA + c4);
+            const __amdgpu_buffer_rsrc_t dz_vh = slot_rsrc(p.dz, SAVE_VH, kHalf);
             f32x4 w4[4];
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) w4[cc] = *reinterpret_cast<const f32x4*>(p.wts + L.res_w + 4 * (c4 + cc));
+            for (int cc = 0; cc < 4; ++cc) w4[cc] = wb.vec4((L.res_w + 4 * cc) * 4, 16 * c4);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int pt = (tid >> 5) + 8 * i;
+            for (int i = 0; i < VH_IT; ++i) {
+                constexpr int HALF = VH_IT / 2;
+                const int pt = (tid >> 5) + VH_STEP * i;
                 const int gp = tile * kPts + pt;
                 const bool valid = gp < p.n_points;
-                const float* f = reinterpret_cast<const float*>(ldsb + rows.f[i >> 2] + (i & 3) * 8 * kRowH);
+                const float* f = reinterpret_cast<const float*>(ldsb + rows.f[i / HALF] + (i % HALF) * VH_STEP * kRowH);
                 const float d0 = f[4], d1 = f[5], d2 = f[6];
                 float v[4];
 #pragma unroll
@@ -317,10 +343,11 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
                 }
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) v[cc] = act[cc] > 0.0f ? v[cc] : 0.0f;
-                split_store4(ldsb + rows.st[i >> 2][0] + (i & 3) * 8 * kRowH, ldsb + rows.st[i >> 2][1] + (i & 3) * 8 * kRowH, v, amax2);
-                if (valid) {
+                split_store4(ldsb + rows.st[i / HALF][0] + (i % HALF) * VH_STEP * kRowH, ldsb + rows.st[i / HALF][1] + (i % HALF) * VH_STEP * kRowH,
+                             v, amax2);
+                {   // (a point beyond the end: act = 0 -> v = 0, and the store is dropped)
                     const f32x4 o = f32x4{v[0], v[1], v[2], v[3]} * f[8];
-                    *reinterpret_cast<f32x4*>(p.dz + p.off[SAVE_VH] + (size_t)gp * kHalf + c4) = o;
+                    store4(dz_vh, vh_voff, (tile * kPts + VH_STEP * i) * kHalf * 4, o);
                     gmax = fmaxf(gmax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
                 }
                 if (i & 1) __builtin_amdgcn_sched_barrier(0);      // two points at a time: unfenced, the scheduler interleaves all of them and spills
@@ -333,35 +360,32 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
         const int pt0 = tile * kPts + (lane & 31);
         const bool valid0 = pt0 < p.n_points, valid1 = pt0 + 32 < p.n_points;
         const float s0 = ptf(lane & 31)[8], s1 = ptf((lane & 31) + 32)[8];
-        auto gptr = [&](const float* base, int slot) { return base + p.off[slot] + (size_t)pt0 * kWidth + 64 * wave + 4 * (lane >> 5); };
+        auto gptr = [&](const float* base, int slot) { return base + p.off[slot] + (size_t)pt0 * kWidth + WCH * wave + 4 * (lane >> 5); };
         auto dz_dst = [&](int slot) {                 // 256-wide slots only (every layer this kernel runs on the matrix core)
             DzDst d;
             d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dz + p.off[slot], 0, (int)((unsigned)p.n_points * (unsigned)kWidth * 4u), 0x00020000);
-            d.voff = (int)((((unsigned)tile * kPts + 4u * (unsigned)(lane >> 5)) * (unsigned)kWidth + 64u * (unsigned)wave + (unsigned)(lane & 31)) * 4u);
+            d.voff = (int)((((unsigned)tile * kPts + 4u * (unsigned)(lane >> 5)) * (unsigned)kWidth + (unsigned)(WCH * wave) + (unsigned)(lane & 31)) * 4u);
             d.width = kWidth;
             d.srow = reinterpret_cast<const float*>(ldsb) + 8 + 4 * (lane >> 5) * (kRowH / 2);
             return d;
         };
-        f32x16 am[2][2];
-        f32x4 act_as1[16];
-        {
-            const int c4 = (tid & 63) * 4;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int gp = tile * kPts + (tid >> 6) + 4 * i;
-                act_as1[i] = gp < p.n_points ? *reinterpret_cast<const f32x4*>(p.save + p.off[SAVE_AS1H] + (size_t)gp * kWidth + c4)
-                                             : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            }
-        }
+        f32x16 am[RB][2];
+        f32x4 act_as1[AS_IT];
 
         // ---------------- d feature = W_views^T[:256] dZ_vh -> B (feature_linear has no activation: this is its dZ) ----------------
-        wide_gemm_h<2, 8, 0>(preA, wb, frag(L.views_t, 8), xr, kColA, 0, lane, am);
+        wide_gemm_h<RB, 8, 0, kRowH, kPlaneH, true, KS>(preA, wb, frag(L.views_t, 8), xr, kColA, 0, lane, am);
+        {   // the next stage's activations: in flight during this layer's epilogue (requested before the GEMM they sat in front
+            // of its weight stream - returns are in order - and cost it 9 k cycles)
+            const __amdgpu_buffer_rsrc_t r = slot_rsrc(p.save, SAVE_AS1H, kWidth);
+#pragma unroll
+            for (int i = 0; i < AS_IT; ++i) act_as1[i] = load4(r, as_voff, (tile * kPts + AS_STEP * i) * kWidth * 4);
+        }
         {
             const float inv = wb.scalar(L.views_t.b * 4);
-            prefetch_w<2>(preA, wb, frag(L.feat_t, 16));
-            prefetch_w<2>(preB, wb, frag(L.as1_t, 16));
+            prefetch_w<RB, KS>(preA, wb, frag(L.feat_t, 16));
+            prefetch_w<RB, KS>(preB, wb, frag(L.as1_t, 16));
             NoAlpha none;
-            bwd_store<2>(am, inv, nullptr, nullptr, 0.0f, 0.0f, xd + kColB, amax2, dz_dst(SAVE_FEAT), sel, s0, s1, valid0, valid1, gmax,
+            bwd_store<RB>(am, inv, nullptr, nullptr, 0.0f, 0.0f, xd + kColB, amax2, dz_dst(SAVE_FEAT), sel, s0, s1, valid0, valid1, gmax,
                          u32x2{0u, 0u}, none);
         }
         STAMP();
@@ -372,15 +396,17 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
         {
             const int c4 = (tid & 63) * 4;
             const StageRows rows(tid >> 6, kColA + c4);
+            const __amdgpu_buffer_rsrc_t dz_as = slot_rsrc(p.dz, SAVE_AS1H, kWidth);
             f32x4 w4[4];
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) w4[cc] = *reinterpret_cast<const f32x4*>(p.wts + L.as2_w + 4 * (c4 + cc));
+            for (int cc = 0; cc < 4; ++cc) w4[cc] = wb.vec4((L.as2_w + 4 * cc) * 4, 16 * c4);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int pt = (tid >> 6) + 4 * i;
+            for (int i = 0; i < AS_IT; ++i) {
+                constexpr int HALF = AS_IT / 2;
+                const int pt = (tid >> 6) + AS_STEP * i;
                 const int gp = tile * kPts + pt;
                 const bool valid = gp < p.n_points;
-                const float* f = reinterpret_cast<const float*>(ldsb + rows.f[i >> 3] + (i & 7) * 4 * kRowH);
+                const float* f = reinterpret_cast<const float*>(ldsb + rows.f[i / HALF] + (i % HALF) * AS_STEP * kRowH);
                 const float d0 = f[0], d1 = f[1], d2 = f[2], d3 = f[3];
                 float v[4];
 #pragma unroll
@@ -394,10 +420,11 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
                 }
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) v[cc] = act[cc] > 0.0f ? v[cc] : 0.0f;
-                split_store4(ldsb + rows.st[i >> 3][0] + (i & 7) * 4 * kRowH, ldsb + rows.st[i >> 3][1] + (i & 7) * 4 * kRowH, v, amax2);
-                if (valid) {
+                split_store4(ldsb + rows.st[i / HALF][0] + (i % HALF) * AS_STEP * kRowH, ldsb + rows.st[i / HALF][1] + (i % HALF) * AS_STEP * kRowH,
+                             v, amax2);
+                {
                     const f32x4 o = f32x4{v[0], v[1], v[2], v[3]} * f[8];
-                    *reinterpret_cast<f32x4*>(p.dz + p.off[SAVE_AS1H] + (size_t)gp * kWidth + c4) = o;
+                    store4(dz_as, as_voff, (tile * kPts + AS_STEP * i) * kWidth * 4, o);
                     gmax = fmaxf(gmax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
                 }
                 if (i & 1) __builtin_amdgcn_sched_barrier(0);
@@ -408,28 +435,28 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
         STAMP();
 
         // ---------------- d h7 = W_feat^T d feature + W_as1^T dZ_as1 (+ W_sem1^T dZ_semh) + w_alpha d sigma ----------------
-        f32x4 h7v[2][2][4];                  // h7 of this lane's values: ReLU mask AND operand of the alpha_linear weight gradient
+        f32x4 h7v[RB][2][4];                 // h7 of this lane's values: ReLU mask AND operand of the alpha_linear weight gradient
         {
-            const float* src = gptr(p.save, SAVE_H7);
+            const __amdgpu_buffer_rsrc_t r = slot_rsrc(p.save, SAVE_H7, kWidth);
+            const int voff = ((lane & 31) * kWidth + WCH * wave + 4 * (lane >> 5)) * 4;
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
+            for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                 for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
-                        h7v[rb][pb][g] = (pb == 0 ? valid0 : valid1) ? *reinterpret_cast<const f32x4*>(src + (size_t)pb * 32 * kWidth + 32 * rb + 8 * g)
-                                                                     : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                        h7v[rb][pb][g] = load4(r, voff, ((tile * kPts + 32 * pb) * kWidth + 32 * rb + 8 * g) * 4);
         }
-        wide_gemm_h<2, 16, 0>(preA, wb, frag(L.feat_t, 16), xr, kColB, 0, lane, am);
-        if (sem) prefetch_w<2>(preA, wb, frag(L.sem1_t, 8));
-        else     prefetch_w<2>(preA, wb, frag(L.trunk_t[7], 16));
-        wide_gemm_h<2, 16, 0, kRowH, kPlaneH, false>(preB, wb, frag(L.as1_t, 16), xr, kColA, 0, lane, am);
+        wide_gemm_h<RB, 16, 0, kRowH, kPlaneH, true, KS>(preA, wb, frag(L.feat_t, 16), xr, kColB, 0, lane, am);
+        if (sem) prefetch_w<RB, KS>(preA, wb, frag(L.sem1_t, 8));
+        else     prefetch_w<RB, KS>(preA, wb, frag(L.trunk_t[7], 16));
+        wide_gemm_h<RB, 16, 0, kRowH, kPlaneH, false, KS>(preB, wb, frag(L.as1_t, 16), xr, kColA, 0, lane, am);
         if (sem) {
             __syncthreads();                 // A and B are free
             const int c4 = (tid & 31) * 4;
 #pragma unroll 1
-            for (int i = 0; i < 8; ++i) {
-                const int pt = (tid >> 5) + 8 * i;
+            for (int i = 0; i < VH_IT; ++i) {
+                const int pt = (tid >> 5) + VH_STEP * i;
                 const int gp = tile * kPts + pt;
                 const bool valid = gp < p.n_points;
                 const float* f = ptf(pt);
@@ -455,22 +482,22 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
                 }
             }
             __syncthreads();
-            wide_gemm_h<2, 8, 0, kRowH, kPlaneH, false>(preA, wb, frag(L.sem1_t, 8), xr, kColA, 0, lane, am);
-            prefetch_w<2>(preA, wb, frag(L.trunk_t[7], 16));
+            wide_gemm_h<RB, 8, 0, kRowH, kPlaneH, false, KS>(preA, wb, frag(L.sem1_t, 8), xr, kColA, 0, lane, am);
+            prefetch_w<RB, KS>(preA, wb, frag(L.trunk_t[7], 16));
         }
         {
             const float inv = wb.scalar(L.feat_t.b * 4);            // common scale of feat_t / as1_t / sem1_t
-            f32x4 aw[2][4];
+            f32x4 aw[RB][4];
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
+            for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    aw[rb][g] = wb.vec4((L.alpha_w + 64 * wave + 32 * rb + 8 * g) * 4, 16 * (lane >> 5)) * kActScale;
+                    aw[rb][g] = wb.vec4((L.alpha_w + WCH * wave + 32 * rb + 8 * g) * 4, 16 * (lane >> 5)) * kActScale;
             const float e0 = ptf(lane & 31)[7], e1 = ptf((lane & 31) + 32)[7];
             STAMP();
             __syncthreads();                 // every wave is done reading A and B
             STAMP();
-            bwd_store<2>(am, inv, h7v, aw, e0, e1, xd + kColA, amax2, dz_dst(SAVE_H7), sel, s0, s1, valid0, valid1, gmax,
+            bwd_store<RB>(am, inv, h7v, aw, e0, e1, xd + kColA, amax2, dz_dst(SAVE_H7), sel, s0, s1, valid0, valid1, gmax,
                          u32x2{0u, 0u}, halpha);       // (accumulated whether or not `heads`)
         }
         STAMP();
@@ -482,14 +509,16 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
         for (int l = kDepth - 1; l >= 1; --l) {
             const int src = ((kDepth - 1 - l) & 1) ? kColB : kColA;
             const int dst = ((kDepth - 1 - l) & 1) ? kColA : kColB;
-            const u32x2 mbits = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
-                bits_rsrc, lane * 8, (((tile * kReluBitLayers + (l - 1)) * 4 + wave) * 64) * 8, 0));
-            wide_gemm_h<2, 16, 0>(preA, wb, frag(L.trunk_t[l], 16), xr, src, 0, lane, am);
+            u32x2 mbits;                        // this lane's mask words of the layer (layout.h relu_bits_offset)
+            const int mbase = (((tile * kReluBitLayers + (l - 1)) * 4 + wave4) * 64) * 8;
+            if constexpr (RB == 2) mbits = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(bits_rsrc, lane * 8, mbase, 0));
+            else mbits = u32x2{__builtin_amdgcn_raw_buffer_load_b32(bits_rsrc, lane * 8, mbase + 4 * rbsel, 0), 0u};
+            wide_gemm_h<RB, 16, 0, kRowH, kPlaneH, true, KS>(preA, wb, frag(L.trunk_t[l], 16), xr, src, 0, lane, am);
             const float inv = wb.scalar(L.trunk_t[l].b * 4);
-            if (l > 1) prefetch_w<2>(preA, wb, frag(L.trunk_t[l - 1], 16));
-            else       prefetch_w<2>(preA, wb, frag(L.views_t, 8));
+            if (l > 1) prefetch_w<RB, KS>(preA, wb, frag(L.trunk_t[l - 1], 16));
+            else       prefetch_w<RB, KS>(preA, wb, frag(L.views_t, 8));
             NoAlpha none;
-            bwd_store<2, true>(am, inv, nullptr, nullptr, 0.0f, 0.0f, xd + dst, amax2, dz_dst(SAVE_H0 + l - 1), sel, s0, s1, valid0, valid1,
+            bwd_store<RB, true>(am, inv, nullptr, nullptr, 0.0f, 0.0f, xd + dst, amax2, dz_dst(SAVE_H0 + l - 1), sel, s0, s1, valid0, valid1,
                                gmax, mbits, none);
             STAMP();
             __syncthreads();
@@ -498,7 +527,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
     }
     if (heads) {                          // reduce over the threads / lanes that shared a channel group, through LDS
         __syncthreads();
-        float* red = reinterpret_cast<float*>(ldsb);            // [256 threads][28]: hres 12 | has2 16
+        constexpr int AST = 16 * RB + 1;                        // padded stride of a lane's alpha accumulators
+        float* red = reinterpret_cast<float*>(ldsb);            // [NT threads][28]: hres 12 | has2 16
         float* mine = red + tid * 28;
 #pragma unroll
         for (int j = 0; j < 3; ++j)
@@ -508,38 +538,38 @@ __global__ __launch_bounds__(256, 1) void k_mlp_dgrad(const BwdParams p) {
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) mine[12 + 4 * j + cc] = has2[j][cc];
-        float* alpha_red = red + 256 * 28;                      // [4 waves][64 lanes][32]: halpha
+        float* alpha_red = red + NT * 28;                       // [NW waves][64 lanes][AST]: halpha
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+        for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) alpha_red[(wave * 64 + lane) * 33 + 16 * rb + 4 * g + i] = halpha[rb][g][i];
-        float* bias_red = alpha_red + 256 * 33;                 // [64][8]
+                for (int i = 0; i < 4; ++i) alpha_red[(wave * 64 + lane) * AST + 16 * rb + 4 * g + i] = halpha[rb][g][i];
+        float* bias_red = alpha_red + NT * AST;                 // [64][8]
         if (tid < kPts)
 #pragma unroll
             for (int k = 0; k < 8; ++k) bias_red[tid * 8 + k] = hb[k];
         __syncthreads();
         float* out = p.head_partial + (size_t)blockIdx.x * kHeadFloats;
-        // residual: channel c = 4 * (tid & 31) + cc was accumulated by the 8 threads tid & 31 + 32 * k
-        for (int e = tid; e < 3 * kHalf; e += 256) {
+        // residual: channel c = 4 * (tid & 31) + cc was accumulated by the NT / 32 threads (tid & 31) + 32 * k
+        for (int e = tid; e < 3 * kHalf; e += NT) {
             const int j = e / kHalf, c = e % kHalf;
             float v = 0.0f;
-            for (int k = 0; k < 8; ++k) v += red[((c >> 2) + 32 * k) * 28 + 4 * j + (c & 3)];
+            for (int k = 0; k < NT / 32; ++k) v += red[((c >> 2) + 32 * k) * 28 + 4 * j + (c & 3)];
             out[kHeadRes + e] = v;
         }
-        // albedo|shading outputs: channel c = 4 * (tid & 63) + cc, 4 threads tid & 63 + 64 * k
-        for (int e = tid; e < 4 * kWidth; e += 256) {
+        // albedo|shading outputs: channel c = 4 * (tid & 63) + cc, NT / 64 threads (tid & 63) + 64 * k
+        for (int e = tid; e < 4 * kWidth; e += NT) {
             const int j = e / kWidth, c = e % kWidth;
             float v = 0.0f;
-            for (int k = 0; k < 4; ++k) v += red[((c >> 2) + 64 * k) * 28 + 12 + 4 * j + (c & 3)];
+            for (int k = 0; k < NT / 64; ++k) v += red[((c >> 2) + 64 * k) * 28 + 12 + 4 * j + (c & 3)];
             out[kHeadAs2 + e] = v;
         }
-        // alpha: channel c of wave w = c >> 6: register slot (rb, g, i) with c & 63 = 32 rb + 8 g + 4 h + i; sum over the 32 lanes of half h
-        {
-            const int c = tid, w = c >> 6, cl = c & 63, rb = cl >> 5, g = (cl >> 3) & 3, hh = (cl >> 2) & 1, i = cl & 3;
+        // alpha: channel c of wave w = c / WCH: register slot (rb, g, i) with c % WCH = 32 rb + 8 g + 4 h + i; sum over the 32 lanes of half h
+        if (tid < kWidth) {
+            const int c = tid, w = c / WCH, cl = c % WCH, rb = cl >> 5, g = (cl >> 3) & 3, hh = (cl >> 2) & 1, i = cl & 3;
             float v = 0.0f;
-            for (int l = 0; l < 32; ++l) v += alpha_red[(w * 64 + 32 * hh + l) * 33 + 16 * rb + 4 * g + i];
+            for (int l = 0; l < 32; ++l) v += alpha_red[(w * 64 + 32 * hh + l) * AST + 16 * rb + 4 * g + i];
             out[kHeadAlpha + c] = v;
         }
         if (tid < 8) {
@@ -589,13 +619,17 @@ extern "C" int inerf_mlp_backward_inputs(const inerf_net_desc* net, const float*
     p.n_classes = ssr ? net->n_classes : 0;
     p.channels = INERF_BASE_CHANNELS + p.n_classes + (p.endpoint ? INERF_ENDPOINT_DIM : 0);
     const int grid = p.n_tiles < device_cus() ? p.n_tiles : device_cus();
-    void (*kern)(const BwdParams) = ssr ? k_mlp_dgrad<true> : k_mlp_dgrad<false>;
-    static PerDeviceOnce attr_set[2];
-    if (attr_set[ssr].first()) {
+    // eight waves per workgroup (two per SIMD) by default; INERF_DGRAD_WAVES=4 keeps the one-wave-per-SIMD form for A/B runs
+    const char* form = getenv("INERF_DGRAD_WAVES");
+    const bool eight = !(form && form[0] == '4');
+    void (*kern)(const BwdParams) = eight ? (ssr ? k_mlp_dgrad<true, 8> : k_mlp_dgrad<false, 8>) : (ssr ? k_mlp_dgrad<true, 4> : k_mlp_dgrad<false, 4>);
+    static PerDeviceOnce attr_set[4];
+    const int variant = 2 * (int)eight + (int)ssr;
+    if (attr_set[variant].first()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesH);
         if (e != hipSuccess) return record(e);
-        attr_set[ssr].mark();
+        attr_set[variant].mark();
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kLdsBytesH, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(eight ? 512 : 256), kLdsBytesH, (hipStream_t)stream, p);
     return record(hipGetLastError());
 }

@@ -104,7 +104,9 @@ __device__ __forceinline__ void wide_prefetch_h(WidePreH<RB>& pre, const WeightB
     pre.inv = wb.scalar(scale_bytes);
 }
 
-template <int RB, int KB0, int KB1, int ROW = kRowH, int PLANE = kPlaneH, bool ZERO = true>
+// KSTRIDE: bytes between a wave's consecutive k-blocks in the packed stream (default: its RB row blocks are contiguous; a
+// wave that takes ONE of the two row blocks of the 4-wave packing passes 4096)
+template <int RB, int KB0, int KB1, int ROW = kRowH, int PLANE = kPlaneH, bool ZERO = true, int KSTRIDE = RB * 2048>
 __device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const WeightBuf& wb, int frag_bytes,
                                             const _Float16* xl,      // plane_hi + (lane&31)*kRowH + 8*(lane>>5)
                                             int col0, int col1, int lane, f32x16 (&am)[RB][2]) {
@@ -145,7 +147,7 @@ __device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const Weigh
         const int xo_ = xoff(k1_);                                                                                   \
         _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                                            \
             _Pragma("unroll") for (int part = 0; part < 2; ++part)                                                   \
-                w[((I) + 2) & 3][rb][part] = wb.frag(frag_bytes + ((k2_ * RB + rb) * 2 + part) * 1024);              \
+                w[((I) + 2) & 3][rb][part] = wb.frag(frag_bytes + k2_ * KSTRIDE + (rb * 2 + part) * 1024);          \
         _Pragma("unroll") for (int pb = 0; pb < 2; ++pb)                                                             \
             _Pragma("unroll") for (int part = 0; part < 2; ++part)                                                   \
                 x[((I) + 1) & 1][pb][part] =                                                                         \
@@ -325,14 +327,14 @@ __device__ __forceinline__ f32x4 skinny_gemm_h(const WeightBuf& wb, int frag_byt
 __device__ __forceinline__ float sigmoid_ref_h(float x) { return __fdiv_rn(1.0f, 1.0f + expf(-x)); }
 
 
-template <int RB>
+template <int RB, int KSTRIDE = RB * 2048>
 __device__ __forceinline__ void prefetch_w(WidePreH<RB>& pre, const WeightBuf& wb, int frag_bytes) {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-            for (int part = 0; part < 2; ++part) pre.w[kb][rb][part] = wb.frag(frag_bytes + ((kb * RB + rb) * 2 + part) * 1024);
+            for (int part = 0; part < 2; ++part) pre.w[kb][rb][part] = wb.frag(frag_bytes + kb * KSTRIDE + (rb * 2 + part) * 1024);
 }
 
 template <int RB>
