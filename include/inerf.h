@@ -30,7 +30,7 @@ extern "C" {
 #define INERF_VERSION_MINOR 2
 /* Bumped whenever a struct layout, an argument list or the packed-weight format of this header changes; bindings
  * compare it with inerf_abi_version() of the library they loaded (a stale .so then fails loudly, not silently). */
-#define INERF_ABI_VERSION 20004
+#define INERF_ABI_VERSION 20005
 
 /* error codes */
 #define INERF_OK              0
@@ -142,6 +142,9 @@ int inerf_debug_encode_mlp(const inerf_net_desc* net, const float* packed_weight
  *   slot 0 enc 64 | 1 dir 32 | 2..9 h0..h7 256 | 10 albedo|shading hidden 256 | 11 feature 256 |
  *   12 views hidden 128 | 13 semantic hidden 128 (SSR with classes, else width 0) |
  *   14 (dz only) head pre-activation gradients 8: albedo 3, shading 1, residual 3, sigma 1.
+ * Behind the slots `save` carries the ReLU masks of h0..h6 as bits (14 336 bytes per 64-point tile, written by
+ * inerf_encode_mlp_train and read by inerf_mlp_backward_inputs in place of the activations; layout private to the
+ * two kernels): always pass a buffer that inerf_encode_mlp_train itself filled, of inerf_mlp_save_floats() floats.
  * The gradient w.r.t. the semantic logits is d_raw[..., 11:11+C] itself (no activation).
  * ------------------------------------------------------------------------------------------- */
 #define INERF_SAVE_SLOTS 15
