@@ -1,0 +1,87 @@
+"""ReLU-mask words of the training forward (layout.h relu_bits_offset) and what the input-gradient chain does with them."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from intrinsicnerf_amd import _capi, kernels, packing
+
+pytestmark = pytest.mark.gpu
+
+
+def _rays(n, s, dev, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    o = torch.tensor([[2.5, 1.5, 2.0]]).expand(n, 3)
+    d = -o / o.norm(dim=-1, keepdim=True) + 0.2 * torch.randn(n, 3, generator=g)
+    rays = torch.cat([o, d, 2 * torch.ones(n, 1), 6 * torch.ones(n, 1), d / d.norm(dim=-1, keepdim=True)], -1).to(dev)
+    z = torch.sort(torch.rand(n, s, generator=g) * 4 + 2, -1)[0].to(dev)
+    return rays, z
+
+
+@pytest.mark.parametrize("variant,classes,endpoint,n,s", [("object", 0, False, 37, 19),      # 703 points: a ragged last tile
+                                                           ("ssr", 28, False, 64, 5),
+                                                           ("ssr", 5, True, 21, 7),           # one-workgroup training forward
+                                                           ("object", 0, False, 700, 37)])    # more tiles than workgroups
+@pytest.mark.parametrize("waves", ["8", "4"])
+def test_mask_words_equal_saved_activations_and_gate_the_chain(variant, classes, endpoint, n, s, waves, monkeypatch):
+    monkeypatch.setenv("INERF_DGRAD_WAVES", waves)
+    dev = torch.device("cuda:0")
+    ssr = variant == "ssr"
+    desc = _capi.net_desc(_capi.VARIANT_SSR if ssr else _capi.VARIANT_OBJECT, classes, 10, 4, 10.0 if ssr else 1.0, _capi.PREC_F16X3)
+    sd = {k: v.to(dev) for k, v in oracle.make_state_dict(variant, classes, seed=3).items()}
+    pf, pb = packing.device_packer(desc, False, dev)(sd), packing.device_packer(desc, True, dev)(sd)
+    rays, z = _rays(n, s, dev)
+    raw, save = kernels.encode_mlp_train(desc, pf, rays, z, endpoint=endpoint)
+    p = n * s
+    X = kernels.save_slot_views(desc, save, p)
+    tiles = (p + 63) // 64
+    words = save[-tiles * 3584:].view(torch.int32).view(tiles, 7, 4, 64, 2).cpu().numpy().astype(np.uint32)
+    t, w, l, rb, pb_, g, i = np.meshgrid(np.arange(tiles), np.arange(4), np.arange(64), np.arange(2), np.arange(2), np.arange(4), np.arange(4), indexing="ij")
+    chan = 64 * w + 32 * rb + 8 * g + 4 * (l >> 5) + i
+    point = 64 * t + 32 * pb_ + (l & 31)
+    ok = point < p
+    for layer in range(7):
+        h = X[kernels.SAVE_H0 + layer].cpu().numpy()
+        bit = (words[t, layer, w, l, rb] >> (31 - (16 * pb_ + 4 * g + i))) & 1
+        want = h[np.minimum(point, p - 1), chan] > 0
+        assert not ((bit != want) & ok).any(), f"layer {layer}: mask bits differ from (h > 0)"
+        assert 0.05 < want[ok].mean() < 0.95
+    ch = raw.shape[-1]
+    d_raw = torch.randn(p, ch, device=dev)
+    dz = kernels.mlp_backward_inputs(desc, pb, raw.view(p, ch), d_raw, save, endpoint=endpoint)
+    G = kernels.save_slot_views(desc, dz, p)
+    for layer in range(8):
+        gz, h = G[kernels.SAVE_H0 + layer], X[kernels.SAVE_H0 + layer]
+        assert not ((gz != 0) & (h <= 0)).any(), f"dZ of layer {layer} leaks through a closed ReLU"
+        assert torch.isfinite(gz).all() and float(gz.abs().max()) > 0
+
+
+def test_chain_forms_agree():
+    """Eight-wave and four-wave forms of the chain: same arithmetic, same order of operations per value."""
+    import os
+    dev = torch.device("cuda:0")
+    desc = _capi.net_desc(_capi.VARIANT_OBJECT, 0, 10, 4, 1.0, _capi.PREC_F16X3)
+    sd = {k: v.to(dev) for k, v in oracle.make_state_dict("object", 0, seed=5).items()}
+    pf, pb = packing.device_packer(desc, False, dev)(sd), packing.device_packer(desc, True, dev)(sd)
+    rays, z = _rays(300, 11, dev, seed=1)
+    raw, save = kernels.encode_mlp_train(desc, pf, rays, z)
+    p = 300 * 11
+    d_raw = torch.randn(p, 11, device=dev)
+    out = {}
+    old = os.environ.get("INERF_DGRAD_WAVES")
+    try:
+        for wv in ("8", "4"):
+            os.environ["INERF_DGRAD_WAVES"] = wv
+            dz, heads = kernels.mlp_backward_inputs(desc, pb, raw.view(p, 11), d_raw, save, want_heads=True)
+            # (the gradient buffer's enc / dir slots and its mask area are never written: compare the slots the chain fills)
+            out[wv] = ([g.clone() for g in kernels.save_slot_views(desc, dz, p)[kernels.SAVE_H0:]], heads.clone())
+    finally:
+        if old is None:
+            os.environ.pop("INERF_DGRAD_WAVES", None)
+        else:
+            os.environ["INERF_DGRAD_WAVES"] = old
+    for slot, (a, b) in enumerate(zip(out["8"][0], out["4"][0])):
+        assert torch.equal(a, b), f"slot {kernels.SAVE_H0 + slot}: max |diff| {float((a - b).abs().max()):.3e} of {float(b.abs().max()):.3e}"
+
+    # head sums: different partial-sum trees over 3 300 cancelling terms
+    torch.testing.assert_close(out["8"][1], out["4"][1], rtol=1e-4, atol=1e-5 * float(out["4"][1].abs().max()))
