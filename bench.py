@@ -32,6 +32,7 @@ Prints ONE JSON line (rank 0) with the bench contract's fields plus
   "configs"      : BASELINE.json configs[1] (coarse-only 800x800) and configs[3] (320x240 SSR room frame, C = 28)
                    through their front-ends: rays/s and the MLP kernel's roofline fraction at their launch shapes;
   "frame_costs"  : where a frame's wall time goes besides the kernels (host, packing, gather, status read).
+  "f16_range_fallback": cost of a frame on which the f16x3 range guard trips (one wasted attempt + the exact-fp32 re-run).
 """
 import argparse
 import json
@@ -415,6 +416,28 @@ def main():
         exact = {"value": n_total / dt32, "unit": "rays/s", "ms_per_step": dt32 * 1e3, "steps": 1,
                  "note": "whole path with INERF_PRECISION=f32 (v_mfma_f32_32x32x2_f32 everywhere)"}
 
+    # what the f16x3 range guard costs when it trips ("the fallback cost is not reported anywhere"): the same frame
+    # with a fine network whose hidden activations exceed the split's range (one trunk layer scaled by 2^17): the front-end
+    # renders the whole frame in f16x3, reads the range word at the end of the frame and renders it again in exact fp32
+    fallback = None
+    if extras and f16:
+        import copy
+        import warnings
+        big = copy.deepcopy(net_f)
+        with torch.no_grad():
+            big.pts_linears[3].weight.mul_(131072.0)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            render_band(ro_l, rd_l, network_fine=big); fence()
+            t1 = time.perf_counter()
+            fmaps, _ = render_band(ro_l, rd_l, network_fine=big)
+            fence()
+        dtf = time.perf_counter() - t1
+        fallback = {"ms_per_step": dtf * 1e3, "vs_f16x3_frame": dtf / (dt / args.steps), "finite": bool(torch.isfinite(fmaps["rgb_map"]).all()),
+                    "note": "frame whose fine network leaves the f16x3 activation range (|activation| >= 7.5e3): one f16x3 attempt + "
+                            "the exact-fp32 re-run of the whole frame; INERF_PRECISION=f32 skips the attempt"}
+        del big
+
     # ---- BASELINE.json configs[1] and configs[3] through their front-ends (rank 0, N = 1 only; not part of `value`) ----
     configs = None
     if extras:
@@ -535,7 +558,7 @@ def main():
                        "rays_per_step": n_total, "parallelism": f"ray-sharded x{world}",
                        "gather": "all_gather of 12 floats/ray" if world > 1 else "none"},
             "roofline": roofline, "roofline_f32_kernel": roofline_f32, "exact_f32_path": exact, "parity": parity,
-            "configs": configs, "frame_costs": frame_costs, "train_step": train, "cpu_baseline": cpu}))
+            "configs": configs, "frame_costs": frame_costs, "f16_range_fallback": fallback, "train_step": train, "cpu_baseline": cpu}))
         sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
