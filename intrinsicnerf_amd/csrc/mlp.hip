@@ -365,6 +365,13 @@ int device_cus() {
 // tiles, two workgroups per CU (124.8 TFLOP/s: the second workgroup hides barriers/epilogues but
 // doubles the weight stream and halves the skinny-GEMM parallelism).  INERF_TILE_POINTS=64|32
 // selects for A/B measurements.
+int stagger_units(int n_tiles, int grid) {
+    if (n_tiles < 4 * grid) return 0;
+    const char* e = getenv("INERF_TRAIN_STAGGER");
+    const int u = e ? atoi(e) : 4;
+    return u < 0 ? 0 : (u > 64 ? 64 : u);
+}
+
 int tile_blocks() {
     static int pb = 0;
     if (pb == 0) {

@@ -38,6 +38,7 @@ struct BwdParams {
     int64_t bits_off;       // ReLU masks of h0..h6 inside `save` (layout.h relu_bits_offset)
     BwdLayout L;
     int n_points, n_tiles, channels, n_classes, endpoint;
+    int stagger;            // start offset of the workgroups (mlp_common.h stagger_start), 0 = none
 };
 
 // Per-workgroup partial gradients of the heads with 1-4 output rows (their operands pass through this kernel's
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
 #else
 #define STAMP() do { } while (0)
 #endif
+    stagger_start(p.stagger);
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         STAMP();
         // The saved activations the three VALU stages need are requested a stage ahead (with one wave per SIMD a load issued
@@ -619,6 +621,7 @@ extern "C" int inerf_mlp_backward_inputs(const inerf_net_desc* net, const float*
     p.n_classes = ssr ? net->n_classes : 0;
     p.channels = INERF_BASE_CHANNELS + p.n_classes + (p.endpoint ? INERF_ENDPOINT_DIM : 0);
     const int grid = p.n_tiles < device_cus() ? p.n_tiles : device_cus();
+    p.stagger = stagger_units(p.n_tiles, grid);
     // eight waves per workgroup (two per SIMD) by default; INERF_DGRAD_WAVES=4 keeps the one-wave-per-SIMD form for A/B runs
     const char* form = getenv("INERF_DGRAD_WAVES");
     const bool eight = !(form && form[0] == '4');

@@ -28,6 +28,18 @@ struct MlpParams {
     float xyz_div;
 };
 
+// Staggered start of the input-gradient chain.  Every workgroup walks the same stages at the same pace, so the whole chip asks HBM for the same kind of rows at the same moment - 64 KB per CU x 256 CUs is
+// 6 000 cycles of HBM whatever the kernel does meanwhile.  A start offset of ((b ^ (b >> 3)) & 7) x units x 2 048 cycles spreads
+// those bursts over an eighth of a tile each: chain 2.20 -> 2.04 ms on 393 216 points.  INERF_TRAIN_STAGGER=<units> (0: off).
+// (No effect on the training forward, whose two workgroups per CU drift apart by themselves: 2.13 vs 2.12 ms.)
+#ifdef __HIPCC__
+__device__ __forceinline__ void stagger_start(int units) {
+    const int b = blockIdx.x;
+    for (int d = ((b ^ (b >> 3)) & 7) * units; d > 0; --d) __builtin_amdgcn_s_sleep(32);
+}
+#endif
+int stagger_units(int n_tiles, int grid);       // 0 when a workgroup has fewer than four tiles
+
 int device_cus();                 // CU count of the CURRENT device (cached per device id)
 int current_device();             // hipGetDevice, 0 on error
 int tile_blocks();
