@@ -5,6 +5,7 @@ torch is plumbing here - it owns device memory and the HIP stream; all arithmeti
 no CPU or eager fallback.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -139,7 +140,7 @@ def check_f16_range(status, what, deferrable=False):
     ``deferred_range_checks`` block and with ``deferrable``, leave the word for the block's single check."""
     if status is None:
         return
-    if deferrable and _deferred is not None:
+    if deferrable and _deferred is not None and os.environ.get("INERF_EAGER_RANGE_CHECKS", "0") == "0":      # (A/B switch)
         _deferred.append(status.reshape(1))
         return
     if int(status.item()) & _capi.STATUS_F16_RANGE:
@@ -663,7 +664,7 @@ class _FusedMlpFn(torch.autograd.Function):
         act_max = torch.zeros(1, dtype=torch.float32, device=rays.device)
         packed = packing.device_packer(desc, False, rays.device)(named)
         raw, save = encode_mlp_train(desc, packed, rays.detach(), z_vals.detach(), endpoint, status, act_max)
-        check_f16_range(status, "training forward")
+        check_f16_range(status, "training forward", deferrable=True)      # the front-ends read both networks' words once per batch
         ctx.save_for_backward(raw, save, act_max, *params)
         ctx.cfg = (desc, endpoint, names)
         return raw
@@ -685,9 +686,9 @@ class _FusedMlpFn(torch.autograd.Function):
         heads = None
         if hip_wgrad:
             dz, heads = dz
-        check_f16_range(status, "training backward")
         ranges = torch.cat([dz_max, act_max]) if hip_wgrad else None
         grads = mlp_weight_gradients(desc, names, save, dz, d2, n * s, endpoint, ranges, heads)
+        check_f16_range(status, "training backward")      # read AFTER the weight-gradient launches are enqueued: the GPU works through them meanwhile
         return (None, None, None, None, None) + tuple(grads[k] for k in names)
 
 

@@ -363,29 +363,56 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
         # user-supplied network, or a training step: the stages run on the HIP kernels (compositing differentiably),
         # the network is called as given / through its torch forward
         rays_o, rays_d, viewdirs = ray_batch[:, 0:3], ray_batch[:, 3:6].contiguous(), ray_batch[:, -3:]
-        def query(z, fn):
-            raw = _train_query(train_desc, fn, ray_batch, z) if train_desc is not None else None        # nq's encoders
-            if raw is None:
-                pts = rays_o[..., None, :] + rays_d[..., None, :] * z[..., :, None]
-                raw = network_query_fn(pts, viewdirs, fn)
-            return raw
 
-        z_vals = kernels.sample_coarse(ray_batch, t_vals, t_rand, lindisp)
-        raw = query(z_vals, network_fn)
-        c = kernels.composite(raw.float(), z_vals, rays_d, noise(N_samples), white_bkgd)
-        ret = {rk: c[ok] for rk, ok in _RET_MAP}
-        if N_importance > 0:
-            c0 = c
-            u = _draw_u(n, N_importance, perturb == 0., pytest, dev)
-            z_samples, z_vals, z_std = kernels.sample_fine(z_vals, c0["weights"], u, N_importance)
-            raw = query(z_vals, network_fn if network_fine is None else network_fine)
-            c = kernels.composite(raw.float(), z_vals, rays_d, noise(N_samples + N_importance), white_bkgd)
+        def staged(td):
+            def query(z, fn):
+                raw = _train_query(td, fn, ray_batch, z) if td is not None else None        # nq's encoders
+                if raw is None:
+                    pts = rays_o[..., None, :] + rays_d[..., None, :] * z[..., :, None]
+                    raw = network_query_fn(pts, viewdirs, fn)
+                return raw
+
+            z_vals = kernels.sample_coarse(ray_batch, t_vals, t_rand, lindisp)
+            raw = query(z_vals, network_fn)
+            c = kernels.composite(raw.float(), z_vals, rays_d, noise(N_samples), white_bkgd)
             ret = {rk: c[ok] for rk, ok in _RET_MAP}
-            for rk, ok in _RET_0:
-                ret[rk] = c0[ok]
-            ret["z_std"] = z_std
-        if retraw:
-            ret["raw"] = raw
+            if N_importance > 0:
+                c0 = c
+                u = _draw_u(n, N_importance, perturb == 0., pytest, dev)
+                z_samples, z_vals, z_std = kernels.sample_fine(z_vals, c0["weights"], u, N_importance)
+                raw = query(z_vals, network_fn if network_fine is None else network_fine)
+                c = kernels.composite(raw.float(), z_vals, rays_d, noise(N_samples + N_importance), white_bkgd)
+                ret = {rk: c[ok] for rk, ok in _RET_MAP}
+                for rk, ok in _RET_0:
+                    ret[rk] = c0[ok]
+                ret["z_std"] = z_std
+            if retraw:
+                ret["raw"] = raw
+            return ret
+
+        if train_desc is None:
+            ret = staged(None)
+        else:
+            # ONE read of the f16 range words per training forward, after every launch of the batch has been enqueued (a read
+            # after each network leaves the GPU idle while the host prepares the next launches).  If it trips, the whole batch
+            # is evaluated again with the layers in torch - with the random draws repeated, so it consumes the RNG like the
+            # reference would.
+            redraw = raw_noise_std > 0. or (perturb > 0. and N_importance > 0)
+            rng = (torch.get_rng_state(), torch.cuda.get_rng_state(dev) if dev.type == "cuda" else None) if redraw else None
+            np_state = np.random.get_state() if pytest else None
+            try:
+                with kernels.deferred_range_checks("render_rays (training step)"):
+                    ret = staged(train_desc)
+            except FloatingPointError as e:
+                import warnings
+                warnings.warn(f"{e}  Evaluating this batch with torch autograd instead.")
+                if rng is not None:
+                    torch.set_rng_state(rng[0])
+                    if rng[1] is not None:
+                        torch.cuda.set_rng_state(rng[1], dev)
+                if np_state is not None:
+                    np.random.set_state(np_state)
+                ret = staged(None)
     if verbose:   # the reference's DEBUG nan/inf scan (run_nerf.py:524-526); each check is a device sync
         for k in ret:
             if torch.isnan(ret[k]).any() or torch.isinf(ret[k]).any():

@@ -397,7 +397,17 @@ class SSRRenderMixin:
 
         if _wants_grad(self.ssr_net_coarse, self.ssr_net_fine):
             _training_path_notice("volumetric_rendering")
-            o = self._staged(ray_batch, t_vals, t_rand, noise_c, u, noise_f, ep, _train_desc(desc))
+            td = _train_desc(desc)
+            if td is None:
+                o = self._staged(ray_batch, t_vals, t_rand, noise_c, u, noise_f, ep, None)
+            else:       # one read of both networks' f16 range words, after the whole forward has been enqueued (object_level.render_rays)
+                try:
+                    with kernels.deferred_range_checks("volumetric_rendering (training step)"):
+                        o = self._staged(ray_batch, t_vals, t_rand, noise_c, u, noise_f, ep, td)
+                except FloatingPointError as e:
+                    import warnings
+                    warnings.warn(f"{e}  Evaluating this batch with torch autograd instead.")
+                    o = self._staged(ray_batch, t_vals, t_rand, noise_c, u, noise_f, ep, None)
         else:
             o = kernels.with_f32_fallback(desc, run)
         ret = {}

@@ -422,6 +422,43 @@ def test_weight_gradient_kernel_vs_fp64(p, m, n):
 
 
 @pytest.mark.gpu
+def test_training_batch_outside_f16_range_is_reevaluated_with_torch_layers(monkeypatch):
+    """The training forward reads the f16 range words of both networks ONCE, after the batch is enqueued.  A batch that trips it is
+    evaluated again with the layers in torch - same random draws (the RNG state is put back), hence the same maps and gradients
+    as a run that used torch layers from the start."""
+    import warnings
+    from intrinsicnerf_amd import object_level as ol
+    dev = torch.device("cuda:0")
+    fx = load_golden("object_chair_det")
+    embed, ch = ol.get_embedder(10, 0); embed_d, ch_d = ol.get_embedder(4, 0)
+    mk = lambda: ol.NeRF(D=8, W=256, input_ch=ch, output_ch=5, skips=[4], input_ch_views=ch_d, use_viewdirs=True).to(dev)
+    net_c, net_f = mk(), mk()
+    sd_c, sd_f = case_weights(fx)
+    net_c.load_state_dict(sd_c); net_f.load_state_dict(sd_f)
+    with torch.no_grad():
+        net_f.pts_linears[2].weight.mul_(1.0e6)                  # hidden activations of the fine network far beyond 7.5e3
+    rays = torch.from_numpy(fx["rays"][:9]).to(dev)
+    out = {}
+    for mode in ("hip", "torch"):
+        monkeypatch.setenv("INERF_TRAIN_MLP", mode)
+        net_c.zero_grad(); net_f.zero_grad()
+        torch.manual_seed(11)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            ret = ol.render_rays(rays, net_c, ol.NetworkQuery(embed, embed_d), 64, retraw=True, N_importance=32, network_fine=net_f,
+                                 white_bkgd=True, perturb=1.0, raw_noise_std=1.0)
+        told = any("torch autograd instead" in str(x.message) for x in w)
+        assert told == (mode == "hip")
+        (ret["rgb_map"].square().sum() + ret["acc0"].sum()).backward()
+        out[mode] = ({k: v.detach().clone() for k, v in ret.items()},
+                     {k: p.grad.clone() for k, p in list(net_c.named_parameters()) + [("f." + k, p) for k, p in net_f.named_parameters()]})
+    for k in out["torch"][0]:
+        assert torch.equal(out["hip"][0][k], out["torch"][0][k]), k
+    for k in out["torch"][1]:
+        assert torch.equal(out["hip"][1][k], out["torch"][1][k]), k
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(8))
 def test_composite_backward_randomized_shapes(seed):
     """Compositing backward against autograd through the oracle over ragged sample counts (chunks of 64 with a partial last
