@@ -452,10 +452,10 @@ def test_training_batch_outside_f16_range_is_reevaluated_with_torch_layers(monke
         (ret["rgb_map"].square().sum() + ret["acc0"].sum()).backward()
         out[mode] = ({k: v.detach().clone() for k, v in ret.items()},
                      {k: p.grad.clone() for k, p in list(net_c.named_parameters()) + [("f." + k, p) for k, p in net_f.named_parameters()]})
-    for k in out["torch"][0]:
-        assert torch.equal(out["hip"][0][k], out["torch"][0][k]), k
+    for k in out["torch"][0]:          # bit for bit (NaN disparities of empty rays included)
+        torch.testing.assert_close(out["hip"][0][k], out["torch"][0][k], rtol=0, atol=0, equal_nan=True, msg=k)
     for k in out["torch"][1]:
-        assert torch.equal(out["hip"][1][k], out["torch"][1][k]), k
+        torch.testing.assert_close(out["hip"][1][k], out["torch"][1][k], rtol=0, atol=0, equal_nan=True, msg=k)
 
 
 @pytest.mark.gpu

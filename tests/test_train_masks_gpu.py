@@ -85,3 +85,29 @@ def test_chain_forms_agree():
 
     # head sums: different partial-sum trees over 3 300 cancelling terms
     torch.testing.assert_close(out["8"][1], out["4"][1], rtol=1e-4, atol=1e-5 * float(out["4"][1].abs().max()))
+
+
+@pytest.mark.parametrize("waves", ["8", "4"])
+def test_chain_repeats_bit_for_bit_over_many_launches(waves, monkeypatch):
+    """120 launches of the chain on the same inputs: every slot identical every time.  (A 16-byte buffer store with its SGPR
+    offset in a register gets no wait state before its data registers are overwritten; the last row of the two VALU stages
+    came out wrong in 4 % of the launches of the eight-wave form until the offset moved into the VGPR operand.)"""
+    monkeypatch.setenv("INERF_DGRAD_WAVES", waves)
+    dev = torch.device("cuda:0")
+    desc = _capi.net_desc(_capi.VARIANT_OBJECT, 0, 10, 4, 1.0, _capi.PREC_F16X3)
+    sd = {k: v.to(dev) for k, v in oracle.lcg_state_dict("object", 0, seed=23, sigma_gain_log2=3, freq_decay=True).items()}
+    pf, pb = packing.device_packer(desc, False, dev)(sd), packing.device_packer(desc, True, dev)(sd)
+    n, s = 700, 48                      # 525 whole tiles: two per workgroup
+    rays, z = _rays(n, s, dev, seed=5)
+    p = n * s
+    cot = torch.randn(p, 11, device=dev)
+    raw, save = kernels.encode_mlp_train(desc, pf, rays, z)
+    ref = None
+    for it in range(120):
+        dz, heads = kernels.mlp_backward_inputs(desc, pb, raw.view(p, 11), cot, save, want_heads=True)
+        cur = [g.clone() for g in kernels.save_slot_views(desc, dz, p)[kernels.SAVE_H0:]] + [heads.clone()]
+        if ref is None:
+            ref = cur
+            continue
+        for slot, (a, b) in enumerate(zip(cur, ref)):
+            assert torch.equal(a, b), f"launch {it}: slot {kernels.SAVE_H0 + slot} differs at {int((a != b).sum())} elements"
