@@ -27,4 +27,14 @@ for f in dual quad halves pipe single; do echo "$f: $(INERF_F16_KERNEL=$f python
 python scripts/bench_ssr_frame.py --frames 5 > $OUT/${tag}_ssr_frame.txt 2>&1
 python scripts/bench_train_step.py --iters 8 > $OUT/${tag}_train_step.txt 2>&1
 python scripts/bench_train_step.py --iters 8 --ssr 28 >> $OUT/${tag}_train_step.txt 2>&1
+# 6. the training step under rocprofv3, and PMC passes on the training kernels (fine-pass batch: 2048 rays x 192 samples)
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof/${tag}_train -o t -- python $REPO/scripts/bench_train_step.py --iters 8 > /dev/null 2>&1 )
+find $OUT/prof/${tag}_train -name "*kernel_stats.csv" -exec cp {} $OUT/${tag}_train_step_kernel_stats.csv \;
+export BENCH_SCRIPT=scripts/bench_train_kernels.py BENCH_SIZE="--rays 2048 --iters 1" BENCH_ARGS=""
+bash scripts/pmc_pass.sh ${tag}_tr_w WRITE_SIZE
+bash scripts/pmc_pass.sh ${tag}_tr_f FETCH_SIZE
+bash scripts/pmc_pass.sh ${tag}_tr_m GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU
+python scripts/pmc_report.py $OUT/prof/${tag}_tr_w $OUT/prof/${tag}_tr_f $OUT/prof/${tag}_tr_m > $OUT/${tag}_train_pmc_summary.txt 2>&1
+for p in w f m; do find $OUT/prof/${tag}_tr_$p -name "*counter_collection.csv" -exec cp {} $OUT/${tag}_train_pmc_$p.csv \; ; done
+python scripts/bench_train_kernels.py > $OUT/${tag}_train_kernels.txt 2>&1
 tail -c 600 $OUT/${tag}_bench.err; tail -3 $OUT/${tag}_kernel_forms.txt; tail -2 $OUT/${tag}_ssr_frame.txt; tail -2 $OUT/${tag}_train_step.txt
