@@ -664,7 +664,11 @@ class _FusedMlpFn(torch.autograd.Function):
         act_max = torch.zeros(1, dtype=torch.float32, device=rays.device)
         packed = packing.device_packer(desc, False, rays.device)(named)
         raw, save = encode_mlp_train(desc, packed, rays.detach(), z_vals.detach(), endpoint, status, act_max)
+        # the transposed blob of the backward pass is packed NOW, behind the forward kernel in the queue: at the start of the
+        # backward the queue is empty, and its ~25 small launches would each cost a host round trip of GPU idle time
+        packed_bwd = packing.device_packer(desc, True, rays.device)(named) if os.environ.get("INERF_PACK_BWD_EARLY", "1") != "0" else None
         check_f16_range(status, "training forward", deferrable=True)      # the front-ends read both networks' words once per batch
+        ctx.packed_bwd = packed_bwd
         ctx.save_for_backward(raw, save, act_max, *params)
         ctx.cfg = (desc, endpoint, names)
         return raw
@@ -678,7 +682,7 @@ class _FusedMlpFn(torch.autograd.Function):
         n, s, ch = raw.shape
         status = _new_status(raw)
         dz_max = torch.zeros(1, dtype=torch.float32, device=raw.device)
-        packed_bwd = packing.device_packer(desc, True, raw.device)(dict(zip(names, params)))
+        packed_bwd = ctx.packed_bwd if ctx.packed_bwd is not None else packing.device_packer(desc, True, raw.device)(dict(zip(names, params)))
         d2 = d_raw.contiguous().view(n * s, ch).float()
         import os
         hip_wgrad = os.environ.get("INERF_WGRAD", "hip") != "library"
