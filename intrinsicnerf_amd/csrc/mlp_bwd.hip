@@ -368,7 +368,6 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
         const int pt0 = tile * kPts + (lane & 31);
         const bool valid0 = pt0 < p.n_points, valid1 = pt0 + 32 < p.n_points;
         const float s0 = ptf(lane & 31)[8], s1 = ptf((lane & 31) + 32)[8];
-        auto gptr = [&](const float* base, int slot) { return base + p.off[slot] + (size_t)pt0 * kWidth + WCH * wave + 4 * (lane >> 5); };
         auto dz_dst = [&](int slot) {                 // 256-wide slots only (every layer this kernel runs on the matrix core)
             DzDst d;
             d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dz + p.off[slot], 0, (int)((unsigned)p.n_points * (unsigned)kWidth * 4u), 0x00020000);
@@ -411,9 +410,6 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
 #pragma unroll
             for (int i = 0; i < AS_IT; ++i) {
                 constexpr int HALF = AS_IT / 2;
-                const int pt = (tid >> 6) + AS_STEP * i;
-                const int gp = tile * kPts + pt;
-                const bool valid = gp < p.n_points;
                 const float* f = reinterpret_cast<const float*>(ldsb + rows.f[i / HALF] + (i % HALF) * AS_STEP * kRowH);
                 const float d0 = f[0], d1 = f[1], d2 = f[2], d3 = f[3];
                 float v[4];

@@ -944,7 +944,6 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_quad(const MlpParam
             constexpr integral_constant<int, 0> HA{};
             constexpr integral_constant<int, 1> HB{};
             constexpr integral_constant<bool, true> EPI{};
-            constexpr integral_constant<bool, false> NOEPI{};
             // layer 0: half A stored now (exposed), half B left pending with its bias in set 1 - the pipeline's entry state
             want_bias(1, L.trunk[0]);
             prefetch_q4(pre4, wb, frag256(L.trunk[1], 16), kStride256);
