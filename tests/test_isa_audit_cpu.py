@@ -1,0 +1,84 @@
+"""Audit of the machine code inside libinerf.so (no GPU needed: the gfx950 code objects are pulled out of the library's
+.hip_fatbin section and disassembled with ROCm's llvm-objdump / llvm-readelf).
+
+* A 16-byte (or 12-byte) buffer store whose SGPR offset operand is a REGISTER gets no wait state from the compiler before its data
+  registers may be overwritten, and on gfx950 the store then sometimes sends what the next instruction wrote (found in round 2 in
+  the input-gradient chain).  With the constant 0 in that operand the compiler inserts the s_nop.  No such
+  store may appear anywhere in the library.
+* The default inference kernel must stay (nearly) free of scratch: its 2 workgroups per CU sit at the 256-register limit, and a
+  change that makes it spill is a performance regression before it is anything else."""
+import os
+import re
+import shutil
+import struct
+import subprocess
+
+import pytest
+
+from intrinsicnerf_amd import _build, _capi
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def _code_objects(tmp_path):
+    objcopy = shutil.which("objcopy")
+    if objcopy is None or not os.path.exists(f"{LLVM}/llvm-objdump"):
+        pytest.skip("objcopy / llvm-objdump not available")
+    _capi.lib()                                            # builds the library if it is missing or stale
+    fat = tmp_path / "fat.bin"
+    subprocess.run([objcopy, "-O", "binary", "--only-section=.hip_fatbin", _build.LIB_PATH, str(fat)], check=True)
+    data = fat.read_bytes()
+    out, pos = [], 0
+    while True:
+        i = data.find(MAGIC, pos)
+        if i < 0:
+            break
+        (num,) = struct.unpack_from("<Q", data, i + 24)
+        p = i + 32
+        for _ in range(num):
+            off, size, idl = struct.unpack_from("<QQQ", data, p)
+            p += 24
+            ident = data[p:p + idl].decode()
+            p += idl
+            if "gfx950" in ident and size > 0:
+                path = tmp_path / f"co_{len(out)}.elf"
+                path.write_bytes(data[i + off:i + off + size])
+                out.append(str(path))
+        pos = i + 24
+    assert len(out) >= len([s for s in _build.SOURCES if s.endswith(".hip")]), "one gfx950 code object per HIP source expected"
+    return out
+
+
+def test_no_wide_buffer_store_with_a_register_soffset(tmp_path):
+    wide = bad = 0
+    for co in _code_objects(tmp_path):
+        asm = subprocess.run([f"{LLVM}/llvm-objdump", "-d", co], capture_output=True, text=True, check=True).stdout
+        for line in asm.split("\n"):
+            if re.search(r"\bbuffer_store_dwordx[34]\b", line):
+                wide += 1
+                if re.search(r"\], s\d+\b", line):             # ... v[a:b], vN, s[rsrc], sN  <- SGPR offset in a register
+                    bad += 1
+    assert wide > 500, "the training forward and the chain store 16 bytes per lane in hundreds of places: audit found none?"
+    assert bad == 0, f"{bad} of {wide} 16-byte buffer stores carry their SGPR offset in a register (store-data hazard, DESIGN.md 3.1b)"
+
+
+def test_default_inference_kernels_do_not_live_in_scratch(tmp_path):
+    scratch = {}
+    for co in _code_objects(tmp_path):
+        notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
+        name = None
+        for line in notes.split("\n"):
+            m = re.search(r"\.name:\s+(\S+)", line)
+            if m:
+                name = m.group(1)
+            m = re.search(r"\.private_segment_fixed_size:\s+(\d+)", line)
+            if m and name:
+                scratch[name] = int(m.group(1))
+    dual = {k: v for k, v in scratch.items() if "k_encode_mlp_f16x3_dual" in k}
+    assert len(dual) == 4, sorted(scratch)
+    # <kSave = false>: object-level and SSR inference (mangled: ...dualILb0ELb0EE / ...dualILb0ELb1EE)
+    for k, v in dual.items():
+        if "ILb0E" in k:
+            assert v <= 64, f"{k}: {v} bytes of scratch per lane"
+    assert scratch.get("_ZN5inerf12k_encode_mlpILb0ELi2EEEvNS_9MlpParamsE", 0) == 0
