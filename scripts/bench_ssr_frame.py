@@ -24,6 +24,7 @@ from intrinsicnerf_amd import ssr  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=3)
 ap.add_argument("--classes", type=int, default=28)
+ap.add_argument("--chunk", type=int, default=32768, help="rays per render_rays chunk (SSR_room0_config.yaml: 32768; results do not depend on it)")
 a = ap.parse_args()
 world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
 local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -45,6 +46,7 @@ T = torch.eye(4)[None]                                   # rays are built on the
 rays = ssr.create_rays(1, T, H, W, fx, fy, cx, cy, 0.1, 10.0).reshape(-1, 11).contiguous().to(dev)
 r = ssr.SSRRenderer(a.classes, white_bkgd=False, endpoint_feat=False, device=dev)
 r.return_raw = False
+r.chunk = a.chunk
 r.check_numerics = False
 layout = idist.ssr_map_layout(a.classes)
 
