@@ -1,5 +1,7 @@
 """CPU: host logic of the reference-signature front-ends - module/state-dict compatibility, ray
 generators, and loud failure (no silent CPU / eager fallback) when asked to render without a HIP device."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -217,6 +219,15 @@ def test_deferred_range_checks_read_the_status_words_once():
         with kernels.deferred_range_checks("inner"):
             kernels.check_f16_range(ok, "x", deferrable=True)
         assert len(kernels._deferred) == 1
+    # INERF_EAGER_RANGE_CHECKS=1: every check reads its word at once, block or not (A/B switch for the deferred reads)
+    os.environ["INERF_EAGER_RANGE_CHECKS"] = "1"
+    try:
+        with pytest.raises(FloatingPointError, match="chunk 1"):
+            with kernels.deferred_range_checks("frame"):
+                kernels.check_f16_range(bad, "chunk 1", deferrable=True)
+    finally:
+        del os.environ["INERF_EAGER_RANGE_CHECKS"]
+    assert kernels._deferred is None
     # the whole-frame retry switches the default precision for its duration only
     before = _capi.default_precision()
     with _capi.forced_precision(_capi.PREC_F32):
