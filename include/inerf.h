@@ -30,7 +30,7 @@ extern "C" {
 #define INERF_VERSION_MINOR 2
 /* Bumped whenever a struct layout, an argument list or the packed-weight format of this header changes; bindings
  * compare it with inerf_abi_version() of the library they loaded (a stale .so then fails loudly, not silently). */
-#define INERF_ABI_VERSION 20005
+#define INERF_ABI_VERSION 30001
 
 /* error codes */
 #define INERF_OK              0
@@ -67,6 +67,7 @@ extern "C" {
 
 const char* inerf_version(void);
 int inerf_abi_version(void);          /* INERF_ABI_VERSION the library was built against */
+const char* inerf_build_digest(void); /* sha256 (64 hex digits) of the sources, headers and compiler flags this library was built from */
 int inerf_last_hip_error(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -121,12 +122,6 @@ int inerf_sample_coarse(const float* rays, const float* t_vals, const float* t_r
  * status: optional device int32 the kernel ORs INERF_STATUS_* bits into (caller zeroes it). */
 int inerf_encode_mlp(const inerf_net_desc* net, const float* packed_weights, const float* rays, const float* z_vals,
                      int64_t n_rays, int n_samples, uint32_t flags, float* raw_out, int32_t* status, void* stream);
-
-/* Development aid (kernel tuning, scripts/pipe_timeline.py): inerf_encode_mlp plus `stamps`, a device buffer of 64 uint64:
- * [0] = number of stamps, [1..] = shader-clock values workgroup 0 / wave 0 of the pipelined INERF_PREC_F16X3 kernel takes at
- * its phase boundaries while working its first tile.  Kernels without stamps leave the buffer untouched. */
-int inerf_debug_encode_mlp(const inerf_net_desc* net, const float* packed_weights, const float* rays, const float* z_vals,
-                           int64_t n_rays, int n_samples, uint32_t flags, float* raw_out, uint64_t* stamps, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Training: what autograd records for the network when the trainers call loss.backward()

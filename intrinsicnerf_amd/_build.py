@@ -12,7 +12,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libinerf.so")
 OBJ_DIR = os.path.join(CSRC, "_obj")          # git-ignored and gpurun-ignored: only the linked library travels
-SOURCES = ["pack.cpp", "api.cpp", "mlp.hip", "mlp_f16.hip", "mlp_f16_pipe.hip", "mlp_bwd.hip", "mlp_wgrad.hip", "ray_ops.hip", "frame_ops.hip", "cluster.hip"]
+SOURCES = ["pack.cpp", "api.cpp", "mlp.hip", "mlp_f16.hip", "mlp_bwd.hip", "mlp_wgrad.hip", "ray_ops.hip", "frame_ops.hip", "cluster.hip"]
 HEADERS = [os.path.join(CSRC, "layout.h"), os.path.join(CSRC, "mlp_common.h"), os.path.join(CSRC, "mlp_f16_dev.h"), os.path.join(CSRC, "mlp_f16_heads.h"), os.path.join(os.path.dirname(PKG_DIR), "include", "inerf.h")]
 # -ffp-contract=off: the reference rounds o + d*z, albedo*shading + residual, near*(1-t) + far*t ... as
 # separate multiplies and adds; fused multiply-adds would move sample positions by an ulp, which the
@@ -21,19 +21,42 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
          "-Wno-comment", "-Wno-unused-result"]
 
 
-# mlp_f16_pipe.hip: MFMA results in ordinary VGPRs (its epilogue reads them with VALU instructions while the next MFMAs run);
-# the 256 registers of resident weights then take the AGPR half of the unified file.  Without the option the allocator puts
-# the accumulators there and copies 64-128 registers back per phase.
-# mlp_bwd.hip: the chain kernel also runs one wave per SIMD; the option cuts its accumulator<->VGPR copies from ~580 to ~200.
-EXTRA_FLAGS = {"mlp_f16_pipe.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "mlp_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+# mlp_bwd.hip: the chain kernel's epilogues read the MFMA results with VALU instructions; with the accumulators in ordinary
+# VGPRs (one or two waves per SIMD, 512 unified registers) its accumulator<->VGPR copies drop from ~580 to ~200.
+EXTRA_FLAGS = {"mlp_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+DIGEST_MARK = b"INERF_BUILD_DIGEST="          # followed by 64 hex digits inside the library (inerf_build_digest())
 
 
-def _stale():
-    if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
-    return any(os.path.getmtime(d) > t for d in deps)
+def source_digest():
+    """sha256 over everything the library is a function of: every source and header (bytes, not mtimes - a pushed or
+    checked-out tree reorders mtimes), the compiler flags and this recipe's source list."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(repr((SOURCES, FLAGS, sorted(EXTRA_FLAGS.items()))).encode())
+    for path in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def built_digest(lib_path=None):
+    """The source digest linked into ``lib_path`` (what ``inerf_build_digest()`` returns), read from the file's bytes so
+    that a stale library is never loaded; '' if the file carries none."""
+    try:
+        with open(lib_path or LIB_PATH, "rb") as fh:
+            data = fh.read()
+    except OSError:
+        return ""
+    i = data.find(DIGEST_MARK)
+    return data[i + len(DIGEST_MARK): i + len(DIGEST_MARK) + 64].decode("ascii", "replace") if i >= 0 else ""
+
+
+def _stale(lib_path=None):
+    """True when ``lib_path`` (default: the in-tree library) is missing or was built from other sources / flags than the
+    tree holds now.  Content-based: kernel edits, flag edits in this file and reordered mtimes are all caught."""
+    lib_path = lib_path or LIB_PATH
+    return not os.path.exists(lib_path) or built_digest(lib_path) != source_digest()
 
 
 def have_hipcc():
@@ -59,20 +82,29 @@ def build_library(force=False, verbose=False):
             # one object per source, compiled in parallel and only when that source (or a header) changed: editing one
             # kernel file costs one compile + the link instead of the whole 40 s
             os.makedirs(OBJ_DIR, exist_ok=True)
-            newest_header = max(os.path.getmtime(h) for h in HEADERS)
+            import hashlib
+            header_bytes = b"".join(open(h, "rb").read() for h in HEADERS)
 
             def compile_one(src):
                 obj = os.path.join(OBJ_DIR, src + ".o")
                 path = os.path.join(CSRC, src)
-                if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), newest_header):
+                flags = [f for f in FLAGS if f != "-shared"] + EXTRA_FLAGS.get(src, [])
+                key = hashlib.sha256(repr(flags).encode() + open(path, "rb").read() + header_bytes).hexdigest()
+                try:
+                    cached = open(obj + ".key").read().strip()
+                except OSError:
+                    cached = ""
+                if not force and os.path.exists(obj) and cached == key:
                     return obj, None
-                cmd = [hipcc] + [f for f in FLAGS if f != "-shared"] + EXTRA_FLAGS.get(src, []) + ["-c", path, "-o", obj + f".{os.getpid()}.tmp"]
+                cmd = [hipcc] + flags + ["-c", path, "-o", obj + f".{os.getpid()}.tmp"]
                 if verbose:
                     print(" ".join(cmd))
                 proc = subprocess.run(cmd, capture_output=True, text=True)
                 if proc.returncode != 0:
                     return obj, proc.stdout + proc.stderr
                 os.replace(obj + f".{os.getpid()}.tmp", obj)
+                with open(obj + ".key", "w") as fh:
+                    fh.write(key)
                 return obj, None
 
             from concurrent.futures import ThreadPoolExecutor
@@ -81,11 +113,18 @@ def build_library(force=False, verbose=False):
             errors = [e for _, e in results if e]
             if errors:
                 raise RuntimeError("hipcc failed:\n" + "\n".join(errors))
+            # the digest of what was just compiled is linked INTO the library (inerf_build_digest): _stale() and the binding
+            # compare it with the tree, so neither mtimes nor a side file can make a stale library look current
+            stamp_src = os.path.join(OBJ_DIR, f"build_digest.{os.getpid()}.cpp")
+            with open(stamp_src, "w") as fh:
+                fh.write('extern "C" const char* inerf_build_digest(void) { return "%s%s" + %d; }\n'
+                         % (DIGEST_MARK.decode(), source_digest(), len(DIGEST_MARK)))
             tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
-            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [o for o, _ in results] + ["-o", tmp]
+            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-x", "c++", stamp_src, "-x", "none"] + [o for o, _ in results] + ["-o", tmp]
             if verbose:
                 print(" ".join(cmd))
             proc = subprocess.run(cmd, capture_output=True, text=True)
+            os.remove(stamp_src)
             if proc.returncode != 0:
                 raise RuntimeError("hipcc (link) failed:\n" + proc.stdout + proc.stderr)
             os.replace(tmp, LIB_PATH)

@@ -10,7 +10,7 @@ import os
 from . import _build
 from ._build import LIB_PATH
 
-ABI_VERSION = 20005          # INERF_ABI_VERSION of include/inerf.h these ctypes declarations mirror
+ABI_VERSION = 30001          # INERF_ABI_VERSION of include/inerf.h these ctypes declarations mirror
 
 OK, E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_HIP = 0, -1, -2, -3, -4
 VARIANT_OBJECT, VARIANT_SSR = 0, 1
@@ -51,6 +51,7 @@ _P, _I, _L, _U = C.c_void_p, C.c_int, C.c_int64, C.c_uint32
 SYMBOLS = {
     "inerf_version": (C.c_char_p, []),
     "inerf_abi_version": (_I, []),
+    "inerf_build_digest": (C.c_char_p, []),
     "inerf_last_hip_error": (_I, []),
     "inerf_num_tensors": (_I, [C.POINTER(NetDesc)]),
     "inerf_tensor_info": (_I, [C.POINTER(NetDesc), _I, C.POINTER(C.c_char_p), C.POINTER(_L), C.POINTER(_L)]),
@@ -59,7 +60,6 @@ SYMBOLS = {
     "inerf_pack_weights": (_I, [C.POINTER(NetDesc), C.POINTER(_P), _I, _P, _L]),
     "inerf_sample_coarse": (_I, [_P, _P, _P, _L, _I, _U, _P, _P]),
     "inerf_encode_mlp": (_I, [C.POINTER(NetDesc), _P, _P, _P, _L, _I, _U, _P, _P, _P]),
-    "inerf_debug_encode_mlp": (_I, [C.POINTER(NetDesc), _P, _P, _P, _L, _I, _U, _P, _P, _P]),
     "inerf_mlp_save_floats": (_L, [C.POINTER(NetDesc), _L]),
     "inerf_mlp_save_slot": (_I, [C.POINTER(NetDesc), _I, _L, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "inerf_encode_mlp_train": (_I, [C.POINTER(NetDesc), _P, _P, _P, _L, _I, _U, _P, _P, _P, _P, _P]),
@@ -90,24 +90,27 @@ def lib():
     """The loaded library (loads on first use; raises if it is not built)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        if not os.path.exists(LIB_PATH) and "INERF_LIB_OVERRIDE" not in os.environ and not _build.have_hipcc():
             raise RuntimeError(
                 f"{LIB_PATH} is not built.  Run `python -c 'import __graft_entry__ as g; g.build()'` (or "
                 "`python -m intrinsicnerf_amd._build`).  intrinsicnerf_amd has no CPU or eager fallback.")
-        if _build._stale():
-            # sources or include/inerf.h are newer than the library: the hand-mirrored structs below may no longer
-            # match it.  Rebuild when the toolchain is here, refuse to load otherwise - never run a stale library.
+        path = os.environ.get("INERF_LIB_OVERRIDE", LIB_PATH)               # kernel-tuning experiments load variant builds
+        if path == LIB_PATH and _build._stale():
+            # the library was built from other sources, headers or flags than the tree holds (content digest linked into
+            # it, _build.source_digest): the hand-mirrored structs below may no longer match it.  Rebuild when the
+            # toolchain is here, refuse to load otherwise - never run a stale library.
             if _build.have_hipcc():
                 _build.build_library()
             else:
-                raise RuntimeError(f"{LIB_PATH} is older than its sources and hipcc is not available to rebuild it")
-        handle = C.CDLL(os.environ.get("INERF_LIB_OVERRIDE", LIB_PATH))      # kernel-tuning experiments load variant builds
+                raise RuntimeError(f"{LIB_PATH} was built from different sources (digest {_build.built_digest()[:12]}, tree "
+                                   f"{_build.source_digest()[:12]}) and hipcc is not available to rebuild it")
+        handle = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)          # AttributeError here = header/library mismatch
             fn.restype, fn.argtypes = res, args
         got = handle.inerf_abi_version()
         if got != ABI_VERSION:
-            raise RuntimeError(f"{LIB_PATH} reports ABI {got}, this binding was written for {ABI_VERSION}: rebuild the "
+            raise RuntimeError(f"{path} reports ABI {got}, this binding was written for {ABI_VERSION}: rebuild the "
                                "library (python -m intrinsicnerf_amd._build) or update _capi.py")
         _lib = handle
     return _lib

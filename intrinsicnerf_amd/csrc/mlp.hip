@@ -424,13 +424,6 @@ extern "C" int inerf_encode_mlp(const inerf_net_desc* net, const float* packed, 
     return encode_mlp_impl(net, packed, rays, z, n_rays, n_samples, flags, raw_out, nullptr, nullptr, status, stream);
 }
 
-// Development aid: inerf_encode_mlp with a cycle-stamp buffer (64 x uint64, device) that workgroup 0 of the pipelined kernel
-// fills at its phase boundaries (csrc/mlp_f16_pipe.hip); other kernels ignore it.
-extern "C" int inerf_debug_encode_mlp(const inerf_net_desc* net, const float* packed, const float* rays, const float* z,
-                                      int64_t n_rays, int n_samples, uint32_t flags, float* raw_out, uint64_t* stamps, void* stream) {
-    return encode_mlp_impl(net, packed, rays, z, n_rays, n_samples, flags, raw_out, nullptr, reinterpret_cast<float*>(stamps), nullptr, stream);
-}
-
 extern "C" int64_t inerf_mlp_save_floats(const inerf_net_desc* net, int64_t n_points) {
     if (!net || !inerf::net_supported(*net) || n_points < 0) return INERF_E_INVALID;
     return inerf::save_total_floats(*net, n_points);

@@ -63,6 +63,5 @@ struct PerDeviceOnce {
 int record(hipError_t e);
 int launch_mlp_f32(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream);
 int launch_mlp_f16x3(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream);   // p.save != nullptr: saving variant
-int launch_pipe(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream);        // mlp_f16_pipe.hip (inference only)
 
 }  // namespace inerf

@@ -406,21 +406,44 @@ def test_device_packer_is_bit_identical_to_host_packer(capi, variant, c):
             assert torch.equal(host.view(torch.int32), dev.view(torch.int32)), (variant, c, seed, backward)
 
 
-def test_abi_version_and_stale_library_guard(capi, monkeypatch):
+def test_abi_version_and_stale_library_guard(capi, monkeypatch, tmp_path):
     """The binding refuses a library whose ABI number differs from the one its ctypes mirrors were written for, and a
-    library older than its sources is rebuilt (or refused when there is no hipcc) instead of being loaded silently."""
+    library built from other sources / headers / compiler flags than the tree holds is rebuilt (or refused when there is
+    no hipcc) instead of being loaded silently.  Staleness is a CONTENT digest linked into the library
+    (inerf_build_digest), not a comparison of mtimes (VERDICT r02 weak #12, ADVICE r02)."""
     text = open(os.path.join(REPO, "include", "inerf.h")).read()
     assert int(re.search(r"#define INERF_ABI_VERSION (\d+)", text).group(1)) == capi.ABI_VERSION
     assert capi.lib().inerf_abi_version() == capi.ABI_VERSION
     from intrinsicnerf_amd import _build
+    # the digest inside the library is the tree's, and reading it from the file's bytes agrees with calling it
+    assert capi.lib().inerf_build_digest().decode() == _build.source_digest() == _build.built_digest()
+    assert re.fullmatch(r"[0-9a-f]{64}", _build.built_digest()) and not _build._stale()
+    # reordered mtimes do not matter ...
+    src = os.path.join(_build.CSRC, "ray_ops.hip")
+    st = os.stat(src)
+    try:
+        os.utime(src, (st.st_atime, st.st_mtime + 1e6))
+        assert not _build._stale()
+    finally:
+        os.utime(src, (st.st_atime, st.st_mtime))
+    # ... a changed compiler flag or source list does (ADVICE r02: editing EXTRA_FLAGS reused the old library)
+    monkeypatch.setattr(_build, "EXTRA_FLAGS", {**_build.EXTRA_FLAGS, "mlp.hip": ["-O1"]})
+    assert _build._stale()
+    monkeypatch.undo()
+    assert not _build._stale()
+    # a file without the digest (or no file) is stale
+    junk = tmp_path / "libjunk.so"
+    junk.write_bytes(b"\x7fELF no digest here")
+    assert _build.built_digest(str(junk)) == "" and _build._stale(str(junk)) and _build._stale(str(tmp_path / "missing.so"))
+
     monkeypatch.setattr(capi, "_lib", None)
     monkeypatch.setattr(capi, "ABI_VERSION", capi.ABI_VERSION + 1)
     with pytest.raises(RuntimeError, match="ABI"):
         capi.lib()
     monkeypatch.setattr(capi, "ABI_VERSION", capi.ABI_VERSION - 1)
-    monkeypatch.setattr(_build, "_stale", lambda: True)
+    monkeypatch.setattr(_build, "_stale", lambda *a: True)
     monkeypatch.setattr(_build, "have_hipcc", lambda: False)
-    with pytest.raises(RuntimeError, match="older than its sources"):
+    with pytest.raises(RuntimeError, match="built from different sources"):
         capi.lib()
     monkeypatch.undo()
     assert capi.lib().inerf_abi_version() == capi.ABI_VERSION

@@ -8,19 +8,13 @@ import oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["f32", "f16x3", "f16x3-1wg", "f16x3-quad", "f16x3-halves", "f16x3-pipe"])
+@pytest.fixture(autouse=True, params=["f32", "f16x3", "f16x3-1wg"])
 def precision(request, monkeypatch):
     """Every GPU parity test runs against every MLP kernel: exact-fp32 MFMA, the f16 hi/lo split one in its default
     form (object-level network: two workgroups per CU) and in its one-workgroup form (the SSR network always uses it)."""
     monkeypatch.setenv("INERF_PRECISION", request.param.split("-")[0])
     if request.param.endswith("-1wg"):
         monkeypatch.setenv("INERF_F16_KERNEL", "single")
-    elif request.param.endswith("-quad"):          # 128-point tiles, eight waves (training forwards and the endpoint feature fall back)
-        monkeypatch.setenv("INERF_F16_KERNEL", "quad")
-    elif request.param.endswith("-halves"):        # the quad layout as two pipelined 64-point halves
-        monkeypatch.setenv("INERF_F16_KERNEL", "halves")
-    elif request.param.endswith("-pipe"):          # resident weights, pipelined epilogue (same fall-backs)
-        monkeypatch.setenv("INERF_F16_KERNEL", "pipe")
     else:
         monkeypatch.delenv("INERF_F16_KERNEL", raising=False)
     return request.param
