@@ -28,11 +28,17 @@ Prints ONE JSON line (rank 0) with the bench contract's fields plus
                    peak.  "roofline_f32_kernel" always carries the exact-fp32 kernel's figures too;
   "cpu_baseline" : the CPU oracle (PyTorch-CPU restatement == reference, see oracle/) timed on this
                    box's host cores on a bounded sample of the same workload (best thread count and 1 thread);
-  "parity"       : the check described above;
+  "parity"       : the check described above, plus "stagewise": every HIP stage fed the oracle's (== reference's) input for
+                   that stage on the sampled rays of the timed frame and held to the PLAIN 1e-4 on every ray
+                   (oracle/stagewise.py; "stagewise_violations" must be 0), and "psnr_delta_db": PSNR(HIP, T) - PSNR(oracle,
+                   T) of the timed frame's maps on those rays, T = the fp64 evaluation + a fixed 30 dB perturbation;
   "configs"      : BASELINE.json configs[1] (coarse-only 800x800) and configs[3] (320x240 SSR room frame, C = 28)
                    through their front-ends: rays/s and the MLP kernel's roofline fraction at their launch shapes;
   "frame_costs"  : where a frame's wall time goes besides the kernels (host, packing, gather, status read).
-  "f16_range_fallback": cost of a frame on which the f16x3 range guard trips (one wasted attempt + the exact-fp32 re-run).
+  "f16_range_fallback": cost of a frame (chunk = 32768 rays, the reference's default) in which ONE chunk trips the f16x3
+                   range guard: that chunk - and only that chunk - is rendered again in exact fp32.
+With N > 1 GPUs the line also carries configs.ssr_room0_320x240 rendered through distributed.render_sharded (BASELINE.json
+configs[4]: the Replica frame tiled over the ranks, one all-gather of 26 + 2C floats per ray).
 """
 import argparse
 import json
@@ -78,6 +84,21 @@ def chair_pose(theta_deg=40.0, phi_deg=-30.0, radius=4.0):
 def chair_intrinsics():
     focal = 0.5 * W / np.tan(0.5 * CAMERA_ANGLE_X)
     return np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+
+
+def overflow_above(net, pose, y_min, gain=1.0e6):
+    """Copy of ``net`` whose first trunk unit is ``relu(gain * (y_cam - y_min))``, y_cam = a point's height above the optical
+    axis of camera ``pose`` ([3, 4] camera-to-world): the f16x3 kernel's activation range (|a| < 7.5e3) is left exactly on the
+    rays that reach y_cam > y_min + 7.5e3 / gain - a sub-volume only the top image rows see - and nowhere else."""
+    import copy
+    big = copy.deepcopy(net)
+    up, origin = pose[:3, 1].double(), pose[:3, 3].double()
+    with torch.no_grad():
+        w, b = big.pts_linears[0].weight, big.pts_linears[0].bias
+        w[0].zero_()
+        w[0, 0:3] = (gain * up).to(w)                                  # the encoding's first three columns are xyz itself
+        b[0] = float(-gain * (y_min + float(up @ origin)))
+    return big
 
 
 def host_description():
@@ -216,7 +237,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle: no cpu_baseline and no parity check")
-    ap.add_argument("--cpu-baseline-full", action="store_true", help="SURVEY.md 8d: one 32768-ray chunk x 3 (takes minutes)")
+    ap.add_argument("--cpu-baseline-quick", action="store_true",
+                    help="time the CPU oracle on the 4077-ray parity sample only (default: SURVEY.md 8d - one 32768-ray chunk x 3, ~3 min)")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="(the default since round 3; accepted for old command lines)")
     ap.add_argument("--no-extras", action="store_true", help="skip configs / train_step / exact-fp32 extras")
     args = ap.parse_args()
 
@@ -235,7 +258,10 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo" if share else "nccl", rank=rank, world_size=world)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:       # device_id binds the communicator to this rank's GPU up front (eager RCCL init; no device guessing in barrier())
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import __graft_entry__
     __graft_entry__.build()
@@ -257,23 +283,34 @@ def main():
     vd_s = rd[sel] / rd[sel].norm(dim=-1, keepdim=True)
     rays_s = torch.cat([ro[sel], rd[sel], NEAR * torch.ones_like(vd_s[:, :1]), FAR * torch.ones_like(vd_s[:, :1]), vd_s], -1).cpu()
     torch.set_num_threads(min(16, torch.get_num_threads()))
-    sd_c = cal.calibrated_default_init("object", 0, 0, rays_s)      # default init, seeds 0 / 1, calibrated density head
-    sd_f = cal.calibrated_default_init("object", 0, 1, rays_s)
     embed, ch = ol.get_embedder(10, 0)
     embed_d, ch_d = ol.get_embedder(4, 0)
     mk = lambda: ol.NeRF(D=8, W=256, input_ch=ch, output_ch=5, skips=[4], input_ch_views=ch_d, use_viewdirs=True).to(dev)
     net_c, net_f = mk(), mk()
-    net_c.load_state_dict(sd_c)
-    net_f.load_state_dict(sd_f)
+    sd_c = sd_f = None
+
+    def replicate(*modules):
+        """Rank 0's parameters to every rank (the networks are replicated, 2 x 2.7 MB): one broadcast per tensor."""
+        if world > 1:
+            for m in modules:
+                for t in m.state_dict().values():
+                    dist.broadcast(t, 0)
+
+    if rank == 0:       # the CPU probe that calibrates the density head runs once, not once per rank
+        sd_c = cal.calibrated_default_init("object", 0, 0, rays_s)      # default init, seeds 0 / 1, calibrated density head
+        sd_f = cal.calibrated_default_init("object", 0, 1, rays_s)
+        net_c.load_state_dict(sd_c)
+        net_f.load_state_dict(sd_f)
+    replicate(net_c, net_f)
     query = ol.NetworkQuery(embed, embed_d)
     kw = dict(network_fn=net_c, network_fine=net_f, network_query_fn=query, N_samples=N_SAMPLES,
               N_importance=N_IMPORTANCE, white_bkgd=True, perturb=False, raw_noise_std=0., use_viewdirs=True, ndc=False,
               lindisp=False)
     map_keys = ("rgb_map", "disp_map", "acc_map", "albedo_map", "shading_map", "residual_map")
 
-    def render_band(o, d, **over):
+    def render_band(o, d, chunk=None, **over):
         with torch.no_grad():
-            r = ol.render(H, W, K, chunk=max(1, o.shape[0]), rays=(o, d), near=NEAR, far=FAR, **{**kw, **over})
+            r = ol.render(H, W, K, chunk=chunk or max(1, o.shape[0]), rays=(o, d), near=NEAR, far=FAR, **{**kw, **over})
         return dict(zip(map_keys, r[:6])), r[6]
 
     def step():
@@ -416,27 +453,118 @@ def main():
         exact = {"value": n_total / dt32, "unit": "rays/s", "ms_per_step": dt32 * 1e3, "steps": 1,
                  "note": "whole path with INERF_PRECISION=f32 (v_mfma_f32_32x32x2_f32 everywhere)"}
 
-    # what the f16x3 range guard costs when it trips ("the fallback cost is not reported anywhere"): the same frame
-    # with a fine network whose hidden activations exceed the split's range (one trunk layer scaled by 2^17): the front-end
-    # renders the whole frame in f16x3, reads the range word at the end of the frame and renders it again in exact fp32
+    # what the f16x3 range guard costs when it trips (chunk-granular).  The frame is rendered in the reference's
+    # default chunks of 32768 rays (run_nerf.py:559) with a fine network that leaves the split's activation range only in a
+    # sub-volume that the first ~28 image rows see, i.e. inside chunk 0 of 20: the front-end enqueues all chunks in f16x3, reads
+    # their range words ONCE at the end of the frame and renders chunk 0 - only chunk 0 - again with the exact fp32 kernel.
     fallback = None
     if extras and f16:
-        import copy
         import warnings
-        big = copy.deepcopy(net_f)
-        with torch.no_grad():
-            big.pts_linears[3].weight.mul_(131072.0)
+        focal = K[0][0]
+        big = overflow_above(net_f, chair_pose(), y_min=FAR * (0.5 * H - 29.0) / focal)
+        ck = 32768
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            render_band(ro_l, rd_l, network_fine=big); fence()
+            render_band(ro_l, rd_l, chunk=ck); fence()
             t1 = time.perf_counter()
-            fmaps, _ = render_band(ro_l, rd_l, network_fine=big)
-            fence()
-        dtf = time.perf_counter() - t1
-        fallback = {"ms_per_step": dtf * 1e3, "vs_f16x3_frame": dtf / (dt / args.steps), "finite": bool(torch.isfinite(fmaps["rgb_map"]).all()),
-                    "note": "frame whose fine network leaves the f16x3 activation range (|activation| >= 7.5e3): one f16x3 attempt + "
-                            "the exact-fp32 re-run of the whole frame; INERF_PRECISION=f32 skips the attempt"}
+            render_band(ro_l, rd_l, chunk=ck); fence()
+            dt_ck = time.perf_counter() - t1                        # the same frame in the same chunks, nothing trips
+            calls = []
+            real_rr = ol.render_rays
+            ol.render_rays = lambda rb, **k: (calls.append(_capi.default_precision()), real_rr(rb, **k))[1]
+            try:
+                render_band(ro_l, rd_l, chunk=ck, network_fine=big); fence()
+                calls.clear()
+                t1 = time.perf_counter()
+                fmaps, _ = render_band(ro_l, rd_l, chunk=ck, network_fine=big)
+                fence()
+                dtf = time.perf_counter() - t1
+            finally:
+                ol.render_rays = real_rr
+        n_chunks = (n_local + ck - 1) // ck
+        fallback = {"ms_per_step": dtf * 1e3, "vs_f16x3_frame": dtf / (dt / args.steps), "vs_same_chunking_untripped": dtf / dt_ck,
+                    "chunks": n_chunks, "chunk_rays": ck, "chunks_rerun_in_f32": sum(p == _capi.PREC_F32 for p in calls),
+                    "f16x3_chunk_calls": sum(p == _capi.PREC_F16X3 for p in calls),
+                    "finite": bool(torch.isfinite(fmaps["rgb_map"]).all()),
+                    "note": "800x800 frame in 20 chunks of 32768 rays whose fine network leaves the f16x3 activation range "
+                            "(|activation| >= 7.5e3) on rays of chunk 0 only: one read of the 20 range words at the end of the frame, "
+                            "then chunk 0 alone again in exact fp32 (round 2 re-rendered the whole frame: 4.18x); "
+                            "INERF_PRECISION=f32 skips the attempt"}
         del big
+
+    def ssr_frame_leg():
+        """configs[3] (N = 1) / configs[4] (N > 1): the 320x240 Replica room_0-like frame through ssr.SSRRenderer.render_rays
+        (trainer.py:1251), C = 28, 64+128, chunk 32768.  N > 1: distributed.render_sharded - this rank's band of rays, then one
+        all-gather straight into the final [76800, 26 + 2C] layout; value = rays of the WHOLE frame / max-over-ranks time."""
+        from intrinsicnerf_amd import ssr
+        SH, SW = 240, 320
+        fx = SW / 2.0 / np.tan(np.deg2rad(45.0))
+        srays = ssr.create_rays(1, torch.eye(4)[None], SH, SW, fx, fx, (SW - 1) / 2.0, (SH - 1) / 2.0, 0.1, 10.0).reshape(-1, 11).contiguous()
+        r = ssr.SSRRenderer(SSR_CLASSES, white_bkgd=False, endpoint_feat=False, device=dev)
+        if rank == 0:
+            ssel = srays[::srays.shape[0] // 1024]
+            r.ssr_net_coarse.load_state_dict(cal.calibrated_default_init("ssr", SSR_CLASSES, 0, ssel))
+            r.ssr_net_fine.load_state_dict(cal.calibrated_default_init("ssr", SSR_CLASSES, 1, ssel))
+        replicate(r.ssr_net_coarse, r.ssr_net_fine)
+        r.return_raw = False
+        r.check_numerics = False
+        srays = srays.to(dev)
+        n_s = srays.shape[0]
+        layout = idist.ssr_map_layout(SSR_CLASSES)
+        frame_fn = (lambda: idist.render_sharded(r.render_rays, srays, layout)) if world > 1 else (lambda: r.render_rays(srays))
+        n_steps = max(3, args.steps)
+        with torch.no_grad():
+            sret = frame_fn(); fence()
+            t1 = time.perf_counter()
+            for _ in range(n_steps):
+                sret = frame_fn()
+            fence()
+        dts = (time.perf_counter() - t1) / n_steps
+        if world > 1:
+            t = torch.tensor([dts], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dts = float(t.item())
+        assert sret["rgb_fine"].shape[0] == n_s and torch.isfinite(sret["rgb_fine"]).all() and float(sret["acc_fine"].min()) < 0.999
+        out = {"workload": f"Replica room_0-like 320x240 frame ({n_s} rays), Semantic_NeRF C = {SSR_CLASSES}, 64+128 samples, depth "
+                           "[0.1, 10], xyz/10, eval, chunks of <= 32768 rays" +
+                           (f", rays tiled over {world} ranks + one all-gather of {sum(w for _, w in layout)} floats/ray (BASELINE configs[4])"
+                            if world > 1 else " (BASELINE configs[3])"),
+               "value": n_s / dts, "unit": "rays/s", "ms_per_step": dts * 1e3, "steps": n_steps, "n_gpus": world,
+               "frame_tflops_algorithmic": FLOP_PER_POINT_SSR * n_s * (2 * N_SAMPLES + N_IMPORTANCE) / dts / 1e12}
+        if world > 1:
+            # every rank must hold the same full frame; the gather alone, timed on a band that is already rendered
+            chk = torch.stack([sret[k].double().sum() for k in ("rgb_fine", "sem_logits_fine", "depth_fine", "z_std")])
+            lo, hi = chk.clone(), chk.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            assert torch.equal(lo, hi), "ranks disagree on the gathered SSR frame"
+            b0, e0 = idist.shard_bounds(n_s, rank, world)
+            with torch.no_grad():
+                local = r.render_rays(srays[b0:e0].contiguous())
+            fence()
+            t1 = time.perf_counter()
+            idist.gather_maps(local, n_s, layout)
+            fence()
+            out["gather_ms"] = (time.perf_counter() - t1) * 1e3
+            out["gather_bytes"] = 4 * n_s * sum(w for _, w in layout)
+            out["checksums"] = {k: float(v) for k, v in zip(("rgb_fine", "sem_logits_fine", "depth_fine", "z_std"), chk.tolist())}
+            out["checksum_identical_on_all_ranks"] = True
+        # roofline of this network's MLP kernel on the frame's OWN fine launch: chunk 0's rays and the z_fine the frame computed
+        sdesc = r.ssr_net_fine.fused_desc()
+        sdesc.xyz_div = 10.0
+        spk_c, spk_f = packing.packed_for_module(r.ssr_net_coarse, sdesc, dev), packing.packed_for_module(r.ssr_net_fine, sdesc, dev)
+        b0, e0 = idist.shard_bounds(n_s, rank, world)
+        chunk = srays[b0:e0][:32768].contiguous()
+        st = kernels.render_rays_fused(sdesc, spk_c, spk_f, chunk, N_SAMPLES, N_IMPORTANCE, t_vals, u, white_bkgd=False, want_stages=True)
+        sz = st["z_fine"]
+        del st
+        kernels.encode_mlp(sdesc, spk_f, chunk, sz)
+        s_ms, s_durs = events_ms(lambda: kernels.encode_mlp(sdesc, spk_f, chunk, sz), 3)
+        flop_s = FLOP_PER_POINT_SSR * chunk.shape[0] * (N_SAMPLES + N_IMPORTANCE)
+        out["roofline"] = roofline_entry(f16, "k_encode_mlp_f16x3_dual<false, true>" if f16 else "k_encode_mlp<true, 2>",
+                                         flop_s / (s_ms * 1e-3) / 1e12, s_ms, len(s_durs), flop_s, chunk.shape[0] * (N_SAMPLES + N_IMPORTANCE))
+        out["roofline"]["launch"] = f"fine pass of this rank's first chunk ({chunk.shape[0]} rays x 192) on the depths the frame itself resampled"
+        return out
 
     # ---- BASELINE.json configs[1] and configs[3] through their front-ends (rank 0, N = 1 only; not part of `value`) ----
     configs = None
@@ -457,42 +585,12 @@ def main():
             "value": n_total / dtc, "unit": "rays/s", "ms_per_step": dtc * 1e3, "steps": args.steps,
             "roofline": roofline_entry(f16, roofline["kernel"], flop_c / (coarse_launch_ms * 1e-3) / 1e12, coarse_launch_ms,
                                        max(1, args.steps), flop_c, n_local * N_SAMPLES)}
-        # configs[3]: Replica room_0-like 320x240 frame through ssr.SSRRenderer.render_rays (C = 28, 64+128, chunk 32768)
-        from intrinsicnerf_amd import ssr
-        SH, SW = 240, 320
-        fx = SW / 2.0 / np.tan(np.deg2rad(45.0))
-        srays = ssr.create_rays(1, torch.eye(4)[None], SH, SW, fx, fx, (SW - 1) / 2.0, (SH - 1) / 2.0, 0.1, 10.0).reshape(-1, 11).contiguous()
-        r = ssr.SSRRenderer(SSR_CLASSES, white_bkgd=False, endpoint_feat=False, device=dev)
-        ssel = srays[::srays.shape[0] // 1024]
-        r.ssr_net_coarse.load_state_dict(cal.calibrated_default_init("ssr", SSR_CLASSES, 0, ssel))
-        r.ssr_net_fine.load_state_dict(cal.calibrated_default_init("ssr", SSR_CLASSES, 1, ssel))
-        r.return_raw = False
-        r.check_numerics = False
-        srays = srays.to(dev)
-        with torch.no_grad():
-            sret = r.render_rays(srays); fence()
-            t1 = time.perf_counter()
-            for _ in range(max(3, args.steps)):
-                sret = r.render_rays(srays)
-            fence()
-        dts = (time.perf_counter() - t1) / max(3, args.steps)
-        assert torch.isfinite(sret["rgb_fine"]).all() and float(sret["acc_fine"].min()) < 0.999
-        sdesc = r.ssr_net_fine.fused_desc()
-        sdesc.xyz_div = 10.0
-        spk = packing.packed_for_module(r.ssr_net_fine, sdesc, dev)
-        chunk = srays[:32768].contiguous()
-        sz = torch.sort(torch.rand(chunk.shape[0], N_SAMPLES + N_IMPORTANCE, device=dev) * 9.9 + 0.1, -1)[0]
-        kernels.encode_mlp(sdesc, spk, chunk, sz)
-        s_ms, s_durs = events_ms(lambda: kernels.encode_mlp(sdesc, spk, chunk, sz), 3)
-        flop_s = FLOP_PER_POINT_SSR * chunk.shape[0] * (N_SAMPLES + N_IMPORTANCE)
-        configs["ssr_room0_320x240"] = {
-            "workload": f"Replica room_0-like 320x240 frame (76800 rays), Semantic_NeRF C = {SSR_CLASSES}, 64+128 samples, depth "
-                        "[0.1, 10], xyz/10, eval, 3 chunks of <= 32768 rays (BASELINE configs[3])",
-            "value": srays.shape[0] / dts, "unit": "rays/s", "ms_per_step": dts * 1e3, "steps": max(3, args.steps),
-            "frame_tflops_algorithmic": FLOP_PER_POINT_SSR * srays.shape[0] * (2 * N_SAMPLES + N_IMPORTANCE) / dts / 1e12,
-            "roofline": roofline_entry(f16, "k_encode_mlp_f16x3_dual<false, true>" if f16 else "k_encode_mlp<true, 2>",
-                                       flop_s / (s_ms * 1e-3) / 1e12, s_ms, len(s_durs), flop_s, chunk.shape[0] * (N_SAMPLES + N_IMPORTANCE))}
-        del r, sret, srays, spk, sz
+        configs["ssr_room0_320x240"] = ssr_frame_leg()
+
+    if world > 1 and not args.no_extras:
+        # BASELINE.json configs[4]: the Replica frame tiled over the ranks (distributed.render_sharded: contiguous ray bands,
+        # ONE all-gather of the 26 + 2C floats per ray SSRTrainer.render_rays returns; raw_* never travels) - every rank runs it
+        configs = {"ssr_room0_320x240": ssr_frame_leg()}
 
     # the reference's training step through the same front-end (rank 0, N = 1 only; untimed
     # relative to `value`): 1024 rays + one neighbour each (run_nerf.py:918-929), 64 + 128 samples, forward + backward + Adam
@@ -530,20 +628,51 @@ def main():
     cpu = parity = None
     problems = []
     if rank == 0 and not args.no_cpu_baseline:
-        if args.cpu_baseline_full:
-            sel_full = torch.arange(0, n_total, n_total // 32768 + 1, device=dev)[:32768]
-            vdf = rd[sel_full] / rd[sel_full].norm(dim=-1, keepdim=True)
-            rays_full = torch.cat([ro[sel_full], rd[sel_full], NEAR * torch.ones_like(vdf[:, :1]), FAR * torch.ones_like(vdf[:, :1]), vdf], -1).cpu()
-            _, cpu = cpu_oracle_run(rays_full, sd_c, sd_f, full_spec=True)
-            o32, _ = cpu_oracle_run(rays_s, sd_c, sd_f)
-        else:
-            o32, cpu = cpu_oracle_run(rays_s, sd_c, sd_f)
+        from oracle import stagewise
+        o32, quick = cpu_oracle_run(rays_s, sd_c, sd_f)                 # the parity reference; its timing is the "quick" CPU figure
+        if world == 1:
+            if args.cpu_baseline_quick:
+                cpu = quick
+            else:       # SURVEY.md section 8d's procedure (the default since round 3): one 32768-ray chunk x 3, all-core probe, 1 thread
+                sel_full = torch.arange(0, n_total, n_total // 32768 + 1, device=dev)[:32768]
+                vdf = rd[sel_full] / rd[sel_full].norm(dim=-1, keepdim=True)
+                rays_full = torch.cat([ro[sel_full], rd[sel_full], NEAR * torch.ones_like(vdf[:, :1]), FAR * torch.ones_like(vdf[:, :1]), vdf], -1).cpu()
+                _, cpu = cpu_oracle_run(rays_full, sd_c, sd_f, full_spec=True)
+                cpu["quick_sample"] = {k: quick[k] for k in ("value", "cores", "single_thread_rays_per_s", "sample")}
         to64 = lambda sd: {k: v.double() for k, v in sd.items()}
         with torch.no_grad():
             o64 = oracle.render_rays(rays_s.double(), to64(sd_c), to64(sd_f),
                                      oracle.RenderConfig(variant="object", n_samples=N_SAMPLES, n_importance=N_IMPORTANCE, white_bkgd=True),
                                      stages=True)
         parity, problems = parity_report(frame, sel, o32, o64, rays_s, sd_f)
+        # stage by stage, every sampled ray, plain tolerance: each HIP stage on the oracle's (== reference's) input for that stage
+        ref = {k: v.numpy() for k, v in o32.items() if v is not None}
+        d0 = _capi.net_desc(_capi.VARIANT_OBJECT, 0, 10, 4, 1.0, prec)
+        got = stagewise.hip_stages(d0, packing.packed_for_module(net_c, d0, dev), packing.packed_for_module(net_f, d0, dev),
+                                   rays_s.to(dev), ref, True)
+        per, stage_problems = stagewise.strict_report(got, ref)
+        parity["stagewise"] = per
+        parity["stagewise_violations"] = int(sum(v["violations"] for v in per.values()))
+        parity["stagewise_rays"] = int(len(sel))
+        parity["stagewise_note"] = ("every HIP stage fed the oracle's input for that stage (z_coarse / z_fine -> inerf_encode_mlp + "
+                                    "inerf_composite; weights_coarse -> inerf_sample_fine) on the sampled rays of the timed frame; worst = "
+                                    "max |got - want| / (1e-5 + 1e-4 |want|) over ALL those rays (disp: 5e-4; resampled depths: + "
+                                    "oracle.stagewise.sample_pdf_allowance)")
+        problems += ["stagewise " + p for p in stage_problems]
+        # PSNR delta (north_star: <= 1e-4 dB): the timed frame's maps on the sampled rays, and the fine pass on the oracle's depths
+        e2e, staged, own = {}, {}, {}
+        for fk, ok in (("rgb_map", "rgb_fine"), ("albedo_map", "albedo_fine"), ("shading_map", "shading_fine"), ("residual_map", "residual_fine")):
+            hip = frame[fk].reshape(H * W, -1)[sel].cpu().numpy().reshape(o32[ok].shape)
+            e2e[fk] = stagewise.psnr_delta_db(hip, o32[ok].numpy(), o64[ok].numpy())
+            staged[fk] = stagewise.psnr_delta_db(got[ok].reshape(o32[ok].shape), o32[ok].numpy(), o64[ok].numpy())
+            own[fk] = stagewise.psnr_delta_db(o32[ok].numpy(), o64[ok].numpy(), o64[ok].numpy())
+        parity["psnr_delta_db"] = max(abs(v) for v in e2e.values())
+        parity["psnr_delta_db_per_map"] = e2e
+        parity["psnr_delta_db_fine_pass_on_reference_depths"] = staged
+        parity["psnr_oracle_fp32_vs_fp64_db"] = own
+        parity["psnr_note"] = ("PSNR(x, T) = -10 log10 mean (x - T)^2 (run_nerf_helpers.py:11-12) over the sampled rays of the TIMED frame; "
+                               "T = the oracle's fp64 maps + a fixed N(0, 10^-1.5) perturbation (so PSNR(fp64, T) = 30 dB); delta = PSNR(HIP, T) "
+                               "- PSNR(oracle fp32, T); 'oracle_fp32_vs_fp64' = the reference arithmetic's own delta against fp64")
 
     if rank == 0:
         print(json.dumps({

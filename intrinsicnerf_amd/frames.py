@@ -83,14 +83,15 @@ def unpack_frame(frame, widths, keys, image_shape):
 def write_png(path, image):
     """Minimal PNG encoder (8-bit grey / RGB, 16-bit grey) for hosts without imageio - the reference writes its frames
     with ``imageio.imwrite`` (run_nerf.py:193-211), which is used instead when importable."""
-    try:
-        import imageio
-        if hasattr(imageio, "imwrite"):
-            imageio.imwrite(path, image)
-            return
-    except ImportError:
-        pass
     a = np.ascontiguousarray(image)
+    if a.dtype != np.uint16:          # 16-bit maps (disp / depth in mm, trainer.py:1359,1365: format="png", prefer_uint8=False) always
+        try:                          # take the encoder below: what imageio does with uint16 depends on its version and plugin
+            import imageio
+            if hasattr(imageio, "imwrite"):
+                imageio.imwrite(path, image)
+                return
+        except ImportError:
+            pass
     if a.dtype == np.uint16:
         depth, a = 16, a.astype(">u2")
     elif a.dtype == np.uint8:

@@ -105,34 +105,50 @@ def _new_status(like):
     return torch.zeros(1, dtype=torch.int32, device=like.device)
 
 
-_deferred = None          # list of status words collected by an open deferred_range_checks() block, else None
+_deferred = None          # the innermost open deferred_range_checks() block, else None
 
 
 class deferred_range_checks:
-    """Context manager for a multi-chunk frame rendered under no_grad: ``check_f16_range(..., deferrable=True)`` calls
-    inside only remember their status word, and ONE device->host read at the end of the block checks them all - a
-    frame costs one host synchronisation instead of one per chunk.  Raises FloatingPointError at exit if any chunk
-    left f16's range; the caller then re-renders the frame in exact fp32 (``_capi.forced_precision``)."""
+    """Context manager for launches whose f16 range words can be read later: ``check_f16_range(..., deferrable=True)`` calls
+    inside only remember their status word (together with the block's current ``tag``), and ONE device->host read at the
+    end of the block checks them all - a multi-chunk frame costs one host synchronisation instead of one per chunk.
 
-    def __init__(self, what):
-        self.what = what
+    At exit ``tripped`` holds the tags (in order, without repeats) whose launches left f16's range.  With
+    ``raise_on_trip`` (default) a non-empty set raises FloatingPointError; the chunk loops of the front-ends pass False,
+    tag every chunk with its index and re-render ONLY the tripped chunks in exact fp32.
+
+    Blocks do not delegate: a block opened inside another one (a training step inside a frame loop) reads its OWN words at
+    its own exit, so its handler - which restores the RNG and re-evaluates the same draws - is the one that runs."""
+
+    def __init__(self, what, raise_on_trip=True):
+        self.what, self.raise_on_trip = what, raise_on_trip
+        self.tag, self.tripped = None, []
+        self.words, self.tags = [], []
+
+    def __len__(self):
+        return len(self.words)
 
     def __enter__(self):
         global _deferred
-        self.outer, _deferred = _deferred, []
+        self.outer, _deferred = _deferred, self
         return self
 
     def __exit__(self, exc_type, exc, tb):
         global _deferred
-        mine, _deferred = _deferred, self.outer
-        if exc_type is not None or not mine:
+        _deferred = self.outer
+        if exc_type is not None or not self.words:
             return False
-        if self.outer is not None:                 # nested block: hand the words to the enclosing one
-            self.outer.extend(mine)
-            return False
-        word = mine[0] if len(mine) == 1 else torch.cat(mine).max()
-        check_f16_range(word, self.what)
+        flags = (self.words[0] if len(self.words) == 1 else torch.cat(self.words)).cpu().tolist()      # the block's one sync
+        for flag, tag in zip(flags, self.tags):
+            if int(flag) & _capi.STATUS_F16_RANGE and tag not in self.tripped:
+                self.tripped.append(tag)
+        if self.tripped and self.raise_on_trip:
+            raise FloatingPointError(_RANGE_MESSAGE.format(what=self.what))
         return False
+
+
+_RANGE_MESSAGE = ("{what}: an activation exceeded the f16 range (|v| > 6e4) in the split-precision MLP kernel; "
+                  "results are invalid - re-run with precision f32 (INERF_PRECISION=f32)")
 
 
 def check_f16_range(status, what, deferrable=False):
@@ -141,12 +157,11 @@ def check_f16_range(status, what, deferrable=False):
     if status is None:
         return
     if deferrable and _deferred is not None and os.environ.get("INERF_EAGER_RANGE_CHECKS", "0") == "0":      # (A/B switch)
-        _deferred.append(status.reshape(1))
+        _deferred.words.append(status.reshape(1))
+        _deferred.tags.append(_deferred.tag)
         return
     if int(status.item()) & _capi.STATUS_F16_RANGE:
-        raise FloatingPointError(
-            f"{what}: an activation exceeded the f16 range (|v| > 6e4) in the split-precision MLP kernel; "
-            "results are invalid - re-run with precision f32 (INERF_PRECISION=f32)")
+        raise FloatingPointError(_RANGE_MESSAGE.format(what=what))
 
 
 _warned_fallback = False

@@ -423,26 +423,25 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
 def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
     """Render rays in chunks - run_nerf.py:59-71.  Results do not depend on ``chunk``.
 
-    The split-precision kernel's range word is read ONCE per call, after the last chunk (kernels.deferred_range_checks):
-    a frame is one host synchronisation, not one per chunk.  If it reports an out-of-range activation the whole call is
-    repeated with the exact fp32 kernel (only eval-mode chunks defer, so no random draw is repeated)."""
-    def run():
-        all_ret = {}
-        for i in range(0, rays_flat.shape[0], chunk):
-            ret = render_rays(rays_flat[i:i + chunk], **kwargs)
-            for k in ret:
-                all_ret.setdefault(k, []).append(ret[k])
-        return {k: (all_ret[k][0] if len(all_ret[k]) == 1 else torch.cat(all_ret[k], 0)) for k in all_ret}
-
-    try:
-        with kernels.deferred_range_checks("render"):
-            return run()
-    except FloatingPointError as e:
-        if _capi.default_precision() != _capi.PREC_F16X3:
-            raise
-        kernels.warn_f32_fallback(e)
+    The split-precision kernel's range words are read ONCE per call, after the last chunk has been enqueued
+    (kernels.deferred_range_checks): a frame is one host synchronisation, not one per chunk.  Chunks whose word reports an
+    out-of-range activation - and only those - are rendered again with the exact fp32 kernel (only eval-mode chunks defer,
+    so no random draw is repeated; chunks that draw random numbers check and fall back inside render_rays)."""
+    starts = list(range(0, rays_flat.shape[0], chunk))
+    rets = []
+    with kernels.deferred_range_checks("render", raise_on_trip=False) as block:
+        for j, i in enumerate(starts):
+            block.tag = j
+            rets.append(render_rays(rays_flat[i:i + chunk], **kwargs))
+    if block.tripped:
+        kernels.warn_f32_fallback(f"render: {len(block.tripped)} of {len(starts)} chunks left the f16 range of the split-precision "
+                                  "MLP kernel.")
         with _capi.forced_precision(_capi.PREC_F32):
-            return run()
+            for j in block.tripped:
+                rets[j] = render_rays(rays_flat[starts[j]:starts[j] + chunk], **kwargs)
+    if not rets:
+        return {}
+    return {k: (rets[0][k] if len(rets) == 1 else torch.cat([r[k] for r in rets], 0)) for k in rets[0]}
 
 
 def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,

@@ -226,13 +226,24 @@ def create_rays(num_rays, Ts_c2w, height, width, fx, fy, cx, cy, near, far, c2w_
 
 
 def batchify_rays(render_fn, rays_flat, chunk=1024 * 32):
-    """training_utils.py:5-17."""
-    all_ret = {}
-    for i in range(0, rays_flat.shape[0], chunk):
-        ret = render_fn(rays_flat[i:i + chunk])
-        for k in ret:
-            all_ret.setdefault(k, []).append(ret[k])
-    return {k: torch.cat(all_ret[k], 0) for k in all_ret}
+    """training_utils.py:5-17.  As in object_level.batchify_rays the chunks' f16 range words are read together after the
+    last chunk (one host synchronisation per frame) and only the chunks that left the range are rendered again in exact
+    fp32."""
+    starts = list(range(0, rays_flat.shape[0], chunk))
+    rets = []
+    with kernels.deferred_range_checks("render_rays", raise_on_trip=False) as block:
+        for j, i in enumerate(starts):
+            block.tag = j
+            rets.append(render_fn(rays_flat[i:i + chunk]))
+    if block.tripped:
+        kernels.warn_f32_fallback(f"render_rays: {len(block.tripped)} of {len(starts)} chunks left the f16 range of the "
+                                  "split-precision MLP kernel.")
+        with _capi.forced_precision(_capi.PREC_F32):
+            for j in block.tripped:
+                rets[j] = render_fn(rays_flat[starts[j]:starts[j] + chunk])
+    if not rets:
+        return {}
+    return {k: torch.cat([r[k] for r in rets], 0) for k in rets[0]}
 
 
 # ----------------------------------------------------------------------------------------------
@@ -254,15 +265,7 @@ class SSRRenderMixin:
 
     def render_rays(self, flat_rays):
         ray_shape = flat_rays.shape
-        try:      # one host synchronisation per frame: the chunks' f16 range words are read together at the end
-            with kernels.deferred_range_checks("render_rays"):
-                all_ret = batchify_rays(self.volumetric_rendering, flat_rays, self.chunk)
-        except FloatingPointError as e:
-            if _capi.default_precision() != _capi.PREC_F16X3:
-                raise
-            kernels.warn_f32_fallback(e)
-            with _capi.forced_precision(_capi.PREC_F32):
-                all_ret = batchify_rays(self.volumetric_rendering, flat_rays, self.chunk)
+        all_ret = batchify_rays(self.volumetric_rendering, flat_rays, self.chunk)      # one host synchronisation per frame
         for k in all_ret:
             all_ret[k] = torch.reshape(all_ret[k], list(ray_shape[:-1]) + list(all_ret[k].shape[1:]))
         return all_ret
@@ -292,6 +295,8 @@ class SSRRenderMixin:
         if self.enable_semantic:
             keys += ["sem_label", "sem_entropy"]
         cmap = getattr(self, "valid_colour_map", None)
+        if cmap is not None:      # the trainer keeps it on the GPU (trainer.py:262,449,588: valid_colour_map.cuda()); indexed on the host here
+            cmap = cmap.detach().cpu().numpy() if isinstance(cmap, torch.Tensor) else np.asarray(cmap)
         if save_dir is not None:
             assert os.path.exists(save_dir)
         acc = {k: [] for k in ("rgb", "disp", "dep", "vis_dep", "albedo", "shading", "residual", "sem", "vis_sem", "ent", "vis_ent")}
@@ -308,7 +313,7 @@ class SSRRenderMixin:
                 label = m["sem_label"].astype(np.uint8)
                 acc["sem"].append(label); acc["ent"].append(m["sem_entropy"])
                 if cmap is not None:
-                    acc["vis_sem"].append(np.asarray(cmap)[label.astype(np.int64)].astype(np.uint8))
+                    acc["vis_sem"].append(cmap[label.astype(np.int64)].astype(np.uint8))
                 if depth2rgb is not None:
                     acc["vis_ent"].append(depth2rgb(acc["ent"][-1]))
             if update_cluster:
@@ -359,6 +364,17 @@ class SSRRenderMixin:
                                           "SSR/training/cluster.py:101-182); set self.cluster_manager_factory to that class")
             cluster_manager = factory(class_num=1 if getattr(self, "no_semantic_tree", False) else self.num_valid_semantic_class)
             cluster_manager.update_center(np.stack(sample_labels, 0), np.stack(sample_pixels, 0), band_factor=b_f)
+            # trainer.py:1425-1440: every rendered albedo snapped to its cluster centres (c*.png) and the image re-composed from
+            # the clustered albedo (edit*.png); manager.dest_color is the reference's method (cluster.dest_color: the HIP lookup)
+            dev = rays[0].device if isinstance(rays[0], torch.Tensor) else torch.device("cpu")
+            for i, albedo in enumerate(acc["albedo"]):
+                pixel = torch.from_numpy(albedo).reshape(-1, 3).to(dev)
+                label = torch.from_numpy(acc["sem"][i]).reshape(-1, 1).to(dev)
+                result = cluster_manager.dest_color(pixel, label).reshape(albedo.shape).cpu().numpy()
+                if save_dir is not None:
+                    frames.write_png(os.path.join(save_dir, "c{:03d}.png".format(i)), frames.to8b(result))
+                    edit = (result.reshape(-1, 3) * acc["shading"][i].reshape(-1, 1) + acc["residual"][i].reshape(-1, 3)).reshape(result.shape)
+                    frames.write_png(os.path.join(save_dir, "edit{:03d}.png".format(i)), frames.to8b(edit))
         return (st("rgb"), st("disp"), st("dep"), st("vis_dep"), st("sem"), st("vis_sem"), st("ent"), st("vis_ent"),
                 st("albedo"), st("shading"), st("residual"), cluster_manager)
 

@@ -14,7 +14,12 @@ reproduces itself (fp32 vs fp64) - VERDICT r01 asked for the opposite as well.  
 * the reference's ``render_rays`` / ``SSRTrainer.render_rays`` run on ALL of them; the oracle is asserted to
   reproduce every output bit for bit; stored next to the reference's fp32 outputs are the same arithmetic's
   fp64 outputs (oracle in double), which tests use to rank an implementation's errors against the reference's
-  own irreproducibility (``oracle.calibration.rank_report``).
+  own irreproducibility (``oracle.calibration.rank_report``);
+* the reference's OWN intermediate tensors are recorded while it runs (``captured_stages``: its ``raw2outputs`` and
+  ``sample_pdf`` are wrapped, not replaced): ``stage_z_coarse``, ``stage_weights_coarse``, ``stage_z_samples``,
+  ``stage_z_fine``, ``stage_weights_fine`` for every ray and ``stage_raw_coarse`` / ``stage_raw_fine`` for every
+  ``stage_raw_rows``-th one.  With the reference's depths as INPUT each stage is well-conditioned again, so the GPU
+  tests hold every stage of these default-init, unfiltered rays to the plain 1e-4 (tests/test_unfiltered_parity.py).
 
 Cases: ``uncurated_object_coarse_only_wb`` (BASELINE configs[1] in miniature: 64 coarse samples, coarse network
 only, white background - the only coarse-only fixture of make_golden.py has lindisp and no white background),
@@ -61,6 +66,55 @@ def frame_rays_room(ssr_rays, n):
     return rays[torch.arange(0, H * W, H * W // n + 1)[:n]].contiguous()
 
 
+class captured_stages:
+    """Record what the REAL reference computes between its stages while ``render_rays`` / ``volumetric_rendering`` runs:
+    the module-level names ``raw2outputs`` and ``sample_pdf`` that those functions look up (run_nerf.py:493,500,510;
+    trainer.py:754,760,774) are wrapped - the reference's own functions still do the work - and their arguments and
+    results are kept: call 1 of raw2outputs = (raw_coarse, z_coarse) -> weights_coarse, sample_pdf -> z_samples, call 2 of
+    raw2outputs = (raw_fine, z_fine) -> weights_fine.  ``weights_at`` is the position of ``weights`` in the returned tuple
+    (3 in both code bases: run_nerf.py:412, model_utils.py:116)."""
+
+    def __init__(self, module, weights_at=3):
+        self.module, self.weights_at = module, weights_at
+        self.composites, self.samples = [], []
+
+    def __enter__(self):
+        self.saved = (self.module.raw2outputs, self.module.sample_pdf)
+        ref_r2o, ref_pdf = self.saved
+
+        def r2o(raw, z_vals, *a, **k):
+            out = ref_r2o(raw, z_vals, *a, **k)
+            self.composites.append(dict(raw=raw.detach().clone(), z=z_vals.detach().clone(), weights=out[self.weights_at].detach().clone()))
+            return out
+
+        def pdf(bins, weights, *a, **k):
+            out = ref_pdf(bins, weights, *a, **k)
+            self.samples.append(out.detach().clone())
+            return out
+
+        self.module.raw2outputs, self.module.sample_pdf = r2o, pdf
+        return self
+
+    def __exit__(self, *exc):
+        self.module.raw2outputs, self.module.sample_pdf = self.saved
+
+    def fixture_entries(self, mine, raw_rows):
+        """stage_* / ref_raw_* fixture entries; asserts the oracle's stage tensors equal the reference's bit for bit."""
+        out = {}
+        names = ("coarse", "fine")[:len(self.composites)]
+        for lvl, c in zip(names, self.composites):
+            for key, ok in (("z", f"z_{lvl}"), ("weights", f"weights_{lvl}"), ("raw", f"raw_{lvl}")):
+                mg.check_same(f"stage {ok}", c[key], mine[ok], tol=0.0)
+            out[f"stage_z_{lvl}"], out[f"stage_weights_{lvl}"] = c["z"], c["weights"]
+            out[f"stage_raw_{lvl}"] = c["raw"][raw_rows]
+        if self.samples:
+            assert len(self.samples) == 1
+            mg.check_same("stage z_samples", self.samples[0], mine["z_samples"], tol=0.0)
+            out["stage_z_samples"] = self.samples[0]
+        out["stage_raw_rows"] = raw_rows
+        return out
+
+
 def head_calibration(sd, base):
     g = float((sd["alpha_linear.weight"] / base["alpha_linear.weight"]).flatten()[0])
     return g, float(sd["alpha_linear.bias"])
@@ -78,7 +132,7 @@ def fine_hazard(fx, rays, sd_f, cfg, mine, m64, pairs):
     return cal.fine_pass_hazard(rays, sd_f, cfg, mine, m64, subset=score <= 0.2)
 
 
-def object_case(run_nerf, H_ref, name, n, n_importance):
+def object_case(run_nerf, H_ref, name, n, n_importance, raw_every=4):
     rays = frame_rays_object(H_ref, n)
     cfg = oracle.RenderConfig(variant="object", n_samples=64, n_importance=n_importance, white_bkgd=True)
     sd_c, sd_f = cal.calibrated_default_init("object", 0, 0, rays), cal.calibrated_default_init("object", 0, 1, rays)
@@ -89,8 +143,9 @@ def object_case(run_nerf, H_ref, name, n, n_importance):
     net_c.load_state_dict(sd_c); net_f.load_state_dict(sd_f)
     q = lambda x, v, fn: run_nerf.run_network(x, v, fn, embed_fn=embed, embeddirs_fn=embed_d, netchunk=65536)
     with torch.no_grad():
-        ref = run_nerf.render_rays(rays, net_c, q, 64, retraw=False, perturb=0.0, N_importance=n_importance,
-                                   network_fine=net_f if n_importance > 0 else None, white_bkgd=True, raw_noise_std=0.0)
+        with captured_stages(run_nerf) as cap:
+            ref = run_nerf.render_rays(rays, net_c, q, 64, retraw=False, perturb=0.0, N_importance=n_importance,
+                                       network_fine=net_f if n_importance > 0 else None, white_bkgd=True, raw_noise_std=0.0)
         mine = oracle.render_rays(rays, sd_c, sd_f if n_importance > 0 else None, cfg, stages=True)
         m64 = oracle.render_rays(rays.double(), to64(sd_c), to64(sd_f) if n_importance > 0 else None, cfg, stages=True)
     lvl = "fine" if n_importance > 0 else "coarse"
@@ -114,17 +169,20 @@ def object_case(run_nerf, H_ref, name, n, n_importance):
             fx["stage_score_" + k] = cal.scaled_errors(mine[k].numpy(), m64[k].numpy())
     if n_importance > 0:
         fx["stage_score_fine_pass_hazard"] = fine_hazard(fx, rays, sd_f, cfg, mine, m64, pairs)
+    # the reference's OWN intermediate tensors: depths and weights of every ray, raw of every raw_every-th
+    fx.update(cap.fixture_entries(mine, torch.arange(0, n, raw_every)))
     mg.save(name, **fx)
 
 
-def ssr_case(SSRTrainer, ssr_rays, name, n, n_classes):
+def ssr_case(SSRTrainer, ssr_rays, name, n, n_classes, raw_every=8):
     rays = frame_rays_room(ssr_rays, n)
     cfg = oracle.RenderConfig(variant="ssr", n_samples=64, n_importance=128, white_bkgd=False, n_classes=n_classes, netchunk=32768)
     sd_c = cal.calibrated_default_init("ssr", n_classes, 0, rays)
     sd_f = cal.calibrated_default_init("ssr", n_classes, 1, rays)
     tr = mg.ssr_trainer(SSRTrainer, n_classes, False, False, False)
     tr.ssr_net_coarse.load_state_dict(sd_c); tr.ssr_net_fine.load_state_dict(sd_f)
-    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+    import SSR.training.trainer as trainer_module
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()), captured_stages(trainer_module) as cap:
         ref = tr.render_rays(rays)
     with torch.no_grad():
         mine = oracle.render_rays(rays, sd_c, sd_f, cfg, stages=True)
@@ -146,6 +204,7 @@ def ssr_case(SSRTrainer, ssr_rays, name, n, n_classes):
     for k in ("z_samples", "weights_coarse", "weights_fine", "z_fine"):
         fx["stage_score_" + k] = cal.scaled_errors(mine[k].numpy(), m64[k].numpy())
     fx["stage_score_fine_pass_hazard"] = fine_hazard(fx, rays, sd_f, cfg, mine, m64, pairs)
+    fx.update(cap.fixture_entries(mine, torch.arange(0, n, raw_every)))
     mg.save(name, **fx)
 
 

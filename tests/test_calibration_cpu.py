@@ -1,9 +1,11 @@
 """CPU: the un-curated-parity tooling (oracle/calibration.py) - the calibrated default-init network is deterministic and
 non-degenerate, and the rank-statistics comparison accepts like-distributed errors and rejects worse ones."""
 import numpy as np
+import pytest
 import torch
 
 import oracle
+from conftest import golden_names, load_golden
 from oracle import calibration as cal
 
 
@@ -51,3 +53,72 @@ def test_rank_report_accepts_same_distribution_and_rejects_worse():
     assert cal.rank_report(bad, np.zeros(100)) != []
     e = cal.scaled_errors(np.array([[1.0, np.nan], [1.0, 2.0]]), np.array([[1.0, 3.0], [1.0001, 2.0]]))
     assert np.isinf(e[0]) and abs(e[1] - 1e-4 / (1e-5 + 1e-4 * 1.0001)) < 1e-9
+
+
+# ------------------------------------------------------------------------------------------------
+# stage-wise strict checker (oracle/stagewise.py) on the un-curated reference fixtures
+# ------------------------------------------------------------------------------------------------
+def _stage_reference(fx):
+    ref = {k[len("stage_"):]: fx[k] for k in fx if k.startswith("stage_") and not k.startswith("stage_score_")}
+    ref.update({k[len("ref_"):]: fx[k] for k in fx if k.startswith("ref_")})
+    return ref
+
+
+@pytest.mark.parametrize("name", golden_names("uncurated_"))
+def test_oracle_reproduces_the_reference_stage_tensors(name):
+    """The stage tensors recorded from the REAL reference (z, raw, weights of both passes, z_samples) are what the oracle
+    computes - bit for bit - so every ``worst`` of the strict report is exactly 0 and nothing is skipped."""
+    from _cases import uncurated_config, uncurated_weights
+    from oracle import stagewise
+    fx = load_golden(name)
+    cfg = uncurated_config(fx)
+    sd_c, sd_f = uncurated_weights(fx)
+    with torch.no_grad():
+        o = oracle.render_rays(torch.from_numpy(fx["rays"]), sd_c, sd_f if cfg.n_importance > 0 else None, cfg, stages=True)
+    rows = fx["stage_raw_rows"]
+    got = {k: v.numpy() for k, v in o.items() if v is not None}
+    for lvl in ("coarse", "fine"):
+        if "raw_" + lvl in got:
+            got["raw_" + lvl] = got["raw_" + lvl][rows]
+    per, problems = stagewise.strict_report(got, _stage_reference(fx), raw_rows=rows)
+    assert not problems, problems
+    assert {"z_coarse", "raw_coarse", "weights_coarse", "rgb_coarse"} <= set(per)
+    if cfg.n_importance > 0:
+        assert {"z_samples", "z_fine", "z_std", "raw_fine", "weights_fine", "rgb_fine"} <= set(per)
+    assert all(v["worst"] == 0.0 for v in per.values()), per
+
+
+def test_sample_pdf_allowance_admits_another_fp32_summation_order_and_nothing_more():
+    """``sample_pdf`` on the reference's own bins / weights, in fp32 but with the cdf built by a Hillis-Steele scan (what a
+    wavefront does) instead of ATen's sequential sum: differs from the reference's z_samples by up to 1e-3 on a handful of
+    samples (u = 1 against a cdf[-1] of 1 +- 2 ulp; bins at the 1e-5 switch) - all inside ``sample_pdf_allowance``; a sample
+    moved by a tenth of a bin is not."""
+    from oracle import stagewise
+    fx = load_golden("uncurated_object_chair_wb")
+    z, w = fx["stage_z_coarse"].astype(np.float32), fx["stage_weights_coarse"].astype(np.float32)
+    n = z.shape[0]
+    u = np.linspace(0, 1, 128, dtype=np.float32)
+    bins = (np.float32(0.5) * (z[:, 1:] + z[:, :-1])).astype(np.float32)
+    ww = (w[:, 1:-1] + np.float32(1e-5)).astype(np.float32)
+    pdf = (ww / ww.sum(1, dtype=np.float32)[:, None]).astype(np.float32)
+    x, o = pdf.copy(), 1
+    while o < x.shape[1]:
+        y = x.copy()
+        y[:, o:] = (x[:, o:] + x[:, :-o]).astype(np.float32)
+        x, o = y, 2 * o
+    cdf = np.concatenate([np.zeros((n, 1), np.float32), x], 1)
+    out = np.zeros((n, 128), np.float32)
+    for r in range(n):
+        idx = np.searchsorted(cdf[r], u, side="right")
+        lo, hi = np.clip(idx - 1, 0, None), np.clip(idx, None, 62)
+        den = (cdf[r, hi] - cdf[r, lo]).astype(np.float32)
+        den = np.where(den < np.float32(1e-5), np.float32(1), den)
+        out[r] = bins[r, lo] + ((u - cdf[r, lo]) / den).astype(np.float32) * (bins[r, hi] - bins[r, lo])
+    ref = {"z_coarse": z, "weights_coarse": w, "z_samples": fx["stage_z_samples"]}
+    assert np.abs(out - fx["stage_z_samples"]).max() > 1e-4          # the two fp32 evaluations do differ visibly ...
+    per, problems = stagewise.strict_report({"z_samples": out}, ref)
+    assert not problems and per["z_samples"]["worst"] < 0.5, per      # ... and only where the allowance says they may
+    bad = out.copy()
+    bad[7, 40] += 0.1 * (z[7, 1] - z[7, 0])
+    _, problems = stagewise.strict_report({"z_samples": bad}, ref)
+    assert problems and "z_samples: 1 of" in problems[0]

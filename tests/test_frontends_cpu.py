@@ -215,10 +215,24 @@ def test_deferred_range_checks_read_the_status_words_once():
             kernels.check_f16_range(bad, "training forward")                  # not deferrable: immediately
     assert kernels._deferred is None
     kernels.check_f16_range(None, "fp32 kernel has no status word")
-    with kernels.deferred_range_checks("outer"):                              # nested blocks hand their words outwards
-        with kernels.deferred_range_checks("inner"):
-            kernels.check_f16_range(ok, "x", deferrable=True)
-        assert len(kernels._deferred) == 1
+    # nested blocks do NOT delegate: the inner block - a training step inside a frame loop - reads its own words
+    # and raises at its own exit, where its handler (RNG restore + same-draw torch re-evaluation) lives
+    with kernels.deferred_range_checks("outer") as outer:
+        with pytest.raises(FloatingPointError, match="inner"):
+            with kernels.deferred_range_checks("inner"):
+                kernels.check_f16_range(bad, "x", deferrable=True)
+        assert kernels._deferred is outer and len(outer) == 0
+        kernels.check_f16_range(ok, "y", deferrable=True)
+        assert len(outer) == 1
+    assert kernels._deferred is None
+    # chunk loops: raise_on_trip=False + tags -> exactly the tripped chunks are known after the block's single read
+    with kernels.deferred_range_checks("frame", raise_on_trip=False) as block:
+        for j, word in enumerate((ok, bad, ok, bad, bad)):
+            block.tag = j
+            kernels.check_f16_range(word, f"chunk {j}", deferrable=True)
+            if j == 3:
+                kernels.check_f16_range(word, f"chunk {j} (fine pass)", deferrable=True)       # two words of one chunk
+    assert block.tripped == [1, 3, 4]
     # INERF_EAGER_RANGE_CHECKS=1: every check reads its word at once, block or not (A/B switch for the deferred reads)
     os.environ["INERF_EAGER_RANGE_CHECKS"] = "1"
     try:

@@ -164,3 +164,44 @@ def test_uncurated_reference_fixtures(name, precision):
     problems, summary = uncurated_judge(fx, {k: v.cpu().numpy() for k, v in got.items()}, f"{name}/{precision}")
     print("\n" + summary)
     assert not problems, "\n".join(problems) + "\n" + summary
+
+
+def _stage_reference(fx):
+    """The reference's own stage tensors and maps of an ``uncurated_*`` fixture under the oracle's key names."""
+    ref = {k[len("stage_"):]: fx[k] for k in fx if k.startswith("stage_") and not k.startswith("stage_score_")}
+    ref.update({k[len("ref_"):]: fx[k] for k in fx if k.startswith("ref_")})
+    return ref
+
+
+@pytest.mark.parametrize("name", golden_names("uncurated_"))
+def test_uncurated_stagewise_strict(name, precision):
+    """the PLAIN 1e-4 tolerance on EVERY ray of the un-curated fixtures (default-init networks, unfiltered
+    rays of the benchmark frames), stage by stage against tensors recorded from the REAL reference while it ran
+    (make_golden_uncurated.py: captured_stages): each HIP stage gets the reference's input for that stage
+    (oracle/stagewise.py) - the reference's z_coarse / z_fine go through inerf_encode_mlp + inerf_composite and must
+    reproduce raw, the compositing weights and every map; the reference's weights_coarse go through inerf_sample_fine and
+    must reproduce z_samples / z_fine / z_std up to what two correct fp32 sample_pdf evaluations can differ by."""
+    from intrinsicnerf_amd import _capi, packing
+    from oracle import stagewise
+    fx = load_golden(name)
+    cfg = uncurated_config(fx)
+    sd_c, sd_f = uncurated_weights(fx)
+    dev = torch.device("cuda:0")
+    ssr = cfg.variant == "ssr"
+    desc = _capi.net_desc(_capi.VARIANT_SSR if ssr else _capi.VARIANT_OBJECT, cfg.n_classes if ssr else 0, 10, 4, cfg.xyz_div)
+    ref = _stage_reference(fx)
+    rows = fx["stage_raw_rows"]
+    got = stagewise.hip_stages(desc, packing.pack_state_dict(desc, sd_c).to(dev),
+                               packing.pack_state_dict(desc, sd_f).to(dev) if cfg.n_importance > 0 else None,
+                               torch.from_numpy(fx["rays"]).to(dev), ref, cfg.white_bkgd, cfg.n_classes if ssr else 0, raw_rows=rows)
+    per, problems = stagewise.strict_report(got, ref, raw_rows=rows)
+    print(f"\n[{name}/{precision}] " + "  ".join(f"{k}:{v['worst']:.2g}" for k, v in per.items()))
+    expected = {"z_coarse", "raw_coarse", "weights_coarse", "rgb_coarse", "acc_coarse", "albedo_coarse"}
+    if cfg.n_importance > 0:
+        expected |= {"z_samples", "z_fine", "z_std", "raw_fine", "weights_fine", "rgb_fine", "disp_fine", "acc_fine", "albedo_fine",
+                     "shading_fine", "residual_fine"}
+    if ssr:
+        expected |= {"sem_coarse", "sem_fine", "depth_fine"}
+    assert expected <= set(per), f"stages not judged: {sorted(expected - set(per))}"
+    assert all(v["rays"] == (len(rows) if k.startswith("raw_") else len(fx["rays"])) for k, v in per.items())
+    assert not problems, f"{name}/{precision}:\n" + "\n".join(problems)
