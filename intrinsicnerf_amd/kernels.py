@@ -106,6 +106,22 @@ def _new_status(like):
 
 
 _deferred = None          # the innermost open deferred_range_checks() block, else None
+captured_status = None    # list collecting the status words of launches recorded into a HIP graph (graphs.GraphedTrainStep)
+
+
+def _capturing():
+    """True while the current stream records a HIP graph: nothing may be read back to the host then."""
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
+def _defer_to_graph_owner(words):
+    """Status words of launches that are being CAPTURED cannot be read here; they are handed to whoever owns the graph
+    (graphs.GraphedTrainStep reads them after every replay).  Capturing without an owner would silently drop the f16 range
+    guard, so that is an error."""
+    if captured_status is None:
+        raise RuntimeError("split-precision MLP launches are being captured into a HIP graph outside graphs.GraphedTrainStep: "
+                           "their f16 range words would never be checked")
+    captured_status.extend(words)
 
 
 class deferred_range_checks:
@@ -138,6 +154,9 @@ class deferred_range_checks:
         _deferred = self.outer
         if exc_type is not None or not self.words:
             return False
+        if _capturing():
+            _defer_to_graph_owner(self.words)
+            return False
         flags = (self.words[0] if len(self.words) == 1 else torch.cat(self.words)).cpu().tolist()      # the block's one sync
         for flag, tag in zip(flags, self.tags):
             if int(flag) & _capi.STATUS_F16_RANGE and tag not in self.tripped:
@@ -155,6 +174,9 @@ def check_f16_range(status, what, deferrable=False):
     """Raise if a PREC_F16X3 launch met an activation outside f16's range (one device sync) - or, inside a
     ``deferred_range_checks`` block and with ``deferrable``, leave the word for the block's single check."""
     if status is None:
+        return
+    if _capturing():
+        _defer_to_graph_owner([status.reshape(1)])
         return
     if deferrable and _deferred is not None and os.environ.get("INERF_EAGER_RANGE_CHECKS", "0") == "0":      # (A/B switch)
         _deferred.words.append(status.reshape(1))

@@ -397,7 +397,7 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
             # after each network leaves the GPU idle while the host prepares the next launches).  If it trips, the whole batch
             # is evaluated again with the layers in torch - with the random draws repeated, so it consumes the RNG like the
             # reference would.
-            redraw = raw_noise_std > 0. or (perturb > 0. and N_importance > 0)
+            redraw = (raw_noise_std > 0. or (perturb > 0. and N_importance > 0)) and not kernels._capturing()
             rng = (torch.get_rng_state(), torch.cuda.get_rng_state(dev) if dev.type == "cuda" else None) if redraw else None
             np_state = np.random.get_state() if pytest else None
             try:

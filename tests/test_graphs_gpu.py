@@ -1,0 +1,97 @@
+"""GPU: the training step as HIP graphs (intrinsicnerf_amd/graphs.py) against the same step issued launch by launch.
+
+The library's kernels are launched through hipLaunchKernelGGL on the stream torch hands over, so stream capture turns them
+into graph nodes; these tests pin that the replayed graphs compute exactly what the eager step computes (same kernels, same
+inputs, deterministic reductions: bit for bit), that a new batch per step flows through the static inputs, and that a batch
+which trips the f16 range guard never reaches the optimizer through the graph."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from _cases import case_weights
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(dev, seed_shift=0.0):
+    from intrinsicnerf_amd import object_level as ol
+    fx = load_golden("object_chair_det")
+    embed, ch = ol.get_embedder(10, 0); embed_d, ch_d = ol.get_embedder(4, 0)
+    mk = lambda: ol.NeRF(D=8, W=256, input_ch=ch, output_ch=5, skips=[4], input_ch_views=ch_d, use_viewdirs=True).to(dev)
+    net_c, net_f = mk(), mk()
+    sd_c, sd_f = case_weights(fx)
+    net_c.load_state_dict(sd_c); net_f.load_state_dict(sd_f)
+    rays = torch.from_numpy(fx["rays"]).to(dev)
+    return ol, net_c, net_f, ol.NetworkQuery(embed, embed_d), rays
+
+
+@pytest.mark.parametrize("perturb", [0.0, 1.0])
+def test_graphed_step_equals_the_eager_step(perturb, monkeypatch):
+    from intrinsicnerf_amd import graphs
+    monkeypatch.setenv("INERF_PRECISION", "f16x3")
+    dev = torch.device("cuda:0")
+    results = {}
+    for mode in ("eager", "graph"):
+        ol, net_c, net_f, query, rays = _setup(dev)
+        n = 12
+        batches = [rays[i:i + n] for i in (0, 7, 3, 11)]
+        targets = [torch.rand(n, 3, generator=torch.Generator().manual_seed(i)).to(dev) for i in range(4)]
+        opt = torch.optim.Adam(list(net_c.parameters()) + list(net_f.parameters()), lr=1e-4, capturable=True)
+
+        def loss_fn(r, t):
+            ret = ol.render_rays(r, net_c, query, 64, retraw=True, perturb=perturb, N_importance=64, network_fine=net_f, white_bkgd=True)
+            return ((ret["rgb_map"] - t) ** 2).mean() + ((ret["rgb0"] - t) ** 2).mean() + 0.01 * ret["albedo_map"].abs().mean()
+
+        losses = []
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if mode == "graph":
+                step = graphs.GraphedTrainStep(loss_fn, (batches[0], targets[0]), opt)      # its warm-up steps must leave no trace
+                assert step.status is not None, "the step's f16 range words must be part of the graph"
+            torch.manual_seed(5)
+            for r, t in zip(batches, targets):
+                if mode == "eager":
+                    opt.zero_grad(set_to_none=True)
+                    loss = loss_fn(r, t)
+                    loss.backward()
+                    opt.step()
+                else:
+                    loss = step(r, t)
+                losses.append(float(loss))
+        if mode == "graph":
+            assert step.fallbacks == 0
+        results[mode] = (losses, [p.detach().clone() for p in list(net_c.parameters()) + list(net_f.parameters())])
+    assert np.isfinite(results["graph"][0]).all()
+    if perturb == 0.0:          # no random draws: the replayed graphs ARE the eager step
+        assert results["eager"][0] == results["graph"][0], (results["eager"][0], results["graph"][0])
+        for a, b in zip(results["eager"][1], results["graph"][1]):
+            assert torch.equal(a, b)
+    else:                       # jitter comes from the graph-safe generator: another sample of the same distribution
+        np.testing.assert_allclose(results["eager"][0], results["graph"][0], rtol=0.2)
+
+
+def test_a_batch_outside_the_f16_range_does_not_reach_the_optimizer_through_the_graph(monkeypatch):
+    from intrinsicnerf_amd import graphs
+    monkeypatch.setenv("INERF_PRECISION", "f16x3")
+    dev = torch.device("cuda:0")
+    ol, net_c, net_f, query, rays = _setup(dev)
+    r, t = rays[:9], torch.rand(9, 3, device=dev)
+    opt = torch.optim.Adam(list(net_c.parameters()) + list(net_f.parameters()), lr=1e-4, capturable=True)
+
+    def loss_fn(r, t):
+        ret = ol.render_rays(r, net_c, query, 64, retraw=True, perturb=0.0, N_importance=32, network_fine=net_f, white_bkgd=True)
+        return ((ret["rgb_map"] - t) ** 2).mean()
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        step = graphs.GraphedTrainStep(loss_fn, (r, t), opt)
+        assert float(step(r, t)) > 0 and step.fallbacks == 0
+        with torch.no_grad():
+            net_f.pts_linears[2].weight.mul_(1.0e6)              # hidden activations of the fine network far beyond 7.5e3
+        loss = step(r, t)
+    assert step.fallbacks == 1, "the graph's range word must have sent this batch to the eager path"
+    assert torch.isfinite(loss).all()
+    assert all(torch.isfinite(p).all() for p in list(net_c.parameters()) + list(net_f.parameters()))

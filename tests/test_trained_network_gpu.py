@@ -1,0 +1,51 @@
+"""GPU: a (briefly) TRAINED network through the product path - the 200-step version of scripts/fit_synthetic.py.
+
+Every other fixture's weights are default-init or closed-form; here both networks are fitted to an analytic scene through
+``object_level.render_rays`` under autograd (the reference's training step, run_nerf.py:868-1027) and the trained weights are
+then rendered and judged: activations against the f16x3 range guard, the held-out view against the CPU oracle (rank
+statistics + the stage-wise strict report), the PSNR delta against the analytic target, and the HIP network backward against
+torch's layers over the same run."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+
+def _fit_module():
+    spec = importlib.util.spec_from_file_location("fit_synthetic", os.path.join(REPO, "scripts", "fit_synthetic.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_200_step_fit_and_what_the_trained_weights_do(monkeypatch):
+    monkeypatch.setenv("INERF_PRECISION", "f16x3")
+    monkeypatch.delenv("INERF_TRAIN_MLP", raising=False)
+    fs = _fit_module()
+    dev = torch.device("cuda:0")
+    rays, target = fs.training_set(dev, n_poses=8, side=48)
+    assert 0.02 < float((target < 0.99).float().mean()) < 0.98, "the analytic scene must be visible and not fill the frame"
+    net_c, net_f, query = fs.make_nets(dev)
+    losses = fs.fit(net_c, net_f, query, rays, target, steps=200)
+    assert np.isfinite(losses).all() and losses[-20:].mean() < 0.5 * losses[:5].mean(), (losses[:5], losses[-20:])
+    lines = []
+    s = fs.evaluate(net_c, net_f, query, dev, 24, lines)
+    print("\n".join(lines))
+    assert s["worst_activation"] < 7.5e3, "a trained network left the f16x3 activation range"
+    assert s["stagewise_violations"] == 0, "\n".join(lines)
+    assert not any(m["rank_violations"] for m in s["maps"].values()), "\n".join(lines)
+    assert abs(s["psnr_delta_db"]) <= 1e-4, s
+    # the HIP network backward tracks torch's layers: same initial weights, batches and jitter
+    curves = {}
+    for mode in ("hip", "torch"):
+        monkeypatch.setenv("INERF_TRAIN_MLP", mode)
+        nc, nf, q = fs.make_nets(dev)
+        curves[mode] = fs.fit(nc, nf, q, rays, target, steps=40)
+    np.testing.assert_allclose(curves["hip"][:10], curves["torch"][:10], rtol=2e-3)
+    assert abs(curves["hip"][-10:].mean() / curves["torch"][-10:].mean() - 1.0) < 0.1, (curves["hip"][-10:], curves["torch"][-10:])
