@@ -50,7 +50,8 @@ def sample_pdf_allowance(z_coarse, weights_coarse, u):
 
     * CDF_ROUNDOFF x |d sample / d cdf| = CDF_ROUNDOFF x (bin width) / (cdf difference of its bin);
     * for samples in a bin whose cdf difference is within DENOM_ROUNDOFF of the 1e-5 switch: the distance between the
-      two branches' results, ``|(u - cdf_lo) / denom - (u - cdf_lo)| x (bin width)``;
+      two branches' results, ``|(u - cdf_lo) / denom - (u - cdf_lo)| x (bin width)`` (on top of the dividing branch's
+      round-off sensitivity, which applies there even when the exact difference is below 1e-5);
     * a ``u`` within CDF_ROUNDOFF of a cdf entry (the deterministic u = 0 and u = 1 always are: cdf[0] = 0, cdf[-1] = 1 up to
       round-off) may be bracketed by ``searchsorted`` one bin to either side: such samples get the largest of the
       neighbouring bins' allowances too (e.g. u = 1 with an fp32 cdf[-1] of 1 + 2 ulp lands in the last real bin, whose
@@ -67,9 +68,11 @@ def sample_pdf_allowance(z_coarse, weights_coarse, u):
             lo, hi = np.clip(idx - 1, 0, last), np.clip(idx, 0, last)
             raw = cdf[r, hi] - cdf[r, lo]
             width = np.abs(bins[r, hi] - bins[r, lo])
-            a = CDF_ROUNDOFF * width / np.where(raw < 1e-5, 1.0, raw)
+            amb = np.abs(raw - 1e-5) <= DENOM_ROUNDOFF                     # either branch is a correct fp32 evaluation
+            # cdf round-off through 1/denom: the dividing branch's sensitivity wherever that branch can be taken
+            a = CDF_ROUNDOFF * width / np.where((raw < 1e-5) & ~amb, 1.0, np.maximum(raw, 1e-30))
             du = u[r] - cdf[r, lo]
-            return a + np.where(np.abs(raw - 1e-5) <= DENOM_ROUNDOFF, np.abs(du / np.maximum(raw, 1e-30) - du) * width, 0.0)
+            return a + np.where(amb, np.abs(du / np.maximum(raw, 1e-30) - du) * width, 0.0)
 
         idx = np.searchsorted(cdf[r], u[r], side="right")                 # in 1 .. last + 1
         a = bin_allowance(idx)
@@ -136,9 +139,23 @@ def strict_report(got, ref, raw_rows=None, u=None):
         if not same:
             problems.append("z_coarse: not bit-identical to the reference")
     for lvl in ("coarse", "fine"):
-        for key in (f"raw_{lvl}", f"weights_{lvl}"):
-            if key in ref and key in got:
-                judge(key, scaled_errors(got[key], ref[key], RTOL, ATOL))
+        key = f"raw_{lvl}"
+        if key in ref and key in got:
+            # |got - want| <= ATOL x scale(channel) + RTOL |want|, scale = max(1, rms of the channel over the tensor): ten of the
+            # eleven base channels are sigmoids in [0, 1] (scale 1 - the plain tolerance); the density sigma = alpha_linear(h) is
+            # unbounded, and the un-curated networks carry a x512 gain on that head (oracle.calibration), so its fp32 round-off
+            # is x512 too: the reference's OWN fp32 sigma is up to 1.4e-5 (object) / 8.7e-5 (SSR, x/10) from its fp64 value on
+            # these fixtures.  An absolute floor that ignores a channel's scale would not be a statement about arithmetic.
+            w = np.asarray(ref[key], np.float64)
+            scale = np.maximum(1.0, np.sqrt(np.nanmean(w.reshape(-1, w.shape[-1]) ** 2, 0)))
+            g = np.asarray(got[key], np.float64)
+            e = np.abs(g - w) / (ATOL * scale + RTOL * np.abs(w))
+            e = np.where(np.isnan(g) != np.isnan(w), np.inf, np.where(np.isnan(e), 0.0, e))
+            judge(key, e.reshape(len(w), -1).max(1))
+            per[key]["channel_scale_max"] = float(scale.max())
+        key = f"weights_{lvl}"
+        if key in ref and key in got:
+            judge(key, scaled_errors(got[key], ref[key], RTOL, ATOL))
         for m in MAPS:
             key = f"{m}_{lvl}"
             if key in ref and key in got:
@@ -167,11 +184,24 @@ def psnr(x, target):
     return float(-10.0 * np.log10(np.mean((x - target) ** 2)))
 
 
-def psnr_delta_db(hip, ref32, ref64, target_psnr_db=30.0, seed=0):
+def psnr_delta_db(hip, ref32, ref64, target_psnr_db=30.0, seed=0, detail=False):
     """PSNR(hip, T) - PSNR(ref32, T) in dB for a target T = ref64 + a FIXED pseudo-random perturbation sized so that the
     reference's own PSNR is ``target_psnr_db`` (no dataset image exists here; a trained IntrinsicNeRF reaches ~30 dB on
-    its targets).  north_star: |delta| <= 1e-4 dB."""
-    ref64 = np.asarray(ref64, np.float64)
+    its targets).  north_star: |delta| <= 1e-4 dB.
+
+    ``detail``: also return the statistic's two parts.  With e = hip - ref32 and r = ref32 - T,
+    MSE(hip) - MSE(ref32) = mean(e^2) + 2 mean(e r): the first term is SYSTEMATIC (it survives any number of pixels), the
+    second is a zero-mean sum over the perturbation whose standard deviation, 2 sigma_T sqrt(mean(e^2) / n), shrinks with the
+    number of values n - on a few thousand sampled rays of an ill-conditioned network it is the larger one."""
+    hip, ref32, ref64 = (np.asarray(a, np.float64) for a in (hip, ref32, ref64))
+    sigma_t = 10.0 ** (-target_psnr_db / 20.0)
     rng = np.random.RandomState(seed)
-    target = ref64 + rng.randn(*ref64.shape) * 10.0 ** (-target_psnr_db / 20.0)
-    return psnr(hip, target) - psnr(ref32, target)
+    target = ref64 + rng.randn(*ref64.shape) * sigma_t
+    delta = psnr(hip, target) - psnr(ref32, target)
+    if not detail:
+        return delta
+    mse = float(np.mean((ref32 - target) ** 2))
+    e2 = float(np.mean((hip - ref32) ** 2))
+    k = 10.0 / np.log(10.0)
+    return {"delta_db": delta, "systematic_db": -k * e2 / mse, "sampling_sigma_db": k * 2.0 * sigma_t * np.sqrt(e2 / hip.size) / mse,
+            "rms_hip_minus_reference": np.sqrt(e2), "values": int(hip.size)}

@@ -65,9 +65,9 @@ def test_ssr_raw2outputs_tuple(wb):
     # disabled heads come back as torch.tensor(0) (model_utils.py:95-96,103), the other eight elements are unchanged
     off = ssr.raw2outputs(raw, z, d, 0, bool(fx["white_bkgd"]), enable_semantic=False, num_sem_class=0, endpoint_feat=False)
     assert off[5].dim() == 0 and int(off[5]) == 0 and off[6].dim() == 0 and int(off[6]) == 0
-    for i, k in enumerate(order):
+    for i, k in enumerate(order):       # (the kernel sums depth / acc in another lane order when the extra heads ride along: ulps)
         if k not in ("sem", "feat"):
-            assert torch.equal(off[i], out[i]), k
+            assert_maps_close(off[i].cpu().numpy(), out[i].cpu().numpy(), 1e-5, 1e-7, f"heads off vs on: {k}")
     with pytest.raises(AssertionError):
         ssr.raw2outputs(raw, z, d, 0, False, enable_semantic=True, num_sem_class=0)              # model_utils.py:53-54
     # training noise: one torch.randn draw (model_utils.py:70-72)
