@@ -694,13 +694,20 @@ class _FusedMlpFn(torch.autograd.Function):
     (packing.DevicePacker).  rays / z get no gradient (as in the reference: rays are data, resampled depths are detached)."""
 
     @staticmethod
-    def forward(ctx, rays, z_vals, desc, endpoint, names, *params):
+    def forward(ctx, rays, z_vals, desc, endpoint, names, exact, *params):
         from . import packing
         named = dict(zip(names, params))
         status = _new_status(rays)
         act_max = torch.zeros(1, dtype=torch.float32, device=rays.device)
         packed = packing.device_packer(desc, False, rays.device)(named)
         raw, save = encode_mlp_train(desc, packed, rays.detach(), z_vals.detach(), endpoint, status, act_max)
+        if exact:
+            # INERF_PRECISION=f32: the values that leave the node come from the exact-fp32 MFMA kernel (bit for bit what a
+            # no_grad render returns); the split-precision forward above is kept for what it SAVES - activations, ReLU masks,
+            # operand ranges - which is what the backward kernels consume (22-bit operands, fp32 accumulation: within 1e-5 of
+            # fp64 autograd, DESIGN.md).  The chain takes its sigmoid' from the exact outputs.
+            d32 = _capi.NetDesc(desc.variant, desc.n_classes, desc.l_xyz, desc.l_dir, desc.xyz_div, _capi.PREC_F32)
+            raw = encode_mlp(d32, packing.device_packer_f32(desc, rays.device)(named), rays.detach(), z_vals.detach(), endpoint)
         # the transposed blob of the backward pass is packed NOW, behind the forward kernel in the queue: at the start of the
         # backward the queue is empty, and its ~25 small launches would each cost a host round trip of GPU idle time
         packed_bwd = packing.device_packer(desc, True, rays.device)(named) if os.environ.get("INERF_PACK_BWD_EARLY", "1") != "0" else None
@@ -730,15 +737,17 @@ class _FusedMlpFn(torch.autograd.Function):
         ranges = torch.cat([dz_max, act_max]) if hip_wgrad else None
         grads = mlp_weight_gradients(desc, names, save, dz, d2, n * s, endpoint, ranges, heads)
         check_f16_range(status, "training backward")      # read AFTER the weight-gradient launches are enqueued: the GPU works through them meanwhile
-        return (None, None, None, None, None) + tuple(grads[k] for k in names)
+        return (None, None, None, None, None, None) + tuple(grads[k] for k in names)
 
 
 TRAIN_POINTS_PER_NODE = 2 * 1024 * 1024
 
 
 def mlp_train(desc, module, rays, z_vals, endpoint=False):
-    """Differentiable fused network evaluation for a training step: ``module``'s parameters receive gradients."""
+    """Differentiable fused network evaluation for a training step: ``module``'s parameters receive gradients.
+    ``desc.precision`` = INERF_PREC_F32: the forward values come from the exact-fp32 kernel (see _FusedMlpFn.forward)."""
     from . import packing
+    exact = desc.precision == _capi.PREC_F32
     d = _capi.NetDesc(desc.variant, desc.n_classes, desc.l_xyz, desc.l_dir, desc.xyz_div, _capi.PREC_F16X3)
     names = tuple(name for name, _ in packing.tensor_table(d))
     named = dict(module.named_parameters())
@@ -746,6 +755,6 @@ def mlp_train(desc, module, rays, z_vals, endpoint=False):
     n, s = z_vals.shape
     per = max(1, TRAIN_POINTS_PER_NODE // s)        # the library keeps 11 KB per point; one node stays below its 4 M-point limit
     if n <= per:
-        return _FusedMlpFn.apply(rays, z_vals, d, bool(endpoint), names, *params)
-    return torch.cat([_FusedMlpFn.apply(rays[i:i + per], z_vals[i:i + per], d, bool(endpoint), names, *params)
+        return _FusedMlpFn.apply(rays, z_vals, d, bool(endpoint), names, exact, *params)
+    return torch.cat([_FusedMlpFn.apply(rays[i:i + per], z_vals[i:i + per], d, bool(endpoint), names, exact, *params)
                       for i in range(0, n, per)], 0)

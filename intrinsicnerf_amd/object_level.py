@@ -185,8 +185,8 @@ def _training_path_notice(what):
     """Training steps (run_nerf.py:942-1018, trainer.py:882-990) take the STAGED path: sampling and compositing run
     on the HIP kernels - compositing with its HIP backward (inerf_composite_backward) - and each network is one
     autograd node (kernels.mlp_train): fused HIP forward that keeps the activations, HIP input-gradient chain, weight
-    gradients by the split-K MFMA kernel.  ``INERF_TRAIN_MLP=torch`` (or a precision other than f16x3, or a network outside the
-    fused architecture) evaluates the layers with their torch ``forward`` instead.  Said once per process."""
+    gradients by the split-K MFMA kernel.  ``INERF_TRAIN_MLP=torch`` (or a network outside the fused architecture)
+    evaluates the layers with their torch ``forward`` instead.  Said once per process."""
     global _told_training_path
     if not _told_training_path:
         import warnings
@@ -198,9 +198,9 @@ def _training_path_notice(what):
 def _train_desc(desc):
     """Descriptor for the fused training evaluation of a fusable network, or None when torch autograd has to do it."""
     import os
-    if desc is None or _capi.default_precision() != _capi.PREC_F16X3 or os.environ.get("INERF_TRAIN_MLP", "hip") == "torch":
+    if desc is None or os.environ.get("INERF_TRAIN_MLP", "hip") == "torch":
         return None
-    return desc
+    return desc           # precision f32: exact-fp32 forward values, split-precision saved activations + HIP backward (kernels.mlp_train)
 
 
 def _train_query(train_desc, fn, ray_batch, z_vals, endpoint=False):

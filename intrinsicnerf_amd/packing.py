@@ -65,8 +65,8 @@ def packed_for_module(module, desc, device):
     ``packing.invalidate(module)`` after such a write, or the next render uses the previously packed weights.
 
     Modules whose parameters already live on ``device`` are re-packed there (``DevicePacker``: a gather, a per-group
-    max and an f16 split, ~0.3 ms, bit-identical to the host packer) instead of through a device->host copy and the
-    C packer (~25 ms); the exact-fp32 format and CPU-resident modules go through the host packer."""
+    max and an f16 split, ~0.3 ms, bit-identical to the host packer; the exact-fp32 format: ``DevicePackerF32``, one gather)
+    instead of through a device->host copy and the C packer (~25 ms); CPU-resident modules go through the host packer."""
     params = list(module.parameters())
     versions = tuple((p._version, p.data_ptr()) for p in params) + (str(device), desc.n_classes, desc.l_xyz, desc.l_dir, desc.precision)
     per_module = _cache.setdefault(module, {})
@@ -79,6 +79,9 @@ def packed_for_module(module, desc, device):
         if desc.precision == _capi.PREC_F16X3 and on_device and params:
             with torch.no_grad():
                 ent.blob = device_packer(desc, False, params[0].device)(dict(module.named_parameters()))
+        elif desc.precision == _capi.PREC_F32 and on_device and params:
+            with torch.no_grad():
+                ent.blob = device_packer_f32(desc, params[0].device)(dict(module.named_parameters()))
         else:
             ent.blob = pack_state_dict(desc, module.state_dict()).to(device)
         per_module[desc.precision] = ent
@@ -179,4 +182,39 @@ def device_packer(desc, backward, device):
     key = (desc.variant, desc.n_classes, desc.l_xyz, desc.l_dir, bool(backward), str(device))
     if key not in _device_packers:
         _device_packers[key] = DevicePacker(desc, backward, device)
+    return _device_packers[key]
+
+
+class DevicePackerF32:
+    """The exact-fp32 blob (INERF_PREC_F32) re-packed on the device: that format is a pure permutation of the parameters
+    into MFMA-fragment order plus zero padding and a few constant 1.0 entries (the per-GEMM scale slots the split format
+    fills), so the map is what the host packer makes of index-valued tensors (element j of the flattened parameters carries
+    the value j + 2 < 2^24, exact in fp32; 0 and 1 stay themselves) and re-packing is one gather.
+    ``verify`` (tests/test_capi_cpu.py) pins "pure permutation" against the host packer on real weights."""
+
+    def __init__(self, desc, device):
+        d = _capi.NetDesc(desc.variant, desc.n_classes, desc.l_xyz, desc.l_dir, desc.xyz_div, _capi.PREC_F32)
+        table = tensor_table(d)
+        self.names = [name for name, _ in table]
+        index_sd, flat = {}, 0
+        for name, (rows, cols) in table:
+            count = rows * (cols if cols else 1)
+            if flat + count >= 1 << 24:
+                raise ValueError("network too large for the index-valued packing map")
+            index_sd[name] = torch.arange(flat + 2, flat + count + 2, dtype=torch.float32).reshape((rows, cols) if cols else (rows,))
+            flat += count
+        src = pack_state_dict(d, index_sd)
+        if not torch.equal(src, src.round()) or float(src.min()) < 0 or float(src.max()) > flat + 1:
+            raise RuntimeError("the fp32 blob is not a permutation of the parameters: DevicePackerF32 does not apply")
+        self.src = src.to(torch.int64).to(device)
+
+    def __call__(self, named_params):
+        flat = torch.cat([named_params[k].detach().reshape(-1).float() for k in self.names])
+        return torch.cat([flat.new_tensor([0.0, 1.0]), flat])[self.src]
+
+
+def device_packer_f32(desc, device):
+    key = (desc.variant, desc.n_classes, desc.l_xyz, desc.l_dir, "f32", str(device))
+    if key not in _device_packers:
+        _device_packers[key] = DevicePackerF32(desc, device)
     return _device_packers[key]

@@ -406,6 +406,21 @@ def test_device_packer_is_bit_identical_to_host_packer(capi, variant, c):
             assert torch.equal(host.view(torch.int32), dev.view(torch.int32)), (variant, c, seed, backward)
 
 
+@pytest.mark.parametrize("variant,c", [("object", 0), ("ssr", 28), ("ssr", 101)])
+def test_device_packer_f32_is_bit_identical_to_the_host_packer(capi, variant, c):
+    """packing.DevicePackerF32 (the exact-fp32 blob as one gather; used by the INERF_PRECISION=f32 training forward, which
+    re-packs after every optimiser step) against inerf_pack_weights on real weights - the fp32 format must be a pure
+    permutation + zero padding, with no derived constants."""
+    from intrinsicnerf_amd import packing
+    desc = capi.net_desc(capi.VARIANT_SSR if variant == "ssr" else capi.VARIANT_OBJECT, c, 10, 4, 10.0 if variant == "ssr" else 1.0,
+                         precision=capi.PREC_F32)
+    packer = packing.DevicePackerF32(desc, "cpu")
+    for seed in (3, 4):
+        sd = oracle.make_state_dict(variant, c, seed=seed)
+        host = packing.pack_state_dict(desc, sd)
+        assert torch.equal(host.view(torch.int32), packer(sd).view(torch.int32)), (variant, c, seed)
+
+
 def test_abi_version_and_stale_library_guard(capi, monkeypatch, tmp_path):
     """The binding refuses a library whose ABI number differs from the one its ctypes mirrors were written for, and a
     library built from other sources / headers / compiler flags than the tree holds is rebuilt (or refused when there is
