@@ -620,9 +620,39 @@ def main():
                 train_step()
             fence()
         t_train = (time.perf_counter() - t1) / 5
+        # the same step recorded once as two HIP graphs and replayed (intrinsicnerf_amd/graphs.py): no per-launch host work
+        from intrinsicnerf_amd import graphs
+
+        def loss_fn(rays_b, target_b):
+            ret = ol.render_rays(rays_b, tnet_c, query, N_SAMPLES, retraw=True, perturb=1.0, N_importance=N_IMPORTANCE,
+                                 network_fine=tnet_f, white_bkgd=True)
+            return ((ret["rgb_map"] - target_b) ** 2).mean() + ((ret["rgb0"] - target_b) ** 2).mean() + 0.01 * ret["albedo_map"].abs().mean()
+
+        t_graph = n_fallbacks = None
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                gopt = torch.optim.Adam(list(tnet_c.parameters()) + list(tnet_f.parameters()), lr=5e-4, capturable=True)
+                gstep = graphs.GraphedTrainStep(loss_fn, (tr, target), gopt)
+                for _ in range(2):
+                    gstep(tr, target)
+                fence()
+                t1 = time.perf_counter()
+                for _ in range(10):
+                    gloss = gstep(tr, target)
+                fence()
+            t_graph = (time.perf_counter() - t1) / 10
+            n_fallbacks = gstep.fallbacks
+            assert torch.isfinite(gloss).all()
+        except Exception as e:        # reported, not fatal: the eager figure above stands
+            t_graph = None
+            n_fallbacks = f"{type(e).__name__}: {e}"
         train = {"ms_per_step": t_train * 1e3, "rays": int(tr.shape[0]), "rays_per_s": tr.shape[0] / t_train,
+                 "graphed_ms_per_step": None if t_graph is None else t_graph * 1e3, "graphed_eager_fallbacks": n_fallbacks,
                  "note": "the reference's training batch (2048 rays x (64+128) samples) through object_level.render_rays under "
-                         "autograd: HIP forward + backward (networks, compositing) + torch Adam; not part of `value`"}
+                         "autograd: HIP forward + backward (networks, compositing) + torch Adam; not part of `value`.  graphed: the "
+                         "same step as two HIP graphs (graphs.GraphedTrainStep: render + loss + backward | one read of the f16 range "
+                         "words | optimizer.step), replayed"}
 
     # ---- CPU oracle on the sampled rays of the timed frame: cpu_baseline (its fp32 run, timed) + parity (fp32 and fp64) ----
     cpu = parity = None

@@ -30,7 +30,7 @@ extern "C" {
 #define INERF_VERSION_MINOR 2
 /* Bumped whenever a struct layout, an argument list or the packed-weight format of this header changes; bindings
  * compare it with inerf_abi_version() of the library they loaded (a stale .so then fails loudly, not silently). */
-#define INERF_ABI_VERSION 30001
+#define INERF_ABI_VERSION 30002
 
 /* error codes */
 #define INERF_OK              0
@@ -180,6 +180,20 @@ int inerf_mlp_backward_grid(int64_t n_points);
 int inerf_wgrad_grid(int64_t n_points);
 int inerf_mlp_weight_gradient(const float* G, int ldg, const float* X, int ldx, int64_t n_points, int M, int N,
                               const float* ranges, float* partial, float* bias_partial, int64_t partial_stride, void* stream);
+
+/* The network's whole backward pass in ONE call: the input-gradient chain, every weight-gradient product (split-K launches,
+ * the workgroups' partial tiles side by side in the workspace) and one reduction that writes every sum into its place in
+ * grads_out - the flat concatenation (inerf_param_floats() floats) of the reference's parameter tensors in
+ * inerf_tensor_info() order, i.e. what autograd leaves in .grad of every nn.Linear after loss.backward()
+ * (run_nerf.py:1018, trainer.py:990).  raw / d_raw [n_points, CH]; save: the buffer inerf_encode_mlp_train filled for these
+ * points; act_max: the device float that call max-ed |activation| into.  workspace: inerf_mlp_backward_workspace_bytes()
+ * bytes (the pre-activation gradients of every layer, 11 KB per point, live only there).  Asynchronous on `stream`,
+ * deterministic (fixed summation order).  n_points == 0 zeroes grads_out. */
+int64_t inerf_param_floats(const inerf_net_desc* net);
+int64_t inerf_mlp_backward_workspace_bytes(const inerf_net_desc* net, int64_t n_points);
+int inerf_mlp_backward(const inerf_net_desc* net, const float* packed_bwd, const float* raw, const float* d_raw, const float* save,
+                       const float* act_max, int64_t n_points, uint32_t flags, float* grads_out, void* workspace,
+                       int64_t workspace_bytes, int32_t* status, void* stream);
 
 /* Where every element of a packed blob comes from, so that a caller can re-pack ON THE DEVICE after each
  * optimiser step (a gather, a per-group max for the power-of-two scales, an f16 hi/lo split) instead of moving the

@@ -1,0 +1,314 @@
+// train_api.hip - the network's whole backward pass behind ONE entry point of the C ABI.
+//
+// inerf_mlp_backward enqueues, for one network evaluation kept by inerf_encode_mlp_train, everything loss.backward()
+// records for run_network + NeRF.forward / Semantic_NeRF.forward (run_nerf.py:1018 through run_nerf_helpers.py:284-321;
+// trainer.py:990 through semantic_nerf.py:123-181):
+//   1. the input-gradient chain (k_mlp_dgrad) with the 1-4-row heads' gradients accumulated on the way,
+//   2. every 128/256-row weight-gradient product dW = dZ^T X as a split-K launch (k_mlp_wgrad), the per-workgroup partial
+//      tiles of ALL products side by side in one [grid, total] buffer,
+//   3. one reduction over the workgroups that writes each sum straight into its place in the caller's gradient blob - the
+//      reference's parameter tensors in inerf_tensor_info() order (the cat([pts, h]) and cat([feature, views]) layers are
+//      assembled by column offset, padded columns are dropped).
+// No host synchronisation, no allocation (caller's workspace), deterministic (fixed summation order, no float atomics).
+// Until round 3 steps 2-3 were driven from Python: 26 ctypes calls + torch reductions per network and step.
+#include <cstring>
+#include <string>
+
+#include "mlp_common.h"
+
+namespace inerf {
+namespace {
+
+constexpr int64_t kAlign = 256;
+inline int64_t up(int64_t bytes) { return (bytes + kAlign - 1) / kAlign * kAlign; }
+constexpr int kHeadRes = 0, kHeadAs2 = 384, kHeadAlpha = 1408, kHeadBias = 1664, kHeadFloats = 1672;     // mlp_bwd.hip
+
+// a rectangular piece of a job's [m, n] result (or of its [m] bias) and where it goes in the gradient blob.  32-bit fields:
+// the table travels as a kernel argument (< 4 KB) and every offset is far below 2^31 floats.
+struct Piece {
+    int32_t row0, row1;    // rows [row0, row1) of the job's result (row1 == 0: unused)
+    int32_t dst;           // float offset of the destination tensor's first element
+    int32_t dst_ld;        // its row length
+    int32_t dst_col0;      // column offset inside the destination rows
+    int32_t cols;          // valid columns (the rest of the job's n is padding)
+};
+struct BiasPiece { int32_t row0, row1, dst; };
+struct Job {
+    int32_t src;           // float offset of the [m, n] tile inside a partial row
+    int32_t bias_src;      // ... of its [m] column sums of G, or -1
+    int32_t m, n;
+    Piece w[2];
+    BiasPiece b[2];
+};
+constexpr int kMaxJobs = 16;
+struct ReduceTable {       // device side (kernel argument)
+    Job job[kMaxJobs];
+    int32_t n_jobs;
+    int32_t total;         // floats per partial row
+    int32_t grid;          // partial rows
+};
+struct Launch { int g_slot, x_slot, sem; };          // host side: operands of job k
+struct Table {
+    ReduceTable dev;
+    Launch launch[kMaxJobs];
+};
+static_assert(sizeof(ReduceTable) <= 3072, "kernel-argument budget");
+
+struct ParamTable {        // float offsets of the reference's tensors inside the gradient blob
+    int64_t total = 0;
+    int64_t off(const inerf_net_desc& net, const std::string& name, int64_t* cols = nullptr) const {
+        const int n = inerf_num_tensors(&net);
+        int64_t o = 0;
+        for (int i = 0; i < n; ++i) {
+            const char* nm; int64_t r, c;
+            inerf_tensor_info(&net, i, &nm, &r, &c);
+            if (name == nm) { if (cols) *cols = c; return o; }
+            o += r * (c ? c : 1);
+        }
+        return -1;
+    }
+};
+
+int64_t param_floats(const inerf_net_desc& net) {
+    const int n = inerf_num_tensors(&net);
+    int64_t o = 0;
+    for (int i = 0; i < n; ++i) {
+        const char* nm; int64_t r, c;
+        inerf_tensor_info(&net, i, &nm, &r, &c);
+        o += r * (c ? c : 1);
+    }
+    return o;
+}
+
+// the products of kernels.mlp_weight_gradients (round 2), as data
+Table build_table(const inerf_net_desc& net, int sem_rows) {
+    Table tb{};
+    ReduceTable& t = tb.dev;
+    const ParamTable P;
+    const bool obj = net.variant == INERF_VARIANT_OBJECT;
+    const bool sem = net.variant == INERF_VARIANT_SSR && net.n_classes > 0;
+    const int e = 3 + 6 * net.l_xyz, dv = 3 + 6 * net.l_dir;
+    const std::string sh1 = obj ? "test_linear1" : "shading_linear1";
+    int32_t off = 0;
+    bool have_bias[SAVE_SLOTS] = {};
+    int n_w[kMaxJobs] = {};
+    auto add = [&](int g_slot, int x_slot, int m, int n) -> int {
+        const int k = t.n_jobs++;
+        Job& j = t.job[k];
+        j = Job{};
+        tb.launch[k] = Launch{g_slot, x_slot, 0};
+        j.m = m; j.n = n;
+        j.src = off; off += m * n;
+        j.bias_src = -1;
+        if (g_slot >= 0 && !have_bias[g_slot]) { j.bias_src = off; off += m; have_bias[g_slot] = true; }
+        return k;
+    };
+    auto wpiece = [&](int k, int r0, int r1, const std::string& name, int col0, int cols) {
+        int64_t ld;
+        const int64_t o = P.off(net, name + ".weight", &ld);
+        t.job[k].w[n_w[k]++] = Piece{r0, r1, (int32_t)o, (int32_t)ld, col0, cols};
+    };
+    auto bpiece = [&](int k, int q, int r0, int r1, const std::string& name) {
+        t.job[k].b[q] = BiasPiece{r0, r1, (int32_t)P.off(net, name + ".bias")};
+    };
+    {   const int k = add(SAVE_H0, SAVE_ENC, kWidth, kEncCols);                  // pts_linears.0
+        wpiece(k, 0, kWidth, "pts_linears.0", 0, e); bpiece(k, 0, 0, kWidth, "pts_linears.0"); }
+    for (int i = 1; i < kDepth; ++i) {                                           // pts_linears.1-7 (layer 5: its h columns)
+        const int k = add(SAVE_H0 + i, SAVE_H0 + i - 1, kWidth, kWidth);
+        const std::string name = "pts_linears." + std::to_string(i);
+        wpiece(k, 0, kWidth, name, i == kSkipInput ? e : 0, kWidth); bpiece(k, 0, 0, kWidth, name);
+    }
+    {   const int k = add(SAVE_H0 + kSkipInput, SAVE_ENC, kWidth, kEncCols);    // ... and its encoding columns: cat([pts, h]), helpers:290-291
+        wpiece(k, 0, kWidth, "pts_linears." + std::to_string(kSkipInput), 0, e); }
+    {   const int k = add(SAVE_AS1H, SAVE_H7, kWidth, kWidth);                   // albedo_linear1 | shading hidden
+        wpiece(k, 0, kHalf, "albedo_linear1", 0, kWidth); wpiece(k, kHalf, kWidth, sh1, 0, kWidth);
+        bpiece(k, 0, 0, kHalf, "albedo_linear1"); bpiece(k, 1, kHalf, kWidth, sh1); }
+    {   const int k = add(SAVE_FEAT, SAVE_H7, kWidth, kWidth);
+        wpiece(k, 0, kWidth, "feature_linear", 0, kWidth); bpiece(k, 0, 0, kWidth, "feature_linear"); }
+    {   const int k = add(SAVE_VH, SAVE_FEAT, kHalf, kWidth);                     // views_linears.0 over cat([feature, views]), helpers:308
+        wpiece(k, 0, kHalf, "views_linears.0", 0, kWidth); bpiece(k, 0, 0, kHalf, "views_linears.0"); }
+    {   const int k = add(SAVE_VH, SAVE_DIR, kHalf, kDirCols);
+        wpiece(k, 0, kHalf, "views_linears.0", kWidth, dv); }
+    if (sem) {
+        {   const int k = add(SAVE_SEMH, SAVE_H7, kHalf, kWidth);
+            wpiece(k, 0, kHalf, "semantic_linear.0.0", 0, kWidth); bpiece(k, 0, 0, kHalf, "semantic_linear.0.0"); }
+        {   const int k = add(-1, SAVE_SEMH, sem_rows, kHalf);                   // semantic_linear.1: G = padded d_logits
+            tb.launch[k].sem = 1;
+            t.job[k].bias_src = off; off += sem_rows;
+            wpiece(k, 0, net.n_classes, "semantic_linear.1", 0, kHalf); bpiece(k, 0, 0, net.n_classes, "semantic_linear.1"); }
+    }
+    t.total = off;
+    return tb;
+}
+
+struct Plan {
+    int64_t dz, scalars, heads, partial, gsem, total;
+    int bwd_grid, wg_grid, sem_rows;
+};
+
+Plan make_plan(const inerf_net_desc& net, int64_t n_points) {
+    Plan p{};
+    const bool sem = net.variant == INERF_VARIANT_SSR && net.n_classes > 0;
+    p.sem_rows = sem ? (net.n_classes <= kHalf ? kHalf : kWidth) : 0;
+    p.bwd_grid = inerf_mlp_backward_grid(n_points);
+    p.wg_grid = inerf_wgrad_grid(n_points);
+    const ReduceTable t = build_table(net, p.sem_rows).dev;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) { int64_t o = off; off += up(bytes); return o; };
+    p.dz = take(save_total_floats(net, n_points) * 4);
+    p.scalars = take(16 * 4);
+    p.heads = take((int64_t)p.bwd_grid * kHeadFloats * 4);
+    p.partial = take((int64_t)p.wg_grid * t.total * 4);
+    p.gsem = take(n_points * (int64_t)p.sem_rows * 4);
+    p.total = off;
+    return p;
+}
+
+// scalars: [0] dz_max  [1] gsem_max  [4..5] ranges {dz_max, act_max}  [8..9] sem ranges {gsem_max, act_max}
+__global__ void k_sem_pad(const float* __restrict__ d_raw, int channels, int n_classes, int rows, int64_t n_points,
+                          float* __restrict__ g, float* __restrict__ gmax) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    float v = 0.0f;
+    if (i < n_points * rows) {
+        const int64_t p = i / rows;
+        const int c = (int)(i - p * rows);
+        v = c < n_classes ? d_raw[p * channels + INERF_BASE_CHANNELS + c] : 0.0f;
+        g[i] = v;
+    }
+    float m = fabsf(v);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.0f && m == m) atomicMax(reinterpret_cast<unsigned int*>(gmax), __builtin_bit_cast(unsigned int, m));
+}
+
+__global__ void k_ranges(float* __restrict__ s, const float* __restrict__ act_max) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float a = act_max[0];
+        s[4] = s[0]; s[5] = a;
+        s[8] = fmaxf(s[1], 1e-30f); s[9] = a;
+    }
+}
+
+// one thread per element of a partial row: sum over the workgroups' rows, then scatter
+__global__ void k_reduce_scatter(const ReduceTable t, const float* __restrict__ partial, float* __restrict__ grads) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= t.total) return;
+    float v = 0.0f;
+    for (int g = 0; g < t.grid; ++g) v += partial[(int64_t)g * t.total + i];
+    for (int k = 0; k < t.n_jobs; ++k) {
+        const Job& j = t.job[k];
+        if (i >= j.src && i < j.src + j.m * j.n) {
+            const int r = (int)(i - j.src) / j.n, c = (int)(i - j.src) % j.n;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const Piece& w = j.w[q];
+                if (r >= w.row0 && r < w.row1 && c < w.cols) grads[w.dst + (r - w.row0) * w.dst_ld + w.dst_col0 + c] = v;
+            }
+            return;
+        }
+        if (j.bias_src >= 0 && i >= j.bias_src && i < j.bias_src + j.m) {
+            const int r = (int)(i - j.bias_src);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const BiasPiece& b = j.b[q];
+                if (r >= b.row0 && r < b.row1) grads[b.dst + (r - b.row0)] = v;
+            }
+            return;
+        }
+    }
+}
+
+struct HeadDst { int64_t res_w, as2_w, sh2_w, alpha_w, as2_b, sh2_b, res_b, alpha_b; };
+
+__global__ void k_reduce_heads(const float* __restrict__ heads, int grid, HeadDst d, float* __restrict__ grads) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= kHeadFloats) return;
+    float v = 0.0f;
+    for (int g = 0; g < grid; ++g) v += heads[(size_t)g * kHeadFloats + i];
+    if (i < kHeadAs2) grads[d.res_w + i] = v;                                                 // residual head [3][128]
+    else if (i < kHeadAlpha) {
+        const int j = (i - kHeadAs2) / kWidth, c = (i - kHeadAs2) % kWidth;
+        if (j < 3 && c < kHalf) grads[d.as2_w + j * kHalf + c] = v;                          // albedo_linear2 [3][128]
+        else if (j == 3 && c >= kHalf) grads[d.sh2_w + (c - kHalf)] = v;                     // shading output [1][128]
+    } else if (i < kHeadBias) grads[d.alpha_w + (i - kHeadAlpha)] = v;                        // alpha_linear [1][256]
+    else {
+        const int b = i - kHeadBias;
+        if (b < 3) grads[d.as2_b + b] = v;
+        else if (b == 3) grads[d.sh2_b] = v;
+        else if (b < 7) grads[d.res_b + (b - 4)] = v;
+        else grads[d.alpha_b] = v;
+    }
+}
+
+}  // namespace
+}  // namespace inerf
+
+extern "C" int64_t inerf_param_floats(const inerf_net_desc* net) {
+    if (!net || !inerf::net_supported(*net)) return INERF_E_INVALID;
+    return inerf::param_floats(*net);
+}
+
+extern "C" int64_t inerf_mlp_backward_workspace_bytes(const inerf_net_desc* net, int64_t n_points) {
+    if (!net || !inerf::net_supported(*net) || n_points < 0) return INERF_E_INVALID;
+    if (n_points == 0) return 0;
+    return inerf::make_plan(*net, n_points).total;
+}
+
+extern "C" int inerf_mlp_backward(const inerf_net_desc* net, const float* packed_bwd, const float* raw, const float* d_raw,
+                                  const float* save, const float* act_max, int64_t n_points, uint32_t flags, float* grads_out,
+                                  void* workspace, int64_t workspace_bytes, int32_t* status, void* stream_) {
+    using namespace inerf;
+    if (!net || !grads_out || n_points < 0) return INERF_E_INVALID;
+    if (!net_supported(*net)) return INERF_E_UNSUPPORTED;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t n_params = param_floats(*net);
+    if (n_points == 0) return record(hipMemsetAsync(grads_out, 0, n_params * 4, stream));        // no sample points: every gradient is zero
+    if (!packed_bwd || !raw || !d_raw || !save || !act_max) return INERF_E_INVALID;
+    if (n_points >= (int64_t)1 << 31) return INERF_E_UNSUPPORTED;
+    const Plan plan = make_plan(*net, n_points);
+    if (!workspace || workspace_bytes < plan.total) return INERF_E_WORKSPACE;
+    char* ws = static_cast<char*>(workspace);
+    float* dz = reinterpret_cast<float*>(ws + plan.dz);
+    float* sc = reinterpret_cast<float*>(ws + plan.scalars);
+    float* heads = reinterpret_cast<float*>(ws + plan.heads);
+    float* partial = reinterpret_cast<float*>(ws + plan.partial);
+    float* gsem = reinterpret_cast<float*>(ws + plan.gsem);
+    const bool ssr = net->variant == INERF_VARIANT_SSR;
+    const bool sem = ssr && net->n_classes > 0;
+    const int channels = INERF_BASE_CHANNELS + (ssr ? net->n_classes : 0) + ((ssr && (flags & INERF_FLAG_ENDPOINT)) ? INERF_ENDPOINT_DIM : 0);
+
+    hipError_t e = hipMemsetAsync(sc, 0, 16 * 4, stream);
+    if (e != hipSuccess) return record(e);
+    int rc = inerf_mlp_backward_inputs(net, packed_bwd, raw, d_raw, save, n_points, flags, dz, sc + 0, heads, status, stream);
+    if (rc) return rc;
+    if (sem) {
+        const int64_t n = n_points * plan.sem_rows;
+        hipLaunchKernelGGL(k_sem_pad, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_raw, channels, net->n_classes, plan.sem_rows,
+                           n_points, gsem, sc + 1);
+    }
+    hipLaunchKernelGGL(k_ranges, dim3(1), dim3(64), 0, stream, sc, act_max);
+    Table tb = build_table(*net, plan.sem_rows);
+    ReduceTable& t = tb.dev;
+    t.grid = plan.wg_grid;
+    for (int k = 0; k < t.n_jobs; ++k) {
+        const Job& j = t.job[k];
+        const Launch& l = tb.launch[k];
+        const float* G = l.sem ? gsem : dz + save_offset(*net, l.g_slot, n_points);
+        const int ldg = l.sem ? plan.sem_rows : save_width(*net, l.g_slot);
+        const float* X = save + save_offset(*net, l.x_slot, n_points);
+        rc = inerf_mlp_weight_gradient(G, ldg, X, save_width(*net, l.x_slot), n_points, j.m, j.n, sc + (l.sem ? 8 : 4), partial + j.src,
+                                       j.bias_src >= 0 ? partial + j.bias_src : nullptr, t.total, stream);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_reduce_scatter, dim3((unsigned)((t.total + 255) / 256)), dim3(256), 0, stream, t, partial, grads_out);
+    const ParamTable P;
+    const bool obj = net->variant == INERF_VARIANT_OBJECT;
+    const std::string sh2 = obj ? "test_linear2" : "shading_linear2", res = obj ? "shading_linear" : "residual_linear";
+    HeadDst d;
+    d.res_w = P.off(*net, res + ".weight");        d.res_b = P.off(*net, res + ".bias");
+    d.as2_w = P.off(*net, "albedo_linear2.weight"); d.as2_b = P.off(*net, "albedo_linear2.bias");
+    d.sh2_w = P.off(*net, sh2 + ".weight");        d.sh2_b = P.off(*net, sh2 + ".bias");
+    d.alpha_w = P.off(*net, "alpha_linear.weight"); d.alpha_b = P.off(*net, "alpha_linear.bias");
+    hipLaunchKernelGGL(k_reduce_heads, dim3((kHeadFloats + 255) / 256), dim3(256), 0, stream, heads, plan.bwd_grid, d, grads_out);
+    return record(hipGetLastError());
+}

@@ -287,6 +287,11 @@ class _CompositeFn(torch.autograd.Function):
         raw_c, z_c, d_c = raw.detach().float().contiguous(), z_vals.detach().float().contiguous(), rays_d.detach().float().contiguous()
         noise_c = None if noise is None else noise.detach().float().contiguous()
         out = _composite_forward(raw_c, z_c, d_c, noise_c, white_bkgd, n_classes, feat_dim, "weights" in keys)
+        # Outputs the loss does not use must arrive as None, not as zero tensors: the reference's autograd never visits the
+        # branch of an unused output, while a ZERO cotangent on disp = 1 / (depth / acc) turns into NaN on every ray with
+        # acc == 0 (0 x d(1/(0/0))) - and a trained network has such rays (sigma <= 0 along a ray through empty space) in every
+        # batch.  Found by scripts/fit_synthetic.py: with materialised zeros the fit went NaN after a few hundred steps.
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(raw_c, z_c, d_c, *([] if noise_c is None else [noise_c]))
         ctx.cfg = (white_bkgd, n_classes, feat_dim, keys, noise_c is not None)
         return tuple(out[k] for k in keys)
@@ -503,6 +508,41 @@ def mlp_backward_inputs(desc, packed_bwd, raw, d_raw, save, endpoint=False, stat
                                                    None if status is None else C.c_void_p(status.data_ptr()), _stream(raw))
     _capi.check(rc, "inerf_mlp_backward_inputs")
     return (dz, heads.sum(0)) if want_heads else dz
+
+
+def mlp_backward(desc, packed_bwd, raw, d_raw, save, act_max, endpoint=False, status=None):
+    """The network's whole backward pass through ``inerf_mlp_backward`` (ONE call: chain, every weight-gradient product,
+    reduction, scatter into the reference's parameter layout).  Returns the flat gradient blob - the parameter tensors of
+    ``packing.tensor_table(desc)`` in order; ``param_views`` cuts it into named views."""
+    L = _capi.lib()
+    raw = _dev(raw, "raw", (None, None))
+    p, ch = raw.shape
+    d_raw = _dev(d_raw, "d_raw", (p, ch))
+    save = _dev(save, "save", (None,))
+    packed_bwd = _dev(packed_bwd, "packed transposed weights", (None,))
+    act_max = _dev(act_max, "act_max", (1,))
+    grads = _new(raw, L.inerf_param_floats(desc))
+    ws_bytes = L.inerf_mlp_backward_workspace_bytes(desc, p)
+    if ws_bytes < 0:
+        _capi.check(int(ws_bytes), "inerf_mlp_backward_workspace_bytes")
+    ws = torch.empty(max(int(ws_bytes), 1), dtype=torch.uint8, device=raw.device)
+    with torch.cuda.device(raw.device):
+        rc = L.inerf_mlp_backward(desc, _ptr(packed_bwd), _ptr(raw), _ptr(d_raw), _ptr(save), _ptr(act_max), p,
+                                  FLAG_ENDPOINT if endpoint else 0, _ptr(grads), C.c_void_p(ws.data_ptr()), int(ws_bytes),
+                                  None if status is None else C.c_void_p(status.data_ptr()), _stream(raw))
+    _capi.check(rc, "inerf_mlp_backward")
+    return grads
+
+
+def param_views(desc, flat):
+    """name -> view of the flat gradient / parameter blob with the reference's shapes (packing.tensor_table order)."""
+    from . import packing
+    out, off = {}, 0
+    for name, (rows, cols) in packing.tensor_table(desc):
+        n = rows * (cols if cols else 1)
+        out[name] = flat[off:off + n].view((rows, cols) if cols else (rows,))
+        off += n
+    return out
 
 
 def _head_names(desc):
@@ -729,7 +769,15 @@ class _FusedMlpFn(torch.autograd.Function):
         packed_bwd = ctx.packed_bwd if ctx.packed_bwd is not None else packing.device_packer(desc, True, raw.device)(dict(zip(names, params)))
         d2 = d_raw.contiguous().view(n * s, ch).float()
         import os
-        hip_wgrad = os.environ.get("INERF_WGRAD", "hip") != "library"
+        mode = os.environ.get("INERF_WGRAD", "hip")
+        if mode == "hip":          # one C call: chain + weight gradients + reduction + scatter (inerf_mlp_backward)
+            flat = mlp_backward(desc, packed_bwd, raw.view(n * s, ch), d2, save, act_max, endpoint, status)
+            grads = param_views(desc, flat)
+            check_f16_range(status, "training backward")      # read AFTER everything is enqueued: the GPU works through it meanwhile
+            return (None, None, None, None, None, None) + tuple(grads[k] for k in names)
+        # INERF_WGRAD=staged: the round-2 path (chain, then one inerf_mlp_weight_gradient call per product from Python, torch
+        # reductions); =library: library GEMMs for the products (A/B runs)
+        hip_wgrad = mode != "library"
         dz = mlp_backward_inputs(desc, packed_bwd, raw.view(n * s, ch), d2, save, endpoint, status, dz_max, want_heads=hip_wgrad)
         heads = None
         if hip_wgrad:

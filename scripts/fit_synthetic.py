@@ -112,6 +112,9 @@ def fit(net_c, net_f, query, rays, target, steps, batch=2048, lr=5e-4, seed=1, l
             losses[it] = loss.detach()
             if log_every and (it + 1) % log_every == 0:
                 print(f"  step {it + 1}: loss {float(loss):.5f}", flush=True)
+            if (it + 1) % 100 == 0 and not bool(torch.isfinite(losses[it - 99:it + 1]).all()):
+                bad = int(torch.nonzero(~torch.isfinite(losses[:it + 1]))[0])
+                raise FloatingPointError(f"the loss became non-finite at step {bad} (mode {os.environ.get('INERF_TRAIN_MLP', 'hip')})")
     return losses.cpu().numpy()
 
 

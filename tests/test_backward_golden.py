@@ -564,3 +564,85 @@ def test_short_training_run_matches_torch_layers(monkeypatch):
         curves[mode] = np.array(losses)
     assert curves["hip"][-1] < 0.5 * curves["hip"][0], curves["hip"]
     np.testing.assert_allclose(curves["hip"], curves["torch"], rtol=1e-3, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant,c,endpoint", [("object", 0, False), ("ssr", 28, False), ("ssr", 5, True), ("ssr", 150, False)])
+def test_one_call_backward_equals_the_staged_one(variant, c, endpoint, monkeypatch):
+    """inerf_mlp_backward (chain + every weight-gradient product + reduction + scatter in ONE C call, the default since round 3)
+    against the round-2 path that drives the same kernels from Python (INERF_WGRAD=staged): the same numbers up to the
+    summation order of the workgroups' partial tiles; plus the entry's own contract (workspace check, empty batch)."""
+    import ctypes as C
+    from intrinsicnerf_amd import _capi, kernels, object_level as ol, ssr
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    sd = oracle.lcg_state_dict(variant, c, seed=29, sigma_gain_log2=3, freq_decay=True)
+    if variant == "object":
+        embed, ch = ol.get_embedder(10, 0); embed_d, ch_d = ol.get_embedder(4, 0)
+        net = ol.NeRF(D=8, W=256, input_ch=ch, output_ch=5, skips=[4], input_ch_views=ch_d, use_viewdirs=True).to(dev)
+    else:
+        embed, ch = ssr.get_embedder(10, 0, scalar_factor=10); embed_d, ch_d = ssr.get_embedder(4, 0, scalar_factor=1)
+        net = ssr.Semantic_NeRF(c > 0, c, D=8, W=256, input_ch=ch, output_ch=5, skips=[4], input_ch_views=ch_d, use_viewdirs=True).to(dev)
+    net.load_state_dict(sd)
+    n, s = 300, 48
+    d = torch.randn(n, 3, generator=g)
+    rays = torch.cat([torch.rand(n, 3, generator=g) * 2 - 1, d, torch.zeros(n, 2), d / d.norm(dim=-1, keepdim=True)], -1).to(dev)
+    z = torch.sort(torch.rand(n, s, generator=g) * 3 + 0.5, -1)[0].to(dev)
+    cot = torch.randn(n, s, 11 + c + (128 if endpoint else 0), generator=g).to(dev)
+    desc = net.fused_desc()
+    desc.xyz_div = embed.scalar_factor
+    out = {}
+    for mode in ("hip", "staged"):
+        monkeypatch.setenv("INERF_WGRAD", mode)
+        net.zero_grad()
+        raw = kernels.mlp_train(desc, net, rays, z, endpoint)
+        (raw * cot).sum().backward()
+        out[mode] = {k: p.grad.clone() for k, p in net.named_parameters()}
+    for k in out["hip"]:
+        a, b = out["hip"][k].double(), out["staged"][k].double()
+        assert a.shape == b.shape and float((a - b).norm()) <= 2e-6 * float(b.norm()) + 1e-12, k
+    lib = _capi.lib()
+    d16 = _capi.NetDesc(desc.variant, desc.n_classes, desc.l_xyz, desc.l_dir, desc.xyz_div, _capi.PREC_F16X3)
+    n_params = lib.inerf_param_floats(d16)
+    assert n_params == sum(p.numel() for p in net.parameters())
+    grads = torch.full((n_params,), 7.0, device=dev)
+    assert lib.inerf_mlp_backward(d16, None, None, None, None, None, 0, 0, C.c_void_p(grads.data_ptr()), None, 0, None, None) == _capi.OK
+    torch.cuda.synchronize()
+    assert float(grads.abs().max()) == 0.0                                   # empty batch: every gradient is zero
+    need = lib.inerf_mlp_backward_workspace_bytes(d16, n * s)
+    assert need > 4 * n * s * 2784                                            # holds the pre-activation gradients of every layer
+    one = torch.zeros(1, device=dev)
+    rc = lib.inerf_mlp_backward(d16, C.c_void_p(one.data_ptr()), C.c_void_p(one.data_ptr()), C.c_void_p(one.data_ptr()), C.c_void_p(one.data_ptr()),
+                                C.c_void_p(one.data_ptr()), n * s, 0, C.c_void_p(grads.data_ptr()), C.c_void_p(one.data_ptr()), need - 1, None, None)
+    assert rc == _capi.E_WORKSPACE
+
+
+@pytest.mark.gpu
+def test_unused_outputs_of_an_empty_ray_do_not_poison_the_gradients(monkeypatch):
+    """A ray on which every density is <= 0 has acc == 0 and disp == NaN (run_nerf.py:404, as in the reference).  A loss that
+    does not use disp must still give finite gradients - the reference's autograd never visits disp's branch then.  (Autograd
+    Functions materialise unused outputs' cotangents as ZEROS by default, and 0 x d disp / d acc is NaN at acc == 0: found by
+    scripts/fit_synthetic.py, whose trained network has empty rays in every batch.)"""
+    from intrinsicnerf_amd import kernels
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    n, s = 6, 64
+    raw = torch.randn(n, s, 11, generator=g)
+    raw[0, :, 3] = -raw[0, :, 3].abs() - 0.1                       # ray 0: empty
+    raw[1, :, 3] = 0.0                                             # ray 1: sigma == 0 exactly
+    z = torch.sort(torch.rand(n, s, generator=g) * 4 + 2, -1)[0]
+    d = torch.randn(n, 3, generator=g)
+    for wb in (False, True):
+        r = raw.clone().to(dev).requires_grad_(True)
+        out = kernels.composite(r, z.to(dev), d.to(dev), None, wb)
+        assert torch.isnan(out["disp"][0]) and float(out["acc"][0]) == 0.0
+        (out["rgb"].square().sum() + out["albedo"].sum()).backward()
+        assert torch.isfinite(r.grad).all()
+        rc = raw.clone().requires_grad_(True)
+        want = oracle.composite(rc, z, d, oracle.RenderConfig(variant="object", white_bkgd=wb))
+        (want["rgb"].square().sum() + want["albedo"].sum()).backward()
+        assert_maps_close(r.grad.cpu().numpy(), rc.grad.numpy(), 1e-4, 1e-6, "d_raw with unused disp")
+        # ... and a loss that DOES use disp is NaN on that ray in the reference's autograd too
+        r2 = raw.clone().to(dev).requires_grad_(True)
+        kernels.composite(r2, z.to(dev), d.to(dev), None, wb)["disp"][2:].sum().backward()
+        assert torch.isfinite(r2.grad[2:]).all()
