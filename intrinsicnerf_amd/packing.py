@@ -15,8 +15,19 @@ import torch
 from . import _capi
 
 
+_tables = {}
+
+
 def tensor_table(desc):
-    """[(name, (rows, cols))] in the C packer's canonical order; cols == 0 marks a bias."""
+    """[(name, (rows, cols))] in the C packer's canonical order; cols == 0 marks a bias.  (Cached per description: the training
+    step asks for it several times per network and step.)"""
+    key = (desc.variant, desc.n_classes, desc.l_xyz, desc.l_dir)
+    if key not in _tables:
+        _tables[key] = tuple(_tensor_table(desc))
+    return list(_tables[key])
+
+
+def _tensor_table(desc):
     L = _capi.lib()
     n = L.inerf_num_tensors(desc)
     if n < 0:
