@@ -37,7 +37,8 @@ for a, b in (("bench.json", "bench.json"), ("bench_under_rocprof.json", "bench_u
              ("mlp_pmc_summary.txt", "mlp_pmc_summary.txt"), ("kernel_forms.txt", "kernel_forms_same_box.txt"), ("ssr_frame.txt", "ssr_frame.txt"),
              ("train_step.txt", "train_step.txt"), ("train_step_kernel_stats.csv", "train_step_kernel_stats.csv"),
              ("train_pmc_summary.txt", "train_pmc_summary.txt"), ("train_pmc_w.csv", "train_pmc_w.csv"), ("train_pmc_f.csv", "train_pmc_f.csv"),
-             ("train_pmc_m.csv", "train_pmc_m.csv"), ("train_kernels.txt", "train_kernels.txt")):
+             ("train_pmc_m.csv", "train_pmc_m.csv"), ("train_kernels.txt", "train_kernels.txt"), ("bench_n2_shared.json", "bench_n2_shared.json"),
+             ("trained_network.txt", "trained_network.txt")):
     if os.path.exists(f"{src}{tag}_{a}"):
         shutil.copy(f"{src}{tag}_{a}", f"{dst}{tag}_{b}")
 
