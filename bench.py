@@ -63,10 +63,10 @@ PEAK_F32_MFMA_TFLOPS = 157.3                 # MI355X_MICROARCH.md: dense fp32 m
 PEAK_F16_MFMA_TFLOPS = 2500.0                # MI355X_MICROARCH.md: dense f16/bf16 matrix peak
 MEASURED_F16_MFMA_ONLY_TFLOPS = 1590.0       # dense f16, random operands, 170-340 ms runs (zero operands: 2470)
 # HBM bytes per sample point of the encode+MLP kernels from the PMC passes (FETCH_SIZE + WRITE_SIZE, separate passes).
-# f16x3: profiles/r02_mlp_pmc_traffic.txt, measured on the bench frame's own fine launch (640,000 rays x 192 samples):
-# 6232.4 MB per 122,880,000-point launch (algorithmic 5929.1 MB).  f32: profiles/r01_mlp_pmc_traffic.txt (kernel unchanged).
+# f16x3: profiles/r03_pmc_digest.txt, measured on the bench frame's own fine launch (640,000 rays x 192 samples):
+# 6230.5 MB per 122,880,000-point launch (algorithmic 5929.1 MB).  f32: profiles/r01_mlp_pmc_traffic.txt (kernel unchanged).
 PMC_HBM_BYTES_PER_POINT = {"f16x3": 50.7, "f32": 49.5}
-PMC_SOURCE = {"f16x3": ("profiles/r02_mlp_pmc_traffic.txt", "1.05"), "f32": ("profiles/r01_mlp_pmc_traffic.txt", "1.02")}
+PMC_SOURCE = {"f16x3": ("profiles/r03_pmc_digest.txt", "1.05"), "f32": ("profiles/r01_mlp_pmc_traffic.txt", "1.02")}
 PARITY_RAYS = 4096
 RTOL, ATOL, RTOL_DISP = 1e-4, 1e-5, 5e-4
 

@@ -21,6 +21,7 @@
 namespace inerf {
 namespace {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int64_t kAlign = 256;
 inline int64_t up(int64_t bytes) { return (bytes + kAlign - 1) / kAlign * kAlign; }
 constexpr int kHeadRes = 0, kHeadAs2 = 384, kHeadAlpha = 1408, kHeadBias = 1664, kHeadFloats = 1672;     // mlp_bwd.hip
@@ -228,12 +229,23 @@ __global__ void k_ranges(float* __restrict__ s, const float* __restrict__ act_ma
     }
 }
 
-// one thread per element of a partial row: sum over the workgroups' rows, then scatter
+// one thread per FOUR consecutive elements of a partial row (every tile and bias vector starts and ends on a multiple of 4, and
+// a tile's rows are multiples of 32 long, so a quad never straddles a row or a job): sum over the workgroups' rows with 16-byte
+// loads, eight rows in flight, then scatter.  The [grid, total] buffer (1 GB for the reference's fine batch) was just written
+// by the products and does not fit any cache: this kernel runs at HBM speed or not at all.
 __global__ void k_reduce_scatter(const ReduceTable t, const float* __restrict__ partial, float* __restrict__ grads) {
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t i = 4 * (blockIdx.x * (int64_t)blockDim.x + threadIdx.x);
     if (i >= t.total) return;
-    float v = 0.0f;
-    for (int g = 0; g < t.grid; ++g) v += partial[(int64_t)g * t.total + i];
+    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+    int g = 0;
+    for (; g + 8 <= t.grid; g += 8) {
+        f32x4 r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(partial + (int64_t)(g + k) * t.total + i));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v += r[k];           // fixed order: deterministic
+    }
+    for (; g < t.grid; ++g) v += *reinterpret_cast<const f32x4*>(partial + (int64_t)g * t.total + i);
     for (int k = 0; k < t.n_jobs; ++k) {
         const Job& j = t.job[k];
         if (i >= j.src && i < j.src + j.m * j.n) {
@@ -241,7 +253,10 @@ __global__ void k_reduce_scatter(const ReduceTable t, const float* __restrict__ 
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const Piece& w = j.w[q];
-                if (r >= w.row0 && r < w.row1 && c < w.cols) grads[w.dst + (r - w.row0) * w.dst_ld + w.dst_col0 + c] = v;
+                if (r >= w.row0 && r < w.row1)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (c + e < w.cols) grads[w.dst + (r - w.row0) * w.dst_ld + w.dst_col0 + c + e] = v[e];
             }
             return;
         }
@@ -250,18 +265,27 @@ __global__ void k_reduce_scatter(const ReduceTable t, const float* __restrict__ 
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const BiasPiece& b = j.b[q];
-                if (r >= b.row0 && r < b.row1) grads[b.dst + (r - b.row0)] = v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (r + e >= b.row0 && r + e < b.row1) grads[b.dst + (r + e - b.row0)] = v[e];
             }
             return;
         }
     }
 }
 
-__global__ void k_reduce_heads(const float* __restrict__ heads, int grid, HeadDst d, float* __restrict__ grads) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= kHeadFloats) return;
+// the 1-4-row heads' partials [grid][kHeadFloats]: 64 columns per workgroup, its four waves take every fourth row
+__global__ __launch_bounds__(256) void k_reduce_heads(const float* __restrict__ heads, int grid, HeadDst d, float* __restrict__ grads) {
+    __shared__ float part[4][64];
+    const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + col;
     float v = 0.0f;
-    for (int g = 0; g < grid; ++g) v += heads[(size_t)g * kHeadFloats + i];
+    if (i < kHeadFloats)
+        for (int g = rg; g < grid; g += 4) v += heads[(size_t)g * kHeadFloats + i];
+    part[rg][col] = v;
+    __syncthreads();
+    if (rg != 0 || i >= kHeadFloats) return;
+    v = ((part[0][col] + part[1][col]) + part[2][col]) + part[3][col];
     if (i < kHeadAs2) grads[d.res_w + i] = v;                                                 // residual head [3][128]
     else if (i < kHeadAlpha) {
         const int j = (i - kHeadAs2) / kWidth, c = (i - kHeadAs2) % kWidth;
@@ -338,8 +362,8 @@ extern "C" int inerf_mlp_backward(const inerf_net_desc* net, const float* packed
                                        j.bias_src >= 0 ? partial + j.bias_src : nullptr, t.total, stream);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_reduce_scatter, dim3((unsigned)((t.total + 255) / 256)), dim3(256), 0, stream, t, partial, grads_out);
+    hipLaunchKernelGGL(k_reduce_scatter, dim3((unsigned)((t.total / 4 + 255) / 256)), dim3(256), 0, stream, t, partial, grads_out);
     const HeadDst& d = cache.heads;
-    hipLaunchKernelGGL(k_reduce_heads, dim3((kHeadFloats + 255) / 256), dim3(256), 0, stream, heads, plan.bwd_grid, d, grads_out);
+    hipLaunchKernelGGL(k_reduce_heads, dim3((kHeadFloats + 63) / 64), dim3(256), 0, stream, heads, plan.bwd_grid, d, grads_out);
     return record(hipGetLastError());
 }

@@ -48,7 +48,7 @@ if a.ssr >= 0:          # trainer.py:876-991: 1024 rays (512 + neighbours), dept
 
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        for _ in range(3):
+        for _ in range(10):
             sstep()
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(a.iters):
@@ -82,8 +82,8 @@ def step():
 
 with warnings.catch_warnings():
     warnings.simplefilter("ignore")
-    for _ in range(3):
-        step()
+    for _ in range(10):          # the caching allocator needs a few steps to settle on the step's multi-GB blocks (3 warm-ups measured
+        step()                   # 13.1 ms where the steady state is 11.4)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.iters):
