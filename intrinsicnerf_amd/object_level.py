@@ -413,7 +413,7 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
                 if np_state is not None:
                     np.random.set_state(np_state)
                 ret = staged(None)
-    if verbose:   # the reference's DEBUG nan/inf scan (run_nerf.py:524-526); each check is a device sync
+    if verbose and not kernels._capturing():   # the reference's DEBUG nan/inf scan (run_nerf.py:524-526); each check is a device sync
         for k in ret:
             if torch.isnan(ret[k]).any() or torch.isinf(ret[k]).any():
                 print(f"! [Numerical Error] {k} contains nan or inf.")

@@ -443,7 +443,7 @@ class SSRRenderMixin:
                 ret["raw_fine"] = o["raw_fine"]
             if ep:
                 ret["feat_map_fine"] = o["feat_fine"]
-        if self.check_numerics:
+        if self.check_numerics and not kernels._capturing():      # (a host read per key: not possible while a HIP graph records)
             for k in ret:
                 if torch.isnan(ret[k]).any() or torch.isinf(ret[k]).any():
                     print(f"! [Numerical Error] {k} contains nan or inf.")

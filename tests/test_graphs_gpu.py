@@ -95,3 +95,51 @@ def test_a_batch_outside_the_f16_range_does_not_reach_the_optimizer_through_the_
     assert step.fallbacks == 1, "the graph's range word must have sent this batch to the eager path"
     assert torch.isfinite(loss).all()
     assert all(torch.isfinite(p).all() for p in list(net_c.parameters()) + list(net_f.parameters()))
+
+
+def test_graphed_ssr_trainer_step_equals_the_eager_step(monkeypatch):
+    """The SSR trainer's step (trainer.py:876-991: render_rays -> photometric + semantic cross-entropy -> backward -> Adam) through
+    SSRRenderMixin.render_rays as HIP graphs: bit for bit the eager step (no jitter / noise, so no random draws)."""
+    from intrinsicnerf_amd import graphs, ssr
+    from oracle import calibration as cal
+    monkeypatch.setenv("INERF_PRECISION", "f16x3")
+    dev = torch.device("cuda:0")
+    C, n = 5, 40
+    g = torch.Generator().manual_seed(2)
+    d = torch.randn(n, 3, generator=g)
+    d = d / d.norm(dim=-1, keepdim=True)
+    rays = torch.cat([torch.tensor([[0.5, 0.2, 0.1]]).expand(n, 3), d, 0.1 * torch.ones(n, 1), 10 * torch.ones(n, 1), d], -1)
+    sd_c, sd_f = cal.calibrated_default_init("ssr", C, 0, rays), cal.calibrated_default_init("ssr", C, 1, rays)
+    target = torch.rand(n, 3, generator=g).to(dev)
+    labels = torch.randint(0, C, (n,), generator=g).to(dev)
+    rays = rays.to(dev)
+    out = {}
+    for mode in ("eager", "graph"):
+        r = ssr.SSRRenderer(C, white_bkgd=False, endpoint_feat=False, chunk=16, device=dev, perturb=0., raw_noise_std=0.)
+        r.ssr_net_coarse.load_state_dict(sd_c); r.ssr_net_fine.load_state_dict(sd_f)
+        r.training = True                                                    # check_numerics stays on: skipped while a graph records
+        opt = torch.optim.Adam(list(r.ssr_net_coarse.parameters()) + list(r.ssr_net_fine.parameters()), lr=1e-4, capturable=True)
+
+        def loss_fn(rb, tg):
+            ret = r.render_rays(rb)                                          # three chunks of <= 16 rays
+            ce = torch.nn.functional.cross_entropy
+            return ((ret["rgb_fine"] - tg) ** 2).mean() + ((ret["rgb_coarse"] - tg) ** 2).mean() \
+                + 0.04 * ce(ret["sem_logits_fine"], labels) + 0.04 * ce(ret["sem_logits_coarse"], labels)
+
+        losses = []
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            step = graphs.GraphedTrainStep(loss_fn, (rays, target), opt) if mode == "graph" else None
+            for _ in range(3):
+                if step is None:
+                    opt.zero_grad(set_to_none=True)
+                    loss = loss_fn(rays, target)
+                    loss.backward()
+                    opt.step()
+                else:
+                    loss = step(rays, target)
+                losses.append(float(loss))
+        out[mode] = (losses, [p.detach().clone() for p in list(r.ssr_net_coarse.parameters()) + list(r.ssr_net_fine.parameters())])
+    assert out["eager"][0] == out["graph"][0] and out["graph"][0][-1] < out["graph"][0][0], out
+    for a, b in zip(out["eager"][1], out["graph"][1]):
+        assert torch.equal(a, b)
