@@ -111,6 +111,8 @@ def uncurated_weights(fx):
     """The two default-init state dicts of an ``uncurated_*`` fixture: seeded ``make_state_dict`` plus the stored
     calibration of the density head (a power-of-two gain on alpha_linear.weight, the bias as stored)."""
     variant, c = str(fx["variant"]), int(fx["n_classes"])
+    if any(k.startswith("w_coarse/") for k in fx):       # trained weights, stored in the fixture (make_golden_trained.py)
+        return [{k.split("/", 1)[1]: torch.from_numpy(np.array(fx[k])) for k in fx if k.startswith(f"w_{lvl}/")} for lvl in ("coarse", "fine")]
     out = []
     for lvl in ("coarse", "fine"):
         sd = oracle.make_state_dict(variant, c, seed=int(fx["seed_" + lvl]))

@@ -64,7 +64,7 @@ def _stage_reference(fx):
     return ref
 
 
-@pytest.mark.parametrize("name", golden_names("uncurated_"))
+@pytest.mark.parametrize("name", golden_names("uncurated_") + golden_names("trained_"))
 def test_oracle_reproduces_the_reference_stage_tensors(name):
     """The stage tensors recorded from the REAL reference (z, raw, weights of both passes, z_samples) are what the oracle
     computes - bit for bit - so every ``worst`` of the strict report is exactly 0 and nothing is skipped."""

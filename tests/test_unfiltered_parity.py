@@ -143,7 +143,7 @@ def test_unfiltered_rays_rank_statistics(variant, precision):
         print(f"  {k:16s} hip-vs-fp32: {cal.summarize(e_hip[k])}\n  {'':16s} fp32-vs-fp64: {cal.summarize(e_ref[k])}")
 
 
-@pytest.mark.parametrize("name", golden_names("uncurated_"))
+@pytest.mark.parametrize("name", golden_names("uncurated_") + golden_names("trained_"))
 def test_uncurated_reference_fixtures(name, precision):
     """The same judgement against outputs of the REAL reference (tests/golden/make_golden_uncurated.py): default-init
     networks, every k-th ray of the benchmark frames, nothing selected.  ``uncurated_object_coarse_only_wb`` is BASELINE
@@ -173,7 +173,7 @@ def _stage_reference(fx):
     return ref
 
 
-@pytest.mark.parametrize("name", golden_names("uncurated_"))
+@pytest.mark.parametrize("name", golden_names("uncurated_") + golden_names("trained_"))
 def test_uncurated_stagewise_strict(name, precision):
     """the PLAIN 1e-4 tolerance on EVERY ray of the un-curated fixtures (default-init networks, unfiltered
     rays of the benchmark frames), stage by stage against tensors recorded from the REAL reference while it ran
