@@ -184,10 +184,17 @@ def evaluate(net_c, net_f, query, dev, side, lines, target_fn=analytic_render):
     p_hip = stagewise.psnr(got["rgb_map"].cpu().numpy(), target)
     p_o32 = stagewise.psnr(o32["rgb_fine"].numpy(), target)
     p_o64 = stagewise.psnr(o64["rgb_fine"].numpy(), target)
-    summary.update(psnr_hip=p_hip, psnr_oracle=p_o32, psnr_delta_db=p_hip - p_o32, worst_activation=worst_act)
+    e2 = float(np.mean((got["rgb_map"].cpu().numpy().astype(np.float64) - o32["rgb_fine"].numpy()) ** 2))
+    mse = float(np.mean((o32["rgb_fine"].numpy().astype(np.float64) - target) ** 2))
+    kdb = 10.0 / np.log(10.0)
+    # MSE(HIP) - MSE(oracle) = mean(e^2) + 2 mean(e r), e = HIP - oracle, r = oracle - target: the first term is systematic, the
+    # second averages out over the pixels (scale 2 sqrt(mean(e^2) mean(r^2) / n)) - it dominates on a small view of a barely fitted net
+    summary.update(psnr_hip=p_hip, psnr_oracle=p_o32, psnr_delta_db=p_hip - p_o32, worst_activation=worst_act,
+                   psnr_delta_systematic_db=-kdb * e2 / mse, psnr_delta_sampling_db=kdb * 2.0 * np.sqrt(e2 * mse / target.size) / mse)
     lines.append("## 3. PSNR of the held-out view against the analytic target (run_nerf_helpers.py:11-12)")
     lines.append(f"PSNR(HIP) = {p_hip:.7f} dB   PSNR(oracle fp32) = {p_o32:.7f} dB   delta = {p_hip - p_o32:+.3e} dB   "
-                 f"(oracle fp32 vs fp64: {p_o32 - p_o64:+.3e} dB; budget 1e-4 dB)")
+                 f"(oracle fp32 vs fp64: {p_o32 - p_o64:+.3e} dB; budget 1e-4 dB; systematic part {summary['psnr_delta_systematic_db']:+.1e} dB, "
+                 f"pixel-sampling scale {summary['psnr_delta_sampling_db']:.1e} dB on {target.size} values)")
     return summary
 
 

@@ -40,7 +40,10 @@ def test_200_step_fit_and_what_the_trained_weights_do(monkeypatch):
     assert s["worst_activation"] < 7.5e3, "a trained network left the f16x3 activation range"
     assert s["stagewise_violations"] == 0, "\n".join(lines)
     assert not any(m["rank_violations"] for m in s["maps"].values()), "\n".join(lines)
-    assert abs(s["psnr_delta_db"]) <= 1e-4, s
+    # 200 steps give ~18 dB on a 24x24 view: the delta's pixel-sampling term (fit_synthetic.evaluate) is of the budget's size there;
+    # its systematic part must be far inside the 1e-4 dB budget, and the delta itself inside budget + sampling scale
+    assert abs(s["psnr_delta_systematic_db"]) <= 1e-5, s
+    assert abs(s["psnr_delta_db"]) <= 1e-4 + 4.0 * s["psnr_delta_sampling_db"], s
     # the HIP network backward tracks torch's layers: same initial weights, batches and jitter
     curves = {}
     for mode in ("hip", "torch"):
