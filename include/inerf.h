@@ -30,7 +30,7 @@ extern "C" {
 #define INERF_VERSION_MINOR 2
 /* Bumped whenever a struct layout, an argument list or the packed-weight format of this header changes; bindings
  * compare it with inerf_abi_version() of the library they loaded (a stale .so then fails loudly, not silently). */
-#define INERF_ABI_VERSION 30002
+#define INERF_ABI_VERSION 30003
 
 /* error codes */
 #define INERF_OK              0
@@ -122,6 +122,16 @@ int inerf_sample_coarse(const float* rays, const float* t_vals, const float* t_r
  * status: optional device int32 the kernel ORs INERF_STATUS_* bits into (caller zeroes it). */
 int inerf_encode_mlp(const inerf_net_desc* net, const float* packed_weights, const float* rays, const float* z_vals,
                      int64_t n_rays, int n_samples, uint32_t flags, float* raw_out, int32_t* status, void* stream);
+
+/* The same with a caller-owned scratch buffer of inerf_encode_mlp_workspace_bytes() bytes (0 for most configurations).  With
+ * it the INERF_PREC_F16X3 kernel of the SSR network splits the semantic hidden layer (semantic_nerf.py:110,150-152) over the
+ * waves by channel and parks the per-wave partial logits in the scratch until the tile's activations are dead - the weights of
+ * semantic_linear.0.0 are then streamed once per 64-point tile instead of four times.  Same results as inerf_encode_mlp up to
+ * the summation order of the logits.  inerf_render_rays uses this form (its workspace includes the scratch). */
+int64_t inerf_encode_mlp_workspace_bytes(const inerf_net_desc* net, int64_t n_rays, int n_samples, uint32_t flags);
+int inerf_encode_mlp_ws(const inerf_net_desc* net, const float* packed_weights, const float* rays, const float* z_vals,
+                        int64_t n_rays, int n_samples, uint32_t flags, float* raw_out, int32_t* status, void* workspace,
+                        int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Training: what autograd records for the network when the trainers call loss.backward()

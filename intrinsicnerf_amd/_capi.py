@@ -10,7 +10,7 @@ import os
 from . import _build
 from ._build import LIB_PATH
 
-ABI_VERSION = 30002          # INERF_ABI_VERSION of include/inerf.h these ctypes declarations mirror
+ABI_VERSION = 30003          # INERF_ABI_VERSION of include/inerf.h these ctypes declarations mirror
 
 OK, E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_HIP = 0, -1, -2, -3, -4
 VARIANT_OBJECT, VARIANT_SSR = 0, 1
@@ -60,6 +60,8 @@ SYMBOLS = {
     "inerf_pack_weights": (_I, [C.POINTER(NetDesc), C.POINTER(_P), _I, _P, _L]),
     "inerf_sample_coarse": (_I, [_P, _P, _P, _L, _I, _U, _P, _P]),
     "inerf_encode_mlp": (_I, [C.POINTER(NetDesc), _P, _P, _P, _L, _I, _U, _P, _P, _P]),
+    "inerf_encode_mlp_workspace_bytes": (_L, [C.POINTER(NetDesc), _L, _I, _U]),
+    "inerf_encode_mlp_ws": (_I, [C.POINTER(NetDesc), _P, _P, _P, _L, _I, _U, _P, _P, _P, _L, _P]),
     "inerf_mlp_save_floats": (_L, [C.POINTER(NetDesc), _L]),
     "inerf_mlp_save_slot": (_I, [C.POINTER(NetDesc), _I, _L, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "inerf_encode_mlp_train": (_I, [C.POINTER(NetDesc), _P, _P, _P, _L, _I, _U, _P, _P, _P, _P, _P]),

@@ -12,7 +12,7 @@ constexpr int64_t kAlign = 256;
 inline int64_t up(int64_t b) { return (b + kAlign - 1) / kAlign * kAlign; }
 
 struct Plan {
-    int64_t z_c, w_c, raw_c, z_s, z_f, raw_f, total;
+    int64_t z_c, w_c, raw_c, z_s, z_f, raw_f, mlp_ws, mlp_ws_bytes, total;
     int ch_c, ch_f, s_f;
 };
 
@@ -46,6 +46,12 @@ Plan plan(const inerf_net_desc& net, int64_t n, int sc, int ni, uint32_t flags, 
         p.z_f = take(n * p.s_f, kHaveZf);
         p.raw_f = take(n * p.s_f * p.ch_f, kHaveRawF);
     }
+    // scratch of the encode+MLP launches (the SSR network's channel-split semantic head); one region serves both passes
+    const int64_t ws_c = inerf_encode_mlp_workspace_bytes(&net, n, sc, flags & ~INERF_FLAG_ENDPOINT);
+    const int64_t ws_f = ni > 0 ? inerf_encode_mlp_workspace_bytes(&net, n, p.s_f, flags) : 0;
+    p.mlp_ws_bytes = ws_c > ws_f ? ws_c : ws_f;
+    p.mlp_ws = off;
+    off += up(p.mlp_ws_bytes);
     p.total = off;
     return p;
 }
@@ -85,7 +91,8 @@ extern "C" int inerf_render_rays(const inerf_render_args* a, void* stream) {
     if (rc) return rc;
     float* raw_c = a->raw_coarse ? a->raw_coarse : f(p.raw_c);
     // the coarse net never emits the endpoint feature (trainer.py:751-755: endpoint_feat=False)
-    rc = inerf_encode_mlp(&a->net, a->packed_coarse, a->rays, z_c, n, sc, a->flags & ~INERF_FLAG_ENDPOINT, raw_c, a->status, stream);
+    rc = inerf_encode_mlp_ws(&a->net, a->packed_coarse, a->rays, z_c, n, sc, a->flags & ~INERF_FLAG_ENDPOINT, raw_c, a->status,
+                             ws + p.mlp_ws, p.mlp_ws_bytes, stream);
     if (rc) return rc;
     inerf_composite_out oc = a->coarse;
     oc.feat = nullptr;
@@ -101,7 +108,7 @@ extern "C" int inerf_render_rays(const inerf_render_args* a, void* stream) {
     if (rc) return rc;
     float* raw_f = a->raw_fine ? a->raw_fine : f(p.raw_f);
     const float* w_fine = a->packed_fine ? a->packed_fine : a->packed_coarse;   // run_nerf.py:506
-    rc = inerf_encode_mlp(&a->net, w_fine, a->rays, z_f, n, p.s_f, a->flags, raw_f, a->status, stream);
+    rc = inerf_encode_mlp_ws(&a->net, w_fine, a->rays, z_f, n, p.s_f, a->flags, raw_f, a->status, ws + p.mlp_ws, p.mlp_ws_bytes, stream);
     if (rc) return rc;
     const bool ep = ssr && (a->flags & INERF_FLAG_ENDPOINT);
     inerf_composite_out of = a->fine;

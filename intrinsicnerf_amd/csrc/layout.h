@@ -55,7 +55,8 @@ constexpr int kLdsBytes = kTilePoints * kLdsStride * 4;   // 156,672 B of the CU
 // stored as 32x16 A fragments whose k order follows the accumulator registers:
 //     [wave][q][hi|lo][lane][8 halfs],  row = lane & 31 (zero beyond the head's rows),
 //     hidden channel = wave * 16*Q + regop_chan(q, lane >> 5, c),  Q = k-blocks per wave (4: as2r, 2: resr).
-// The semantic head of that kernel works per wave on v_mfma_f32_16x16x32_f16 (16 points x 16 rows): sem1s is sem1 in the
+// sem2q: the same per 32-class block rb: [rb][wave][q][hi|lo][lane][8 halfs], row = 32*rb + (lane & 31), Q = 2.
+// The semantic head of that kernel's TRAINING form works per wave on v_mfma_f32_16x16x32_f16 (16 points x 16 rows): sem1s is sem1 in the
 // skinny format with sem1's scale; its four-row accumulators (lane l: rows 4*(l>>4) .. +3 of a 16-row block) of two
 // neighbouring row blocks form one 32-deep B operand, so sem2r stores semantic_linear.1 as skinny fragments whose k order is
 //     hidden channel = 32*kb + regop16_chan(lane >> 4, c),   regop16_chan(g, c) = 16*(c >> 2) + 4*g + (c & 3).
@@ -83,7 +84,11 @@ struct NetLayout {
     GemmSlot sem1s;           // sem1 again, in the skinny format (8 row blocks, K=256; w only): every wave of the two-workgroup
                               //   kernel computes the whole semantic hidden layer for its own 16 points
     GemmSlot sem2r;           // sem2 again, as 16-row register-operand fragments (w only)
+    GemmSlot sem2q;           // sem2 once more, as 32-row register-operand fragments per 32-class block (w only): the inference form
+                              //   of the two-workgroup kernel splits the semantic hidden layer over the waves BY CHANNEL (32 each,
+                              //   like the view layer), so semantic_linear.0.0 is streamed once per tile instead of four times
     int32_t sem_rbs;          // ceil(C/16), 0 when the semantic head is absent
+    int32_t sem_rb32;         // ceil(C/32)
     int32_t total_floats;
 };
 
@@ -121,6 +126,8 @@ inline NetLayout make_layout(const inerf_net_desc& net) {
     if (L.sem_rbs > 0) {
         L.sem1s.w = take(kHalf * kWidth);           L.sem1s.b = L.sem1.b;
         L.sem2r.w = take(L.sem_rbs * 16 * kHalf);   L.sem2r.b = L.sem2.b;
+        L.sem_rb32 = (net.n_classes + 31) / 32;
+        L.sem2q.w = take(L.sem_rb32 * 32 * kHalf);  L.sem2q.b = L.sem2.b;      // per block: 4 waves x 2 k-blocks x (hi + lo) KiB
     }
     L.total_floats = off;
     return L;

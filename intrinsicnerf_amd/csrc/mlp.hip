@@ -416,7 +416,23 @@ int launch_mlp_f32(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream)
 }  // namespace inerf
 
 static int encode_mlp_impl(const inerf_net_desc* net, const float* packed, const float* rays, const float* z, int64_t n_rays,
-                           int n_samples, uint32_t flags, float* raw_out, float* save, float* act_max, int32_t* status, void* stream);
+                           int n_samples, uint32_t flags, float* raw_out, float* save, float* act_max, int32_t* status, void* stream,
+                           float* sem_scratch = nullptr);
+
+extern "C" int64_t inerf_encode_mlp_workspace_bytes(const inerf_net_desc* net, int64_t n_rays, int n_samples, uint32_t flags) {
+    if (!net || !inerf::net_supported(*net) || n_rays < 0 || n_samples < 1) return INERF_E_INVALID;
+    return inerf::sem_scratch_bytes(*net, n_rays * (int64_t)n_samples, (flags & INERF_FLAG_ENDPOINT) != 0);
+}
+
+extern "C" int inerf_encode_mlp_ws(const inerf_net_desc* net, const float* packed, const float* rays, const float* z, int64_t n_rays,
+                                   int n_samples, uint32_t flags, float* raw_out, int32_t* status, void* workspace,
+                                   int64_t workspace_bytes, void* stream) {
+    if (!net || !inerf::net_supported(*net) || n_rays < 0 || n_samples < 1) return INERF_E_INVALID;
+    const int64_t need = inerf::sem_scratch_bytes(*net, n_rays * (int64_t)n_samples, (flags & INERF_FLAG_ENDPOINT) != 0);
+    if (need > 0 && (!workspace || workspace_bytes < need)) return INERF_E_WORKSPACE;
+    return encode_mlp_impl(net, packed, rays, z, n_rays, n_samples, flags, raw_out, nullptr, nullptr, status, stream,
+                           need > 0 ? static_cast<float*>(workspace) : nullptr);
+}
 
 extern "C" int inerf_encode_mlp(const inerf_net_desc* net, const float* packed, const float* rays, const float* z,
                                 int64_t n_rays, int n_samples, uint32_t flags, float* raw_out, int32_t* status,
@@ -447,7 +463,8 @@ extern "C" int inerf_encode_mlp_train(const inerf_net_desc* net, const float* pa
 }
 
 static int encode_mlp_impl(const inerf_net_desc* net, const float* packed, const float* rays, const float* z, int64_t n_rays,
-                           int n_samples, uint32_t flags, float* raw_out, float* save, float* act_max, int32_t* status, void* stream) {
+                           int n_samples, uint32_t flags, float* raw_out, float* save, float* act_max, int32_t* status, void* stream,
+                           float* sem_scratch) {
     using namespace inerf;
     if (net && n_rays == 0) return net_supported(*net) ? INERF_OK : INERF_E_UNSUPPORTED;      // empty batch: pointers may be null
     if (!net || !packed || !rays || !z || !raw_out || n_rays < 0 || n_samples < 1) return INERF_E_INVALID;
@@ -460,6 +477,7 @@ static int encode_mlp_impl(const inerf_net_desc* net, const float* packed, const
     p.wts = packed; p.rays = rays; p.z = z; p.raw = raw_out; p.status = status;
     p.save = save;
     p.act_max = act_max;
+    p.sem_scratch = sem_scratch;
     for (int s = 0; s < SAVE_SLOTS; ++s) p.save_off[s] = save_offset(*net, s, n_points);
     p.bits_off = relu_bits_offset(*net, n_points);
     p.L = make_layout(*net);

@@ -15,6 +15,7 @@ struct MlpParams {
     int32_t* status;        // optional device word for INERF_STATUS_* bits
     float* save;            // training forward: activation buffer (layout.h SaveSlot), else nullptr
     float* act_max;         // training forward, optional: device float that receives max |activation| (caller zeroes it)
+    float* sem_scratch;     // SSR inference, optional: per-workgroup scratch for the channel-split semantic head (sem_scratch_bytes)
     int64_t save_off[SAVE_SLOTS];   // float offsets of the slots for this launch's n_points
     int64_t bits_off;       // float offset of the ReLU-mask area (layout.h relu_bits_offset)
     NetLayout L;
@@ -63,5 +64,6 @@ struct PerDeviceOnce {
 int record(hipError_t e);
 int launch_mlp_f32(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream);
 int launch_mlp_f16x3(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream);   // p.save != nullptr: saving variant
+int64_t sem_scratch_bytes(const inerf_net_desc& net, int64_t n_points, bool endpoint);   // 0 when the launch would not use one
 
 }  // namespace inerf

@@ -282,8 +282,16 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
 // LDS per workgroup: two planes (hi, lo) of X[64 points][296 halfs] = [h 256 | dir 32 | pad 8]; 592-byte rows
 // put the 16 rows of a ds_read_b128 lane group on 16 distinct bank slots.
 // ================================================================================================
-template <bool kSave, bool kSsr>
+// kSplit (SSR inference with a scratch buffer): the semantic hidden layer is split over the waves by CHANNEL like the other
+// hidden layers - wave w computes channels 32w .. 32w+31 for all 64 points, so semantic_linear.0.0 is streamed once per tile
+// instead of four times (in the per-wave form below the head's weight stream, 512 KB per tile through the CU's 64 B/clk vector
+// memory path, takes 2.7x the cycles of its own MFMAs).  The price is that the logits then exist as four per-wave partial sums
+// while LDS is still full of h7: each wave parks ITS partials (32 accumulator registers per 32 classes) in a private,
+// L2-resident scratch slot - an explicit spill, placed where nothing waits for it - and fetches them back at the end of the
+// tile, when the activation planes are dead and the four partials can meet in LDS.
+template <bool kSave, bool kSsr, bool kSplit = false>
 __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParams p) {
+    static_assert(!kSplit || (kSsr && !kSave), "the channel-split semantic head is the SSR inference form");
     constexpr int kPts = kTilePoints;
     constexpr int kParts = 256 / kPts;
     extern __shared__ __attribute__((aligned(16))) _Float16 ldsd[];
@@ -451,12 +459,37 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
             wide_gemm_h<2, 16, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.as1, 16), xr, 0, 0, lane, am2);
             load_bias<2>(bias2, inv2, wb, (L.as1.b + 64 * wave) * 4, (L.as1.b + kWidth) * 4, lane);
             prefetch_w<2>(pre2, wb, frag256(L.feat, 16));
+            if constexpr (kSplit) prefetch_w<1>(pre1, wb, frag128(L.sem1, 16));
             f16x8 hi[4][2], lo[4][2];
             const SaveDst sv = save_dst(SAVE_AS1H, kWidth, 64 * wave);
             to_operands<2, kSave>(am2, inv2, bias2, amax2, hi, lo, &sv);
             regop_gemm<4>(wb, (L.as2r.w + wave * 4 * 2 * 256) * 4, hi, lo, part_as);
         }
-        if (kSsr && L.sem_rbs > 0) {               // semantic logits straight to raw[11 .. 11+C) (semantic_nerf.py:150-152)
+        const __amdgpu_buffer_rsrc_t sem_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            p.sem_scratch, 0, kSplit ? (int)((unsigned)gridDim.x * (unsigned)L.sem_rb32 * (unsigned)kSemScratchBytes) : 0, 0x00020000);
+        if constexpr (kSplit) {                    // semantic_nerf.py:150-152, hidden layer split over the waves by channel
+            f32x16 am1[1][2];
+            f32x4 bias1[1][4];
+            float inv1;
+            wide_gemm_h<1, 16, 0, kRowD, kPlaneD>(pre1, wb, frag128(L.sem1, 16), xr, 0, 0, lane, am1);
+            load_bias<1>(bias1, inv1, wb, (L.sem1.b + 32 * wave) * 4, (L.sem1.b + kHalf) * 4, lane);
+            f16x8 hi[2][2], lo[2][2];
+            to_operands<1, false>(am1, inv1, bias1, amax2, hi, lo, nullptr);
+#pragma unroll 1
+            for (int rb = 0; rb < L.sem_rb32; ++rb) {      // this wave's partial logits of classes 32 rb .. +31 -> its scratch slot
+                f32x16 acc[2];
+                regop_gemm_full<2>(wb, (L.sem2q.w + (rb * 4 + wave) * 2 * 2 * 256) * 4, hi, lo, acc);
+                const int slot = ((int)blockIdx.x * L.sem_rb32 + rb) * kSemScratchBytes + wave * (kSemScratchBytes / 4);
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 v = {acc[pb][4 * g], acc[pb][4 * g + 1], acc[pb][4 * g + 2], acc[pb][4 * g + 3]};
+                        // (whole offset in the VGPR operand: a 16-byte buffer store with a register SGPR offset gets no hazard wait state, tests/test_isa_audit_cpu.py)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), sem_rsrc, lane * 16 + slot + (pb * 4 + g) * 1024, 0, 0);
+                    }
+            }
+        } else if (kSsr && L.sem_rbs > 0) {        // semantic logits straight to raw[11 .. 11+C), every wave the whole head for its 16 points
             SaveDst sv;
             sv.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save + (kSave ? p.save_off[SAVE_SEMH] : 0), 0,
                                                         kSave ? (int)((unsigned)p.n_points * (unsigned)kHalf * 4u) : 0, 0x00020000);
@@ -515,6 +548,42 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
             __builtin_nontemporal_store(sh, out_row + 7);
             __builtin_nontemporal_store(r0, out_row + 8); __builtin_nontemporal_store(r1, out_row + 9); __builtin_nontemporal_store(r2, out_row + 10);
         }
+        if constexpr (kSplit) {
+            // The four waves' partial logits meet in the (dead) lo plane: row = point, floats [wave][32 classes].  Each wave fetches
+            // its own partials back from its scratch slot (sc0: past the vector L1, whose lines of a previous tile may be stale),
+            // then sums, for its 16 points, the four waves' rows in a fixed order.
+            float* const lo_rows = reinterpret_cast<float*>(ldsd + kPlaneD);
+            constexpr int kRowF = kRowD / 2;                                  // floats per LDS row
+            const float inv2 = wb.scalar((L.sem2.b + 16 * L.sem_rbs) * 4);
+#pragma unroll 1
+            for (int rb = 0; rb < L.sem_rb32; ++rb) {
+                if (rb > 0) __syncthreads();                                  // the previous block's sums have been read
+                const int slot = ((int)blockIdx.x * L.sem_rb32 + rb) * kSemScratchBytes + wave * (kSemScratchBytes / 4);
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(sem_rsrc, lane * 16, slot + (pb * 4 + g) * 1024, 1);
+                        *reinterpret_cast<u32x4*>(lo_rows + (32 * pb + (lane & 31)) * kRowF + 32 * wave + 8 * g + 4 * (lane >> 5)) = v;
+                    }
+                __syncthreads();
+                const float* row = lo_rows + (16 * wave + (lane & 15)) * kRowF + 8 * (lane >> 4);
+                f32x4 s0 = {0.0f, 0.0f, 0.0f, 0.0f}, s1 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    s0 += *reinterpret_cast<const f32x4*>(row + 32 * w);
+                    s1 += *reinterpret_cast<const f32x4*>(row + 32 * w + 4);
+                }
+                const int c0 = 32 * rb + 8 * (lane >> 4);
+                const f32x4 b0 = wb.vec4((L.sem2.b + c0) * 4, 0), b1 = wb.vec4((L.sem2.b + c0 + 4) * 4, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (my_valid && c0 + i < p.n_classes) __builtin_nontemporal_store(__builtin_fmaf(s0[i], inv2, b0[i]), out_row + INERF_BASE_CHANNELS + c0 + i);
+                    if (my_valid && c0 + 4 + i < p.n_classes) __builtin_nontemporal_store(__builtin_fmaf(s1[i], inv2, b1[i]), out_row + INERF_BASE_CHANNELS + c0 + 4 + i);
+                }
+            }
+            __syncthreads();                       // the next tile's encode writes columns 0..63 of both planes
+        }
     }
     const float amax_all = fmaxf(amax, fmaxf((float)amax2[0], (float)amax2[1]));
     if (p.status && __any(!(amax_all <= kF16Safe)) && lane == 0) atomicOr(p.status, INERF_STATUS_F16_RANGE);
@@ -526,15 +595,26 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
     }
 }
 
+int64_t sem_scratch_bytes(const inerf_net_desc& net, int64_t n_points, bool endpoint) {
+    const char* form = getenv("INERF_F16_KERNEL");
+    if (net.precision != INERF_PREC_F16X3 || net.variant != INERF_VARIANT_SSR || net.n_classes <= 0 || endpoint || n_points <= 0) return 0;
+    if (form && (form[0] == 's' || form[0] == 'w')) return 0;          // single: one workgroup per CU; wave: the per-wave head (A/B runs)
+    const int64_t tiles = (n_points + kTilePoints - 1) / kTilePoints;
+    const int64_t grid = tiles < 2 * device_cus() ? tiles : 2 * device_cus();
+    return grid * ((net.n_classes + 31) / 32) * kSemScratchBytes;
+}
+
 static int launch_dual(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream) {
     p.n_tiles = (int)((n_points + kTilePoints - 1) / kTilePoints);
     const int max_grid = 2 * device_cus();
     const int grid = p.n_tiles < max_grid ? p.n_tiles : max_grid;
     const bool save = p.save != nullptr;
-    void (*kern)(const MlpParams) = ssr ? (save ? k_encode_mlp_f16x3_dual<true, true> : k_encode_mlp_f16x3_dual<false, true>)
+    const bool split = ssr && !save && p.sem_scratch && p.L.sem_rbs > 0;
+    void (*kern)(const MlpParams) = split ? k_encode_mlp_f16x3_dual<false, true, true>
+                                  : ssr ? (save ? k_encode_mlp_f16x3_dual<true, true> : k_encode_mlp_f16x3_dual<false, true>)
                                         : (save ? k_encode_mlp_f16x3_dual<true, false> : k_encode_mlp_f16x3_dual<false, false>);
-    static PerDeviceOnce attr_set[4];
-    const int variant = 2 * (int)ssr + (int)save;
+    static PerDeviceOnce attr_set[5];
+    const int variant = split ? 4 : 2 * (int)ssr + (int)save;
     if (attr_set[variant].first()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesD);
         if (e != hipSuccess) return record(e);

@@ -79,6 +79,28 @@ __device__ __forceinline__ void regop_gemm(const WeightBuf& wb, int frag_bytes, 
     for (int pb = 0; pb < 2; ++pb) part[pb] = f32x4{acc[pb][0], acc[pb][1], acc[pb][2], acc[pb][3]};   // rows 0..3: lanes 0..31
 }
 
+// all 32 rows of a register-operand product (the semantic logits of one 32-class block, summed over this wave's Q k-blocks)
+template <int Q>
+__device__ __forceinline__ void regop_gemm_full(const WeightBuf& wb, int frag_bytes, const f16x8 (&hi)[Q][2], const f16x8 (&lo)[Q][2],
+                                                f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[pb][r] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const f16x8 wh = wb.frag(frag_bytes + (2 * q) * 1024), wl = wb.frag(frag_bytes + (2 * q + 1) * 1024);
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hi[q][pb], acc[pb], 0, 0, 0);
+            acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, lo[q][pb], acc[pb], 0, 0, 0);
+            acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, hi[q][pb], acc[pb], 0, 0, 0);
+        }
+    }
+}
+
+constexpr int kSemScratchBytes = 4 * 2 * 16 * 64 * 4;      // per workgroup and 32-class block: [wave][point block][16 registers][64 lanes] floats = 32 KiB
+
 // semantic head of the two-workgroup kernel (SSR): there is no room in LDS for the 128-channel hidden layer and no
 // registers to hold partial logits across the feature / view layers, so every wave does the whole head for ITS 16
 // points on v_mfma_f32_16x16x32_f16: hidden = relu(sem1 . h7) from the skinny-format copy of sem1 (streamed by all four

@@ -188,15 +188,16 @@ float pack_skinny_f16(float* dst_f, int rbs, int k_total, const Elem& w, float f
 
 // register-operand copy of an output head (layout.h: as2r / resr): 32-row A fragments, k in accumulator order;
 // same scale as the skinny copy of the same weights
-void pack_regop_f16(float* dst_f, int q_per_wave, int rows, int k_total, const Elem& w) {
+// row0 / forced_scale: block `row0 / 32` of a head with more than 32 rows (sem2q), scale of the skinny copy given
+void pack_regop_f16(float* dst_f, int q_per_wave, int rows, int k_total, const Elem& w, int row0 = 0, float forced_scale = 0.0f) {
     _Float16* dst = reinterpret_cast<_Float16*>(dst_f);
     // same matrix as the skinny copy packed just before: same scale, and in map mode the same scale group
-    const float sc = g_map ? 1.0f : weight_scale(rows, k_total, w);
+    const float sc = g_map ? 1.0f : (forced_scale > 0.0f ? forced_scale : weight_scale(rows, k_total, w));
     for (int wave = 0; wave < inerf::kWaves; ++wave)
         for (int q = 0; q < q_per_wave; ++q)
             for (int lane = 0; lane < 64; ++lane)
                 for (int c = 0; c < 8; ++c) {
-                    const int row = lane & 31;
+                    const int row = row0 + (lane & 31);
                     const int kv = wave * 16 * q_per_wave + inerf::regop_chan(q, lane >> 5, c);
                     const int64_t frag = ((int64_t)wave * q_per_wave + q) * 2;
                     if (g_map) {
@@ -422,6 +423,8 @@ int inerf_pack_weights(const inerf_net_desc* net, const float* const* tensors, i
         const Elem sem2 = [=](int r, int kv) { return r < c ? w2[(int64_t)r * kHalf + kv] : 0.0f; };
         pack_skinny(out + L.sem2.w, L.sem_rbs, kHalf, sem2);
         if (f16) pack_regop16_f16(out + L.sem2r.w, L.sem_rbs, kHalf, sem2, last_scale);
+        if (f16)
+            for (int rb = 0; rb < L.sem_rb32; ++rb) pack_regop_f16(out + L.sem2q.w + rb * 32 * kHalf, 2, c, kHalf, sem2, 32 * rb, last_scale);
         copy_bias(L.sem2.b, B("semantic_linear.1"), c);
         finish_skinny(L.sem2, L.sem_rbs);
     }

@@ -225,9 +225,14 @@ def encode_mlp(desc, packed, rays, z_vals, endpoint=False, status=None):
     ch = _capi.lib().inerf_raw_channels(desc, flags, 1)
     raw = _new(rays, n, s, ch)
     with torch.cuda.device(rays.device):
-        rc = _capi.lib().inerf_encode_mlp(desc, _ptr(packed), _ptr(rays), _ptr(z_vals), n, s, flags, _ptr(raw),
-                                          None if status is None else C.c_void_p(status.data_ptr()), _stream(rays))
-    _capi.check(rc, "inerf_encode_mlp")
+        ws_bytes = int(_capi.lib().inerf_encode_mlp_workspace_bytes(desc, n, s, flags))      # > 0: the SSR network's semantic-head scratch
+        if ws_bytes < 0:
+            _capi.check(ws_bytes, "inerf_encode_mlp_workspace_bytes")
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=rays.device) if ws_bytes > 0 else None
+        rc = _capi.lib().inerf_encode_mlp_ws(desc, _ptr(packed), _ptr(rays), _ptr(z_vals), n, s, flags, _ptr(raw),
+                                             None if status is None else C.c_void_p(status.data_ptr()),
+                                             None if ws is None else C.c_void_p(ws.data_ptr()), ws_bytes, _stream(rays))
+    _capi.check(rc, "inerf_encode_mlp_ws")
     return raw
 
 

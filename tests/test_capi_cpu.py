@@ -158,6 +158,8 @@ def _layout(variant, c):
     if variant == "ssr" and c > 0:       # the two-workgroup kernel's semantic head: sem1 in the skinny format, sem2 as 16-row register operands
         slots["sem1s"] = ("skinny", take(128 * 256), slots["sem1"][2], 8, 256)
         slots["sem2r"] = ("regop16", take(((c + 15) // 16) * 16 * 128), slots["sem2"][2], (c + 15) // 16, 128)
+        # ... and its inference form: sem2 as 32-row register operands per 32-class block (the hidden layer split over the waves by channel)
+        slots["sem2q"] = ("regop32", take(((c + 31) // 32) * 32 * 128), slots["sem2"][2], (c + 31) // 32, 128)
     return slots, off
 
 
@@ -267,7 +269,7 @@ def test_packer_regop_heads(capi):
     """The register-operand copies of the output heads hold the same split weights as the skinny copies, permuted
     into accumulator order, and cover every hidden channel exactly once; the fp32 format leaves them zero."""
     from intrinsicnerf_amd import packing
-    for variant, c in (("object", 0), ("ssr", 5)):
+    for variant, c in (("object", 0), ("ssr", 5), ("ssr", 70)):
         desc = capi.net_desc(capi.VARIANT_SSR if variant == "ssr" else capi.VARIANT_OBJECT, c, 10, 4, 1.0, precision=capi.PREC_F16X3)
         sd = oracle.make_state_dict(variant, c, seed=13)
         blob = packing.pack_state_dict(desc, sd).numpy()
@@ -298,6 +300,12 @@ def test_packer_regop_heads(capi):
                             lo_r[16 * rb + (lane & 15), chan] = halfs[rb, kb, 1, lane, cc]
                             seen[16 * rb + (lane & 15), chan] += 1
             assert (seen == 1).all() and np.array_equal(hi_r, hi_s) and np.array_equal(lo_r, lo_s) and hi_r[:c].any()
+            # sem2q: the same weights as 32-row register operands, one block per 32 classes, k in accumulator order (regop_chan, Q = 2)
+            for rb in range(slots["sem2q"][3]):
+                hi_q, lo_q = _unpack_regop_f16(blob, slots["sem2q"][1] + rb * 32 * 128, 2, 128)
+                rows = min(32, 16 * rbs - 32 * rb)
+                assert np.array_equal(hi_q[:rows], hi_s[32 * rb: 32 * rb + rows]) and np.array_equal(lo_q[:rows], lo_s[32 * rb: 32 * rb + rows])
+                assert not hi_q[rows:].any() and not lo_q[max(0, c - 32 * rb):].any()
         desc32 = capi.net_desc(capi.VARIANT_SSR if variant == "ssr" else capi.VARIANT_OBJECT, c, 10, 4, 1.0, precision=capi.PREC_F32)
         blob32 = packing.pack_state_dict(desc32, sd).numpy()
         assert not blob32[slots["as2r"][1]:].any()
@@ -476,13 +484,20 @@ def test_workspace_skips_caller_provided_stage_tensors(capi):
     assert lib.inerf_render_workspace_bytes(C.byref(a)) == full
     up = lambda floats: (floats * 4 + 255) // 256 * 256
     raw_c, raw_f = up(n * sc * (11 + c)), up(n * (sc + ni) * (11 + c + 128))
+    # the encode+MLP launches' own scratch (the SSR network's channel-split semantic head; the fine pass with the endpoint
+    # feature runs the one-workgroup kernel and needs none) stays in the workspace whatever the caller provides
+    mlp_ws = max(lib.inerf_encode_mlp_workspace_bytes(desc, n, sc, 0), lib.inerf_encode_mlp_workspace_bytes(desc, n, sc + ni, capi.FLAG_ENDPOINT))
+    assert lib.inerf_encode_mlp_workspace_bytes(desc, n, sc + ni, capi.FLAG_ENDPOINT) == 0 and mlp_ws % 256 == 0
+    assert mlp_ws > 0 and mlp_ws % (4 * 32768) == 0               # C = 101: four 32-class blocks of 32 KiB per workgroup
     a.raw_coarse, a.raw_fine = 0x1000, 0x2000                       # "provided" (never dereferenced here)
     assert lib.inerf_render_workspace_bytes(C.byref(a)) == full - raw_c - raw_f
     a.z_coarse, a.z_samples, a.z_fine = 0x10, 0x20, 0x30
     a.coarse.weights = 0x40
-    assert lib.inerf_render_workspace_bytes(C.byref(a)) == 0
+    assert lib.inerf_render_workspace_bytes(C.byref(a)) == mlp_ws
     # coarse-only: no resampling, no weights region
     b = capi.RenderArgs()
     b.net, b.n_rays, b.n_samples, b.n_importance = desc, n, sc, 0
-    assert lib.inerf_render_workspace_bytes(C.byref(b)) == up(n * sc) + up(n * sc * (11 + c))
+    assert lib.inerf_render_workspace_bytes(C.byref(b)) == up(n * sc) + up(n * sc * (11 + c)) + mlp_ws
+    obj = capi.net_desc(capi.VARIANT_OBJECT, 0, 10, 4, 1.0)
+    assert lib.inerf_encode_mlp_workspace_bytes(obj, n, sc + ni, 0) == 0
     assert lib.inerf_render_workspace_bytes(None) == capi.E_INVALID

@@ -76,8 +76,9 @@ def test_default_inference_kernels_do_not_live_in_scratch(tmp_path):
             if m and name:
                 scratch[name] = int(m.group(1))
     dual = {k: v for k, v in scratch.items() if "k_encode_mlp_f16x3_dual" in k}
-    assert len(dual) == 4, sorted(scratch)
-    # <kSave = false>: object-level and SSR inference (mangled: ...dualILb0ELb0EE / ...dualILb0ELb1EE)
+    assert len(dual) == 5, sorted(scratch)
+    # <kSave = false>: object-level and SSR inference (mangled: ...dualILb0ELb0ELb0EE / ...dualILb0ELb1ELb0EE, and the SSR form with the
+    # channel-split semantic head ...dualILb0ELb1ELb1EE)
     for k, v in dual.items():
         if "ILb0E" in k:
             assert v <= 64, f"{k}: {v} bytes of scratch per lane"
