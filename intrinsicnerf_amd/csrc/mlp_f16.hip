@@ -512,7 +512,49 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
             to_operands<1, kSave>(am1, inv1, bias1, amax2, hi, lo, &sv);
             regop_gemm<2>(wb, (L.resr.w + wave * 2 * 2 * 256) * 4, hi, lo, part_res);
         }
-        __syncthreads();                           // feature / dir columns are dead: exchange area may be written
+        // kSplit: the four waves' partial logits meet in dead columns too - per point 4 x 32 floats: waves 0, 1 at bytes 256..511 of
+        // the row in the hi plane, waves 2, 3 at bytes 128..383 in the lo plane (clear of the heads' exchange area, bytes 128..255 of
+        // the hi plane, and of what the next tile's encode writes before its first barriers: bytes 0..127 and 512..575).  Each wave
+        // fetches its OWN partials back from its scratch slot (sc0: past the vector L1, whose lines of an earlier tile may be stale);
+        // block 0 is requested here, so that the fetch runs under the barrier and the heads' exchange.
+        constexpr int kRowF = kRowD / 2;                                      // floats per LDS row
+        auto sem_ex = [&](int w, int r) { return reinterpret_cast<float*>(ldsd) + (w < 2 ? 64 + 32 * w : kPlaneD / 2 + 32 * (w - 1)) + r * kRowF; };
+        auto sem_fetch = [&](int rb, u32x4 (&v)[2][4]) {
+            const int slot = ((int)blockIdx.x * L.sem_rb32 + rb) * kSemScratchBytes + wave * (kSemScratchBytes / 4);
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) v[pb][g] = __builtin_amdgcn_raw_buffer_load_b128(sem_rsrc, lane * 16 + slot + (pb * 4 + g) * 1024, 0, 1);
+        };
+        auto sem_post = [&](const u32x4 (&v)[2][4]) {                         // accumulator register 4g + i = class 8g + 4 (lane >> 5) + i
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) *reinterpret_cast<u32x4*>(sem_ex(wave, 32 * pb + (lane & 31)) + 8 * g + 4 * (lane >> 5)) = v[pb][g];
+        };
+        auto sem_sum = [&](int rb, float inv2) {                              // this wave's 16 points x 32 classes: lane = (point, 8 classes)
+            const int r = 16 * wave + (lane & 15), c8 = 8 * (lane >> 4);
+            f32x4 s0 = {0.0f, 0.0f, 0.0f, 0.0f}, s1 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {                                     // fixed order: deterministic
+                s0 += *reinterpret_cast<const f32x4*>(sem_ex(w, r) + c8);
+                s1 += *reinterpret_cast<const f32x4*>(sem_ex(w, r) + c8 + 4);
+            }
+            const int c0 = 32 * rb + c8;
+            const f32x4 b0 = wb.vec4((L.sem2.b + c0) * 4, 0), b1 = wb.vec4((L.sem2.b + c0 + 4) * 4, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (my_valid && c0 + i < p.n_classes) __builtin_nontemporal_store(__builtin_fmaf(s0[i], inv2, b0[i]), out_row + INERF_BASE_CHANNELS + c0 + i);
+                if (my_valid && c0 + 4 + i < p.n_classes) __builtin_nontemporal_store(__builtin_fmaf(s1[i], inv2, b1[i]), out_row + INERF_BASE_CHANNELS + c0 + 4 + i);
+            }
+        };
+        u32x4 sem_v[2][4];
+        float sem_inv2 = 0.0f;
+        if constexpr (kSplit) {
+            sem_fetch(0, sem_v);
+            sem_inv2 = wb.scalar((L.sem2.b + 16 * L.sem_rbs) * 4);
+        }
+        __syncthreads();                           // feature / dir columns are dead: exchange areas may be written
         if (lane < 32) {
 #pragma unroll
             for (int pb = 0; pb < 2; ++pb) {
@@ -521,7 +563,20 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
                 *reinterpret_cast<f32x4*>(ex + 4) = part_res[pb];
             }
         }
+        if constexpr (kSplit) sem_post(sem_v);
         __syncthreads();
+        if constexpr (kSplit) {
+            sem_sum(0, sem_inv2);
+#pragma unroll 1
+            for (int rb = 1; rb < L.sem_rb32; ++rb) {      // more than 32 classes: one block at a time through the same area
+                sem_fetch(rb, sem_v);
+                __syncthreads();                           // the previous block's sums have been read
+                sem_post(sem_v);
+                __syncthreads();
+                sem_sum(rb, sem_inv2);
+            }
+            if (L.sem_rb32 > 1) __syncthreads();           // (keeps the area's last readers ahead of the next tile's fetch-and-post)
+        }
         if (lane < 16 && my_valid) {
             const float* ex = reinterpret_cast<const float*>(ldsd + (16 * wave + lane) * kRowD + kColExD);
             f32x4 as4 = {0.0f, 0.0f, 0.0f, 0.0f}, res4 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -547,42 +602,6 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
             __builtin_nontemporal_store(a0, out_row + 4); __builtin_nontemporal_store(a1, out_row + 5); __builtin_nontemporal_store(a2, out_row + 6);
             __builtin_nontemporal_store(sh, out_row + 7);
             __builtin_nontemporal_store(r0, out_row + 8); __builtin_nontemporal_store(r1, out_row + 9); __builtin_nontemporal_store(r2, out_row + 10);
-        }
-        if constexpr (kSplit) {
-            // The four waves' partial logits meet in the (dead) lo plane: row = point, floats [wave][32 classes].  Each wave fetches
-            // its own partials back from its scratch slot (sc0: past the vector L1, whose lines of a previous tile may be stale),
-            // then sums, for its 16 points, the four waves' rows in a fixed order.
-            float* const lo_rows = reinterpret_cast<float*>(ldsd + kPlaneD);
-            constexpr int kRowF = kRowD / 2;                                  // floats per LDS row
-            const float inv2 = wb.scalar((L.sem2.b + 16 * L.sem_rbs) * 4);
-#pragma unroll 1
-            for (int rb = 0; rb < L.sem_rb32; ++rb) {
-                if (rb > 0) __syncthreads();                                  // the previous block's sums have been read
-                const int slot = ((int)blockIdx.x * L.sem_rb32 + rb) * kSemScratchBytes + wave * (kSemScratchBytes / 4);
-#pragma unroll
-                for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(sem_rsrc, lane * 16, slot + (pb * 4 + g) * 1024, 1);
-                        *reinterpret_cast<u32x4*>(lo_rows + (32 * pb + (lane & 31)) * kRowF + 32 * wave + 8 * g + 4 * (lane >> 5)) = v;
-                    }
-                __syncthreads();
-                const float* row = lo_rows + (16 * wave + (lane & 15)) * kRowF + 8 * (lane >> 4);
-                f32x4 s0 = {0.0f, 0.0f, 0.0f, 0.0f}, s1 = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    s0 += *reinterpret_cast<const f32x4*>(row + 32 * w);
-                    s1 += *reinterpret_cast<const f32x4*>(row + 32 * w + 4);
-                }
-                const int c0 = 32 * rb + 8 * (lane >> 4);
-                const f32x4 b0 = wb.vec4((L.sem2.b + c0) * 4, 0), b1 = wb.vec4((L.sem2.b + c0 + 4) * 4, 0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (my_valid && c0 + i < p.n_classes) __builtin_nontemporal_store(__builtin_fmaf(s0[i], inv2, b0[i]), out_row + INERF_BASE_CHANNELS + c0 + i);
-                    if (my_valid && c0 + 4 + i < p.n_classes) __builtin_nontemporal_store(__builtin_fmaf(s1[i], inv2, b1[i]), out_row + INERF_BASE_CHANNELS + c0 + 4 + i);
-                }
-            }
-            __syncthreads();                       // the next tile's encode writes columns 0..63 of both planes
         }
     }
     const float amax_all = fmaxf(amax, fmaxf((float)amax2[0], (float)amax2[1]));
