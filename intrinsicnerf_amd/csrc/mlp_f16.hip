@@ -618,6 +618,10 @@ int64_t sem_scratch_bytes(const inerf_net_desc& net, int64_t n_points, bool endp
     const char* form = getenv("INERF_F16_KERNEL");
     if (net.precision != INERF_PREC_F16X3 || net.variant != INERF_VARIANT_SSR || net.n_classes <= 0 || endpoint || n_points <= 0) return 0;
     if (form && (form[0] == 's' || form[0] == 'w')) return 0;          // single: one workgroup per CU; wave: the per-wave head (A/B runs)
+    // More than 32 classes go block by block through the exchange area (two barriers and an exposed scratch fetch per extra block):
+    // measured at C = 101 the channel-split head is 8 % SLOWER than the per-wave one (27.8 vs 25.6 ms per 32768 x 192 launch), at
+    // C = 28 it is 2.5 % faster (22.3 vs 22.9 ms) - profiles/r03_mlp_sem_head_forms.txt.  INERF_F16_KERNEL=csplit forces it (tests).
+    if (net.n_classes > 32 && !(form && form[0] == 'c')) return 0;
     const int64_t tiles = (n_points + kTilePoints - 1) / kTilePoints;
     const int64_t grid = tiles < 2 * device_cus() ? tiles : 2 * device_cus();
     return grid * ((net.n_classes + 31) / 32) * kSemScratchBytes;

@@ -315,6 +315,35 @@ def test_encode_mlp_raw(variant, c, s):
     assert_maps_close(raw.cpu().numpy(), want.numpy(), RTOL, ATOL, f"raw {variant} C={c} S={s}")
 
 
+@pytest.mark.parametrize("c", [5, 28, 33, 101, 240])
+def test_ssr_semantic_head_forms_agree(c, precision, monkeypatch):
+    """The SSR network's two semantic-head forms of the two-workgroup kernel - per wave (every wave the whole head for its 16
+    points) and channel-split (hidden layer split over the waves, partial logits through an L2-resident scratch; the default
+    for C <= 32, forced here for every C: more than 32 classes go block by block through the exchange area) - against the
+    oracle and against each other: the 11 base channels bit for bit, the logits up to their summation order."""
+    from intrinsicnerf_amd import kernels
+    if precision != "f16x3":
+        pytest.skip("forms of the default f16x3 kernel")
+    dev = _dev()
+    cfg = oracle.RenderConfig(variant="ssr", n_samples=48, n_importance=0, n_classes=c)
+    sd = oracle.make_state_dict("ssr", c, seed=7)
+    g = torch.Generator().manual_seed(8)
+    n = 1501                                                  # 1501 * 48 points = 1125 full tiles + a ragged one: 2-3 tiles per workgroup
+    d = torch.randn(n, 3, generator=g)
+    rays = torch.cat([torch.randn(n, 3, generator=g), d, 0.1 * torch.ones(n, 1), 10 * torch.ones(n, 1), d / d.norm(dim=-1, keepdim=True)], -1)
+    z = torch.sort(torch.rand(n, 48, generator=g) * 9.9 + 0.1, -1)[0]
+    with torch.no_grad():
+        want = oracle.query_network(sd, rays[:, None, 0:3] + rays[:, None, 3:6] * z[:, :, None], rays[:, 8:11], cfg)
+    out = {}
+    for form in ("wave", "csplit"):
+        monkeypatch.setenv("INERF_F16_KERNEL", form)
+        raw = kernels.encode_mlp(_desc(cfg), _packed(cfg, sd), rays.to(dev), z.to(dev))
+        assert_maps_close(raw.cpu().numpy(), want.numpy(), RTOL, ATOL, f"raw C={c} {form}")
+        out[form] = raw
+    assert torch.equal(out["wave"][..., :11], out["csplit"][..., :11])
+    assert_maps_close(out["csplit"][..., 11:].cpu().numpy(), out["wave"][..., 11:].cpu().numpy(), 1e-5, 1e-6, "logits, split vs per-wave head")
+
+
 def test_run_network_arbitrary_points():
     """run_network(pts, viewdirs, net, ...) on a point grid (what extract_colour_mesh.py:158-162 does)."""
     from intrinsicnerf_amd import ssr
