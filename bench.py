@@ -426,7 +426,7 @@ def main():
                 durs += events_ms(lambda: kernels.encode_mlp(desc, packed, rays_l, z))[1]
         avg_ms = sum(durs) / len(durs)
         f16 = prec == _capi.PREC_F16X3
-        out = roofline_entry(f16, "k_encode_mlp_f16x3_dual<false, false>" if f16 else "k_encode_mlp<false, 2>",
+        out = roofline_entry(f16, "k_encode_mlp_f16x3_dual<false, false, false>" if f16 else "k_encode_mlp<false, 2>",
                              flop_per_launch / (avg_ms * 1e-3) / 1e12, avg_ms, len(durs), flop_per_launch,
                              n_local * (N_SAMPLES + (N_SAMPLES + N_IMPORTANCE)) / 2.0)
         coarse_ms = sum(durs[0::2]) / len(durs[0::2])          # the coarse-shaped launches alone = configs[1]'s kernel
@@ -561,7 +561,7 @@ def main():
         kernels.encode_mlp(sdesc, spk_f, chunk, sz)
         s_ms, s_durs = events_ms(lambda: kernels.encode_mlp(sdesc, spk_f, chunk, sz), 3)
         flop_s = FLOP_PER_POINT_SSR * chunk.shape[0] * (N_SAMPLES + N_IMPORTANCE)
-        out["roofline"] = roofline_entry(f16, "k_encode_mlp_f16x3_dual<false, true>" if f16 else "k_encode_mlp<true, 2>",
+        out["roofline"] = roofline_entry(f16, "k_encode_mlp_f16x3_dual<false, true, true>" if f16 else "k_encode_mlp<true, 2>",
                                          flop_s / (s_ms * 1e-3) / 1e12, s_ms, len(s_durs), flop_s, chunk.shape[0] * (N_SAMPLES + N_IMPORTANCE))
         out["roofline"]["launch"] = f"fine pass of this rank's first chunk ({chunk.shape[0]} rays x 192) on the depths the frame itself resampled"
         return out

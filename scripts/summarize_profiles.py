@@ -11,7 +11,7 @@ import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src, dst = "gpurun_out/", "profiles/"
-KERNEL = "k_encode_mlp_f16x3_dual<false, false>"
+KERNEL = "k_encode_mlp_f16x3_dual<false, false, false>"
 
 rows = [r for r in csv.DictReader(open(f"{src}prof/{tag}_bench/bench_kernel_trace.csv")) if KERNEL in r["Kernel_Name"]]
 durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
@@ -46,7 +46,7 @@ for a, b in (("bench.json", "bench.json"), ("bench_under_rocprof.json", "bench_u
 def pmc(path):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
-        agg[(r["Kernel_Name"].split("(")[0][-44:], r["Counter_Name"])].append(float(r["Counter_Value"]))
+        agg[(r["Kernel_Name"].split("(")[0][-64:], r["Counter_Name"])].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
 
