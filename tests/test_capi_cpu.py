@@ -488,7 +488,13 @@ def test_workspace_skips_caller_provided_stage_tensors(capi):
     # feature runs the one-workgroup kernel and needs none) stays in the workspace whatever the caller provides
     mlp_ws = max(lib.inerf_encode_mlp_workspace_bytes(desc, n, sc, 0), lib.inerf_encode_mlp_workspace_bytes(desc, n, sc + ni, capi.FLAG_ENDPOINT))
     assert lib.inerf_encode_mlp_workspace_bytes(desc, n, sc + ni, capi.FLAG_ENDPOINT) == 0 and mlp_ws % 256 == 0
-    assert mlp_ws > 0 and mlp_ws % (4 * 32768) == 0               # C = 101: four 32-class blocks of 32 KiB per workgroup
+    assert mlp_ws == 0                                               # C = 101 > 32: the per-wave head is the faster one, no scratch
+    d28 = capi.net_desc(capi.VARIANT_SSR, 28, 10, 4, 10.0)
+    ws28 = lib.inerf_encode_mlp_workspace_bytes(d28, n, sc, 0)
+    assert ws28 > 0 and ws28 % 32768 == 0                            # C <= 32: one 32 KiB block per workgroup
+    a28 = capi.RenderArgs()
+    a28.net, a28.n_rays, a28.n_samples, a28.n_importance = d28, n, sc, 0
+    assert lib.inerf_render_workspace_bytes(C.byref(a28)) == up(n * sc) + up(n * sc * (11 + 28)) + ws28
     a.raw_coarse, a.raw_fine = 0x1000, 0x2000                       # "provided" (never dereferenced here)
     assert lib.inerf_render_workspace_bytes(C.byref(a)) == full - raw_c - raw_f
     a.z_coarse, a.z_samples, a.z_fine = 0x10, 0x20, 0x30
@@ -501,3 +507,32 @@ def test_workspace_skips_caller_provided_stage_tensors(capi):
     obj = capi.net_desc(capi.VARIANT_OBJECT, 0, 10, 4, 1.0)
     assert lib.inerf_encode_mlp_workspace_bytes(obj, n, sc + ni, 0) == 0
     assert lib.inerf_render_workspace_bytes(None) == capi.E_INVALID
+
+
+@pytest.mark.parametrize("variant,c", [("object", 0), ("ssr", 0), ("ssr", 28), ("ssr", 150)])
+def test_one_call_backward_sizes(capi, variant, c):
+    """Host-side contract of inerf_mlp_backward (csrc/train_api.hip): the gradient blob is the reference's parameter tensors in
+    inerf_tensor_info order; the workspace holds the pre-activation gradients of every layer (11 KB per point), the partial
+    tiles of every product and - SSR with classes - the padded logit gradients; invalid arguments are refused without a GPU."""
+    from intrinsicnerf_amd import packing
+    lib = capi.lib()
+    desc = capi.net_desc(capi.VARIANT_SSR if variant == "ssr" else capi.VARIANT_OBJECT, c, 10, 4, 1.0, precision=capi.PREC_F16X3)
+    table = packing.tensor_table(desc)
+    n_params = sum(r * (cc if cc else 1) for _, (r, cc) in table)
+    assert lib.inerf_param_floats(desc) == n_params == sum(v.numel() for v in oracle.make_state_dict(variant, c, seed=0).values())
+    assert lib.inerf_mlp_backward_workspace_bytes(desc, 0) == 0
+    p = 64 * 300
+    ws = lib.inerf_mlp_backward_workspace_bytes(desc, p)
+    save = lib.inerf_mlp_save_floats(desc, p) * 4
+    assert ws >= save + (p * 128 * 4 if c > 0 else 0) and ws % 256 == 0
+    assert lib.inerf_mlp_backward_workspace_bytes(desc, 2 * p) > ws
+    assert lib.inerf_mlp_backward_workspace_bytes(None, p) == capi.E_INVALID
+    assert lib.inerf_mlp_backward(None, None, None, None, None, None, p, 0, None, None, 0, None, None) == capi.E_INVALID
+    one = (C.c_float * 4)()
+    # everything but the gradient blob missing: refused before anything is launched
+    assert lib.inerf_mlp_backward(desc, None, None, None, None, None, p, 0, C.cast(one, C.c_void_p), None, 0, None, None) == capi.E_INVALID
+    # param_views cuts the blob into the reference's shapes
+    from intrinsicnerf_amd import kernels
+    views = kernels.param_views(desc, torch.arange(n_params, dtype=torch.float32))
+    assert [tuple(v.shape) for v in views.values()] == [((r, cc) if cc else (r,)) for _, (r, cc) in table]
+    assert float(views[table[-1][0]].flatten()[-1]) == n_params - 1

@@ -42,8 +42,9 @@ def test_200_step_fit_and_what_the_trained_weights_do(monkeypatch):
     assert not any(m["rank_violations"] for m in s["maps"].values()), "\n".join(lines)
     # 200 steps give ~18 dB on a 24x24 view: the delta's pixel-sampling term (fit_synthetic.evaluate) is of the budget's size there;
     # its systematic part must be far inside the 1e-4 dB budget, and the delta itself inside budget + sampling scale
+    # (a sanity bound, not the budget claim: that is made on the full frame and on the 3 000-step fit, profiles/r03_*)
     assert abs(s["psnr_delta_systematic_db"]) <= 1e-5, s
-    assert abs(s["psnr_delta_db"]) <= 1e-4 + 4.0 * s["psnr_delta_sampling_db"], s
+    assert abs(s["psnr_delta_db"]) <= 5e-4, s
     # the HIP network backward tracks torch's layers: same initial weights, batches and jitter
     curves = {}
     for mode in ("hip", "torch"):
