@@ -726,6 +726,8 @@ def main():
             "configs": configs, "frame_costs": frame_costs, "f16_range_fallback": fallback, "train_step": train, "cpu_baseline": cpu}))
         sys.stdout.flush()
     if world > 1:
+        if not problems:
+            dist.barrier()            # the other ranks wait here while rank 0 runs the CPU oracle: nobody tears the job down under it
         dist.destroy_process_group()
     if problems:
         raise SystemExit("bench.py: the timed frame does NOT match the oracle:\n" + "\n".join(problems))
