@@ -30,7 +30,7 @@ extern "C" {
 #define INERF_VERSION_MINOR 2
 /* Bumped whenever a struct layout, an argument list or the packed-weight format of this header changes; bindings
  * compare it with inerf_abi_version() of the library they loaded (a stale .so then fails loudly, not silently). */
-#define INERF_ABI_VERSION 30003
+#define INERF_ABI_VERSION 30004
 
 /* error codes */
 #define INERF_OK              0
@@ -216,6 +216,16 @@ int inerf_mlp_backward(const inerf_net_desc* net, const float* packed_bwd, const
 int64_t inerf_pack_map(const inerf_net_desc* net, int backward, int32_t* half_src, int32_t* half_grp, int64_t half_capacity,
                        int32_t* c_dst, int32_t* c_src, int32_t* c_group, int32_t* c_code, float* c_mult, int64_t const_capacity,
                        int32_t* n_groups);
+
+/* The re-packing that inerf_pack_map describes, done by the library: params = n_tensors DEVICE pointers to the parameter
+ * tensors in canonical order ([host] array; counts = their element counts), the map arrays uploaded to the device as int32
+ * (half_src / half_grp: 2 * packed_floats entries; group_src: [n_groups, longest] flat indices (1-based, 0 = padding) of every
+ * scale group's sources; the constants as returned), gmax_scratch: n_groups device floats.  Writes the packed blob
+ * (packed_floats floats), bit-identical to inerf_pack_weights / inerf_pack_weights_bwd.  A memset and three launches. */
+int inerf_repack(const float* const* params, const int64_t* counts, int n_tensors, const int32_t* half_src, const int32_t* half_grp,
+                 int64_t packed_floats, const int32_t* group_src, int n_groups, int longest, const int32_t* c_dst,
+                 const int32_t* c_src, const int32_t* c_grp, const int32_t* c_code, const float* c_mult, int n_consts,
+                 float* gmax_scratch, float* packed_out, void* stream);
 
 /* Alpha compositing.  Replaces raw2outputs: run_nerf.py:359-412 / model_utils.py:39-116.
  * raw[N,S,CH]; z[N,S]; rays_d: pointer to the first direction, consecutive rays `rays_d_stride`

@@ -10,7 +10,7 @@ import os
 from . import _build
 from ._build import LIB_PATH
 
-ABI_VERSION = 30003          # INERF_ABI_VERSION of include/inerf.h these ctypes declarations mirror
+ABI_VERSION = 30004          # INERF_ABI_VERSION of include/inerf.h these ctypes declarations mirror
 
 OK, E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_HIP = 0, -1, -2, -3, -4
 VARIANT_OBJECT, VARIANT_SSR = 0, 1
@@ -76,6 +76,7 @@ SYMBOLS = {
     "inerf_mlp_backward_workspace_bytes": (_L, [C.POINTER(NetDesc), _L]),
     "inerf_mlp_backward": (_I, [C.POINTER(NetDesc), _P, _P, _P, _P, _P, _L, _U, _P, _P, _L, _P, _P]),
     "inerf_pack_map": (_L, [C.POINTER(NetDesc), _I, _P, _P, _L, _P, _P, _P, _P, _P, _L, C.POINTER(C.c_int32)]),
+    "inerf_repack": (_I, [C.POINTER(_P), C.POINTER(_L), _I, _P, _P, _L, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P]),
     "inerf_composite": (_I, [_P, _P, _P, _I, _P, _L, _I, _I, _I, _I, _U, C.POINTER(CompositeOut), _P]),
     "inerf_composite_backward": (_I, [_P, _P, _P, _I, _P, _L, _I, _I, _I, _I, _U, C.POINTER(CompositeOut), _P, _P]),
     "inerf_sample_fine": (_I, [_P, _P, _P, _L, _I, _I, _U, _P, _P, _P, _P]),

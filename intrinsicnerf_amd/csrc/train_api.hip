@@ -367,3 +367,109 @@ extern "C" int inerf_mlp_backward(const inerf_net_desc* net, const float* packed
     hipLaunchKernelGGL(k_reduce_heads, dim3((kHeadFloats + 63) / 64), dim3(256), 0, stream, heads, plan.bwd_grid, d, grads_out);
     return record(hipGetLastError());
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// inerf_repack: a parameter set -> packed blob ON THE DEVICE, driven by the map of inerf_pack_map (uploaded once per network
+// description).  After every optimiser step both blobs of both networks are rebuilt; as framework operations that was ~16
+// launches per blob (two concatenations, gathers, abs, max, frexp, ldexp, where, casts, an index_put) on a step whose tail is
+// bound by the host's launch rate - here it is a memset and three kernels that read the parameters where they live.
+// Bit-identical to inerf_pack_weights / inerf_pack_weights_bwd (power-of-two scales, round-to-nearest-even f16 casts).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace inerf {
+namespace {
+
+constexpr int kMaxParamTensors = 40;
+struct ParamPtrs {
+    const float* p[kMaxParamTensors];
+    int32_t first[kMaxParamTensors + 1];      // flat index (1-based: 0 = zero padding) of every tensor's first element
+    int32_t n;
+};
+
+__device__ __forceinline__ float param_at(const ParamPtrs& t, int src) {      // src: 1 + index into the flat concatenation, 0 = padding
+    if (src <= 0) return 0.0f;
+    int lo = 0, hi = t.n - 1;
+    while (lo < hi) {                                                          // last tensor whose first element is <= src
+        const int mid = (lo + hi + 1) >> 1;
+        if (t.first[mid] <= src) lo = mid; else hi = mid - 1;
+    }
+    return t.p[lo][src - t.first[lo]];
+}
+
+__device__ __forceinline__ float group_scale(float gmax) {                    // 2^k with gmax * 2^k in [2^13, 2^14); 1 for 0 / inf / nan
+    if (!(gmax > 0.0f) || !(gmax < __builtin_inff())) return 1.0f;
+    int e;
+    frexpf(gmax, &e);
+    return ldexpf(1.0f, 14 - e);
+}
+
+__global__ void k_repack_gmax(const ParamPtrs t, const int32_t* __restrict__ group_src, int longest, float* __restrict__ gmax) {
+    const int g = blockIdx.y;
+    float m = 0.0f;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < longest; j += gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(param_at(t, group_src[(size_t)g * longest + j])));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    // a NaN parameter must poison the scale like torch.amax does: it compares false everywhere above, so test it separately
+    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(reinterpret_cast<unsigned int*>(gmax + g), __builtin_bit_cast(unsigned int, m));
+}
+
+__global__ void k_repack_halves(const ParamPtrs t, const int32_t* __restrict__ half_src, const int32_t* __restrict__ half_grp,
+                                const float* __restrict__ gmax, int64_t n_halves, _Float16* __restrict__ out) {
+    const int64_t h = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (h >= n_halves) return;
+    const int grp = half_grp[h];
+    const float vs = param_at(t, half_src[h]) * group_scale(gmax[grp >= 0 ? grp : -grp - 1]);
+    const _Float16 hi = (_Float16)vs;
+    out[h] = grp >= 0 ? hi : (_Float16)(vs - (float)hi);
+}
+
+__global__ void k_repack_consts(const ParamPtrs t, const int32_t* __restrict__ c_dst, const int32_t* __restrict__ c_src,
+                                const int32_t* __restrict__ c_grp, const int32_t* __restrict__ c_code, const float* __restrict__ c_mult,
+                                const float* __restrict__ gmax, int n, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int code = c_code[i];
+    float v;
+    if (code == 0) v = param_at(t, c_src[i]) * c_mult[i];
+    else {
+        const float inv = 1.0f / group_scale(gmax[c_grp[i]]);
+        v = code == 1 ? inv : inv * 0.125f;
+    }
+    out[c_dst[i]] = v;
+}
+
+}  // namespace
+}  // namespace inerf
+
+extern "C" int inerf_repack(const float* const* params /*[host] device pointers, canonical order*/, const int64_t* counts /*[host]*/,
+                            int n_tensors, const int32_t* half_src, const int32_t* half_grp, int64_t packed_floats,
+                            const int32_t* group_src, int n_groups, int longest, const int32_t* c_dst, const int32_t* c_src,
+                            const int32_t* c_grp, const int32_t* c_code, const float* c_mult, int n_consts, float* gmax_scratch,
+                            float* packed_out, void* stream_) {
+    using namespace inerf;
+    if (!params || !counts || n_tensors < 1 || n_tensors > kMaxParamTensors || !half_src || !half_grp || packed_floats <= 0 || !group_src ||
+        n_groups < 1 || longest < 1 || !gmax_scratch || !packed_out || (n_consts > 0 && (!c_dst || !c_src || !c_grp || !c_code || !c_mult)))
+        return INERF_E_INVALID;
+    ParamPtrs t{};
+    int64_t first = 1;
+    for (int i = 0; i < n_tensors; ++i) {
+        if (!params[i] || counts[i] < 0 || first + counts[i] >= ((int64_t)1 << 31)) return INERF_E_INVALID;
+        t.p[i] = params[i];
+        t.first[i] = (int32_t)first;
+        first += counts[i];
+    }
+    t.first[n_tensors] = (int32_t)first;
+    t.n = n_tensors;
+    hipStream_t stream = (hipStream_t)stream_;
+    hipError_t e = hipMemsetAsync(gmax_scratch, 0, sizeof(float) * (size_t)n_groups, stream);
+    if (e != hipSuccess) return record(e);
+    const int chunks = longest < 256 * 64 ? (longest + 255) / 256 : 64;
+    hipLaunchKernelGGL(k_repack_gmax, dim3(chunks, n_groups), dim3(256), 0, stream, t, group_src, longest, gmax_scratch);
+    const int64_t n_halves = 2 * packed_floats;
+    hipLaunchKernelGGL(k_repack_halves, dim3((unsigned)((n_halves + 255) / 256)), dim3(256), 0, stream, t, half_src, half_grp, gmax_scratch,
+                       n_halves, reinterpret_cast<_Float16*>(packed_out));
+    if (n_consts > 0)
+        hipLaunchKernelGGL(k_repack_consts, dim3((n_consts + 255) / 256), dim3(256), 0, stream, t, c_dst, c_src, c_grp, c_code, c_mult,
+                           gmax_scratch, n_consts, packed_out);
+    return record(hipGetLastError());
+}

@@ -166,9 +166,40 @@ class DevicePacker:
         self.c_dst, self.c_src, self.c_grp = t(c_dst[:n]), t(c_src[:n]), t(c_grp[:n])
         self.c_code = t(c_code[:n])
         self.c_mult = torch.from_numpy(c_mult[:n].copy()).to(device)
+        # the same map as int32 device arrays for the library's own re-packing kernels (inerf_repack; HIP devices only)
+        self.hip = None
+        if torch.device(device).type == "cuda":
+            i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
+            self.hip = dict(half_src=i32(half_src), half_grp=i32(half_grp), group_src=i32(gsrc), longest=int(longest),
+                            c_dst=i32(c_dst[:n]), c_src=i32(c_src[:n]), c_grp=i32(c_grp[:n]), c_code=i32(c_code[:n]), n_consts=int(n))
 
     def __call__(self, named_params):
         """``named_params``: dict name -> tensor (parameters or a state dict) on this packer's device."""
+        import os
+        if self.hip is not None and os.environ.get("INERF_REPACK", "hip") != "torch":
+            return self._repack_hip(named_params)
+        return self._repack_torch(named_params)
+
+    def _repack_hip(self, named_params):
+        """One memset + three kernels of the library (inerf_repack) that read the parameters where they live."""
+        ts = [named_params[k].detach() for k in self.names]
+        ts = [t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous() for t in ts]
+        h = self.hip
+        blob = torch.empty(self.total, dtype=torch.float32, device=ts[0].device)
+        gmax = torch.empty(self.n_groups, dtype=torch.float32, device=ts[0].device)        # zeroed by the library on the stream
+        ptrs = (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        counts = (C.c_int64 * len(ts))(*[t.numel() for t in ts])
+        p = lambda t: C.c_void_p(t.data_ptr())
+        with torch.cuda.device(blob.device):
+            rc = _capi.lib().inerf_repack(ptrs, counts, len(ts), p(h["half_src"]), p(h["half_grp"]), self.total, p(h["group_src"]),
+                                          self.n_groups, h["longest"], p(h["c_dst"]), p(h["c_src"]), p(h["c_grp"]), p(h["c_code"]),
+                                          p(self.c_mult), h["n_consts"], p(gmax), p(blob),
+                                          C.c_void_p(torch.cuda.current_stream(blob.device).cuda_stream))
+        _capi.check(rc, "inerf_repack")
+        return blob
+
+    def _repack_torch(self, named_params):
+        """The same with framework operations (any device; the CPU tests pin it to the host packer bit for bit)."""
         flat = torch.cat([named_params[k].detach().reshape(-1).float() for k in self.names])
         flat1 = torch.cat([flat.new_zeros(1), flat])
         v = flat1[self.half_src]

@@ -1,0 +1,35 @@
+"""GPU: inerf_repack (the library's own device-side re-packing: a memset + three kernels that read the parameters where they
+live) against the host packer (inerf_pack_weights / inerf_pack_weights_bwd) and against the framework-operation twin the CPU
+tests pin - bit for bit, both blobs, object-level and SSR networks, including an all-zero GEMM and a rescaled one."""
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("variant,c", [("object", 0), ("ssr", 28), ("ssr", 101), ("ssr", 0)])
+def test_hip_repack_is_bit_identical_to_the_host_packer(variant, c, monkeypatch):
+    from intrinsicnerf_amd import _capi, packing
+    dev = torch.device("cuda:0")
+    desc = _capi.net_desc(_capi.VARIANT_SSR if variant == "ssr" else _capi.VARIANT_OBJECT, c, 10, 4, 10.0 if variant == "ssr" else 1.0,
+                          precision=_capi.PREC_F16X3)
+    for seed in (3, 4):
+        sd = oracle.make_state_dict(variant, c, seed=seed)
+        if seed == 4:
+            sd["pts_linears.2.weight"] = sd["pts_linears.2.weight"] * 0.0          # an all-zero GEMM: scale 1
+            sd["feature_linear.weight"] = sd["feature_linear.weight"] * 1000.0     # moves the common scale of the d h7 group
+            sd["views_linears.0.weight"] = sd["views_linears.0.weight"].t().contiguous().t()      # a non-contiguous parameter
+        sd_dev = {k: v.to(dev) for k, v in sd.items()}
+        for backward in (False, True):
+            host = packing.pack_state_dict_bwd(desc, sd) if backward else packing.pack_state_dict(desc, sd)
+            packer = packing.DevicePacker(desc, backward, dev)
+            assert packer.hip is not None
+            monkeypatch.setenv("INERF_REPACK", "hip")
+            got = packer(sd_dev)
+            monkeypatch.setenv("INERF_REPACK", "torch")
+            twin = packer(sd_dev)
+            torch.cuda.synchronize()
+            assert torch.equal(host.view(torch.int32), got.cpu().view(torch.int32)), (variant, c, seed, backward, "hip vs host")
+            assert torch.equal(twin.view(torch.int32), got.view(torch.int32)), (variant, c, seed, backward, "hip vs torch twin")
