@@ -1,6 +1,9 @@
 """GPU: inerf_repack (the library's own device-side re-packing: a memset + three kernels that read the parameters where they
-live) against the host packer (inerf_pack_weights / inerf_pack_weights_bwd) and against the framework-operation twin the CPU
-tests pin - bit for bit, both blobs, object-level and SSR networks, including an all-zero GEMM and a rescaled one."""
+live) against the host packer (inerf_pack_weights / inerf_pack_weights_bwd) - bit for bit, both blobs, object-level and SSR
+networks, including an all-zero GEMM, a rescaled one and a non-contiguous parameter.  (The framework-operation twin that the
+CPU tests pin to the host packer is bit-identical on the CPU only: run on the GPU it differs from the host packer in a few
+halves - the first GPU run of this test found that - so the training steps of rounds 1-2 used blobs a rounding away from the
+definition; the library's kernels are now the device path.)"""
 import pytest
 import torch
 
@@ -32,4 +35,7 @@ def test_hip_repack_is_bit_identical_to_the_host_packer(variant, c, monkeypatch)
             twin = packer(sd_dev)
             torch.cuda.synchronize()
             assert torch.equal(host.view(torch.int32), got.cpu().view(torch.int32)), (variant, c, seed, backward, "hip vs host")
-            assert torch.equal(twin.view(torch.int32), got.view(torch.int32)), (variant, c, seed, backward, "hip vs torch twin")
+            differing = int((twin.view(torch.int16) != got.view(torch.int16)).sum())
+            print(f"{variant} C={c} seed {seed} {'bwd' if backward else 'fwd'}: framework twin differs from the host packer in {differing} of "
+                  f"{2 * got.numel()} halves")
+            assert differing < got.numel() // 100
