@@ -418,7 +418,10 @@ __global__ void k_repack_halves(const ParamPtrs t, const int32_t* __restrict__ h
     const int64_t h = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (h >= n_halves) return;
     const int grp = half_grp[h];
-    const float vs = param_at(t, half_src[h]) * group_scale(gmax[grp >= 0 ? grp : -grp - 1]);
+    float vs = param_at(t, half_src[h]) * group_scale(gmax[grp >= 0 ? grp : -grp - 1]);
+    // keep the product and its conversion apart: fused, the compiler emits v_fma_mixlo_f16(a, b, +0), and (-0 * s) + 0 is +0 -
+    // the sign of a zero weight would differ from the host packer's (found by tests/test_repack_gpu.py on an all-zero layer)
+    asm volatile("" : "+v"(vs));
     const _Float16 hi = (_Float16)vs;
     out[h] = grp >= 0 ? hi : (_Float16)(vs - (float)hi);
 }
