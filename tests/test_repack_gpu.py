@@ -1,9 +1,10 @@
 """GPU: inerf_repack (the library's own device-side re-packing: a memset + three kernels that read the parameters where they
 live) against the host packer (inerf_pack_weights / inerf_pack_weights_bwd) - bit for bit, both blobs, object-level and SSR
 networks, including an all-zero GEMM, a rescaled one and a non-contiguous parameter.  (The framework-operation twin that the
-CPU tests pin to the host packer is bit-identical on the CPU only: run on the GPU it differs from the host packer in a few
-halves - the first GPU run of this test found that - so the training steps of rounds 1-2 used blobs a rounding away from the
-definition; the library's kernels are now the device path.)"""
+CPU tests pin to the host packer is bit-identical on the CPU only: run on the GPU it differs from the host packer in about a
+third of the halves - another valid hi/lo split, hi rounded differently and lo compensating; the first GPU run of this test
+found that - so the training steps of rounds 1-2 used blobs that were not the host packer's; the library's kernels are now the
+device path.)"""
 import pytest
 import torch
 
