@@ -234,8 +234,8 @@ def events_ms(fn, reps=1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)           # (the first frames of a process run ~8 % slow on some boxes: clocks, allocator)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle: no cpu_baseline and no parity check")
     ap.add_argument("--cpu-baseline-quick", action="store_true",
                     help="time the CPU oracle on the 4077-ray parity sample only (default: SURVEY.md 8d - one 32768-ray chunk x 3, ~3 min)")
