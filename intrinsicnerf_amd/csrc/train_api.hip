@@ -409,7 +409,8 @@ __global__ void k_repack_gmax(const ParamPtrs t, const int32_t* __restrict__ gro
         m = fmaxf(m, fabsf(param_at(t, group_src[(size_t)g * longest + j])));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    // a NaN parameter must poison the scale like torch.amax does: it compares false everywhere above, so test it separately
+    // fmaxf drops a NaN parameter exactly as the host packer's std::fmax does (weight_scale, pack.cpp): same scale, and the NaN
+    // itself survives as the NaN halves of that element
     if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(reinterpret_cast<unsigned int*>(gmax + g), __builtin_bit_cast(unsigned int, m));
 }
 

@@ -1,8 +1,8 @@
 """HIP graphs for the launch-bound part of the path: the reference's TRAINING STEP (run_nerf.py:918-1027, trainer.py:876-991).
 
-A step through the staged path is ~300 launches (sampling, two fused network forwards, compositing, their backward kernels,
-26 weight-gradient products, re-packing, ~115 small torch kernels of the loss / Adam tail) for ~10.6 ms of GPU work: a tenth
-of the step is the host issuing launches one by one (profiles/r02_train_step.txt).  ``GraphedTrainStep`` records the step
+A step through the staged path is ~250 launches (sampling, two fused network forwards, compositing, their backward kernels,
+the weight-gradient products, re-packing, ~115 small torch kernels of the loss / Adam tail) for ~9.9 ms of GPU work; issued one
+by one the step takes 10.6 ms (profiles/r03_train_step.txt).  ``GraphedTrainStep`` records the step
 ONCE into two HIP graphs and replays them:
 
     graph A:  zero grads -> loss_fn(*static inputs) -> loss.backward()        (every HIP kernel of the library and every
