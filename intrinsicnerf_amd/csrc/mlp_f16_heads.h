@@ -1,6 +1,5 @@
-// mlp_f16_heads.h - pieces of the in-place (296-half rows) split-f16 kernels shared by mlp_f16.hip (two-workgroup and quad
-// forms) and mlp_f16_pipe.hip: row geometry, accumulator -> register-operand conversion, the register-operand output heads
-// and the per-wave semantic head.
+// mlp_f16_heads.h - pieces of the in-place (296-half rows) two-workgroup split-f16 kernel of mlp_f16.hip: row geometry,
+// accumulator -> register-operand conversion, the register-operand output heads and the per-wave semantic head.
 #pragma once
 #include "mlp_f16_dev.h"
 

@@ -5,8 +5,7 @@
 set -e
 name=$1; src=$2; extra=$3
 cd "$(dirname "$0")/../intrinsicnerf_amd"
-pipe=""; [ "$src" = "mlp_f16_pipe.hip" ] && pipe="-mllvm -amdgpu-mfma-vgpr-form=1"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-comment -Wno-unused-result $pipe $extra -c csrc/$src -o csrc/_obj/variant_$name.o
-objs=$(ls csrc/_obj/*.o | grep -v "/$src.o" | grep -v "variant_" | grep -v "pipe_abl")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-comment -Wno-unused-result $extra -c csrc/$src -o csrc/_obj/variant_$name.o
+objs=$(ls csrc/_obj/*.o | grep -v "/$src.o" | grep -v "variant_")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs csrc/_obj/variant_$name.o -o libinerf_$name.so
 ls -la libinerf_$name.so
