@@ -151,6 +151,9 @@ int inerf_encode_mlp_ws(const inerf_net_desc* net, const float* packed_weights, 
  * inerf_encode_mlp_train and read by inerf_mlp_backward_inputs in place of the activations; layout private to the
  * two kernels): always pass a buffer that inerf_encode_mlp_train itself filled, of inerf_mlp_save_floats() floats.
  * The gradient w.r.t. the semantic logits is d_raw[..., 11:11+C] itself (no activation).
+ * One kept evaluation is limited to 4 000 000 sample points (a slot is addressed through a 32-bit buffer descriptor):
+ * inerf_encode_mlp_train, inerf_mlp_backward_inputs and inerf_mlp_backward return INERF_E_UNSUPPORTED beyond it; split a
+ * larger batch into several evaluations and add the parameter gradients (the Python mirror does).
  * ------------------------------------------------------------------------------------------- */
 #define INERF_SAVE_SLOTS 15
 int64_t inerf_mlp_save_floats(const inerf_net_desc* net, int64_t n_points);

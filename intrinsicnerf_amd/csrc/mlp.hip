@@ -458,7 +458,7 @@ extern "C" int inerf_encode_mlp_train(const inerf_net_desc* net, const float* pa
     if (net && n_rays == 0) return INERF_OK;
     if (!save_out || !net) return INERF_E_INVALID;
     if (net->precision != INERF_PREC_F16X3) return INERF_E_UNSUPPORTED;
-    if (n_rays * (int64_t)n_samples > 4000000) return INERF_E_UNSUPPORTED;     // one activation slot stays below 4 GiB (buffer descriptors)
+    if (n_rays * (int64_t)n_samples > inerf::kMaxTrainPoints) return INERF_E_UNSUPPORTED;     // one activation slot stays below 4 GiB (buffer descriptors)
     return encode_mlp_impl(net, packed, rays, z, n_rays, n_samples, flags, raw_out, save_out, act_max, status, stream);
 }
 

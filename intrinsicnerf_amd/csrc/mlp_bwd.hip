@@ -610,7 +610,7 @@ extern "C" int inerf_mlp_backward_inputs(const inerf_net_desc* net, const float*
     if (!net || !packed_bwd || !raw || !d_raw || !save || !dz_out || n_points < 0) return INERF_E_INVALID;
     if (!net_supported(*net)) return INERF_E_UNSUPPORTED;
     if (n_points == 0) return INERF_OK;
-    if (n_points >= (int64_t)1 << 31) return INERF_E_UNSUPPORTED;
+    if (n_points > kMaxTrainPoints) return INERF_E_UNSUPPORTED;       // the slots are read through 32-bit buffer descriptors
     const bool ssr = net->variant == INERF_VARIANT_SSR;
     BwdParams p;
     p.wts = packed_bwd; p.raw = raw; p.d_raw = d_raw; p.save = save; p.dz = dz_out; p.dz_max = dz_max; p.head_partial = head_partial; p.status = status;

@@ -41,6 +41,11 @@ __device__ __forceinline__ void stagger_start(int units) {
 #endif
 int stagger_units(int n_tiles, int grid);       // 0 when a workgroup has fewer than four tiles
 
+// Training entry points: an activation / gradient slot ([n_points, 256] fp32) is addressed through one buffer descriptor
+// (32-bit range), so one evaluation kept for a backward pass is limited to this many sample points; callers split larger
+// batches into several evaluations (kernels.mlp_train does: parameter gradients add up).
+constexpr int64_t kMaxTrainPoints = 4000000;
+
 int device_cus();                 // CU count of the CURRENT device (cached per device id)
 int current_device();             // hipGetDevice, 0 on error
 int tile_blocks();

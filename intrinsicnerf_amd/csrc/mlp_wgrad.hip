@@ -31,26 +31,25 @@ struct WgradParams {
 
 constexpr int kWgFragBytes = 1024;      // one operand fragment: 64 lanes x 8 halfs
 
-// one [32 points x 16 channels] piece of a point-major matrix as transposer operand: lane = point, 8 channels
-__device__ __forceinline__ void load_piece(const float* base, int ld, int pt, int n_points, int col, float (&v)[8]) {
-    if (pt < n_points) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(base + (size_t)pt * ld + col);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(base + (size_t)pt * ld + col + 4);
+// one [32 points x 16 channels] piece of a point-major matrix as transposer operand: lane = point, 8 channels.  Through a
+// buffer descriptor over the matrix's n_points rows and ONE 32-bit offset per (tile, half) that carries the WHOLE offset (the
+// range check sees all of it; the pieces of a half differ by immediates) - with 64-bit per-lane pointers the addresses of a
+// tile's 16 pieces cost more registers than prefetching G leaves room for.  Rows beyond the end read as zeros: no branches.
+__device__ __forceinline__ void load_piece(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, float (&v)[8]) {
+    const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0));
+    const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(voff + 16u), 0, 0));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = 0.0f;
-    }
+    for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
 }
 
+// v * scale -> f16 hi (towards zero) + f16 lo (the remainder, rounded once): mlp_f16_dev.h split_pair, 3 instructions per pair
 __device__ __forceinline__ void split8(const float (&v)[8], float scale, f16x8& hi, f16x8& lo) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float t = v[i] * scale;
-        const float th = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, t) & 0xFFFFE000u);
-        hi[i] = (_Float16)th;
-        lo[i] = (_Float16)(t - th);
+    for (int i = 0; i < 8; i += 2) {
+        f16x2 h2, l2;
+        split_pair(v[i] * scale, v[i + 1] * scale, h2, l2);
+        hi[i] = h2[0]; hi[i + 1] = h2[1];
+        lo[i] = l2[0]; lo[i + 1] = l2[1];
     }
 }
 
@@ -67,9 +66,10 @@ __device__ __forceinline__ float transpose_block(f16x8 g0, f16x8 g1, f16x8 id0, 
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            out[q][i] = (_Float16)d[8 * q + i];
-            sum += d[8 * q + i];
+        for (int i = 0; i < 8; i += 2) {       // the values ARE f16 numbers (f16 x 1.0): any rounding mode converts them exactly
+            const f16x2 pk = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(d[8 * q + i], d[8 * q + i + 1]));
+            out[q][i] = pk[0]; out[q][i + 1] = pk[1];
+            sum += d[8 * q + i] + d[8 * q + i + 1];
         }
     return sum;
 }
@@ -87,7 +87,8 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
     const int lp = lane & 31, lh = lane >> 5;
     // powers of two that bring the operands' bounds into [2^13, 2^14) (f16 hi/lo split range)
     auto pow2_for = [](float m) { int e; if (!(m > 0.0f) || !(m < 3.0e38f)) return 1.0f; frexpf(m, &e); return ldexpf(1.0f, 14 - e); };
-    const float sg = pow2_for(p.ranges[0]), sx = pow2_for(p.ranges[1]);
+    auto uniform = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+    const float sg = uniform(pow2_for(p.ranges[0])), sx = uniform(pow2_for(p.ranges[1]));       // wave-uniform: scalar registers
 
     // identity operands of the transposer: B[k][n] = (n == k) resp. (n == k + 16); lane n holds k = 8 * lh + i
     f16x8 id0, id1;
@@ -111,37 +112,47 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
     };
     constexpr int XS = (CB + NW - 1) / NW;        // column blocks of X this wave converts (cb = wave + NW * i)
 
-    // The next tile's X rows (this wave's share) are requested before the contraction and converted after it; G's rows
-    // are requested at the top of a tile and arrive while the X share is converted.  One barrier per tile.
-    float xraw[XS][2][2][8];
-    auto load_x = [&](int tile) {
-        const int pt_base = tile * kTilePoints;
+    // The next tile's rows - this wave's share of X and its own 32 channels of G - are requested before the contraction and
+    // converted after it: a tile's loads have a whole contraction (~4 000 cycles) to arrive.  (Until round 3 G was requested
+    // at the top of its own tile and waited for - ~3 000 exposed cycles of a tile's 20 000.)  One barrier per tile.
+    const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G), 0, (int)((unsigned)p.n_points * (unsigned)p.ldg * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, (int)((unsigned)p.n_points * (unsigned)p.ldx * 4u), 0x00020000);
+    const unsigned g_voff0 = (unsigned)(lp * p.ldg + 32 * wave + 8 * lh) * 4u, x_voff0 = (unsigned)(lp * p.ldx + 8 * lh) * 4u;
+    float xraw[XS][2][2][8], graw[2][2][8];
+    auto opaque = [](unsigned v) { asm volatile("" : "+v"(v)); return v; };      // keeps `voff + constant` an immediate, not a hoisted register
+    auto load_x = [&](int tile, int ph) {
 #pragma unroll
-        for (int i = 0; i < XS; ++i) {
-            const int cb = wave + NW * i;
-#pragma unroll
-            for (int ph = 0; ph < 2; ++ph)
+            for (int i = 0; i < XS; ++i) {
+                const int cb = wave + NW * i;
+                const unsigned voff = opaque(x_voff0 + ((unsigned)(tile * kTilePoints + 32 * ph) * (unsigned)p.ldx + 32u * cb) * 4u);
 #pragma unroll
                 for (int g = 0; g < 2; ++g)
-                    if (cb < CB) load_piece(p.X, p.ldx, pt_base + 32 * ph + lp, p.n_points, 32 * cb + 16 * g + 8 * lh, xraw[i][ph][g]);
-        }
+                    if (CB % NW == 0 || cb < CB) load_piece(x_rsrc, voff + 64u * g, xraw[i][ph][g]);
+            }
+    };
+    auto load_g = [&](int tile, int ph) {
+        const unsigned voff = opaque(g_voff0 + (unsigned)(tile * kTilePoints + 32 * ph) * (unsigned)p.ldg * 4u);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) load_piece(g_rsrc, voff + 64u * g, graw[ph][g]);
     };
 
+#ifdef INERF_WGRAD_STAMPS   // development build (scripts/build_variant.sh, scripts/wgrad_timeline.py): cycle stamps of workgroup 0's
+    // wave 0 at the phase boundaries of its THIRD tile, kept in scalar registers (selects, no branches: branches around the
+    // stamps changed the register allocation of the whole loop) and written over the start of the partial tile at the end
+    unsigned long long wg_st[7] = {0, 0, 0, 0, 0, 0, 0};
+#define WG_STAMP(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); wg_st[k] = (tile == 2 * (int)gridDim.x) ? now_ : wg_st[k]; } while (0)
+#else
+#define WG_STAMP(k) do { } while (0)
+#endif
     int buf = 0;
-    if ((int)blockIdx.x < p.n_tiles) load_x(blockIdx.x);
+    load_x(blockIdx.x, 0); load_x(blockIdx.x, 1); load_g(blockIdx.x, 0);
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
-        const int pt_base = tile * kTilePoints;
-        float graw[2][2][8];
-#pragma unroll
-        for (int ph = 0; ph < 2; ++ph)
-#pragma unroll
-            for (int g = 0; g < 2; ++g)
-                load_piece(p.G, p.ldg, pt_base + 32 * ph + lp, p.n_points, 32 * wave + 16 * g + 8 * lh, graw[ph][g]);
+        WG_STAMP(0);
         // ---- X: every wave transposes its share of the column blocks and parks the operands in LDS[buf] ----
 #pragma unroll
         for (int i = 0; i < XS; ++i) {
             const int cb = wave + NW * i;
-            if (cb < CB) {
+            if (CB % NW == 0 || cb < CB) {
 #pragma unroll
                 for (int ph = 0; ph < 2; ++ph) {
                     f16x8 h0, l0, h1, l1, th[2], tl[2];
@@ -158,38 +169,71 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
                 }
             }
         }
-        // ---- G: this wave's row block, kept in registers ----
-        f16x8 gh[2][2], gl[2][2];          // [ph][q]
+        // Requests are unconditional: behind the last tile the rows lie beyond the descriptors' range and cost nothing, and the
+        // loop body stays one basic block (with branches around the loads the compiler parked the loaded rows in scratch).
+        WG_STAMP(1);
+        load_g(tile, 1);                           // this tile's second half of G: needed after the first half's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- G: this wave's row block, one 32-point half at a time: converted into registers, contracted against that half's X
+        // operands.  The first half was requested a tile ago (its registers are refilled as soon as it is converted), the
+        // second half's conversion sits behind the barrier between the two halves' MFMAs.
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {
-            f16x8 h0, l0, h1, l1;
-            split8(graw[ph][0], sg, h0, l0);
-            split8(graw[ph][1], sg, h1, l1);
-            bias_sum += transpose_block(h0, h1, id0, id1, gh[ph]);
-            bias_sum += transpose_block(l0, l1, id0, id1, gl[ph]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (tile + (int)gridDim.x < p.n_tiles) load_x(tile + gridDim.x);
-        __syncthreads();                   // LDS[buf] complete; LDS[buf ^ 1] (last read before the previous barrier) is free
-        // ---- contraction over the 64 points of the tile ----
+            f16x8 gh[2], gl[2];                // [q]
+            {
+                f16x8 h0, l0, h1, l1;
+                split8(graw[ph][0], sg, h0, l0);
+                split8(graw[ph][1], sg, h1, l1);
+                bias_sum += transpose_block(h0, h1, id0, id1, gh);
+                bias_sum += transpose_block(l0, l1, id0, id1, gl);
+            }
+            // The next tile's rows, in the order the next tile converts them: X's first half a whole contraction ahead, X's second
+            // half and G's first half from the middle of this one (they are needed 500 / 1 000 cycles into the next tile).
+            WG_STAMP(ph == 0 ? 2 : 5);
+            if (ph == 0) {
+                load_x(tile + gridDim.x, 0);
+                __syncthreads();               // LDS[buf] complete; LDS[buf ^ 1] (last read before the previous barrier) is free
+                WG_STAMP(3);
+            } else {
+                load_x(tile + gridDim.x, 1);
+                load_g(tile + gridDim.x, 0);
+            }
+            // X operands one step ahead of their MFMAs, fenced: unfenced, the scheduler hoists ~20 operand reads (80 registers)
+            // to the top of the half and spills the prefetched rows to make room
+            f16x8 xh[2], xl[2];
+            xh[0] = *reinterpret_cast<const f16x8*>(xfrag(buf, 0, ph, 0, 0));
+            xl[0] = *reinterpret_cast<const f16x8*>(xfrag(buf, 0, ph, 0, 1));
 #pragma unroll
-        for (int ph = 0; ph < 2; ++ph)
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int cb = 0; cb < CB; ++cb) {
-                    const f16x8 xh = *reinterpret_cast<const f16x8*>(xfrag(buf, cb, ph, q, 0));
-                    const f16x8 xl = *reinterpret_cast<const f16x8*>(xfrag(buf, cb, ph, q, 1));
-                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[ph][q], xh, acc[cb], 0, 0, 0);
-                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[ph][q], xl, acc[cb], 0, 0, 0);
-                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl[ph][q], xh, acc[cb], 0, 0, 0);
+            for (int st = 0; st < 2 * CB; ++st) {
+                const int q = st / CB, cb = st % CB;
+                if (st + 1 < 2 * CB) {
+                    xh[(st + 1) & 1] = *reinterpret_cast<const f16x8*>(xfrag(buf, (st + 1) % CB, ph, (st + 1) / CB, 0));
+                    xl[(st + 1) & 1] = *reinterpret_cast<const f16x8*>(xfrag(buf, (st + 1) % CB, ph, (st + 1) / CB, 1));
                 }
+                __builtin_amdgcn_sched_barrier(0);       // reads first (else they share registers with this step's operands and slip behind its MFMAs)
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[q], xh[st & 1], acc[cb], 0, 0, 0);
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[q], xl[st & 1], acc[cb], 0, 0, 0);
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl[q], xh[st & 1], acc[cb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            WG_STAMP(ph == 0 ? 4 : 6);
+        }
         buf ^= 1;
     }
 
     // ---- this workgroup's partial tile: row m = channel of G, column n = channel of X ----
     const float back = 1.0f / (sg * sx);
     float* out = p.partial + (size_t)blockIdx.x * p.partial_stride;
+#ifdef INERF_WGRAD_STAMPS
+    if (blockIdx.x == 0) {
+        if (tid == 0) {
+            unsigned long long* d = reinterpret_cast<unsigned long long*>(p.bias_partial ? p.bias_partial : p.partial);
+            d[0] = 7;
+            for (int i = 0; i < 7; ++i) d[1 + i] = wg_st[i];
+        }
+        return;
+    }
+#endif
     if (p.bias_partial) {              // the two lane halves hold complementary points of the same channel
         const float both = bias_sum + __shfl_xor(bias_sum, 32);
         if (lh == 0) p.bias_partial[(size_t)blockIdx.x * p.partial_stride + 32 * wave + lp] = both / sg;
@@ -222,7 +266,8 @@ extern "C" int inerf_mlp_weight_gradient(const float* G, int ldg, const float* X
                                          void* stream) {
     using namespace inerf;
     if (!G || !X || !ranges || !partial || n_points <= 0 || ldg < M || ldx < N) return INERF_E_INVALID;
-    if (n_points >= (int64_t)1 << 31) return INERF_E_UNSUPPORTED;
+    // rows are addressed through 32-bit buffer descriptors, the prefetch reaches one grid stride of tiles beyond the end
+    if ((n_points + (int64_t)kTilePoints * (device_cus() + 1)) * (ldg > ldx ? ldg : ldx) * 4 >= (int64_t)1 << 32) return INERF_E_UNSUPPORTED;
     if ((ldg & 3) || (ldx & 3) || (((uintptr_t)G | (uintptr_t)X) & 15)) return INERF_E_INVALID;      // 16-byte row pieces
     WgradParams p;
     if (partial_stride < (int64_t)M * N) return INERF_E_INVALID;

@@ -311,6 +311,7 @@ extern "C" int64_t inerf_param_floats(const inerf_net_desc* net) {
 
 extern "C" int64_t inerf_mlp_backward_workspace_bytes(const inerf_net_desc* net, int64_t n_points) {
     if (!net || !inerf::net_supported(*net) || n_points < 0) return INERF_E_INVALID;
+    if (n_points > inerf::kMaxTrainPoints) return INERF_E_UNSUPPORTED;
     if (n_points == 0) return 0;
     return inerf::make_plan(*net, n_points).total;
 }
@@ -326,7 +327,7 @@ extern "C" int inerf_mlp_backward(const inerf_net_desc* net, const float* packed
     const int64_t n_params = cache.n_params;
     if (n_points == 0) return record(hipMemsetAsync(grads_out, 0, n_params * 4, stream));        // no sample points: every gradient is zero
     if (!packed_bwd || !raw || !d_raw || !save || !act_max) return INERF_E_INVALID;
-    if (n_points >= (int64_t)1 << 31) return INERF_E_UNSUPPORTED;
+    if (n_points > kMaxTrainPoints) return INERF_E_UNSUPPORTED;
     const Plan plan = make_plan(*net, n_points);
     if (!workspace || workspace_bytes < plan.total) return INERF_E_WORKSPACE;
     char* ws = static_cast<char*>(workspace);

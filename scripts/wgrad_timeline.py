@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Development aid: cycle stamps of workgroup 0 of one 256 x 256 weight-gradient product at the phase boundaries of its third
+tile.  Needs the stamped build:  scripts/build_variant.sh wgstamps mlp_wgrad.hip "-DINERF_WGRAD_STAMPS=1"
+               INERF_LIB_OVERRIDE=$PWD/intrinsicnerf_amd/libinerf_wgstamps.so python scripts/wgrad_timeline.py"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from intrinsicnerf_amd import _capi  # noqa: E402
+
+dev = torch.device("cuda:0")
+lib = _capi.lib()
+p = 2048 * 192
+g = torch.randn(p, 256, device=dev)
+x = torch.randn(p, 256, device=dev).abs()
+ranges = torch.tensor([float(g.abs().max()), float(x.max())], device=dev)
+grid = lib.inerf_wgrad_grid(p)
+stride = 256 * 256 + 256
+partial = torch.zeros(grid, stride, device=dev)
+names = ["X share: split, transpose, LDS write", "G first half: split, transpose", "barrier wait", "contraction, first half",
+         "G second half: wait, split, transpose", "contraction, second half"]
+for _ in range(3):
+    rc = lib.inerf_mlp_weight_gradient(C.c_void_p(g.data_ptr()), 256, C.c_void_p(x.data_ptr()), 256, p, 256, 256, C.c_void_p(ranges.data_ptr()),
+                                       C.c_void_p(partial.data_ptr()), C.c_void_p(partial[:, 256 * 256:].data_ptr()), stride,
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _capi.check(rc, "inerf_mlp_weight_gradient")
+    torch.cuda.synchronize()
+t = partial[0, 256 * 256:256 * 256 + 18].contiguous().view(torch.int64).cpu().tolist()
+k, v = t[0], t[1:9]
+if not 2 <= k <= 8:
+    k, v = 1, [0] * 8          # not a stamped build: the timing below is still valid
+print(f"{k} stamps; {v[k - 1] - v[0]} cycles for the tile ({grid} workgroups, {p // 64 // grid} tiles each)")
+for i in range(1, k):
+    print(f"  {names[i - 1]:42s} {v[i] - v[i - 1]:8d}")
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    lib.inerf_mlp_weight_gradient(C.c_void_p(g.data_ptr()), 256, C.c_void_p(x.data_ptr()), 256, p, 256, 256, C.c_void_p(ranges.data_ptr()),
+                                  C.c_void_p(partial.data_ptr()), C.c_void_p(partial[:, 256 * 256:].data_ptr()), stride,
+                                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
+e1.record(); e1.synchronize()
+print(f"one 256 x 256 product over {p} points: {e0.elapsed_time(e1) / 10 * 1000:.1f} us")

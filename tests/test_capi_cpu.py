@@ -527,6 +527,12 @@ def test_one_call_backward_sizes(capi, variant, c):
     assert ws >= save + (p * 128 * 4 if c > 0 else 0) and ws % 256 == 0
     assert lib.inerf_mlp_backward_workspace_bytes(desc, 2 * p) > ws
     assert lib.inerf_mlp_backward_workspace_bytes(None, p) == capi.E_INVALID
+    # one kept evaluation is limited to 4 000 000 points (32-bit buffer descriptors; include/inerf.h): refused, not wrapped around
+    assert lib.inerf_mlp_backward_workspace_bytes(desc, 4_000_000) > 0
+    assert lib.inerf_mlp_backward_workspace_bytes(desc, 4_000_001) == capi.E_UNSUPPORTED
+    assert lib.inerf_mlp_backward(desc, C.cast(one4 := (C.c_float * 4)(), C.c_void_p), C.cast(one4, C.c_void_p), C.cast(one4, C.c_void_p),
+                                  C.cast(one4, C.c_void_p), C.cast(one4, C.c_void_p), 4_000_001, 0, C.cast(one4, C.c_void_p), None, 0,
+                                  None, None) == capi.E_UNSUPPORTED
     assert lib.inerf_mlp_backward(None, None, None, None, None, None, p, 0, None, None, 0, None, None) == capi.E_INVALID
     one = (C.c_float * 4)()
     # everything but the gradient blob missing: refused before anything is launched
