@@ -75,16 +75,26 @@ __device__ __forceinline__ float transpose_block(f16x8 g0, f16x8 g1, f16x8 id0, 
 }
 
 // NW waves, each owning one 32-row block of the output (M = 32 * NW); CB: 32-column blocks of the output (N = 32 * CB).
-// M = 256 runs as 8 waves of <= 256 registers (128 of them accumulators): two waves per SIMD, so that one wave's loads and
-// conversions overlap the other's MFMAs.  (With 4 waves x 64 rows - 256 accumulator registers per lane - prefetching the
-// next tile spilled and was 20 % slower than not prefetching at all.)
+// M = 256 runs as 8 waves of <= 256 registers (128 of them accumulators): two waves per SIMD.
+//
+// The points are walked in steps of 32 (one k-block pair of the MFMA).  Per step a wave (a) CONVERTS the next step's rows -
+// its share of X (split, transposed, parked in LDS for everybody) and its own 32 channels of G (kept in registers) - and
+// (b) CONTRACTS the current step: 6 x CB MFMAs against the X operands in LDS.  One barrier per step separates "everybody has
+// converted step k" from "anybody contracts step k"; between two barriers (a) and (b) are independent (double-buffered LDS),
+// so the two waves that share a SIMD do them in OPPOSITE order: waves 0..3 contract first, waves 4..7 convert first - one
+// wave's splits, conversions and LDS writes run under the other's MFMAs.  (Until round 3 every wave converted, then every
+// wave contracted, a 64-point tile at a time: the cycle stamps of scripts/wgrad_timeline.py showed a wave waiting at the
+// barrier for half of a tile's 13 600 cycles while its SIMD partner was still converting and the matrix core idled.)
+// Rows are requested two steps ahead, right after the conversion that frees their registers.
 template <int NW, int CB>
 __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) char ldsw[];
+    constexpr int kStep = 32;                                     // points per step
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lp = lane & 31, lh = lane >> 5;
+    const bool convert_first = NW == 8 && wave >= 4;             // the SIMD partner of wave - 4
     // powers of two that bring the operands' bounds into [2^13, 2^14) (f16 hi/lo split range)
     auto pow2_for = [](float m) { int e; if (!(m > 0.0f) || !(m < 3.0e38f)) return 1.0f; frexpf(m, &e); return ldexpf(1.0f, 14 - e); };
     auto uniform = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
@@ -105,120 +115,115 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
 
-    // LDS: X operands of two tiles (double buffer): [buf][cb][ph][q][plane] fragments
-    constexpr int kBufBytes = CB * 8 * kWgFragBytes;
-    auto xfrag = [&](int buf, int cb, int ph, int q, int plane) {
-        return ldsw + buf * kBufBytes + ((((cb * 2 + ph) * 2 + q) * 2 + plane) * kWgFragBytes) + lane * 16;
+    // LDS: X operands of two steps (double buffer): [buf][cb][q][plane] fragments
+    constexpr int kBufBytes = CB * 4 * kWgFragBytes;
+    auto xfrag = [&](int buf, int cb, int q, int plane) {
+        return ldsw + buf * kBufBytes + (((cb * 2 + q) * 2 + plane) * kWgFragBytes) + lane * 16;
     };
     constexpr int XS = (CB + NW - 1) / NW;        // column blocks of X this wave converts (cb = wave + NW * i)
 
-    // The next tile's rows - this wave's share of X and its own 32 channels of G - are requested before the contraction and
-    // converted after it: a tile's loads have a whole contraction (~4 000 cycles) to arrive.  (Until round 3 G was requested
-    // at the top of its own tile and waited for - ~3 000 exposed cycles of a tile's 20 000.)  One barrier per tile.
     const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G), 0, (int)((unsigned)p.n_points * (unsigned)p.ldg * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, (int)((unsigned)p.n_points * (unsigned)p.ldx * 4u), 0x00020000);
     const unsigned g_voff0 = (unsigned)(lp * p.ldg + 32 * wave + 8 * lh) * 4u, x_voff0 = (unsigned)(lp * p.ldx + 8 * lh) * 4u;
-    float xraw[XS][2][2][8], graw[2][2][8];
+    float xraw[XS][2][8], graw[2][8];
     auto opaque = [](unsigned v) { asm volatile("" : "+v"(v)); return v; };      // keeps `voff + constant` an immediate, not a hoisted register
-    auto load_x = [&](int tile, int ph) {
+    // Requests are unconditional: behind the last step the rows lie beyond the descriptors' range, read as zeros and cost
+    // nothing - and the loop body has no branches around loads (with them the compiler parked the loaded rows in scratch).
+    auto load_rows = [&](int step) {
 #pragma unroll
-            for (int i = 0; i < XS; ++i) {
-                const int cb = wave + NW * i;
-                const unsigned voff = opaque(x_voff0 + ((unsigned)(tile * kTilePoints + 32 * ph) * (unsigned)p.ldx + 32u * cb) * 4u);
+        for (int i = 0; i < XS; ++i) {
+            const int cb = wave + NW * i;
+            const unsigned voff = opaque(x_voff0 + ((unsigned)(step * kStep) * (unsigned)p.ldx + 32u * cb) * 4u);
 #pragma unroll
-                for (int g = 0; g < 2; ++g)
-                    if (CB % NW == 0 || cb < CB) load_piece(x_rsrc, voff + 64u * g, xraw[i][ph][g]);
-            }
+            for (int g = 0; g < 2; ++g)
+                if (CB % NW == 0 || cb < CB) load_piece(x_rsrc, voff + 64u * g, xraw[i][g]);
+        }
+        const unsigned voff = opaque(g_voff0 + (unsigned)(step * kStep) * (unsigned)p.ldg * 4u);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) load_piece(g_rsrc, voff + 64u * g, graw[g]);
     };
-    auto load_g = [&](int tile, int ph) {
-        const unsigned voff = opaque(g_voff0 + (unsigned)(tile * kTilePoints + 32 * ph) * (unsigned)p.ldg * 4u);
-#pragma unroll
-        for (int g = 0; g < 2; ++g) load_piece(g_rsrc, voff + 64u * g, graw[ph][g]);
-    };
-
-#ifdef INERF_WGRAD_STAMPS   // development build (scripts/build_variant.sh, scripts/wgrad_timeline.py): cycle stamps of workgroup 0's
-    // wave 0 at the phase boundaries of its THIRD tile, kept in scalar registers (selects, no branches: branches around the
-    // stamps changed the register allocation of the whole loop) and written over the start of the partial tile at the end
-    unsigned long long wg_st[7] = {0, 0, 0, 0, 0, 0, 0};
-#define WG_STAMP(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); wg_st[k] = (tile == 2 * (int)gridDim.x) ? now_ : wg_st[k]; } while (0)
-#else
-#define WG_STAMP(k) do { } while (0)
-#endif
-    int buf = 0;
-    load_x(blockIdx.x, 0); load_x(blockIdx.x, 1); load_g(blockIdx.x, 0);
-    for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
-        WG_STAMP(0);
-        // ---- X: every wave transposes its share of the column blocks and parks the operands in LDS[buf] ----
+    // (a): the rows in xraw / graw -> X operands in LDS[buf], G operands in gh / gl
+    auto convert = [&](int buf, f16x8 (&gh)[2], f16x8 (&gl)[2]) {
 #pragma unroll
         for (int i = 0; i < XS; ++i) {
             const int cb = wave + NW * i;
             if (CB % NW == 0 || cb < CB) {
+                f16x8 h0, l0, h1, l1, th[2], tl[2];
+                split8(xraw[i][0], sx, h0, l0);
+                split8(xraw[i][1], sx, h1, l1);
+                transpose_block(h0, h1, id0, id1, th);
+                transpose_block(l0, l1, id0, id1, tl);
 #pragma unroll
-                for (int ph = 0; ph < 2; ++ph) {
-                    f16x8 h0, l0, h1, l1, th[2], tl[2];
-                    split8(xraw[i][ph][0], sx, h0, l0);
-                    split8(xraw[i][ph][1], sx, h1, l1);
-                    transpose_block(h0, h1, id0, id1, th);
-                    transpose_block(l0, l1, id0, id1, tl);
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        *reinterpret_cast<f16x8*>(xfrag(buf, cb, ph, q, 0)) = th[q];
-                        *reinterpret_cast<f16x8*>(xfrag(buf, cb, ph, q, 1)) = tl[q];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int q = 0; q < 2; ++q) {
+                    *reinterpret_cast<f16x8*>(xfrag(buf, cb, q, 0)) = th[q];
+                    *reinterpret_cast<f16x8*>(xfrag(buf, cb, q, 1)) = tl[q];
                 }
-            }
-        }
-        // Requests are unconditional: behind the last tile the rows lie beyond the descriptors' range and cost nothing, and the
-        // loop body stays one basic block (with branches around the loads the compiler parked the loaded rows in scratch).
-        WG_STAMP(1);
-        load_g(tile, 1);                           // this tile's second half of G: needed after the first half's MFMAs
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- G: this wave's row block, one 32-point half at a time: converted into registers, contracted against that half's X
-        // operands.  The first half was requested a tile ago (its registers are refilled as soon as it is converted), the
-        // second half's conversion sits behind the barrier between the two halves' MFMAs.
-#pragma unroll
-        for (int ph = 0; ph < 2; ++ph) {
-            f16x8 gh[2], gl[2];                // [q]
-            {
-                f16x8 h0, l0, h1, l1;
-                split8(graw[ph][0], sg, h0, l0);
-                split8(graw[ph][1], sg, h1, l1);
-                bias_sum += transpose_block(h0, h1, id0, id1, gh);
-                bias_sum += transpose_block(l0, l1, id0, id1, gl);
-            }
-            // The next tile's rows, in the order the next tile converts them: X's first half a whole contraction ahead, X's second
-            // half and G's first half from the middle of this one (they are needed 500 / 1 000 cycles into the next tile).
-            WG_STAMP(ph == 0 ? 2 : 5);
-            if (ph == 0) {
-                load_x(tile + gridDim.x, 0);
-                __syncthreads();               // LDS[buf] complete; LDS[buf ^ 1] (last read before the previous barrier) is free
-                WG_STAMP(3);
-            } else {
-                load_x(tile + gridDim.x, 1);
-                load_g(tile + gridDim.x, 0);
-            }
-            // X operands one step ahead of their MFMAs, fenced: unfenced, the scheduler hoists ~20 operand reads (80 registers)
-            // to the top of the half and spills the prefetched rows to make room
-            f16x8 xh[2], xl[2];
-            xh[0] = *reinterpret_cast<const f16x8*>(xfrag(buf, 0, ph, 0, 0));
-            xl[0] = *reinterpret_cast<const f16x8*>(xfrag(buf, 0, ph, 0, 1));
-#pragma unroll
-            for (int st = 0; st < 2 * CB; ++st) {
-                const int q = st / CB, cb = st % CB;
-                if (st + 1 < 2 * CB) {
-                    xh[(st + 1) & 1] = *reinterpret_cast<const f16x8*>(xfrag(buf, (st + 1) % CB, ph, (st + 1) / CB, 0));
-                    xl[(st + 1) & 1] = *reinterpret_cast<const f16x8*>(xfrag(buf, (st + 1) % CB, ph, (st + 1) / CB, 1));
-                }
-                __builtin_amdgcn_sched_barrier(0);       // reads first (else they share registers with this step's operands and slip behind its MFMAs)
-                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[q], xh[st & 1], acc[cb], 0, 0, 0);
-                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[q], xl[st & 1], acc[cb], 0, 0, 0);
-                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl[q], xh[st & 1], acc[cb], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            WG_STAMP(ph == 0 ? 4 : 6);
         }
-        buf ^= 1;
+        f16x8 h0, l0, h1, l1;
+        split8(graw[0], sg, h0, l0);
+        split8(graw[1], sg, h1, l1);
+        bias_sum += transpose_block(h0, h1, id0, id1, gh);
+        bias_sum += transpose_block(l0, l1, id0, id1, gl);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // (b): X operands one read ahead of their MFMAs, fenced: unfenced, the scheduler hoists ~20 operand reads (80 registers) to
+    // the top and spills the prefetched rows to make room; reads first, else they share registers with the running MFMAs'
+    // operands and slip behind them
+    auto contract = [&](int buf, const f16x8 (&gh)[2], const f16x8 (&gl)[2]) {
+        f16x8 xh[2], xl[2];
+        xh[0] = *reinterpret_cast<const f16x8*>(xfrag(buf, 0, 0, 0));
+        xl[0] = *reinterpret_cast<const f16x8*>(xfrag(buf, 0, 0, 1));
+#pragma unroll
+        for (int st = 0; st < 2 * CB; ++st) {
+            const int q = st / CB, cb = st % CB;
+            if (st + 1 < 2 * CB) {
+                xh[(st + 1) & 1] = *reinterpret_cast<const f16x8*>(xfrag(buf, (st + 1) % CB, (st + 1) / CB, 0));
+                xl[(st + 1) & 1] = *reinterpret_cast<const f16x8*>(xfrag(buf, (st + 1) % CB, (st + 1) / CB, 1));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[q], xh[st & 1], acc[cb], 0, 0, 0);
+            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[q], xl[st & 1], acc[cb], 0, 0, 0);
+            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl[q], xh[st & 1], acc[cb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+#ifdef INERF_WGRAD_STAMPS   // development build (scripts/build_variant.sh, scripts/wgrad_timeline.py): cycle stamps of workgroup 0's
+    // waves 0 and 4 at the phase boundaries of one steady-state step, kept in scalar registers (selects, no branches: branches
+    // around the stamps changed the register allocation of the whole loop), written over the start of the partial tile
+    unsigned long long wg_st[5] = {0, 0, 0, 0, 0};
+#define WG_STAMP(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); wg_st[k] = (u == 0 && step == (int)blockIdx.x + 8 * (int)gridDim.x) ? now_ : wg_st[k]; } while (0)
+#else
+#define WG_STAMP(k) do { } while (0)
+#endif
+    // this workgroup's steps: blockIdx.x, + gridDim.x, ... of ceil(n_points / 32)
+    const int n_steps = (p.n_points + kStep - 1) / kStep;
+    f16x8 gh[2][2], gl[2][2];          // [step parity][q]
+    load_rows(blockIdx.x);
+    convert(0, gh[0], gl[0]);
+    load_rows(blockIdx.x + gridDim.x);
+    for (int step = blockIdx.x; step < n_steps; step += 2 * gridDim.x) {
+        // two steps per iteration: the parities of the LDS buffers and of the G operand registers are compile-time constants
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            WG_STAMP(0);
+            __syncthreads();           // every wave has converted step `step + u g`, every wave has contracted the one before
+            WG_STAMP(1);
+            if (convert_first) {
+                convert(u ^ 1, gh[u ^ 1], gl[u ^ 1]);
+                load_rows(step + (u + 2) * gridDim.x);
+            }
+            WG_STAMP(2);
+            contract(u, gh[u], gl[u]);
+            WG_STAMP(3);
+            if (!convert_first) {
+                convert(u ^ 1, gh[u ^ 1], gl[u ^ 1]);
+                load_rows(step + (u + 2) * gridDim.x);
+            }
+            WG_STAMP(4);
+        }
     }
 
     // ---- this workgroup's partial tile: row m = channel of G, column n = channel of X ----
@@ -226,10 +231,10 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
     float* out = p.partial + (size_t)blockIdx.x * p.partial_stride;
 #ifdef INERF_WGRAD_STAMPS
     if (blockIdx.x == 0) {
-        if (lane == 0) {                       // every wave (waves w and w + 4 share a SIMD)
-            unsigned long long* d = reinterpret_cast<unsigned long long*>(p.bias_partial ? p.bias_partial : p.partial) + 8 * wave;
-            d[0] = 7;
-            for (int i = 0; i < 7; ++i) d[1 + i] = wg_st[i];
+        if (tid == 0 || tid == 256) {
+            unsigned long long* d = reinterpret_cast<unsigned long long*>(p.bias_partial ? p.bias_partial : p.partial) + (tid ? 8 : 0);
+            d[0] = 5;
+            for (int i = 0; i < 5; ++i) d[1 + i] = wg_st[i];
         }
         return;
     }
@@ -266,8 +271,8 @@ extern "C" int inerf_mlp_weight_gradient(const float* G, int ldg, const float* X
                                          void* stream) {
     using namespace inerf;
     if (!G || !X || !ranges || !partial || n_points <= 0 || ldg < M || ldx < N) return INERF_E_INVALID;
-    // rows are addressed through 32-bit buffer descriptors, the prefetch reaches one grid stride of tiles beyond the end
-    if ((n_points + (int64_t)kTilePoints * (device_cus() + 1)) * (ldg > ldx ? ldg : ldx) * 4 >= (int64_t)1 << 32) return INERF_E_UNSUPPORTED;
+    // rows are addressed through 32-bit buffer descriptors, the prefetch reaches three grid strides of 32-point steps beyond the end
+    if ((n_points + (int64_t)32 * (3 * device_cus() + 2)) * (ldg > ldx ? ldg : ldx) * 4 >= (int64_t)1 << 32) return INERF_E_UNSUPPORTED;
     if ((ldg & 3) || (ldx & 3) || (((uintptr_t)G | (uintptr_t)X) & 15)) return INERF_E_INVALID;      // 16-byte row pieces
     WgradParams p;
     if (partial_stride < (int64_t)M * N) return INERF_E_INVALID;
@@ -277,7 +282,7 @@ extern "C" int inerf_mlp_weight_gradient(const float* G, int ldg, const float* X
     const int grid = inerf_wgrad_grid(n_points);
     const int cb = N / 32;
     if ((M != 128 && M != 256) || N % 32 || cb < 1 || cb > 8) return INERF_E_UNSUPPORTED;
-    const int lds = 2 * cb * 8 * kWgFragBytes;          // double-buffered X operands
+    const int lds = 2 * cb * 4 * kWgFragBytes;          // X operands of two 32-point steps
     void (*kern)(const WgradParams) = nullptr;
 #define INERF_WG_CASE(NWV, CBV) if (M == 32 * NWV && cb == CBV) kern = k_mlp_wgrad<NWV, CBV>;
     INERF_WG_CASE(8, 8) INERF_WG_CASE(8, 2) INERF_WG_CASE(4, 8) INERF_WG_CASE(4, 1) INERF_WG_CASE(8, 1) INERF_WG_CASE(4, 2)

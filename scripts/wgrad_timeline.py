@@ -28,13 +28,15 @@ for _ in range(3):
                                        C.c_void_p(torch.cuda.current_stream().cuda_stream))
     _capi.check(rc, "inerf_mlp_weight_gradient")
     torch.cuda.synchronize()
-t = partial[0, 256 * 256:256 * 256 + 18].contiguous().view(torch.int64).cpu().tolist()
-k, v = t[0], t[1:9]
-if not 2 <= k <= 8:
-    k, v = 1, [0] * 8          # not a stamped build: the timing below is still valid
-print(f"{k} stamps; {v[k - 1] - v[0]} cycles for the tile ({grid} workgroups, {p // 64 // grid} tiles each)")
-for i in range(1, k):
-    print(f"  {names[i - 1]:42s} {v[i] - v[i - 1]:8d}")
+t = partial[0, 256 * 256:256 * 256 + 128].contiguous().view(torch.int64).cpu().tolist()
+if all(t[8 * w] == 7 for w in range(8)):
+    base = t[1]
+    print("wave   top   X share  G half 1  at barrier  released  contraction 1  G half 2  contraction 2 = end of tile   (cycles; waves w and w + 4 share a SIMD)")
+    for w in range(8):
+        v = [x - base for x in t[8 * w + 1:8 * w + 8]]
+        print(f"  {w}  {v[0]:6d}  {v[1] - v[0]:7d}  {v[2] - v[1]:8d}  {v[2]:10d}  {v[3]:8d}  {v[4] - v[3]:13d}  {v[5] - v[4]:8d}  {v[6] - v[5]:13d} = {v[6]:6d}")
+else:
+    print("(not a stamped build: timing only)")
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(10):
