@@ -189,7 +189,9 @@ int inerf_mlp_backward_grid(int64_t n_points);
  * matrices (a slot of the gradient / activation buffers, or a 32-column-aligned part of one; pointers 16-byte
  * aligned, ld a multiple of 4); M in {128, 256}, N in {32, 64, 128, 256}.  ranges: device floats {gmax, xmax}, upper
  * bounds of |G| and |X| (e.g. the dz_max of inerf_mlp_backward_inputs; 7.5e3 for activations that passed the forward's
- * range check): the kernel scales the operands by the powers of two that bring those bounds into [2^13, 2^14). */
+ * range check): the kernel scales the operands by the powers of two that bring those bounds into [2^13, 2^14).
+ * The rows are read through 32-bit buffer descriptors: n_points * max(ldg, ldx) * 4 bytes (plus a 25 MB prefetch margin) must
+ * stay below 4 GiB - INERF_E_UNSUPPORTED otherwise (4 000 000 points of a 256-wide slot fit). */
 int inerf_wgrad_grid(int64_t n_points);
 int inerf_mlp_weight_gradient(const float* G, int ldg, const float* X, int ldx, int64_t n_points, int M, int N,
                               const float* ranges, float* partial, float* bias_partial, int64_t partial_stride, void* stream);

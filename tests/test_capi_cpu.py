@@ -537,6 +537,9 @@ def test_one_call_backward_sizes(capi, variant, c):
     one = (C.c_float * 4)()
     # everything but the gradient blob missing: refused before anything is launched
     assert lib.inerf_mlp_backward(desc, None, None, None, None, None, p, 0, C.cast(one, C.c_void_p), None, 0, None, None) == capi.E_INVALID
+    # the weight-gradient kernel reads its rows through 32-bit descriptors: a matrix beyond 4 GiB is refused, not wrapped around
+    assert lib.inerf_mlp_weight_gradient(C.cast(one4, C.c_void_p), 256, C.cast(one4, C.c_void_p), 256, 4_200_000, 256, 256,
+                                         C.cast(one4, C.c_void_p), C.cast(one4, C.c_void_p), None, 256 * 256, None) == capi.E_UNSUPPORTED
     # param_views cuts the blob into the reference's shapes
     from intrinsicnerf_amd import kernels
     views = kernels.param_views(desc, torch.arange(n_params, dtype=torch.float32))
