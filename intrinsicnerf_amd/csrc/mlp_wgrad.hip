@@ -15,6 +15,8 @@
 // to f16 (exact: the inputs were f16), IS an operand of the next MFMA.  Two such MFMAs (identity placed in columns
 // 0..15 / 16..31) fill a [32 x 32] block; the resulting k order is the same permutation for G and X, so the
 // contraction is unaffected.  Cost: 2 extra MFMAs per 32 x 32 block and plane (+17 %), no LDS transposes.
+#include <cstdlib>
+
 #include "mlp_f16_dev.h"
 
 namespace inerf {
@@ -247,6 +249,171 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
         }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 256 x 256 products (nine of a network's thirteen, 90 % of the weight-gradient time): ROW-COALESCED form.
+//
+// k_mlp_wgrad above reads its rows with lane = point (the layout the transposing MFMA wants): every request fetches 16 bytes from
+// each of 32 rows, and the cycle stamps (profiles/r03_wgrad_timeline.txt) show the vector-memory front end saturated by them.
+// Here a request is one whole row - 64 lanes x 16 bytes = the 1 KB of a point's 256 channels - and no MFMA transposes anything:
+// a lane that has fetched the same four channels of EIGHT consecutive points holds, per channel, exactly the 8 k-values of one
+// operand slot (lane = channel, 8 consecutive points of a 16-point k-block).  Both matrices go through LDS as operand fragments:
+// waves 0..3 stage G (8 of a step's 32 points each), waves 4..7 stage X; every wave then contracts a [64 rows x 128 columns]
+// part of the tile (2 x 4 accumulator blocks, 24 KB of operand reads per step instead of 36).  Per 32-point step and wave:
+// 8 requests, 16 three-instruction splits, 8 conflict-free ds_write_b128, 48 MFMAs.
+// The point -> (k-block, k-half, element) assignment is the same for G and X, so the contraction does not see it.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kRowStep = 32;                                    // points per step
+constexpr int kRowSetBytes = 8 * 2 * 2 * kWgFragBytes;          // one matrix, one step: [32-channel block][k-block][hi | lo] fragments
+constexpr int kRowBufBytes = 2 * kRowSetBytes;                  // G | X
+
+__global__ __launch_bounds__(512, 1) void k_mlp_wgrad_rows(const WgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) char ldsw[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lp = lane & 31, lh = lane >> 5;
+    const bool is_g = wave < 4;                 // the matrix this wave stages
+    const int w4 = wave & 3;                    // ... and which 8 of a step's 32 points
+    auto pow2_for = [](float m) { int e; if (!(m > 0.0f) || !(m < 3.0e38f)) return 1.0f; frexpf(m, &e); return ldexpf(1.0f, 14 - e); };
+    auto uniform = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+    const float sg = uniform(pow2_for(p.ranges[0])), sx = uniform(pow2_for(p.ranges[1]));
+    const float s_mine = is_g ? sg : sx;
+    const int ld = is_g ? p.ldg : p.ldx;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(is_g ? p.G : p.X), 0,
+                                                                           (int)((unsigned)p.n_points * (unsigned)ld * 4u), 0x00020000);
+    const unsigned row_bytes = (unsigned)ld * 4u;
+    const unsigned voff0 = (unsigned)(8 * w4) * row_bytes + 16u * lane;       // the whole offset goes through the VGPR (range check)
+    auto opaque = [](unsigned v) { asm volatile("" : "+v"(v)); return v; };
+    // rows 32 step + 8 w4 + j, j = 0..7; beyond the end of the matrix they read as zeros (and cost nothing)
+    auto load_rows = [&](int step, f32x4 (&raw)[8]) {
+        const unsigned v = opaque(voff0 + (unsigned)(step * kRowStep) * row_bytes);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) raw[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(v + j * row_bytes), 0, 0));
+    };
+    // Operand slot (16 bytes = 8 points of one channel) of channel n (0..31 of its block) and k-half kh inside a 1 KB fragment:
+    // (n >> 2) + 8 (n & 3) + 32 kh.  A staging lane owns channels 4 (lane & 7) .. + 3 of block lane >> 3: for a given one of its
+    // four channels the 8 lanes of a block write 128 consecutive bytes and the 8 blocks 8 different fragments - every ds_write_b128
+    // is conflict-free.  A contracting lane (n = lane & 31, kh = lane >> 5) reads its own slot: 64 different slots of one fragment.
+    float bias4[4] = {0.0f, 0.0f, 0.0f, 0.0f};     // G waves: sums over this workgroup's points of the lane's four channels
+    auto convert = [&](int buf, const f32x4 (&raw)[8]) {
+        char* set = ldsw + buf * kRowBufBytes + (is_g ? 0 : kRowSetBytes);
+        const int q = w4 >> 1, kh = w4 & 1;        // the 8 points 8 w4 .. + 7 of the step: k-block q, k-half kh, elements 0..7
+        char* dst0 = set + (((lane >> 3) * 2 + q) * 2) * kWgFragBytes + ((lane & 7) + 32 * kh) * 16;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f16x8 hi, lo;
+            float sum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                f16x2 h2, l2;
+                split_pair(raw[j][e] * s_mine, raw[j + 1][e] * s_mine, h2, l2);
+                hi[j] = h2[0]; hi[j + 1] = h2[1];
+                lo[j] = l2[0]; lo[j + 1] = l2[1];
+                sum += raw[j][e] + raw[j + 1][e];
+            }
+            bias4[e] += sum;
+            *reinterpret_cast<f16x8*>(dst0 + 8 * e * 16) = hi;
+            *reinterpret_cast<f16x8*>(dst0 + 8 * e * 16 + kWgFragBytes) = lo;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // this wave's part of the tile: rows 64 (wave & 3) .. + 63, columns 128 (wave >> 2) .. + 127
+    const int rb0 = 2 * (wave & 3), cb0 = 4 * (wave >> 2);
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.0f;
+    const int my_slot = ((lp >> 2) + 8 * (lp & 3) + 32 * lh) * 16;
+    auto frag = [&](const char* set, int block, int q, int plane) {
+        return *reinterpret_cast<const f16x8*>(set + ((block * 2 + q) * 2 + plane) * kWgFragBytes + my_slot);
+    };
+    auto contract = [&](int buf) {
+        const char* gset = ldsw + buf * kRowBufBytes;
+        const char* xset = gset + kRowSetBytes;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            f16x8 gh[2], gl[2], xh[2], xl[2];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) { gh[rb] = frag(gset, rb0 + rb, q, 0); gl[rb] = frag(gset, rb0 + rb, q, 1); }
+            xh[0] = frag(xset, cb0, q, 0); xl[0] = frag(xset, cb0, q, 1);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {     // X operands one read ahead of their MFMAs, fenced (see k_mlp_wgrad)
+                if (cb + 1 < 4) { xh[(cb + 1) & 1] = frag(xset, cb0 + cb + 1, q, 0); xl[(cb + 1) & 1] = frag(xset, cb0 + cb + 1, q, 1); }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[rb], xh[cb & 1], acc[rb][cb], 0, 0, 0);
+                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[rb], xl[cb & 1], acc[rb][cb], 0, 0, 0);
+                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl[rb], xh[cb & 1], acc[rb][cb], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    // this workgroup's steps: blockIdx.x, + gridDim.x, ... of ceil(n_points / 32); rows are converted one step before they are
+    // contracted (two LDS buffers, one barrier per step) and requested one step before they are converted - two steps with
+    // INERF_WGRAD_ROWS_DEPTH2 (a second register set: 32 more registers, spills)
+    const int n_steps = (p.n_points + kRowStep - 1) / kRowStep;
+    const int g = gridDim.x;
+#ifdef INERF_WGRAD_ROWS_DEPTH2
+    f32x4 raw_a[8], raw_b[8];
+    load_rows(blockIdx.x, raw_a);
+    load_rows(blockIdx.x + g, raw_b);
+    convert(0, raw_a);
+    load_rows(blockIdx.x + 2 * g, raw_a);
+    for (int s = blockIdx.x; s < n_steps; s += 2 * g) {
+        __syncthreads();               // LDS[0] holds step s; nobody reads LDS[1] any more
+        contract(0);
+        convert(1, raw_b);             // step s + g
+        load_rows(s + 3 * g, raw_b);
+        __syncthreads();               // LDS[1] holds step s + g (zeros beyond the end); nobody reads LDS[0] any more
+        contract(1);
+        convert(0, raw_a);             // step s + 2 g
+        load_rows(s + 4 * g, raw_a);
+    }
+#else
+    f32x4 raw[8];
+    load_rows(blockIdx.x, raw);
+    convert(0, raw);
+    load_rows(blockIdx.x + g, raw);
+    for (int s = blockIdx.x; s < n_steps; s += 2 * g) {
+        __syncthreads();               // LDS[0] holds step s; nobody reads LDS[1] any more
+        contract(0);
+        convert(1, raw);               // step s + g
+        load_rows(s + 2 * g, raw);
+        __syncthreads();               // LDS[1] holds step s + g (zeros beyond the end); nobody reads LDS[0] any more
+        contract(1);
+        convert(0, raw);               // step s + 2 g
+        load_rows(s + 3 * g, raw);
+    }
+#endif
+
+    // ---- this workgroup's partial tile and its column sums of G ----
+    if (p.bias_partial) {              // the four G waves hold different points of the same 256 channels
+        __syncthreads();
+        float* sums = reinterpret_cast<float*>(ldsw);
+        if (is_g) *reinterpret_cast<f32x4*>(sums + w4 * 256 + 4 * lane) = f32x4{bias4[0], bias4[1], bias4[2], bias4[3]};
+        __syncthreads();
+        if (tid < 256) p.bias_partial[(size_t)blockIdx.x * p.partial_stride + tid] = (sums[tid] + sums[256 + tid]) + (sums[512 + tid] + sums[768 + tid]);
+    }
+    const float back = 1.0f / (sg * sx);
+    float* out = p.partial + (size_t)blockIdx.x * p.partial_stride;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int m = 32 * (rb0 + rb) + (j & 3) + 8 * (j >> 2) + 4 * lh;
+                out[(size_t)m * 256 + 32 * (cb0 + cb) + lp] = acc[rb][cb][j] * back;
+            }
+}
+
 }  // namespace inerf
 
 // G[P, ldg], X[P, ldx] row-major device matrices (pointers to the first used column; M and N columns are read);
@@ -277,6 +444,16 @@ extern "C" int inerf_mlp_weight_gradient(const float* G, int ldg, const float* X
     const int grid = inerf_wgrad_grid(n_points);
     const int cb = N / 32;
     if ((M != 128 && M != 256) || N % 32 || cb < 1 || cb > 8) return INERF_E_UNSUPPORTED;
+    // 256 x 256: the row-coalesced form (INERF_WGRAD_FORM=points keeps the lane = point form for A/B runs)
+    const char* form = getenv("INERF_WGRAD_FORM");
+    if (M == 256 && N == 256 && !(form && form[0] == 'p')) {
+        if ((n_points + (int64_t)kRowStep * (4 * grid + 2)) * (ldg > ldx ? ldg : ldx) * 4 >= (int64_t)1 << 32) return INERF_E_UNSUPPORTED;
+        const int lds_rows = 2 * kRowBufBytes;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_wgrad_rows), hipFuncAttributeMaxDynamicSharedMemorySize, lds_rows);
+        if (e != hipSuccess) return record(e);
+        hipLaunchKernelGGL(k_mlp_wgrad_rows, dim3(grid), dim3(512), lds_rows, (hipStream_t)stream, p);
+        return record(hipGetLastError());
+    }
     const int lds = 2 * cb * 8 * kWgFragBytes;          // double-buffered X operands
     void (*kern)(const WgradParams) = nullptr;
 #define INERF_WG_CASE(NWV, CBV) if (M == 32 * NWV && cb == CBV) kern = k_mlp_wgrad<NWV, CBV>;

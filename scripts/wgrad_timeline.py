@@ -14,8 +14,13 @@ from intrinsicnerf_amd import _capi  # noqa: E402
 dev = torch.device("cuda:0")
 lib = _capi.lib()
 p = 2048 * 192
-g = torch.randn(p, 256, device=dev)
-x = torch.randn(p, 256, device=dev).abs()
+# G and X as two slots of ONE buffer, like the library's [slot][point][width] activation / gradient buffers: X starts
+# p * 256 floats (+ an optional skew, bytes, multiple of 16: argv[1]) behind G
+skew = int(sys.argv[1]) // 4 if len(sys.argv) > 1 else 0
+both = torch.empty(2 * p * 256 + skew + 1024, device=dev)
+g = both[:p * 256].view(p, 256).normal_()
+x = both[p * 256 + skew:2 * p * 256 + skew].view(p, 256).normal_().abs_()
+print(f"G at {g.data_ptr():#x}, X at {x.data_ptr():#x}: X - G = {x.data_ptr() - g.data_ptr():#x}")
 ranges = torch.tensor([float(g.abs().max()), float(x.max())], device=dev)
 grid = lib.inerf_wgrad_grid(p)
 stride = 256 * 256 + 256
