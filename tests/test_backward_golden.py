@@ -429,6 +429,24 @@ def test_weight_gradient_kernel_vs_fp64(p, m, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("p", [1, 31, 33, 5000])
+def test_weight_gradient_forms_of_the_square_product(p, monkeypatch):
+    """256 x 256 products run on the row-coalesced kernel by default and on the lane = point kernel with
+    INERF_WGRAD_FORM=points: both against fp64, down to a single sample point (steps / tiles that are mostly padding)."""
+    from intrinsicnerf_amd import kernels
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(100 + p)
+    G = torch.randn(p, 256, generator=g).to(dev)
+    X = torch.relu(torch.randn(p, 256, generator=g)).to(dev)
+    want_w, want_b = G.double().t() @ X.double(), G.double().sum(0)
+    for form in ("rows", "points"):
+        monkeypatch.setenv("INERF_WGRAD_FORM", form)
+        w, b = kernels.weight_gradient(G, X, 256, 256, want_bias=True)
+        assert float((w.double() - want_w).norm()) <= 2e-6 * float(want_w.norm()), form
+        assert float((b.double() - want_b).norm()) <= 2e-6 * float(want_b.norm()) + 1e-12, form
+
+
+@pytest.mark.gpu
 def test_training_batch_outside_f16_range_is_reevaluated_with_torch_layers(monkeypatch):
     """The training forward reads the f16 range words of both networks ONCE, after the batch is enqueued.  A batch that trips it is
     evaluated again with the layers in torch - same random draws (the RNG state is put back), hence the same maps and gradients
