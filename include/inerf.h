@@ -30,7 +30,7 @@ extern "C" {
 #define INERF_VERSION_MINOR 2
 /* Bumped whenever a struct layout, an argument list or the packed-weight format of this header changes; bindings
  * compare it with inerf_abi_version() of the library they loaded (a stale .so then fails loudly, not silently). */
-#define INERF_ABI_VERSION 30004
+#define INERF_ABI_VERSION 40001
 
 /* error codes */
 #define INERF_OK              0
@@ -142,22 +142,37 @@ int inerf_encode_mlp_ws(const inerf_net_desc* net, const float* packed_weights, 
  *             (the input-gradient chain, MFMA); the weight gradients are then plain GEMMs over the
  *             sample points, dW_l = dZ_l^T X_l, db_l = column sums of dZ_l, left to the caller's
  *             GEMM library.
- * `save` and `dz` are fp32 buffers of inerf_mlp_save_floats() floats laid out [slot][point][width]
- * (every slot a row-major [n_points, width] matrix; inerf_mlp_save_slot() gives offset and width):
+ * `save` and `dz` are buffers of inerf_mlp_save_floats() 4-byte elements laid out [slot][point][width], every slot sized for
+ * WHOLE 64-point tiles (64 * ceil(n_points / 64) points; inerf_mlp_save_slot() gives offset, width and format):
  *   slot 0 enc 64 | 1 dir 32 | 2..9 h0..h7 256 | 10 albedo|shading hidden 256 | 11 feature 256 |
  *   12 views hidden 128 | 13 semantic hidden 128 (SSR with classes, else width 0) |
- *   14 (dz only) head pre-activation gradients 8: albedo 3, shading 1, residual 3, sigma 1.
+ *   14 (dz only) head pre-activation gradients 8: albedo 3, shading 1, residual 3, sigma 1 | 15 (save only) h7 again.
+ * Two slot formats:
+ *   ROWS      a row-major fp32 [n_points, width] matrix.  save: 0, 1, 10, 11, 12, 13, 15; dz: 12, 13, 14.
+ *   FRAGMENTS the operands of the nine 256 x 256 weight-gradient products dW = dZ^T X exactly as the matrix core consumes
+ *             them: every value v is stored as f16 hi = f16(v') (towards zero) and f16 lo = f16(v' - hi), v' = scale * v, in
+ *             1 KB fragments [32 channels x 16 points]: with kb = 16-point block of the tile (0..3), cb = 32-channel block,
+ *               byte offset = (((tile * 4 + kb) * 8 + cb) * 2 + (0: hi, 1: lo)) * 1024 + lane * 16 + 2 * i      (i = 0..7)
+ *               channel = 32 cb + (lane & 31),  point = 64 tile + 32 (kb >> 1) + (i & 3) + 8 ((i >> 2) + 2 (kb & 1)) + 4 (lane >> 5)
+ *             (lane = channel, 8 k-values = 8 points: one 16-byte operand slot of v_mfma_f32_32x32x16_f16; the point order
+ *             inside a block is the accumulator's register order).  save: 2..9 with scale 8; dz: 2..11 with scale 8 / S, S =
+ *             the float at element inerf_mlp_save_floats() - 64 of dz (the largest per-point normaliser of the batch, a
+ *             power of two, written by inerf_mlp_backward_inputs).  Padding points of the last tile hold a copy of the last
+ *             point (save) / zeros (dz).  Same 4 bytes per element as fp32; the producers write whole fragments and
+ *             inerf_mlp_weight_gradient_frag moves them HBM -> LDS by DMA, without a register or a conversion in between.
  * Behind the slots `save` carries the ReLU masks of h0..h6 as bits (14 336 bytes per 64-point tile, written by
  * inerf_encode_mlp_train and read by inerf_mlp_backward_inputs in place of the activations; layout private to the
- * two kernels): always pass a buffer that inerf_encode_mlp_train itself filled, of inerf_mlp_save_floats() floats.
+ * two kernels) and 64 scalars: always pass a buffer that inerf_encode_mlp_train itself filled, of inerf_mlp_save_floats() floats.
  * The gradient w.r.t. the semantic logits is d_raw[..., 11:11+C] itself (no activation).
  * One kept evaluation is limited to 4 000 000 sample points (a slot is addressed through a 32-bit buffer descriptor):
  * inerf_encode_mlp_train, inerf_mlp_backward_inputs and inerf_mlp_backward return INERF_E_UNSUPPORTED beyond it; split a
  * larger batch into several evaluations and add the parameter gradients (the Python mirror does).
  * ------------------------------------------------------------------------------------------- */
-#define INERF_SAVE_SLOTS 15
+#define INERF_SAVE_SLOTS 16
 int64_t inerf_mlp_save_floats(const inerf_net_desc* net, int64_t n_points);
 int inerf_mlp_save_slot(const inerf_net_desc* net, int slot, int64_t n_points, int64_t* offset_floats, int* width);
+/* 1 when `slot` of the gradient buffer (gradient != 0) / the activation buffer is in FRAGMENT format, 0 for rows, negative: error */
+int inerf_mlp_save_slot_is_fragment(int slot, int gradient);
 int inerf_encode_mlp_train(const inerf_net_desc* net, const float* packed_weights, const float* rays, const float* z_vals,
                            int64_t n_rays, int n_samples, uint32_t flags, float* raw_out, float* save_out,
                            float* act_max /* optional device float the kernel max-es |activation| into (caller zeroes it) */,
@@ -195,6 +210,14 @@ int inerf_mlp_backward_grid(int64_t n_points);
 int inerf_wgrad_grid(int64_t n_points);
 int inerf_mlp_weight_gradient(const float* G, int ldg, const float* X, int ldx, int64_t n_points, int M, int N,
                               const float* ranges, float* partial, float* bias_partial, int64_t partial_stride, void* stream);
+/* The same with G a FRAGMENT slot of the gradient buffer (M = 256; s_max: the device float S of that buffer, see above) and X
+ * row-format: N in {64} (the encoding columns of pts_linears.0 / .5).  ranges[1] bounds |X|. */
+int inerf_mlp_weight_gradient_gfrag(const void* G_frag, const float* s_max, const float* X, int ldx, int64_t n_points, int N,
+                                    const float* ranges, float* partial, float* bias_partial, int64_t partial_stride, void* stream);
+/* ... and with BOTH operands FRAGMENT slots (256 x 256: G of the gradient buffer, X of the activation buffer, same points):
+ * a ring of LDS stages filled by LDS-DMA, no conversion - bound by HBM bandwidth. */
+int inerf_mlp_weight_gradient_frag(const void* G_frag, const void* X_frag, const float* s_max, int64_t n_points,
+                                   float* partial, float* bias_partial, int64_t partial_stride, void* stream);
 
 /* The network's whole backward pass in ONE call: the input-gradient chain, every weight-gradient product (split-K launches,
  * the workgroups' partial tiles side by side in the workspace) and one reduction that writes every sum into its place in

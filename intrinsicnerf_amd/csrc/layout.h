@@ -134,10 +134,29 @@ inline NetLayout make_layout(const inerf_net_desc& net) {
 }
 
 // ---- training: activations kept by the forward pass / pre-activation gradients produced by the backward pass ----
-// One fp32 buffer of [slot][point][width]: every slot is a plain row-major [n_points, width] matrix, which is what the
-// weight-gradient GEMMs (dW = dZ^T X, K = n_points) consume.  The same slot list serves both buffers; the gradient
-// buffer leaves SAVE_ENC / SAVE_DIR unused and holds the heads' pre-activation gradients in SAVE_DPRE instead
-// (8 floats per point: albedo 3, shading 1, residual 3, sigma 1).
+// One buffer of [slot][point][width] 4-byte elements per evaluation; the same slot list serves both buffers.  Slots are sized
+// for WHOLE 64-point tiles (padded_points): the last tile's padding rows belong to the slot.  Two slot formats:
+//   * ROWS: a plain row-major fp32 [n_points, width] matrix - what the VALU stages of the chain and the weight-gradient
+//     products with narrow / 128-row operands read;
+//   * FRAGMENTS (256-wide slots that feed the nine 256 x 256 weight-gradient products, dW = dZ^T X with K = sample points):
+//     the values ALREADY SPLIT into f16 hi / lo and stored as the operand fragments of v_mfma_f32_32x32x16_f16 - per 16-point
+//     k-block kb (four per tile) and 32-channel block cb one 1 KB fragment per plane,
+//         byte offset = (((tile * 4 + kb) * 8 + cb) * 2 + plane) * 1024 + lane * 16 + 2 * i,
+//         channel     = 32 * cb + (lane & 31),
+//         point       = 64 * tile + 32 * (kb >> 1) + frag_point(kb & 1, lane >> 5, i)        (i = 0..7),
+//     i.e. exactly what a lane of the weight-gradient kernel feeds the matrix core (lane = channel, 8 k-values = points): the
+//     consumer moves the fragments HBM -> LDS by LDS-DMA and never converts, transposes or even touches them with the VALU.
+//     The producers hold these values as hi / lo planes in LDS anyway (X[point][channel]); the transposition is one pass of
+//     the matrix core over the planes (a 0/1 selector as B operand: D[point][channel] comes back with lane = channel,
+//     registers = points, mlp_f16_dev.h planes_to_frag) and a fragment leaves the CU as ONE contiguous 1 KB store.  Same
+//     4 bytes per element as fp32.  The point order inside a k-block is the accumulator's register order - the same for the
+//     activations and the gradients, and the one the row-format kernel's transposing MFMAs produce - so products may mix
+//     formats (G fragments x row-format X).
+//     Scales: activations are stored as kActScale * h (the forward's own LDS planes); gradients as kActScale * dZ / S, S = the
+//     largest per-point normaliser of the chain (a power of two, found by a pre-pass over d_raw; mlp_bwd.hip).
+//   activation buffer: ENC, DIR, AS1H, FEAT, VH, SEMH, H7R rows; H0..H7 fragments (H7 in both formats: the chain reads its rows);
+//   gradient buffer:   VH, SEMH, DPRE rows; H0..H7, AS1H, FEAT fragments (8 floats per point of DPRE: albedo 3, shading 1,
+//                      residual 3, sigma 1); ENC, DIR, H7R unused.
 enum SaveSlot {
     SAVE_ENC = 0,      // 64  encoded position (63 + zero pad)
     SAVE_DIR,          // 32  encoded view direction (27 + zero pad)
@@ -148,24 +167,37 @@ enum SaveSlot {
     SAVE_VH,           // 128 views_linears.0 output, post-ReLU
     SAVE_SEMH,         // 128 semantic hidden, post-ReLU (SSR with classes only; width 0 otherwise)
     SAVE_DPRE,         // 8   (gradient buffer only)
+    SAVE_H7R,          // 256 h7 once more, as rows (activation buffer only)
     SAVE_SLOTS
 };
+
+constexpr int kFragBytes = 1024;                       // one operand fragment: 64 lanes x 8 halfs
+constexpr int kFragKbBytes = 8 * 2 * kFragBytes;       // one 16-point k-block of a 256-wide slot: [cb 8][hi | lo]
+constexpr int kFragTileBytes = 4 * kFragKbBytes;       // = 64 points x 256 channels x 4 bytes
+inline int frag_point(int q, int h, int i) { return (i & 3) + 8 * ((i >> 2) + 2 * q) + 4 * h; }
+inline int64_t padded_points(int64_t n_points) { return (n_points + kTilePoints - 1) / kTilePoints * kTilePoints; }
 
 inline int save_width(const inerf_net_desc& net, int slot) {
     if (slot == SAVE_ENC) return kEncCols;
     if (slot == SAVE_DIR) return kDirCols;
     if (slot >= SAVE_H0 && slot <= SAVE_H7) return kWidth;
-    if (slot == SAVE_AS1H || slot == SAVE_FEAT) return kWidth;
+    if (slot == SAVE_AS1H || slot == SAVE_FEAT || slot == SAVE_H7R) return kWidth;
     if (slot == SAVE_VH) return kHalf;
     if (slot == SAVE_SEMH) return (net.variant == INERF_VARIANT_SSR && net.n_classes > 0) ? kHalf : 0;
     if (slot == SAVE_DPRE) return 8;
     return 0;
 }
 
+// format of a slot: 1 = fragments, 0 = rows (gradient: the buffer of pre-activation gradients, else the activation buffer)
+inline int save_is_frag(int slot, bool gradient) {
+    if (slot >= SAVE_H0 && slot <= SAVE_H7) return 1;
+    return (gradient && (slot == SAVE_AS1H || slot == SAVE_FEAT)) ? 1 : 0;
+}
+
 inline int64_t save_offset(const inerf_net_desc& net, int slot, int64_t n_points) {     // in floats
     int64_t w = 0;
     for (int s = 0; s < slot; ++s) w += save_width(net, s);
-    return w * n_points;
+    return w * padded_points(n_points);
 }
 
 // Behind the slots of the ACTIVATION buffer: the ReLU masks of the trunk outputs h0..h6, one bit per activation, which the
@@ -179,8 +211,13 @@ constexpr int kReluBitLayers = 7;
 constexpr int kReluBitTileBytes = kReluBitLayers * 4 * 64 * 8;      // 14,336 B per 64-point tile
 inline int64_t relu_bits_offset(const inerf_net_desc& net, int64_t n_points) { return save_offset(net, SAVE_SLOTS, n_points); }
 inline int64_t relu_bits_floats(int64_t n_points) { return (n_points + kTilePoints - 1) / kTilePoints * (kReluBitTileBytes / 4); }
+// Behind the mask area: 64 floats of per-evaluation scalars.  [0] of the GRADIENT buffer = S, the chain's largest per-point
+// normaliser (see above), written by the pre-pass of inerf_mlp_backward_inputs and read by every consumer of its fragments.
+constexpr int kSaveScalars = 64;
+constexpr float kMinGradScale = 0x1p-100f;      // floor of S (keeps 1 / S finite when every gradient of a batch underflows)
+inline int64_t save_scalars_offset(const inerf_net_desc& net, int64_t n_points) { return relu_bits_offset(net, n_points) + relu_bits_floats(n_points); }
 inline int64_t save_total_floats(const inerf_net_desc& net, int64_t n_points) {
-    return relu_bits_offset(net, n_points) + relu_bits_floats(n_points);
+    return save_scalars_offset(net, n_points) + kSaveScalars;
 }
 
 // ---- packed blob of the input-gradient (dgrad) chain, mlp_bwd.hip ----

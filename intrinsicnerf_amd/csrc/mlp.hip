@@ -452,6 +452,11 @@ extern "C" int inerf_mlp_save_slot(const inerf_net_desc* net, int slot, int64_t 
     return INERF_OK;
 }
 
+extern "C" int inerf_mlp_save_slot_is_fragment(int slot, int gradient) {
+    if (slot < 0 || slot >= inerf::SAVE_SLOTS) return INERF_E_INVALID;
+    return inerf::save_is_frag(slot, gradient != 0);
+}
+
 extern "C" int inerf_encode_mlp_train(const inerf_net_desc* net, const float* packed, const float* rays, const float* z,
                                       int64_t n_rays, int n_samples, uint32_t flags, float* raw_out, float* save_out,
                                       float* act_max, int32_t* status, void* stream) {

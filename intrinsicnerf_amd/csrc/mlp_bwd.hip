@@ -31,7 +31,8 @@ struct BwdParams {
     const float* d_raw;     // [P, channels]
     const float* save;      // activations kept by the training forward
     float* dz;              // out: pre-activation gradients, same slot layout
-    float* dz_max;          // out: max |dz| over every slot (caller zeroes it): the weight-gradient kernel's operand scale
+    float* dz_max;          // out: max |dz| over every ROW-format slot (caller zeroes it): the row-format weight-gradient kernel's operand scale
+    const float* s_max;     // in: S, the largest per-point normaliser of the batch (k_head_scale): fragments hold kActScale * dz / S
     float* head_partial;    // out, optional: [grid][kHeadFloats] weight / bias gradients of the 1-4-row heads, per workgroup
     int32_t* status;
     int64_t off[SAVE_SLOTS];
@@ -54,21 +55,21 @@ constexpr int kHeadRes = 0, kHeadAs2 = 384, kHeadAlpha = 1408, kHeadBias = 1664,
 // activation, hi/lo split into LDS (normalised, kActScale domain) and the true gradient to global memory
 struct NoAlpha {};
 
-// Where a layer's dZ goes.  The accumulator layout (lane = point, 16 registers = 4 + 4 + 4 + 4 channels) stores badly: a 16-byte
-// piece per lane is 32 bytes per point and instruction, every 128-byte line is assembled in L2 from four instructions
-// (measured: 1.2-1.5 x write amplification, and the 512 partial-line transactions per wave and layer were most of an
-// epilogue's 10 000 cycles).  So the block is transposed by the matrix core first: with the block's f16 hi / lo halves -
-// which the epilogue has anyway - as the A operand (row = point, k = the lane's channels) and a 0/1 selection matrix as B
-// (B[k][j] = 1/kActScale where channel(k) == j), D'[point][channel] comes back with lane = CHANNEL, registers = points: one
-// dword store per register then writes two complete 128-byte lines.  hi + lo carry 22 bits - exactly what the weight-
-// gradient kernel keeps of a dZ value when it splits it.  4 MFMAs per 32 x 32 block, +8 % of a layer's matrix work.
+// Where a layer's dZ goes: a FRAGMENT slot (layout.h SaveSlot) - the operand fragments of the weight-gradient product
+// dW = dZ^T X, lane = channel, 8 k-values = 8 sample points.  The accumulator layout (lane = point, 16 registers = 4 + 4 + 4 + 4
+// channels) is the transpose of that, and it stores badly anyway (a 16-byte piece per lane is 32 bytes per point and instruction:
+// measured 1.2-1.5 x write amplification, the 512 partial-line transactions per wave and layer were most of an epilogue's 10 000
+// cycles).  So the block is transposed by the matrix core: with the block's f16 hi / lo halves - which the epilogue has anyway -
+// as the A operand (row = point, k = the lane's channels) and a 0/1 selection matrix as B, D'[point][channel] = hi + lo comes
+// back with lane = CHANNEL, registers = points.  Each point's values are then brought from its own normalisation to the
+// batch's (a power of two <= 1: s_p / S), split into f16 hi / lo again (the same 22 bits) and leave as four 1 KB fragments per
+// block - one 16-byte store per lane and fragment, every 128-byte line complete.  4 MFMAs per 32 x 32 block, +8 % of a layer's
+// matrix work.  Until round 4 the transposed block left as fp32 rows and the weight-gradient kernel re-split and re-tiled it.
 struct DzDst {
-    __amdgpu_buffer_rsrc_t rsrc;      // the layer's dZ slot: [n_points][width] fp32 (points beyond the end are dropped by the range check)
-    int voff;                         // bytes: ((tile * 64 + 4 * (lane >> 5)) * width + chan0 + (lane & 31)) * 4
-    int width;                        // floats per point
-    const float* srow;                // LDS: per-point scale s_p of point 4 * (lane >> 5), row stride kRowH / 2 floats
+    __amdgpu_buffer_rsrc_t rsrc;      // the layer's dZ slot: n_tiles * kFragTileBytes (whole tiles: padding points carry zeros)
+    unsigned voff;                    // bytes: tile * kFragTileBytes + (first channel block of this wave) * 2 * kFragBytes + lane * 16
+    const float* frow;                // LDS: per-point factor s_p / S of point 4 * (lane >> 5), row stride kRowH / 2 floats
 };
-struct Selector { f16x8 k[2]; };      // B operand of the transposing MFMAs (see DzDst), per lane: built once per kernel
 template <int RB, bool BITS = false, typename AlphaAcc = NoAlpha>
 __device__ __forceinline__ void bwd_store(const f32x16 (&am)[RB][2], float inv,
                                           const f32x4 (*acts)[2][4] /* [RB][2][4] saved activations of this lane's values (requested
@@ -131,13 +132,21 @@ __device__ __forceinline__ void bwd_store(const f32x16 (&am)[RB][2], float inv,
                 tr = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, sel.k[kb], tr, 0, 0, 0);
                 tr = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, sel.k[kb], tr, 0, 0, 0);
             }
-            const float* sr = dst.srow + pb * 32 * (kRowH / 2);
+            const float* fr = dst.frow + pb * 32 * (kRowH / 2);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int prow = (r & 3) + 8 * (r >> 2);                 // + 4 * (lane >> 5): in voff / srow
-                const float v = tr[r] * sr[prow * (kRowH / 2)];
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), dst.rsrc,
-                                                      dst.voff + ((32 * pb + prow) * dst.width + 32 * rb) * 4, 0, 0);
+            for (int q = 0; q < 2; ++q) {
+                u32x4 oh, ol;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 8 * q + 2 * i;                             // point (r & 3) + 8 (r >> 2) (+ 4 (lane >> 5): in frow)
+                    f16x2 h2, l2;
+                    split_pair(tr[r] * fr[((r & 3) + 8 * (r >> 2)) * (kRowH / 2)], tr[r + 1] * fr[(((r + 1) & 3) + 8 * ((r + 1) >> 2)) * (kRowH / 2)], h2, l2);
+                    oh[i] = __builtin_bit_cast(unsigned, h2);
+                    ol[i] = __builtin_bit_cast(unsigned, l2);
+                }
+                // (whole offset in the VGPR operand: a 16-byte buffer store with a register SGPR offset gets no hazard wait state, tests/test_isa_audit_cpu.py)
+                __builtin_amdgcn_raw_buffer_store_b128(oh, dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, rb, 0)), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(ol, dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, rb, 1)), 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -176,6 +185,51 @@ struct StageRows {
     }
 };
 
+// Pre-activation gradients of one point's output heads (albedo 3, shading 1, residual 3, sigma 1) from d loss / d raw and raw,
+// and the point's normaliser: the power of two above its largest head gradient (1 for a point without gradient).
+__device__ __forceinline__ float head_gradients(const BwdParams& p, int gp, bool sem, float (&dp)[8], bool* has_gradient = nullptr) {
+    const int ch = p.channels;
+    const float* __restrict__ r = p.raw + (size_t)gp * ch;
+    const float* __restrict__ g = p.d_raw + (size_t)gp * ch;
+    const float sh = r[7];
+    float dsh = g[7];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float a = r[4 + k], rs = r[8 + k];
+        dp[k] = (g[k] * sh + g[4 + k]) * (a * (1.0f - a));            // rgb = albedo * shading + residual, sigmoid'
+        dsh += g[k] * a;
+        dp[4 + k] = (g[k] + g[8 + k]) * (rs * (1.0f - rs));
+    }
+    dp[3] = dsh * (sh * (1.0f - sh));
+    dp[7] = g[3];                                                      // sigma has no activation inside the network
+    float m = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m = fmaxf(m, fabsf(dp[k]));
+    if (sem) for (int j = 0; j < p.n_classes; ++j) m = fmaxf(m, fabsf(g[INERF_BASE_CHANNELS + j]));
+    if (p.endpoint) for (int c = 0; c < INERF_ENDPOINT_DIM; ++c) m = fmaxf(m, fabsf(g[ch - INERF_ENDPOINT_DIM + c]));
+    float s = 1.0f;
+    const bool has = m > 0.0f && m < 3.0e38f;
+    if (has) { int e; frexpf(m, &e); s = ldexpf(1.0f, e); }
+    if (has_gradient) *has_gradient = has;
+    return s;
+}
+
+// S = the largest normaliser over the points that HAVE a gradient (so that a batch of tiny gradients keeps its precision):
+// what the chain's fragment outputs are scaled by.  One thread per point, before the chain.
+__global__ __launch_bounds__(256) void k_head_scale(const BwdParams p, float* __restrict__ s_max) {
+    const int gp = blockIdx.x * 256 + threadIdx.x;
+    float s = 0.0f;
+    if (gp < p.n_points) {
+        float dp[8];
+        bool has;
+        const float sp = head_gradients(p, gp, p.n_classes > 0, dp, &has);
+        s = has ? sp : 0.0f;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s = fmaxf(s, __shfl_xor(s, o));
+    if ((threadIdx.x & 63) == 0 && s > 0.0f) atomicMax(reinterpret_cast<unsigned int*>(s_max), __builtin_bit_cast(unsigned int, s));
+}
+
 // NW waves per workgroup: 4 (each wave 64 channels = RB 2 row blocks; one wave per SIMD) or 8 (32 channels each; TWO waves per
 // SIMD, so one wave's epilogue / VALU stage / memory wait runs under the other's MFMAs - with one wave per SIMD a tile was
 // 63 k cycles of MFMA in 192 k).  Same tile, same LDS, same packed weights (an 8-wave wave takes one of the two row blocks of
@@ -200,7 +254,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
     const _Float16* const xr = xw + 8 * (lane >> 5);              // wide GEMM operand reads (+ column)
     _Float16* const xd = xw + 4 * (lane >> 5) + WCH * wave;       // wide stores: this wave's channels (+ column)
     auto ptf = [&](int pt) { return reinterpret_cast<float*>(ldsb + pt * kRowH); };   // per-point scratch in the enc columns:
-                                                                                      // [0..7] head gradients / s, [8] s, [9] 1/s
+                                                                                      // [0..7] head gradients / s, [8] s, [9] 1/s, [10] s / S
     WeightBuf wb;
     wb.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wts), 0, L.total_floats * 4, 0x00020000);
     wb.voff = lane * 16;
@@ -212,11 +266,12 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
     WidePreH<RB> preA, preB;
     prefetch_w<RB, KS>(preA, wb, frag(L.views_t, 8));
     Selector sel;                          // see DzDst: lane (j = lane & 31, kg = lane >> 5) holds Sel[8 kg + m][j], m = 0..7, per k-block
+                                           // (k order of the ACCUMULATOR registers; planes_to_frag's operands come from LDS in channel order)
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int m = 0; m < 8; ++m)
-            sel.k[kb][m] = (16 * kb + 8 * (m >> 2) + 4 * (lane >> 5) + (m & 3)) == (lane & 31) ? (_Float16)(1.0f / kActScale) : (_Float16)0.0f;
+            sel.k[kb][m] = (16 * kb + 8 * (m >> 2) + 4 * (lane >> 5) + (m & 3)) == (lane & 31) ? (_Float16)1.0f : (_Float16)0.0f;
     // Rows of the activation / gradient slots are reached through buffer descriptors (wave-uniform, in SGPRs) + ONE 32-bit
     // per-thread offset per stage + a wave-uniform tile offset: with 64-bit per-thread pointers every stage kept four address
     // registers alive across the tile loop (spilled in the eight-wave form).  The range check also replaces the `valid` tests:
@@ -262,6 +317,9 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
 #else
 #define STAMP() do { } while (0)
 #endif
+    // S: the batch's largest per-point normaliser (k_head_scale), a power of two; the floor keeps 1 / S finite for batches whose
+    // gradients are all below 2^-100 (the consumers apply the same floor)
+    const float inv_smax = 1.0f / fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.s_max[0]))), kMinGradScale);
     stagger_start(p.stagger);
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         STAMP();
@@ -281,25 +339,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
             float dp[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
             float s = 1.0f;
             if (gp < p.n_points) {
-                const float* __restrict__ r = p.raw + (size_t)gp * ch;
-                const float* __restrict__ g = p.d_raw + (size_t)gp * ch;
-                const float sh = r[7];
-                float dsh = g[7];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const float a = r[4 + k], rs = r[8 + k];
-                    dp[k] = (g[k] * sh + g[4 + k]) * (a * (1.0f - a));            // rgb = albedo * shading + residual, sigmoid'
-                    dsh += g[k] * a;
-                    dp[4 + k] = (g[k] + g[8 + k]) * (rs * (1.0f - rs));
-                }
-                dp[3] = dsh * (sh * (1.0f - sh));
-                dp[7] = g[3];                                                      // sigma has no activation inside the network
-                float m = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) m = fmaxf(m, fabsf(dp[k]));
-                if (sem) for (int j = 0; j < p.n_classes; ++j) m = fmaxf(m, fabsf(g[INERF_BASE_CHANNELS + j]));
-                if (kSsr && p.endpoint) for (int c = 0; c < INERF_ENDPOINT_DIM; ++c) m = fmaxf(m, fabsf(g[ch - INERF_ENDPOINT_DIM + c]));
-                if (m > 0.0f && m < 3.0e38f) { int e; frexpf(m, &e); s = ldexpf(1.0f, e); }
+                s = head_gradients(p, gp, sem, dp);
                 float* __restrict__ o = p.dz + p.off[SAVE_DPRE] + (size_t)gp * 8;
                 *reinterpret_cast<f32x4*>(o) = f32x4{dp[0], dp[1], dp[2], dp[3]};
                 *reinterpret_cast<f32x4*>(o + 4) = f32x4{dp[4], dp[5], dp[6], dp[7]};
@@ -312,6 +352,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
             for (int k = 0; k < 8; ++k) f[k] = dp[k] * is;
             f[8] = s;
             f[9] = is;
+            f[10] = s * inv_smax;          // (a point without gradient has s = 1 and only zeros to scale)
         }
         STAMP();
         __syncthreads();
@@ -370,10 +411,9 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
         const float s0 = ptf(lane & 31)[8], s1 = ptf((lane & 31) + 32)[8];
         auto dz_dst = [&](int slot) {                 // 256-wide slots only (every layer this kernel runs on the matrix core)
             DzDst d;
-            d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dz + p.off[slot], 0, (int)((unsigned)p.n_points * (unsigned)kWidth * 4u), 0x00020000);
-            d.voff = (int)((((unsigned)tile * kPts + 4u * (unsigned)(lane >> 5)) * (unsigned)kWidth + (unsigned)(WCH * wave) + (unsigned)(lane & 31)) * 4u);
-            d.width = kWidth;
-            d.srow = reinterpret_cast<const float*>(ldsb) + 8 + 4 * (lane >> 5) * (kRowH / 2);
+            d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dz + p.off[slot], 0, (int)((unsigned)p.n_tiles * (unsigned)kFragTileBytes), 0x00020000);
+            d.voff = (unsigned)tile * (unsigned)kFragTileBytes + (unsigned)(WCH / 32 * wave) * (2u * kFragBytes) + (unsigned)lane * 16u;
+            d.frow = reinterpret_cast<const float*>(ldsb) + 10 + 4 * (lane >> 5) * (kRowH / 2);
             return d;
         };
         f32x16 am[RB][2];
@@ -403,7 +443,6 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
         {
             const int c4 = (tid & 63) * 4;
             const StageRows rows(tid >> 6, kColA + c4);
-            const __amdgpu_buffer_rsrc_t dz_as = slot_rsrc(p.dz, SAVE_AS1H, kWidth);
             f32x4 w4[4];
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) w4[cc] = wb.vec4((L.as2_w + 4 * cc) * 4, 16 * c4);
@@ -426,22 +465,26 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
                 for (int cc = 0; cc < 4; ++cc) v[cc] = act[cc] > 0.0f ? v[cc] : 0.0f;
                 split_store4(ldsb + rows.st[i / HALF][0] + (i % HALF) * AS_STEP * kRowH, ldsb + rows.st[i / HALF][1] + (i % HALF) * AS_STEP * kRowH,
                              v, amax2);
-                {
-                    const f32x4 o = f32x4{v[0], v[1], v[2], v[3]} * f[8];
-                    store4(dz_as, as_voff + (tile * kPts + AS_STEP * i) * kWidth * 4, o);
-                    gmax = fmaxf(gmax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
-                }
                 if (i & 1) __builtin_amdgcn_sched_barrier(0);
             }
         }
         STAMP();
         __syncthreads();
         STAMP();
+        {   // this layer's dZ leaves as fragments too (G of the albedo_linear1 | shading hidden weight gradient): the stage above
+            // works row-wise (lane = four channels of one point), so the transposition is a pass of the matrix core over the
+            // finished planes - this wave's WCH channels of all 64 points
+            FragDst d;
+            d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dz + p.off[SAVE_AS1H], 0, (int)((unsigned)p.n_tiles * (unsigned)kFragTileBytes), 0x00020000);
+            d.voff = (unsigned)tile * (unsigned)kFragTileBytes + (unsigned)(WCH / 32 * wave) * (2u * kFragBytes) + (unsigned)lane * 16u;
+            planes_to_frag<RB, kRowH, kPlaneH, true>(xr + kColA + WCH * wave, plane_selector(lane), d,
+                                                     reinterpret_cast<const float*>(ldsb) + 10 + 4 * (lane >> 5) * (kRowH / 2), kRowH / 2);
+        }
 
         // ---------------- d h7 = W_feat^T d feature + W_as1^T dZ_as1 (+ W_sem1^T dZ_semh) + w_alpha d sigma ----------------
         f32x4 h7v[RB][2][4];                 // h7 of this lane's values: ReLU mask AND operand of the alpha_linear weight gradient
         {
-            const __amdgpu_buffer_rsrc_t r = slot_rsrc(p.save, SAVE_H7, kWidth);
+            const __amdgpu_buffer_rsrc_t r = slot_rsrc(p.save, SAVE_H7R, kWidth);     // (the row copy; SAVE_H7 itself holds fragments)
             const int voff = ((lane & 31) * kWidth + WCH * wave + 4 * (lane >> 5)) * 4;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
@@ -624,17 +667,20 @@ extern "C" int inerf_mlp_backward_inputs(const inerf_net_desc* net, const float*
     p.channels = INERF_BASE_CHANNELS + p.n_classes + (p.endpoint ? INERF_ENDPOINT_DIM : 0);
     const int grid = p.n_tiles < device_cus() ? p.n_tiles : device_cus();
     p.stagger = stagger_units(p.n_tiles, grid);
-    // eight waves per workgroup (two per SIMD) by default; INERF_DGRAD_WAVES=4 keeps the one-wave-per-SIMD form for A/B runs
-    const char* form = getenv("INERF_DGRAD_WAVES");
-    const bool eight = !(form && form[0] == '4');
-    void (*kern)(const BwdParams) = eight ? (ssr ? k_mlp_dgrad<true, 8> : k_mlp_dgrad<false, 8>) : (ssr ? k_mlp_dgrad<true, 4> : k_mlp_dgrad<false, 4>);
-    static PerDeviceOnce attr_set[4];
-    const int variant = 2 * (int)eight + (int)ssr;
-    if (attr_set[variant].first()) {
+    // S, the scale of the chain's fragment outputs (layout.h SaveSlot), lives behind the slots of the gradient buffer
+    float* s_max = dz_out + save_scalars_offset(*net, n_points);
+    p.s_max = s_max;
+    hipError_t e0 = hipMemsetAsync(s_max, 0, sizeof(float), (hipStream_t)stream);
+    if (e0 != hipSuccess) return record(e0);
+    hipLaunchKernelGGL(k_head_scale, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, s_max);
+    // eight waves per workgroup (two per SIMD, 32 channels each)
+    void (*kern)(const BwdParams) = ssr ? k_mlp_dgrad<true, 8> : k_mlp_dgrad<false, 8>;
+    static PerDeviceOnce attr_set[2];
+    if (attr_set[(int)ssr].first()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesH);
         if (e != hipSuccess) return record(e);
-        attr_set[variant].mark();
+        attr_set[(int)ssr].mark();
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(eight ? 512 : 256), kLdsBytesH, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), kLdsBytesH, (hipStream_t)stream, p);
     return record(hipGetLastError());
 }

@@ -149,9 +149,17 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
         // ReLU masks of h0..h6 for the input-gradient chain (layout.h relu_bits_offset): one descriptor for the area
         const __amdgpu_buffer_rsrc_t bits_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             p.save + (kSave ? p.bits_off : 0), 0, kSave ? (int)((unsigned)p.n_tiles * (unsigned)kReluBitTileBytes) : 0, 0x00020000);
-        auto step256 = [&](const GemmSlot& s, auto kb0c, auto kb1c, int c0, int c1, int dcol, bool relu, int slot,
+        // training forward (layout.h SaveSlot): h0..h7 leave as operand fragments of the weight-gradient products (planes_to_frag,
+        // after the layer's barrier), h0..h6 also as ReLU mask bits; h7 (as H7R), the albedo|shading hidden layer and the feature
+        // layer as fp32 rows from the epilogue's registers
+        const Selector fsel = plane_selector(lane);
+        auto step256 = [&](const GemmSlot& s, auto kb0c, auto kb1c, int c0, int c1, int dcol, bool relu, auto slot_c,
                            auto&& prefetch_next) {
             constexpr int KB0 = decltype(kb0c)::value, KB1 = decltype(kb1c)::value;
+            constexpr int slot = decltype(slot_c)::value;
+            constexpr bool kTrunk = slot >= SAVE_H0 && slot <= SAVE_H7;
+            constexpr bool kRows = kSave && slot >= SAVE_H7;             // H7 (-> H7R), AS1H, FEAT
+            constexpr bool kBits = kSave && kTrunk && slot < SAVE_H7;
             f32x16 am[2][2];
             f32x4 bias[2][4];
 #pragma unroll
@@ -161,14 +169,16 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
             const float inv = pre2.inv;
             wide_gemm_h<2, KB0, KB1>(pre2, wb, frag256(s, KB0 + KB1), xr, c0, c1, lane, am);
             prefetch_next();
-            const SaveDst sv = save_dst(slot, kWidth, 64 * wave);
-            if (kSave && slot < SAVE_H7) {          // (a compile-time constant at every call site)
-                const BitsDst bd = {bits_rsrc, (((tile * kReluBitLayers + (slot - SAVE_H0)) * 4 + wave) * 64 + lane) * 8};
-                wide_store_h<2, kRowH, kPlaneH, kSave, kSave>(am, inv, bias, xd + dcol + 64 * wave, relu, amax2, nullptr, 0, 0, 0, &sv, &bd);
-            } else {
-                wide_store_h<2, kRowH, kPlaneH, kSave>(am, inv, bias, xd + dcol + 64 * wave, relu, amax2, nullptr, 0, 0, 0, &sv);
-            }
+            const SaveDst sv = save_dst(slot == SAVE_H7 ? SAVE_H7R : slot, kWidth, 64 * wave);
+            const BitsDst bd = {bits_rsrc, kBits ? (((tile * kReluBitLayers + (slot - SAVE_H0)) * 4 + wave) * 64 + lane) * 8 : 0};
+            wide_store_h<2, kRowH, kPlaneH, kRows, kBits>(am, inv, bias, xd + dcol + 64 * wave, relu, amax2, nullptr, 0, 0, 0, &sv, &bd);
             __syncthreads();
+            if constexpr (kSave && kTrunk) {
+                FragDst d;
+                d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save + p.save_off[slot], 0, (int)((unsigned)p.n_tiles * (unsigned)kFragTileBytes), 0x00020000);
+                d.voff = (unsigned)tile * (unsigned)kFragTileBytes + (unsigned)(2 * wave) * (2u * kFragBytes) + (unsigned)lane * 16u;
+                planes_to_frag<2, kRowH, kPlaneH>(xr + dcol + 64 * wave, fsel, d);
+            }
         };
         auto step128 = [&](const GemmSlot& s, auto kb0c, auto kb1c, int c0, int c1, int dcol, bool relu, float* gout, int slot,
                            auto&& prefetch_next) {
@@ -198,15 +208,15 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
         constexpr integral_constant<int, 16> K16{};
         const bool sem = kSsr && L.sem_rbs > 0;
         // ---------------- trunk ----------------
-        step256(L.trunk[0], K4, K0, kColEnc, 0, kColA, true, SAVE_H0 + 0, pf256(L.trunk[1], 16));
-        step256(L.trunk[1], K16, K0, kColA, 0, kColB, true, SAVE_H0 + 1, pf256(L.trunk[2], 16));
-        step256(L.trunk[2], K16, K0, kColB, 0, kColA, true, SAVE_H0 + 2, pf256(L.trunk[3], 16));
-        step256(L.trunk[3], K16, K0, kColA, 0, kColB, true, SAVE_H0 + 3, pf256(L.trunk[4], 16));
-        step256(L.trunk[4], K16, K0, kColB, 0, kColA, true, SAVE_H0 + 4, pf256(L.trunk[5], 20));
-        step256(L.trunk[5], K4, K16, kColEnc, kColA, kColB, true, SAVE_H0 + 5, pf256(L.trunk[6], 16));
-        step256(L.trunk[6], K16, K0, kColB, 0, kColA, true, SAVE_H0 + 6, pf256(L.trunk[7], 16));
-        if (sem) step256(L.trunk[7], K16, K0, kColA, 0, kColB, true, SAVE_H7, pf128(L.sem1, 16));
-        else     step256(L.trunk[7], K16, K0, kColA, 0, kColB, true, SAVE_H7, pf256(L.as1, 16));
+        step256(L.trunk[0], K4, K0, kColEnc, 0, kColA, true, integral_constant<int, SAVE_H0 + 0>{}, pf256(L.trunk[1], 16));
+        step256(L.trunk[1], K16, K0, kColA, 0, kColB, true, integral_constant<int, SAVE_H0 + 1>{}, pf256(L.trunk[2], 16));
+        step256(L.trunk[2], K16, K0, kColB, 0, kColA, true, integral_constant<int, SAVE_H0 + 2>{}, pf256(L.trunk[3], 16));
+        step256(L.trunk[3], K16, K0, kColA, 0, kColB, true, integral_constant<int, SAVE_H0 + 3>{}, pf256(L.trunk[4], 16));
+        step256(L.trunk[4], K16, K0, kColB, 0, kColA, true, integral_constant<int, SAVE_H0 + 4>{}, pf256(L.trunk[5], 20));
+        step256(L.trunk[5], K4, K16, kColEnc, kColA, kColB, true, integral_constant<int, SAVE_H0 + 5>{}, pf256(L.trunk[6], 16));
+        step256(L.trunk[6], K16, K0, kColB, 0, kColA, true, integral_constant<int, SAVE_H0 + 6>{}, pf256(L.trunk[7], 16));
+        if (sem) step256(L.trunk[7], K16, K0, kColA, 0, kColB, true, integral_constant<int, SAVE_H7>{}, pf128(L.sem1, 16));
+        else     step256(L.trunk[7], K16, K0, kColA, 0, kColB, true, integral_constant<int, SAVE_H7>{}, pf256(L.as1, 16));
 
         // ---------------- heads ----------------
         const int my_pt = tile * kPts + 16 * wave + (lane & 15);
@@ -228,11 +238,11 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
             __syncthreads();
         }
 
-        step256(L.as1, K16, K0, kColB, 0, kColA, true, SAVE_AS1H, pf256(L.feat, 16));
+        step256(L.as1, K16, K0, kColB, 0, kColA, true, integral_constant<int, SAVE_AS1H>{}, pf256(L.feat, 16));
         const f32x4 as4 = skinny_gemm_h<8>(wb, L.as2.w * 4, L.as2.b * 4, (L.as2.b + 16) * 4, xs + kColA, lane);
         __syncthreads();
 
-        step256(L.feat, K16, K0, kColB, 0, kColA, false, SAVE_FEAT, pf128(L.views, 18));
+        step256(L.feat, K16, K0, kColB, 0, kColA, false, integral_constant<int, SAVE_FEAT>{}, pf128(L.views, 18));
         // endpoint feature (semantic_nerf.py:163-164): the fp32 views activation goes straight to raw
         float* ep = nullptr;
         if (kSsr && p.endpoint)
@@ -325,9 +335,17 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
     };
 
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+        // The per-tile slot / output offsets below are sums of a tile part and a lane part; derived from `lane` itself the lane
+        // parts are loop invariants, hoisted out of the tile loop (~15 registers, spilled at this kernel's 256).  Laundered per tile.
+        int lane_t = lane;
+        asm volatile("" : "+v"(lane_t));
         // ---------------- encode -> hi/lo planes (xyz: columns 0..63, dir: columns 256..287) ----------------
         auto encode = [&](bool with_dir) {
-            const int pt = tid % kPts, part = tid / kPts;
+            // (the thread index is laundered per call: derived from `tid` itself, this stage's ~20 LDS / slot addresses are
+            // loop invariants that the compiler hoists out of the tile loop and, at this kernel's 256 registers, spills)
+            int tid_o = tid;
+            asm volatile("" : "+v"(tid_o));
+            const int pt = tid_o % kPts, part = tid_o / kPts;
             int gp = tile * kPts + pt;
             gp = gp < p.n_points ? gp : p.n_points - 1;
             const int ray = gp / p.n_samples;
@@ -393,30 +411,48 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
         f32x16 am2[2][2];
         f32x4 bias2[2][4];
         float inv2;
-        const int pt0 = tile * kPts + (lane & 31);
+        const int pt0 = tile * kPts + (lane_t & 31);
         auto save_dst = [&](int slot, int width, int chan0) {
             SaveDst d;
             d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save + (kSave ? p.save_off[slot] : 0), 0,
                                                        kSave ? (int)((unsigned)p.n_points * (unsigned)width * 4u) : 0, 0x00020000);
-            d.voff = (int)(((unsigned)pt0 * (unsigned)width + (unsigned)(chan0 + 4 * (lane >> 5))) * 4u);
+            d.voff = (int)(((unsigned)pt0 * (unsigned)width + (unsigned)(chan0 + 4 * (lane_t >> 5))) * 4u);
             d.stride = width;
             return d;
         };
         // ReLU masks of h0..h6 for the input-gradient chain (layout.h relu_bits_offset)
         const __amdgpu_buffer_rsrc_t bits_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             p.save + (kSave ? p.bits_off : 0), 0, kSave ? (int)((unsigned)p.n_tiles * (unsigned)kReluBitTileBytes) : 0, 0x00020000);
-        auto store256 = [&](const GemmSlot& s, bool relu, int slot, auto&& prefetch_next, auto bits_tag) {
+        // training forward: where a 256-wide layer goes besides the planes (layout.h SaveSlot) - `rows_slot`: fp32 rows from the
+        // epilogue's registers (16-byte pieces; only what the chain's VALU stages and the narrow products read: FEAT, H7R);
+        // `frag_slot`: operand fragments of the weight-gradient products, transposed out of the finished planes by the matrix
+        // core (planes_to_frag: whole 1 KB stores); the ReLU masks of h0..h6 as bits.
+        auto frag_dst = [&](int slot) {
+            FragDst d;
+            d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save + (kSave ? p.save_off[slot] : 0), 0,
+                                                       kSave ? (int)((unsigned)p.n_tiles * (unsigned)kFragTileBytes) : 0, 0x00020000);
+            d.voff = (unsigned)tile * (unsigned)kFragTileBytes + (unsigned)(2 * wave) * (2u * kFragBytes) + (unsigned)lane_t * 16u;
+            return d;
+        };
+        auto store256 = [&](const GemmSlot& s, bool relu, auto rows_tag, int rows_slot, int frag_slot, auto&& prefetch_next, auto bits_tag) {
             load_bias<2>(bias2, inv2, wb, (s.b + 64 * wave) * 4, (s.b + kWidth) * 4, lane);
             prefetch_next();
-            const SaveDst sv = save_dst(slot, kWidth, 64 * wave);
+            constexpr bool kRows = kSave && decltype(rows_tag)::value;
+            const SaveDst sv = save_dst(kRows ? rows_slot : SAVE_H0, kWidth, 64 * wave);
             constexpr bool kBits = kSave && decltype(bits_tag)::value;
-            const BitsDst bd = {bits_rsrc, kBits ? (((tile * kReluBitLayers + (slot - SAVE_H0)) * 4 + wave) * 64 + lane) * 8 : 0};
+            const BitsDst bd = {bits_rsrc, kBits ? (((tile * kReluBitLayers + (frag_slot - SAVE_H0)) * 4 + wave) * 64 + lane_t) * 8 : 0};
             __syncthreads();                       // every wave has read the layer's input
-            wide_store_h<2, kRowD, kPlaneD, kSave, kBits>(am2, inv2, bias2, xd, relu, amax2, nullptr, 0, 0, 0, &sv, &bd);
+            wide_store_h<2, kRowD, kPlaneD, kRows, kBits>(am2, inv2, bias2, xd, relu, amax2, nullptr, 0, 0, 0, &sv, &bd);
             __syncthreads();
+            if constexpr (kSave)                   // this wave's 64 channels of all 64 points (the layer is complete behind the barrier)
+                if (frag_slot >= 0) {
+                    int lane_o = lane_t;           // (laundered: the selector is rebuilt per layer instead of living in 8 registers)
+                    asm volatile("" : "+v"(lane_o));
+                    planes_to_frag<2, kRowD, kPlaneD>(xr + 64 * wave, plane_selector(lane_o), frag_dst(frag_slot));
+                }
         };
-        constexpr std::true_type kWithBits{};
-        constexpr std::false_type kNoBits{};
+        constexpr std::true_type kWithBits{}, kRowsToo{};
+        constexpr std::false_type kNoBits{}, kNoRows{};
         auto pf256 = [&](const GemmSlot& s, int kbt) { return [&, kbt]() { prefetch_w<2>(pre2, wb, frag256(s, kbt)); }; };
         auto pf256_at = [&](const GemmSlot& s, int kbt, int kb_first) {
             return [&, kbt, kb_first]() { prefetch_w<2>(pre2, wb, frag256(s, kbt) + kb_first * 2 * 2 * 1024); };
@@ -425,12 +461,12 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
 
         // ---------------- trunk ----------------
         wide_gemm_h<2, 4, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.trunk[0], 4), xr, 0, 0, lane, am2);
-        store256(L.trunk[0], true, SAVE_H0, pf256(L.trunk[1], 16), kWithBits);
+        store256(L.trunk[0], true, kNoRows, -1, SAVE_H0, pf256(L.trunk[1], 16), kWithBits);
 #pragma unroll 1
         for (int layer = 1; layer < kSkipInput; ++layer) {
             wide_gemm_h<2, 16, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.trunk[layer], 16), xr, 0, 0, lane, am2);
-            if (layer + 1 < kSkipInput) store256(L.trunk[layer], true, SAVE_H0 + layer, pf256(L.trunk[layer + 1], 16), kWithBits);
-            else                        store256(L.trunk[layer], true, SAVE_H0 + layer, pf256_at(L.trunk[kSkipInput], 20, 4), kWithBits);
+            if (layer + 1 < kSkipInput) store256(L.trunk[layer], true, kNoRows, -1, SAVE_H0 + layer, pf256(L.trunk[layer + 1], 16), kWithBits);
+            else                        store256(L.trunk[layer], true, kNoRows, -1, SAVE_H0 + layer, pf256_at(L.trunk[kSkipInput], 20, 4), kWithBits);
         }
         {   // pts_linears[5] over cat([pts, h]): h-part (k-blocks 4..19 of the stream), then the encoding again
             const GemmSlot& s = L.trunk[kSkipInput];
@@ -440,15 +476,15 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
             encode(false);
             __syncthreads();
             wide_gemm_h<2, 4, 0, kRowD, kPlaneD, false>(pre2, wb, frag256(s, 20), xr, 0, 0, lane, am2);
-            store256(s, true, SAVE_H0 + kSkipInput, pf256(L.trunk[6], 16), kWithBits);
+            store256(s, true, kNoRows, -1, SAVE_H0 + kSkipInput, pf256(L.trunk[6], 16), kWithBits);
         }
         wide_gemm_h<2, 16, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.trunk[6], 16), xr, 0, 0, lane, am2);
-        store256(L.trunk[6], true, SAVE_H0 + 6, pf256(L.trunk[7], 16), kWithBits);
+        store256(L.trunk[6], true, kNoRows, -1, SAVE_H0 + 6, pf256(L.trunk[7], 16), kWithBits);
         wide_gemm_h<2, 16, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.trunk[7], 16), xr, 0, 0, lane, am2);
-        store256(L.trunk[7], true, SAVE_H7, pf256(L.as1, 16), kNoBits);
+        store256(L.trunk[7], true, kRowsToo, SAVE_H7R, SAVE_H7, pf256(L.as1, 16), kNoBits);
 
         // ---------------- heads ----------------
-        const int my_pt = tile * kPts + 16 * wave + (lane & 15);
+        const int my_pt = tile * kPts + 16 * wave + (lane_t & 15);
         const bool my_valid = my_pt < p.n_points;
         float* const out_row = p.raw + (size_t)(my_valid ? my_pt : 0) * p.channels;
         const f32x4 sig4 = skinny_gemm_h<8, kPlaneD>(wb, L.alpha.w * 4, L.alpha.b * 4, (L.alpha.b + 16) * 4, xs, lane);
@@ -493,13 +529,13 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
             SaveDst sv;
             sv.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save + (kSave ? p.save_off[SAVE_SEMH] : 0), 0,
                                                         kSave ? (int)((unsigned)p.n_points * (unsigned)kHalf * 4u) : 0, 0x00020000);
-            sv.voff = (int)(((unsigned)(tile * kPts + 16 * wave + (lane & 15)) * (unsigned)kHalf + (unsigned)(4 * (lane >> 4))) * 4u);
+            sv.voff = (int)(((unsigned)(tile * kPts + 16 * wave + (lane_t & 15)) * (unsigned)kHalf + (unsigned)(4 * (lane_t >> 4))) * 4u);
             sv.stride = kHalf;
             sem_head<kSave>(wb, L, xs, lane, amax2, out_row, my_valid, p.n_classes, &sv);
         }
         // feature (no activation) in place of h7, then the view-dependent layer over [feature | dir] -> registers
         wide_gemm_h<2, 16, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.feat, 16), xr, 0, 0, lane, am2);
-        store256(L.feat, false, SAVE_FEAT, pf128(L.views, 18), kNoBits);
+        store256(L.feat, false, kRowsToo, SAVE_FEAT, -1, pf128(L.views, 18), kNoBits);
         {
             f32x16 am1[1][2];
             f32x4 bias1[1][4];
@@ -555,10 +591,10 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
             sem_inv2 = wb.scalar((L.sem2.b + 16 * L.sem_rbs) * 4);
         }
         __syncthreads();                           // feature / dir columns are dead: exchange areas may be written
-        if (lane < 32) {
+        if (lane_t < 32) {
 #pragma unroll
             for (int pb = 0; pb < 2; ++pb) {
-                float* ex = reinterpret_cast<float*>(ldsd + (lane + 32 * pb) * kRowD + kColExD) + 8 * wave;
+                float* ex = reinterpret_cast<float*>(ldsd + (lane_t + 32 * pb) * kRowD + kColExD) + 8 * wave;
                 *reinterpret_cast<f32x4*>(ex) = part_as[pb];
                 *reinterpret_cast<f32x4*>(ex + 4) = part_res[pb];
             }
@@ -577,8 +613,8 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
             }
             if (L.sem_rb32 > 1) __syncthreads();           // (keeps the area's last readers ahead of the next tile's fetch-and-post)
         }
-        if (lane < 16 && my_valid) {
-            const float* ex = reinterpret_cast<const float*>(ldsd + (16 * wave + lane) * kRowD + kColExD);
+        if (lane_t < 16 && my_valid) {
+            const float* ex = reinterpret_cast<const float*>(ldsd + (16 * wave + lane_t) * kRowD + kColExD);
             f32x4 as4 = {0.0f, 0.0f, 0.0f, 0.0f}, res4 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int w = 0; w < 4; ++w) {

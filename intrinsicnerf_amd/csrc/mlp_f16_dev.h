@@ -231,6 +231,87 @@ struct EncSave {
     }
 };
 
+// ------------------------------------------------------------------------------------------------
+// Fragment slots (layout.h SaveSlot): a layer's output, which sits in the hi / lo planes as X[point][channel], leaves the CU as
+// operand fragments of the weight-gradient products (lane = channel, 8 k-values = 8 sample points).  The transposition is done
+// by the matrix core: a [32 points x 16 channels] piece of a plane, read like any B operand of the layer GEMMs (lane = point,
+// 8 consecutive channels), is the A operand of an MFMA whose B is a 0/1 selector - D[point][channel] = sum_k A[point][k] Sel[k][channel]
+// comes back in accumulator layout: lane = CHANNEL, registers = points (r&3) + 8 (r>>2) + 4 (lane>>5) = frag_point order.
+// The products are f16 x 1.0: exact, and any rounding mode converts them back to the f16 they were.  Per [32 x 32] block
+// and plane: 2 ds_read_b128, 2 MFMAs, 8 conversions and two 1 KB stores (one instruction each, every 128-byte line complete).
+struct Selector { f16x8 k[2]; };      // per lane (n = lane & 31, h = lane >> 5): Sel[8 h + i][n] of k-block kb, i = 0..7
+// operands read from the planes: k-slot 8 h + i of k-block kb is channel 16 kb + 8 h + i of the block
+__device__ __forceinline__ Selector plane_selector(int lane, float value = 1.0f) {
+    Selector s;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s.k[kb][i] = (16 * kb + 8 * (lane >> 5) + i) == (lane & 31) ? (_Float16)value : (_Float16)0.0f;
+    return s;
+}
+struct FragDst {
+    __amdgpu_buffer_rsrc_t rsrc;      // the slot: n_tiles * kFragTileBytes bytes
+    unsigned voff;                    // bytes: tile * kFragTileBytes + (first channel block of this wave) * 2 * kFragBytes + lane * 16
+};
+__device__ __forceinline__ unsigned frag_off(int kb, int cb, int plane) { return (unsigned)((kb * 8 + cb) * 2 + plane) * kFragBytes; }
+
+// NB: 32-channel blocks of this wave (consecutive, starting at the column `xa` points at).  SCALED: every point's values are
+// multiplied by fscale[point * fstride] (powers of two: the chain's per-point normaliser over the largest one) before they are
+// converted - hi and lo are transposed into ONE accumulator (their exact sum, 22 bits) and split again after the scaling.
+template <int NB, int ROW, int PLANE, bool SCALED = false>
+__device__ __forceinline__ void planes_to_frag(const _Float16* xa /* plane_hi + (lane & 31) * ROW + 8 * (lane >> 5) + first column */,
+                                               const Selector& sel, const FragDst& dst,
+                                               const float* fscale = nullptr /* LDS: factor of point 4 * (lane >> 5) */, int fstride = 0) {
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            const _Float16* src = xa + pb * 32 * ROW + 32 * cb;
+            const f16x8 ah0 = *reinterpret_cast<const f16x8*>(src), ah1 = *reinterpret_cast<const f16x8*>(src + 16);
+            const f16x8 al0 = *reinterpret_cast<const f16x8*>(src + PLANE), al1 = *reinterpret_cast<const f16x8*>(src + PLANE + 16);
+            const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            if constexpr (!SCALED) {
+                f32x16 th = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, sel.k[0], zero, 0, 0, 0);
+                f32x16 tl = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, sel.k[0], zero, 0, 0, 0);
+                th = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, sel.k[1], th, 0, 0, 0);
+                tl = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, sel.k[1], tl, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    u32x4 oh, ol;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        oh[i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(th[8 * q + 2 * i], th[8 * q + 2 * i + 1]));
+                        ol[i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(tl[8 * q + 2 * i], tl[8 * q + 2 * i + 1]));
+                    }
+                    // (whole offset in the VGPR operand: a 16-byte buffer store with a register SGPR offset gets no hazard wait state, tests/test_isa_audit_cpu.py)
+                    __builtin_amdgcn_raw_buffer_store_b128(oh, dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, cb, 0)), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(ol, dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, cb, 1)), 0, 0);
+                }
+            } else {
+                f32x16 t = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, sel.k[0], zero, 0, 0, 0);
+                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, sel.k[1], t, 0, 0, 0);
+                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, sel.k[0], t, 0, 0, 0);
+                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, sel.k[1], t, 0, 0, 0);
+                const float* fs = fscale + pb * 32 * fstride;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    u32x4 oh, ol;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 8 * q + 2 * i;
+                        f16x2 h2, l2;
+                        split_pair(t[r] * fs[((r & 3) + 8 * (r >> 2)) * fstride], t[r + 1] * fs[(((r + 1) & 3) + 8 * ((r + 1) >> 2)) * fstride], h2, l2);
+                        oh[i] = __builtin_bit_cast(unsigned, h2);
+                        ol[i] = __builtin_bit_cast(unsigned, l2);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(oh, dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, cb, 0)), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(ol, dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, cb, 1)), 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+}
+
 // word = (word << 1) | (v > 0) in two instructions.  v > 0 <=> its bit pattern, read as a signed integer, is > 0 (-0.0 is
 // INT_MIN); the median of (pattern, 0, 1) is that bit.  (From C the compiler builds compare + select + or.)
 __device__ __forceinline__ unsigned push_positive_bit(unsigned word, float v) {

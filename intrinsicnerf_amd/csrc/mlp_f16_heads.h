@@ -47,6 +47,11 @@ __device__ __forceinline__ void to_operands(const f32x16 (&am)[RB][2], float inv
                 const f16x2 m = __builtin_elementwise_max(__builtin_elementwise_max(f16x2{fh[0], fh[1]}, f16x2{fh[2], fh[3]}),
                                                           __builtin_elementwise_max(f16x2{fh[4], fh[5]}, f16x2{fh[6], fh[7]}));
                 amax2 = __builtin_elementwise_max(amax2, m);
+                {   // pinned: left free, the compiler keeps the eight partial maxima of a call alive (spilled) and folds them in much later
+                    unsigned a = __builtin_bit_cast(unsigned, amax2);
+                    asm volatile("" : "+v"(a));
+                    amax2 = __builtin_bit_cast(f16x2, a);
+                }
                 hi[2 * rb + q2][pb] = fh;
                 lo[2 * rb + q2][pb] = fl;
             }

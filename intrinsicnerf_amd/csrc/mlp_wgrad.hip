@@ -1,20 +1,24 @@
 // mlp_wgrad.hip - weight gradients of the MLP, dW[M, N] = sum over sample points p of G[p, m] * X[p, n]
 // (what autograd computes for every nn.Linear when the trainers call loss.backward(): run_nerf.py:1018,
 // trainer.py:990).  G is a pre-activation gradient slot written by k_mlp_dgrad, X the matching activation slot
-// kept by the training forward: both plain row-major [P, width] fp32 matrices (layout.h SaveSlot).
+// kept by the training forward (layout.h SaveSlot).
 //
 // A GEMM with a tiny output (<= 256 x 256) and K = P in the hundreds of thousands: split over K across the
 // chip, one fp32 accumulator tile per workgroup - 256 x 256 floats are exactly the 512-entry register files of
 // four waves - partial tiles summed afterwards (deterministic, no atomics).  Arithmetic as everywhere on this
 // path: fp32 operands split into f16 hi/lo, three v_mfma_f32_32x32x16_f16 per fp32 MAC.
 //
-// The operands of that MFMA must hold, per lane, 8 consecutive k (= points) of one channel, while G and X are
-// point-major.  The transpose is done by the matrix core itself: an MFMA of a [32 points x 16 channels]
-// fragment (lane = point, 8 consecutive channels: a natural 32-byte read of a point's row) with an identity
-// matrix returns that block in accumulator layout - lane = channel, registers = points - which, converted back
-// to f16 (exact: the inputs were f16), IS an operand of the next MFMA.  Two such MFMAs (identity placed in columns
-// 0..15 / 16..31) fill a [32 x 32] block; the resulting k order is the same permutation for G and X, so the
-// contraction is unaffected.  Cost: 2 extra MFMAs per 32 x 32 block and plane (+17 %), no LDS transposes.
+// The operands of that MFMA must hold, per lane, 8 consecutive k (= points) of one channel, while the network
+// kernels work point-major.  Two kernels:
+//   * k_mlp_wgrad_frag - the nine 256 x 256 products of a network (90 % of the operand bytes): both operands arrive as
+//     FRAGMENT slots, i.e. already split and already in operand order (the producers transpose with the matrix core and
+//     store whole 1 KB fragments).  The kernel is a ring of LDS stages filled by LDS-DMA (buffer_load ... lds: no registers,
+//     no conversion, no VALU) and 24 MFMAs per wave and 16-point k-block; bound by HBM.
+//   * k_mlp_wgrad - every other shape (operands 32..128 wide, or 128 rows): row-format X (and G, unless it is a fragment
+//     slot) transposed inside the kernel by the matrix core: an MFMA of a [32 points x 16 channels] fragment (lane = point,
+//     8 consecutive channels: a natural 32-byte read of a point's row) with an identity matrix returns that block in
+//     accumulator layout - lane = channel, registers = points - which, converted back to f16 (exact: the inputs were f16), IS
+//     an operand of the next MFMA.  The resulting k order is layout.h's frag_point order, the fragment slots' own.
 #include <cstdlib>
 
 #include "mlp_f16_dev.h"
@@ -24,7 +28,8 @@ namespace inerf {
 struct WgradParams {
     const float* G;          // [P, ldg] (pointer to the first used column)
     const float* X;          // [P, ldx]
-    const float* ranges;     // device: {gmax, xmax}: upper bounds of |G| and |X|
+    const float* ranges;     // device: {gmax, xmax}: upper bounds of |G| and |X| (GFRAG: [1] only)
+    const float* s_max;      // GFRAG: G is a fragment slot holding kActScale * dz / S; device: S (layout.h)
     float* partial;          // workgroup g writes its M x N tile at partial + g * partial_stride
     float* bias_partial;     // optional: workgroup g writes its column sums of G at bias_partial + g * partial_stride
     int64_t partial_stride;  // floats
@@ -80,8 +85,11 @@ __device__ __forceinline__ float transpose_block(f16x8 g0, f16x8 g1, f16x8 id0, 
 // M = 256 runs as 8 waves of <= 256 registers (128 of them accumulators): two waves per SIMD, so that one wave's loads and
 // conversions overlap the other's MFMAs.  (With 4 waves x 64 rows - 256 accumulator registers per lane - prefetching the
 // next tile spilled and was 20 % slower than not prefetching at all.)
-template <int NW, int CB>
+// GFRAG: G is a fragment slot (this wave's 32 channels = channel block `wave`): its operands are loaded as they are, one
+// 16-byte request per lane, k-block and plane.
+template <int NW, int CB, bool GFRAG = false>
 __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
+    static_assert(!GFRAG || NW == 8, "fragment slots are 256 channels wide");
     extern __shared__ __attribute__((aligned(16))) char ldsw[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -90,7 +98,8 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
     // powers of two that bring the operands' bounds into [2^13, 2^14) (f16 hi/lo split range)
     auto pow2_for = [](float m) { int e; if (!(m > 0.0f) || !(m < 3.0e38f)) return 1.0f; frexpf(m, &e); return ldexpf(1.0f, 14 - e); };
     auto uniform = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
-    const float sg = uniform(pow2_for(p.ranges[0])), sx = uniform(pow2_for(p.ranges[1]));       // wave-uniform: scalar registers
+    const float sx = uniform(pow2_for(p.ranges[1]));       // wave-uniform: scalar registers
+    const float sg = GFRAG ? uniform(kActScale / fmaxf(p.s_max[0], kMinGradScale)) : uniform(pow2_for(p.ranges[0]));
 
     // identity operands of the transposer: B[k][n] = (n == k) resp. (n == k + 16); lane n holds k = 8 * lh + i
     f16x8 id0, id1;
@@ -117,10 +126,12 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
     // The next tile's rows - this wave's share of X and its own 32 channels of G - are requested before the contraction and
     // converted after it: a tile's loads have a whole contraction (~4 000 cycles) to arrive.  (Until round 3 G was requested
     // at the top of its own tile and waited for - ~3 000 exposed cycles of a tile's 20 000.)  One barrier per tile.
-    const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G), 0, (int)((unsigned)p.n_points * (unsigned)p.ldg * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G), 0,
+        GFRAG ? (int)((unsigned)p.n_tiles * (unsigned)kFragTileBytes) : (int)((unsigned)p.n_points * (unsigned)p.ldg * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, (int)((unsigned)p.n_points * (unsigned)p.ldx * 4u), 0x00020000);
     const unsigned g_voff0 = (unsigned)(lp * p.ldg + 32 * wave + 8 * lh) * 4u, x_voff0 = (unsigned)(lp * p.ldx + 8 * lh) * 4u;
-    float xraw[XS][2][2][8], graw[2][2][8];
+    float xraw[XS][2][2][8], graw[GFRAG ? 1 : 2][2][8];
+    f16x8 gfr[GFRAG ? 2 : 1][2][2];           // GFRAG: [point half][k-block][hi | lo]
     auto opaque = [](unsigned v) { asm volatile("" : "+v"(v)); return v; };      // keeps `voff + constant` an immediate, not a hoisted register
     auto load_x = [&](int tile, int ph) {
 #pragma unroll
@@ -133,9 +144,18 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
             }
     };
     auto load_g = [&](int tile, int ph) {
-        const unsigned voff = opaque(g_voff0 + (unsigned)(tile * kTilePoints + 32 * ph) * (unsigned)p.ldg * 4u);
+        if constexpr (GFRAG) {                 // tiles beyond the end lie outside the descriptor: zeros
+            const unsigned voff = opaque((unsigned)tile * (unsigned)kFragTileBytes + (unsigned)lane * 16u);
 #pragma unroll
-        for (int g = 0; g < 2; ++g) load_piece(g_rsrc, voff + 64u * g, graw[ph][g]);
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int plane = 0; plane < 2; ++plane)
+                    gfr[ph][q][plane] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, (int)(voff + frag_off(2 * ph + q, wave, plane)), 0, 0));
+        } else {
+            const unsigned voff = opaque(g_voff0 + (unsigned)(tile * kTilePoints + 32 * ph) * (unsigned)p.ldg * 4u);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) load_piece(g_rsrc, voff + 64u * g, graw[ph][g]);
+        }
     };
 
 #ifdef INERF_WGRAD_STAMPS   // development build (scripts/build_variant.sh, scripts/wgrad_timeline.py): cycle stamps of workgroup 0's
@@ -182,7 +202,19 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {
             f16x8 gh[2], gl[2];                // [q]
-            {
+            if constexpr (GFRAG) {
+                const f16x2 ones = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    gh[q] = gfr[ph][q][0];
+                    gl[q] = gfr[ph][q][1];
+#pragma unroll
+                    for (int i = 0; i < 8; i += 2) {       // v_dot2_f32_f16: exact products, fp32 sums
+                        bias_sum = __builtin_amdgcn_fdot2(f16x2{gh[q][i], gh[q][i + 1]}, ones, bias_sum, false);
+                        bias_sum = __builtin_amdgcn_fdot2(f16x2{gl[q][i], gl[q][i + 1]}, ones, bias_sum, false);
+                    }
+                }
+            } else {
                 f16x8 h0, l0, h1, l1;
                 split8(graw[ph][0], sg, h0, l0);
                 split8(graw[ph][1], sg, h1, l1);
@@ -251,74 +283,58 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 256 x 256 products (nine of a network's thirteen, 90 % of the weight-gradient time): ROW-COALESCED form.
+// 256 x 256 products (nine of a network's thirteen, 90 % of the weight-gradient bytes): both operands are FRAGMENT slots.
 //
-// k_mlp_wgrad above reads its rows with lane = point (the layout the transposing MFMA wants): every request fetches 16 bytes from
-// each of 32 rows, and the cycle stamps (profiles/r03_wgrad_timeline.txt) show the vector-memory front end saturated by them.
-// Here a request is one whole row - 64 lanes x 16 bytes = the 1 KB of a point's 256 channels - and no MFMA transposes anything:
-// a lane that has fetched the same four channels of EIGHT consecutive points holds, per channel, exactly the 8 k-values of one
-// operand slot (lane = channel, 8 consecutive points of a 16-point k-block).  Both matrices go through LDS as operand fragments:
-// waves 0..3 stage G (8 of a step's 32 points each), waves 4..7 stage X; every wave then contracts a [64 rows x 128 columns]
-// part of the tile (2 x 4 accumulator blocks, 24 KB of operand reads per step instead of 36).  Per 32-point step and wave:
-// 8 requests, 16 three-instruction splits, 8 conflict-free ds_write_b128, 48 MFMAs.
-// The point -> (k-block, k-half, element) assignment is the same for G and X, so the contraction does not see it.
+// Per 16-point k-block a slot holds 16 fragments of 1 KB ([32-channel block][hi | lo], layout.h), contiguous: one LDS stage =
+// 16 KB of G + 16 KB of X.  A ring of kFragStages stages is filled by LDS-DMA - `buffer_load_dwordx4 ... lds` moves a fragment
+// from HBM to LDS in one instruction, lane l's 16 bytes to byte 16 l of the destination, which is exactly where the lane that
+// contracts reads its operand slot (conflict-free by construction) - so the loads need no registers, nothing is converted and
+// the VALU idles; up to kFragStages - 1 stages (96 KB per CU) are in flight while one is contracted.  Eight waves: wave w
+// requests fragments 4 (w & 3) .. + 3 of G (w < 4) or X (w >= 4) of every stage and contracts rows 64 (w & 3) .. + 63 x columns
+// 128 (w >> 2) .. + 127 (2 x 4 accumulator blocks; 12 operand reads and 24 MFMAs per k-block).
+// Synchronisation per stage: every wave waits for ITS OWN requests of the stage (counted vmcnt: the younger stages stay in
+// flight), then one raw s_barrier - behind it every wave's fragments of the stage have landed, and every wave has finished
+// reading the stage before, whose buffer is the one re-filled next.  (A __syncthreads() would drain vmcnt to 0.)
+// The column sums of G (the bias gradient) come from the operands the waves 0..3 read anyway (v_dot2_f32_f16 with ones).
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kRowStep = 32;                                    // points per step
-constexpr int kRowSetBytes = 8 * 2 * 2 * kWgFragBytes;          // one matrix, one step: [32-channel block][k-block][hi | lo] fragments
-constexpr int kRowBufBytes = 2 * kRowSetBytes;                  // G | X
+#ifndef INERF_WGRAD_FRAG_STAGES
+#define INERF_WGRAD_FRAG_STAGES 4
+#endif
+constexpr int kFragStages = INERF_WGRAD_FRAG_STAGES;
+constexpr int kFragStageBytes = 2 * kFragKbBytes;               // G | X of one k-block
+static_assert(kFragStages >= 3 && kFragStages <= 5, "ring depth");
 
-__global__ __launch_bounds__(512, 1) void k_mlp_wgrad_rows(const WgradParams p) {
+struct WgradFragParams {
+    const void* G;           // fragment slot of dZ: kActScale * dz / S
+    const void* X;           // fragment slot of activations: kActScale * h
+    const float* s_max;      // device: S
+    float* partial;          // workgroup g writes its 256 x 256 tile at partial + g * partial_stride
+    float* bias_partial;     // optional: ... its column sums of G
+    int64_t partial_stride;  // floats
+    int n_kb;                // 16-point k-blocks: 4 per tile
+};
+
+__global__ __launch_bounds__(512, 1) void k_mlp_wgrad_frag(const WgradFragParams p) {
     extern __shared__ __attribute__((aligned(16))) char ldsw[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lp = lane & 31, lh = lane >> 5;
-    const bool is_g = wave < 4;                 // the matrix this wave stages
-    const int w4 = wave & 3;                    // ... and which 8 of a step's 32 points
-    auto pow2_for = [](float m) { int e; if (!(m > 0.0f) || !(m < 3.0e38f)) return 1.0f; frexpf(m, &e); return ldexpf(1.0f, 14 - e); };
-    auto uniform = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
-    const float sg = uniform(pow2_for(p.ranges[0])), sx = uniform(pow2_for(p.ranges[1]));
-    const float s_mine = is_g ? sg : sx;
-    const int ld = is_g ? p.ldg : p.ldx;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(is_g ? p.G : p.X), 0,
-                                                                           (int)((unsigned)p.n_points * (unsigned)ld * 4u), 0x00020000);
-    const unsigned row_bytes = (unsigned)ld * 4u;
-    const unsigned voff0 = (unsigned)(8 * w4) * row_bytes + 16u * lane;       // the whole offset goes through the VGPR (range check)
-    auto opaque = [](unsigned v) { asm volatile("" : "+v"(v)); return v; };
-    // rows 32 step + 8 w4 + j, j = 0..7; beyond the end of the matrix they read as zeros (and cost nothing)
-    auto load_rows = [&](int step, f32x4 (&raw)[8]) {
-        const unsigned v = opaque(voff0 + (unsigned)(step * kRowStep) * row_bytes);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) raw[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(v + j * row_bytes), 0, 0));
+    const bool dma_g = wave < 4;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(dma_g ? p.G : p.X), 0,
+                                                                           (int)((unsigned)p.n_kb * (unsigned)kFragKbBytes), 0x00020000);
+    const int my_bytes = (dma_g ? 0 : kFragKbBytes) + (wave & 3) * 4 * kFragBytes;      // this wave's four fragments inside a stage
+    const int src_bytes = (wave & 3) * 4 * kFragBytes;                                   // ... inside its matrix's k-block
+    // one stage: four requests; lane l's 16 bytes of fragment j land at stage + my_bytes + 1024 j + 16 l (the instruction
+    // offset advances the source and the destination alike)
+    auto request = [&](int kb, int buf) {
+        __attribute__((address_space(3))) char* dst = (__attribute__((address_space(3))) char*)(ldsw) + buf * kFragStageBytes + my_bytes;
+        const int soff = (int)((unsigned)kb * (unsigned)kFragKbBytes) + src_bytes;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, lane * 16, soff, 0 * kFragBytes, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, lane * 16, soff, 1 * kFragBytes, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, lane * 16, soff, 2 * kFragBytes, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, lane * 16, soff, 3 * kFragBytes, 0);
     };
-    // Operand slot (16 bytes = 8 points of one channel) of channel n (0..31 of its block) and k-half kh inside a 1 KB fragment:
-    // (n >> 2) + 8 (n & 3) + 32 kh.  A staging lane owns channels 4 (lane & 7) .. + 3 of block lane >> 3: for a given one of its
-    // four channels the 8 lanes of a block write 128 consecutive bytes and the 8 blocks 8 different fragments - every ds_write_b128
-    // is conflict-free.  A contracting lane (n = lane & 31, kh = lane >> 5) reads its own slot: 64 different slots of one fragment.
-    float bias4[4] = {0.0f, 0.0f, 0.0f, 0.0f};     // G waves: sums over this workgroup's points of the lane's four channels
-    auto convert = [&](int buf, const f32x4 (&raw)[8]) {
-        char* set = ldsw + buf * kRowBufBytes + (is_g ? 0 : kRowSetBytes);
-        const int q = w4 >> 1, kh = w4 & 1;        // the 8 points 8 w4 .. + 7 of the step: k-block q, k-half kh, elements 0..7
-        char* dst0 = set + (((lane >> 3) * 2 + q) * 2) * kWgFragBytes + ((lane & 7) + 32 * kh) * 16;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            f16x8 hi, lo;
-            float sum = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 8; j += 2) {
-                f16x2 h2, l2;
-                split_pair(raw[j][e] * s_mine, raw[j + 1][e] * s_mine, h2, l2);
-                hi[j] = h2[0]; hi[j + 1] = h2[1];
-                lo[j] = l2[0]; lo[j + 1] = l2[1];
-                sum += raw[j][e] + raw[j + 1][e];
-            }
-            bias4[e] += sum;
-            *reinterpret_cast<f16x8*>(dst0 + 8 * e * 16) = hi;
-            *reinterpret_cast<f16x8*>(dst0 + 8 * e * 16 + kWgFragBytes) = lo;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    // this wave's part of the tile: rows 64 (wave & 3) .. + 63, columns 128 (wave >> 2) .. + 127
     const int rb0 = 2 * (wave & 3), cb0 = 4 * (wave >> 2);
     f32x16 acc[2][4];
 #pragma unroll
@@ -327,81 +343,71 @@ __global__ __launch_bounds__(512, 1) void k_mlp_wgrad_rows(const WgradParams p) 
         for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.0f;
-    const int my_slot = ((lp >> 2) + 8 * (lp & 3) + 32 * lh) * 16;
-    auto frag = [&](const char* set, int block, int q, int plane) {
-        return *reinterpret_cast<const f16x8*>(set + ((block * 2 + q) * 2 + plane) * kWgFragBytes + my_slot);
-    };
+    float bias_sum[2] = {0.0f, 0.0f};          // waves 0..3: this lane's channel of row block rb, its k-half's points
+    const f16x2 ones = {(_Float16)1.0f, (_Float16)1.0f};
     auto contract = [&](int buf) {
-        const char* gset = ldsw + buf * kRowBufBytes;
-        const char* xset = gset + kRowSetBytes;
+        const char* gset = ldsw + buf * kFragStageBytes + lane * 16;
+        const char* xset = gset + kFragKbBytes;
+        auto frag = [&](const char* set, int block, int plane) { return *reinterpret_cast<const f16x8*>(set + (block * 2 + plane) * kFragBytes); };
+        f16x8 gh[2], gl[2], xh[2], xl[2];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            f16x8 gh[2], gl[2], xh[2], xl[2];
+        for (int rb = 0; rb < 2; ++rb) { gh[rb] = frag(gset, rb0 + rb, 0); gl[rb] = frag(gset, rb0 + rb, 1); }
+        xh[0] = frag(xset, cb0, 0); xl[0] = frag(xset, cb0, 1);
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb) { gh[rb] = frag(gset, rb0 + rb, q, 0); gl[rb] = frag(gset, rb0 + rb, q, 1); }
-            xh[0] = frag(xset, cb0, q, 0); xl[0] = frag(xset, cb0, q, 1);
+        for (int cb = 0; cb < 4; ++cb) {     // X operands one read ahead of their MFMAs, fenced (unfenced, the scheduler hoists every read to the top)
+            if (cb + 1 < 4) { xh[(cb + 1) & 1] = frag(xset, cb0 + cb + 1, 0); xl[(cb + 1) & 1] = frag(xset, cb0 + cb + 1, 1); }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {     // X operands one read ahead of their MFMAs, fenced (see k_mlp_wgrad)
-                if (cb + 1 < 4) { xh[(cb + 1) & 1] = frag(xset, cb0 + cb + 1, q, 0); xl[(cb + 1) & 1] = frag(xset, cb0 + cb + 1, q, 1); }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb) {
-                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[rb], xh[cb & 1], acc[rb][cb], 0, 0, 0);
-                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[rb], xl[cb & 1], acc[rb][cb], 0, 0, 0);
-                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl[rb], xh[cb & 1], acc[rb][cb], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            for (int rb = 0; rb < 2; ++rb) {
+                acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[rb], xh[cb & 1], acc[rb][cb], 0, 0, 0);
+                acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[rb], xl[cb & 1], acc[rb][cb], 0, 0, 0);
+                acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl[rb], xh[cb & 1], acc[rb][cb], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (wave < 4 && p.bias_partial) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) {
+                    bias_sum[rb] = __builtin_amdgcn_fdot2(f16x2{gh[rb][i], gh[rb][i + 1]}, ones, bias_sum[rb], false);
+                    bias_sum[rb] = __builtin_amdgcn_fdot2(f16x2{gl[rb][i], gl[rb][i + 1]}, ones, bias_sum[rb], false);
+                }
         }
     };
 
-    // this workgroup's steps: blockIdx.x, + gridDim.x, ... of ceil(n_points / 32); rows are converted one step before they are
-    // contracted (two LDS buffers, one barrier per step) and requested one step before they are converted - two steps with
-    // INERF_WGRAD_ROWS_DEPTH2 (a second register set: 32 more registers, spills)
-    const int n_steps = (p.n_points + kRowStep - 1) / kRowStep;
-    const int g = gridDim.x;
-#ifdef INERF_WGRAD_ROWS_DEPTH2
-    f32x4 raw_a[8], raw_b[8];
-    load_rows(blockIdx.x, raw_a);
-    load_rows(blockIdx.x + g, raw_b);
-    convert(0, raw_a);
-    load_rows(blockIdx.x + 2 * g, raw_a);
-    for (int s = blockIdx.x; s < n_steps; s += 2 * g) {
-        __syncthreads();               // LDS[0] holds step s; nobody reads LDS[1] any more
-        contract(0);
-        convert(1, raw_b);             // step s + g
-        load_rows(s + 3 * g, raw_b);
-        __syncthreads();               // LDS[1] holds step s + g (zeros beyond the end); nobody reads LDS[0] any more
-        contract(1);
-        convert(0, raw_a);             // step s + 2 g
-        load_rows(s + 4 * g, raw_a);
+    // this workgroup's k-blocks: blockIdx.x, + gridDim.x, ... (neighbouring workgroups stream neighbouring 32 KB: the chip
+    // walks both matrices front to back)
+    const int g = gridDim.x, b = blockIdx.x;
+    const int n_mine = p.n_kb > b ? (p.n_kb - b + g - 1) / g : 0;
+#pragma unroll
+    for (int j = 0; j < kFragStages - 1; ++j)
+        if (j < n_mine) request(b + j * g, j);
+    int buf = 0;
+    for (int i = 0; i < n_mine; ++i) {
+        // requests of stages i + 1 .. may stay in flight: four per stage, at most kFragStages - 2 stages, fewer at the end
+        const int ahead = n_mine - 1 - i;
+        if (ahead >= 3 && kFragStages >= 5) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (ahead >= 2 && kFragStages >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (i + kFragStages - 1 < n_mine) request(b + (i + kFragStages - 1) * g, buf == 0 ? kFragStages - 1 : buf - 1);
+        contract(buf);
+        buf = buf + 1 == kFragStages ? 0 : buf + 1;
     }
-#else
-    f32x4 raw[8];
-    load_rows(blockIdx.x, raw);
-    convert(0, raw);
-    load_rows(blockIdx.x + g, raw);
-    for (int s = blockIdx.x; s < n_steps; s += 2 * g) {
-        __syncthreads();               // LDS[0] holds step s; nobody reads LDS[1] any more
-        contract(0);
-        convert(1, raw);               // step s + g
-        load_rows(s + 2 * g, raw);
-        __syncthreads();               // LDS[1] holds step s + g (zeros beyond the end); nobody reads LDS[0] any more
-        contract(1);
-        convert(0, raw);               // step s + 2 g
-        load_rows(s + 3 * g, raw);
-    }
-#endif
 
     // ---- this workgroup's partial tile and its column sums of G ----
-    if (p.bias_partial) {              // the four G waves hold different points of the same 256 channels
-        __syncthreads();
-        float* sums = reinterpret_cast<float*>(ldsw);
-        if (is_g) *reinterpret_cast<f32x4*>(sums + w4 * 256 + 4 * lane) = f32x4{bias4[0], bias4[1], bias4[2], bias4[3]};
-        __syncthreads();
-        if (tid < 256) p.bias_partial[(size_t)blockIdx.x * p.partial_stride + tid] = (sums[tid] + sums[256 + tid]) + (sums[512 + tid] + sums[768 + tid]);
+    const float s = fmaxf(p.s_max[0], kMinGradScale);
+    if (p.bias_partial && wave < 4) {          // the two lane halves hold complementary points of the same channel
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const float both = bias_sum[rb] + __shfl_xor(bias_sum[rb], 32);
+            if (lh == 0) p.bias_partial[(size_t)blockIdx.x * p.partial_stride + 32 * (rb0 + rb) + lp] = both * (s * (1.0f / kActScale));
+        }
     }
-    const float back = 1.0f / (sg * sx);
+    const float back = s * (1.0f / (kActScale * kActScale));
     float* out = p.partial + (size_t)blockIdx.x * p.partial_stride;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
@@ -428,43 +434,91 @@ extern "C" int inerf_wgrad_grid(int64_t n_points) {
     return (int)(tiles < device_cus() ? tiles : device_cus());
 }
 
+namespace inerf {
+namespace {
+
+int launch_rows(WgradParams& p, bool gfrag, void* stream) {
+    const int grid = inerf_wgrad_grid(p.n_points);
+    const int M = p.M, cb = p.N / 32;
+    if ((M != 128 && M != 256) || p.N % 32 || cb < 1 || cb > 8) return INERF_E_UNSUPPORTED;
+    // rows are addressed through 32-bit buffer descriptors, the prefetch reaches one grid stride of tiles beyond the end
+    const int64_t ld = gfrag ? p.ldx : (p.ldg > p.ldx ? p.ldg : p.ldx);
+    if (((int64_t)p.n_points + (int64_t)kTilePoints * (grid + 1)) * ld * 4 >= (int64_t)1 << 32) return INERF_E_UNSUPPORTED;
+    const int lds = 2 * cb * 8 * kWgFragBytes;          // double-buffered X operands
+    void (*kern)(const WgradParams) = nullptr;
+    int variant = -1;
+    if (gfrag) {
+        if (M == 256 && cb == 2) { kern = k_mlp_wgrad<8, 2, true>; variant = 8; }
+    } else {
+#define INERF_WG_CASE(V, NWV, CBV) if (M == 32 * NWV && cb == CBV) { kern = k_mlp_wgrad<NWV, CBV>; variant = V; }
+        INERF_WG_CASE(0, 8, 8) INERF_WG_CASE(1, 8, 2) INERF_WG_CASE(2, 4, 8) INERF_WG_CASE(3, 4, 1) INERF_WG_CASE(4, 8, 1) INERF_WG_CASE(5, 4, 2)
+        INERF_WG_CASE(6, 8, 4) INERF_WG_CASE(7, 4, 4)
+#undef INERF_WG_CASE
+    }
+    if (!kern) return INERF_E_UNSUPPORTED;
+    static PerDeviceOnce attr_set[9];
+    if (lds > 64 * 1024 && attr_set[variant].first()) {          // only <8, 8> and <4, 8>
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return record(e);
+        attr_set[variant].mark();
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(M * 2), lds, (hipStream_t)stream, p);       // 64 threads per 32-row block
+    return record(hipGetLastError());
+}
+
+}  // namespace
+}  // namespace inerf
+
 extern "C" int inerf_mlp_weight_gradient(const float* G, int ldg, const float* X, int ldx, int64_t n_points, int M, int N,
                                          const float* ranges, float* partial, float* bias_partial, int64_t partial_stride,
                                          void* stream) {
     using namespace inerf;
     if (!G || !X || !ranges || !partial || n_points <= 0 || ldg < M || ldx < N) return INERF_E_INVALID;
-    // rows are addressed through 32-bit buffer descriptors, the prefetch reaches one grid stride of tiles beyond the end
-    if ((n_points + (int64_t)kTilePoints * (device_cus() + 1)) * (ldg > ldx ? ldg : ldx) * 4 >= (int64_t)1 << 32) return INERF_E_UNSUPPORTED;
+    if (n_points > kMaxTrainPoints) return INERF_E_UNSUPPORTED;
     if ((ldg & 3) || (ldx & 3) || (((uintptr_t)G | (uintptr_t)X) & 15)) return INERF_E_INVALID;      // 16-byte row pieces
-    WgradParams p;
     if (partial_stride < (int64_t)M * N) return INERF_E_INVALID;
-    p.G = G; p.X = X; p.ranges = ranges; p.partial = partial; p.bias_partial = bias_partial; p.partial_stride = partial_stride;
+    WgradParams p;
+    p.G = G; p.X = X; p.ranges = ranges; p.s_max = nullptr; p.partial = partial; p.bias_partial = bias_partial; p.partial_stride = partial_stride;
     p.ldg = ldg; p.ldx = ldx; p.n_points = (int)n_points; p.M = M; p.N = N;
     p.n_tiles = (int)((n_points + kTilePoints - 1) / kTilePoints);
+    return launch_rows(p, false, stream);
+}
+
+// G: a FRAGMENT slot of the gradient buffer (256 channels; s_max: the device float S that buffer carries, layout.h); X: rows.
+extern "C" int inerf_mlp_weight_gradient_gfrag(const void* G_frag, const float* s_max, const float* X, int ldx, int64_t n_points, int N,
+                                               const float* ranges, float* partial, float* bias_partial, int64_t partial_stride,
+                                               void* stream) {
+    using namespace inerf;
+    if (!G_frag || !s_max || !X || !ranges || !partial || n_points <= 0 || ldx < N) return INERF_E_INVALID;
+    if (n_points > kMaxTrainPoints) return INERF_E_UNSUPPORTED;
+    if ((ldx & 3) || (((uintptr_t)G_frag | (uintptr_t)X) & 15)) return INERF_E_INVALID;
+    if (partial_stride < (int64_t)kWidth * N) return INERF_E_INVALID;
+    WgradParams p;
+    p.G = static_cast<const float*>(G_frag); p.X = X; p.ranges = ranges; p.s_max = s_max; p.partial = partial; p.bias_partial = bias_partial;
+    p.partial_stride = partial_stride;
+    p.ldg = kWidth; p.ldx = ldx; p.n_points = (int)n_points; p.M = kWidth; p.N = N;
+    p.n_tiles = (int)((n_points + kTilePoints - 1) / kTilePoints);
+    return launch_rows(p, true, stream);
+}
+
+// Both operands FRAGMENT slots (256 x 256): G of the gradient buffer, X of the activation buffer, on the same n_points.
+extern "C" int inerf_mlp_weight_gradient_frag(const void* G_frag, const void* X_frag, const float* s_max, int64_t n_points,
+                                              float* partial, float* bias_partial, int64_t partial_stride, void* stream) {
+    using namespace inerf;
+    if (!G_frag || !X_frag || !s_max || !partial || n_points <= 0) return INERF_E_INVALID;
+    if (n_points > kMaxTrainPoints) return INERF_E_UNSUPPORTED;
+    if ((((uintptr_t)G_frag | (uintptr_t)X_frag) & 15) || partial_stride < (int64_t)kWidth * kWidth) return INERF_E_INVALID;
+    WgradFragParams p;
+    p.G = G_frag; p.X = X_frag; p.s_max = s_max; p.partial = partial; p.bias_partial = bias_partial; p.partial_stride = partial_stride;
+    p.n_kb = (int)((n_points + kTilePoints - 1) / kTilePoints) * 4;
     const int grid = inerf_wgrad_grid(n_points);
-    const int cb = N / 32;
-    if ((M != 128 && M != 256) || N % 32 || cb < 1 || cb > 8) return INERF_E_UNSUPPORTED;
-    // 256 x 256: the row-coalesced form (INERF_WGRAD_FORM=points keeps the lane = point form for A/B runs)
-    const char* form = getenv("INERF_WGRAD_FORM");
-    if (M == 256 && N == 256 && !(form && form[0] == 'p')) {
-        if ((n_points + (int64_t)kRowStep * (4 * grid + 2)) * (ldg > ldx ? ldg : ldx) * 4 >= (int64_t)1 << 32) return INERF_E_UNSUPPORTED;
-        const int lds_rows = 2 * kRowBufBytes;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_wgrad_rows), hipFuncAttributeMaxDynamicSharedMemorySize, lds_rows);
+    constexpr int lds = kFragStages * kFragStageBytes;
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_wgrad_frag), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return record(e);
-        hipLaunchKernelGGL(k_mlp_wgrad_rows, dim3(grid), dim3(512), lds_rows, (hipStream_t)stream, p);
-        return record(hipGetLastError());
+        attr_set.mark();
     }
-    const int lds = 2 * cb * 8 * kWgFragBytes;          // double-buffered X operands
-    void (*kern)(const WgradParams) = nullptr;
-#define INERF_WG_CASE(NWV, CBV) if (M == 32 * NWV && cb == CBV) kern = k_mlp_wgrad<NWV, CBV>;
-    INERF_WG_CASE(8, 8) INERF_WG_CASE(8, 2) INERF_WG_CASE(4, 8) INERF_WG_CASE(4, 1) INERF_WG_CASE(8, 1) INERF_WG_CASE(4, 2)
-    INERF_WG_CASE(8, 4) INERF_WG_CASE(4, 4)
-#undef INERF_WG_CASE
-    if (!kern) return INERF_E_UNSUPPORTED;
-    if (lds > 64 * 1024) {          // only <8, 8> and <4, 8>; set on every launch (a few microseconds): the attribute is per device
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return record(e);
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(M * 2), lds, (hipStream_t)stream, p);       // 64 threads per 32-row block
+    hipLaunchKernelGGL(k_mlp_wgrad_frag, dim3(grid), dim3(512), lds, (hipStream_t)stream, p);
     return record(hipGetLastError());
 }

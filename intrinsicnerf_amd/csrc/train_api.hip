@@ -4,7 +4,8 @@
 // records for run_network + NeRF.forward / Semantic_NeRF.forward (run_nerf.py:1018 through run_nerf_helpers.py:284-321;
 // trainer.py:990 through semantic_nerf.py:123-181):
 //   1. the input-gradient chain (k_mlp_dgrad) with the 1-4-row heads' gradients accumulated on the way,
-//   2. every 128/256-row weight-gradient product dW = dZ^T X as a split-K launch (k_mlp_wgrad), the per-workgroup partial
+//   2. every 128/256-row weight-gradient product dW = dZ^T X as a split-K launch - the nine 256 x 256 products from FRAGMENT
+//      slots by LDS-DMA (k_mlp_wgrad_frag), the narrow ones from rows (k_mlp_wgrad) -, the per-workgroup partial
 //      tiles of ALL products side by side in one [grid, total] buffer,
 //   3. one reduction over the workgroups that writes each sum straight into its place in the caller's gradient blob - the
 //      reference's parameter tensors in inerf_tensor_info() order (the cat([pts, h]) and cat([feature, views]) layers are
@@ -123,7 +124,7 @@ Table build_table(const inerf_net_desc& net, int sem_rows) {
     }
     {   const int k = add(SAVE_H0 + kSkipInput, SAVE_ENC, kWidth, kEncCols);    // ... and its encoding columns: cat([pts, h]), helpers:290-291
         wpiece(k, 0, kWidth, "pts_linears." + std::to_string(kSkipInput), 0, e); }
-    {   const int k = add(SAVE_AS1H, SAVE_H7, kWidth, kWidth);                   // albedo_linear1 | shading hidden
+    {   const int k = add(SAVE_AS1H, SAVE_H7, kWidth, kWidth);                   // albedo_linear1 | shading hidden (fragments x fragments)
         wpiece(k, 0, kHalf, "albedo_linear1", 0, kWidth); wpiece(k, kHalf, kWidth, sh1, 0, kWidth);
         bpiece(k, 0, 0, kHalf, "albedo_linear1"); bpiece(k, 1, kHalf, kWidth, sh1); }
     {   const int k = add(SAVE_FEAT, SAVE_H7, kWidth, kWidth);
@@ -133,7 +134,7 @@ Table build_table(const inerf_net_desc& net, int sem_rows) {
     {   const int k = add(SAVE_VH, SAVE_DIR, kHalf, kDirCols);
         wpiece(k, 0, kHalf, "views_linears.0", kWidth, dv); }
     if (sem) {
-        {   const int k = add(SAVE_SEMH, SAVE_H7, kHalf, kWidth);
+        {   const int k = add(SAVE_SEMH, SAVE_H7R, kHalf, kWidth);                // (rows x rows: h7's row copy)
             wpiece(k, 0, kHalf, "semantic_linear.0.0", 0, kWidth); bpiece(k, 0, 0, kHalf, "semantic_linear.0.0"); }
         {   const int k = add(-1, SAVE_SEMH, sem_rows, kHalf);                   // semantic_linear.1: G = padded d_logits
             tb.launch[k].sem = 1;
@@ -353,14 +354,20 @@ extern "C" int inerf_mlp_backward(const inerf_net_desc* net, const float* packed
     const Table& tb = cache.table;
     ReduceTable t = tb.dev;
     t.grid = plan.wg_grid;
+    const float* s_max = dz + save_scalars_offset(*net, n_points);     // written by the chain's pre-pass (layout.h)
     for (int k = 0; k < t.n_jobs; ++k) {
         const Job& j = t.job[k];
         const Launch& l = tb.launch[k];
         const float* G = l.sem ? gsem : dz + save_offset(*net, l.g_slot, n_points);
         const int ldg = l.sem ? plan.sem_rows : save_width(*net, l.g_slot);
         const float* X = save + save_offset(*net, l.x_slot, n_points);
-        rc = inerf_mlp_weight_gradient(G, ldg, X, save_width(*net, l.x_slot), n_points, j.m, j.n, sc + (l.sem ? 8 : 4), partial + j.src,
-                                       j.bias_src >= 0 ? partial + j.bias_src : nullptr, t.total, stream);
+        float* tile = partial + j.src;
+        float* bias = j.bias_src >= 0 ? partial + j.bias_src : nullptr;
+        const bool g_frag = !l.sem && save_is_frag(l.g_slot, true), x_frag = save_is_frag(l.x_slot, false);
+        if (g_frag && x_frag) rc = inerf_mlp_weight_gradient_frag(G, X, s_max, n_points, tile, bias, t.total, stream);
+        else if (g_frag)      rc = inerf_mlp_weight_gradient_gfrag(G, s_max, X, save_width(*net, l.x_slot), n_points, j.n, sc + 4, tile, bias, t.total, stream);
+        else if (x_frag)      rc = INERF_E_UNSUPPORTED;       // (no product of the table reads row gradients against fragment activations)
+        else rc = inerf_mlp_weight_gradient(G, ldg, X, save_width(*net, l.x_slot), n_points, j.m, j.n, sc + (l.sem ? 8 : 4), tile, bias, t.total, stream);
         if (rc) return rc;
     }
     hipLaunchKernelGGL(k_reduce_scatter, dim3((unsigned)((t.total / 4 + 255) / 256)), dim3(256), 0, stream, t, partial, grads_out);

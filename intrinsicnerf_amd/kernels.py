@@ -464,16 +464,61 @@ def render_rays_fused(desc, packed_coarse, packed_fine, rays, n_samples, n_impor
 # ---------------------------------------------------------------------------------------------------------------------
 # training: fused forward that keeps the activations, MFMA input-gradient chain, split-K MFMA weight gradients
 # ---------------------------------------------------------------------------------------------------------------------
-(SAVE_ENC, SAVE_DIR, SAVE_H0, SAVE_AS1H, SAVE_FEAT, SAVE_VH, SAVE_SEMH, SAVE_DPRE, SAVE_SLOTS) = (0, 1, 2, 10, 11, 12, 13, 14, 15)
+(SAVE_ENC, SAVE_DIR, SAVE_H0, SAVE_AS1H, SAVE_FEAT, SAVE_VH, SAVE_SEMH, SAVE_DPRE, SAVE_H7R, SAVE_SLOTS) = (0, 1, 2, 10, 11, 12, 13, 14, 15, 16)
+ACT_SCALE = 8.0                 # activations travel as f16 hi/lo of 8 * value (csrc/layout.h kActScale)
+SAVE_SCALARS = 64               # floats behind the slots and the mask area; [0] of a gradient buffer: S (include/inerf.h)
 
 
-def save_slot_views(desc, buf, n_points):
-    """The [n_points, width] matrices of an activation / gradient buffer (include/inerf.h: slot list)."""
+def frag_decode(frag, n_points, scale):
+    """A 256-wide FRAGMENT slot (include/inerf.h: f16 hi/lo operand fragments of the weight-gradient products; ``frag``: its
+    elements as a float32 or float16 tensor) -> the fp32 [n_points, 256] matrix it encodes: (hi + lo) / scale."""
+    h = frag.view(torch.float16) if frag.dtype != torch.float16 else frag
+    tiles = h.numel() // (64 * 256 * 2)
+    # [tile, pb, q, cb, plane, h, c, i_hi, i_lo]: point = 32 pb + 16 q + 8 i_hi + 4 h + i_lo, channel = 32 cb + c
+    v = h.view(tiles, 2, 2, 8, 2, 2, 32, 2, 4).float()
+    v = v[:, :, :, :, 0] + v[:, :, :, :, 1]                                  # hi + lo: [tile, pb, q, cb, h, c, i_hi, i_lo]
+    v = v.permute(0, 1, 2, 6, 4, 7, 3, 5).reshape(tiles * 64, 256)          # -> [tile, pb, q, i_hi, h, i_lo, cb, c]
+    return v[:n_points] / scale
+
+
+def frag_encode(rows, scale):
+    """fp32 [n_points, 256] -> the FRAGMENT slot of ``frag_decode`` (float16 tensor of 64 * ceil(n / 64) * 512 halfs): hi = f16
+    of scale * value rounded towards zero, lo = f16(scale * value - hi); padding points are zero.  What the training kernels'
+    epilogues emit, restated with torch for the tests of the weight-gradient kernel."""
+    n = rows.shape[0]
+    tiles = (n + 63) // 64
+    v = torch.zeros(tiles * 64, 256, dtype=torch.float32, device=rows.device)
+    v[:n] = rows.float() * scale
+    hi = (v.view(torch.int32) & ~0x1FFF).view(torch.float32)                 # 13 low mantissa bits cleared: exact in f16's normal range
+    hi16 = hi.clamp(-65504.0, 65504.0).half()
+    sub = hi16.float().abs() < 2.0 ** -14                                   # subnormal results were rounded, not truncated: fix up
+    hi16 = torch.where(sub & (hi16.float().abs() > v.abs()), torch.nextafter(hi16.float(), torch.zeros_like(v)).half(), hi16)
+    lo16 = (v - hi16.float()).half()
+    both = torch.stack([hi16, lo16], 0)                                      # [plane, point, channel]
+    both = both.view(2, tiles, 2, 2, 2, 2, 4, 8, 32)                         # [plane, tile, pb, q, i_hi, h, i_lo, cb, c]
+    return both.permute(1, 2, 3, 7, 0, 5, 8, 4, 6).contiguous().view(-1)     # [tile, pb, q, cb, plane, h, c, i_hi, i_lo]
+
+
+def save_slot_views(desc, buf, n_points, gradient=False):
+    """The [n_points, width] matrices of an activation buffer (``gradient``: of a buffer of pre-activation gradients;
+    include/inerf.h: slot list).  Row-format slots are views; FRAGMENT slots are decoded into new fp32 tensors."""
     views = []
+    lib = _capi.lib()
     off, width = C.c_int64(), C.c_int()
+    s = None
     for slot in range(SAVE_SLOTS):
-        _capi.check(_capi.lib().inerf_mlp_save_slot(desc, slot, n_points, C.byref(off), C.byref(width)), "inerf_mlp_save_slot")
-        views.append(buf[off.value: off.value + n_points * width.value].view(n_points, width.value))
+        _capi.check(lib.inerf_mlp_save_slot(desc, slot, n_points, C.byref(off), C.byref(width)), "inerf_mlp_save_slot")
+        if lib.inerf_mlp_save_slot_is_fragment(slot, 1 if gradient else 0) == 1:
+            padded = (n_points + 63) // 64 * 64
+            frag = buf[off.value: off.value + padded * width.value]
+            if gradient:
+                if s is None:
+                    s = buf[buf.shape[0] - SAVE_SCALARS].clamp_min(2.0 ** -100)
+                views.append(frag_decode(frag, n_points, 1.0) * (s / ACT_SCALE))
+            else:
+                views.append(frag_decode(frag, n_points, ACT_SCALE))
+        else:
+            views.append(buf[off.value: off.value + n_points * width.value].view(n_points, width.value))
     return views
 
 
@@ -643,57 +688,58 @@ def weight_gradient(g, x, m, n, ranges=None, want_bias=False):
     return (b.result(k), b.bias(k)) if want_bias else b.result(k)
 
 
+def weight_gradient_frag(g_frag, x_frag, s_max, n_points, want_bias=False, x_rows=None, n=256, x_max=None):
+    """G^T X with G a FRAGMENT slot of a gradient buffer (256 channels, ``s_max``: float32[1] device tensor S - the slot holds
+    8 * dz / S) through the HIP split-K kernels: against ``x_frag``, a FRAGMENT slot of activations (LDS-DMA kernel, 256 x 256),
+    or, with ``x_rows`` ([n_points, >= n] fp32 rows, ``x_max`` = float32[1] bound of |x|), against row-format activations."""
+    lib = _capi.lib()
+    grid = lib.inerf_wgrad_grid(n_points)
+    total = 256 * n + (256 if want_bias else 0)
+    buf = _new(s_max, grid, total)
+    base = buf.data_ptr()
+    bias = C.c_void_p(base + 4 * 256 * n) if want_bias else None
+    with torch.cuda.device(s_max.device):
+        if x_rows is None:
+            rc = lib.inerf_mlp_weight_gradient_frag(_ptr(g_frag), _ptr(x_frag), _ptr(s_max), n_points, C.c_void_p(base), bias, total, _stream(s_max))
+        else:
+            ranges = torch.cat([torch.zeros_like(x_max), x_max])
+            rc = lib.inerf_mlp_weight_gradient_gfrag(_ptr(g_frag), _ptr(s_max), C.c_void_p(x_rows.data_ptr()), x_rows.stride(0), n_points, n,
+                                                     _ptr(ranges), C.c_void_p(base), bias, total, _stream(s_max))
+    _capi.check(rc, "inerf_mlp_weight_gradient_frag")
+    sums = buf.sum(0)
+    w = sums[:256 * n].view(256, n)
+    return (w, sums[256 * n:]) if want_bias else w
+
+
 def _colsum(g, nc):
     return g.sum(0) if nc == 1 else g.view(nc, g.shape[0] // nc, g.shape[1]).sum(1).sum(0)
 
 
-def mlp_weight_gradients(desc, names, save, dz, d_raw, n_points, endpoint=False, ranges=None, heads=None):
-    """dW = dZ^T X and db = column sums of dZ for every layer.  The 128/256-row layers go through the HIP split-K kernel when
-    ``ranges`` (float32[2] device tensor: max |dz|, max |activation|, as delivered by the two training kernels) is given, else
-    - and the 1-4-row heads, unless ``heads`` (their gradients as accumulated by the chain kernel) is given - through library
-    GEMMs split over K.  Returns a dict name -> gradient with the
-    reference's parameter names and shapes."""
+def mlp_weight_gradients(desc, names, save, dz, d_raw, n_points, endpoint=False, heads=None):
+    """dW = dZ^T X and db = column sums of dZ for every layer, from the buffers of ``encode_mlp_train`` / ``mlp_backward_inputs``
+    through LIBRARY GEMMs split over K (fragment slots are decoded first): the independent restatement that the tests and
+    scripts/bench_train_kernels.py hold ``mlp_backward`` - the product path: one C call, HIP kernels only - against.  The 1-4-row
+    heads' gradients are taken from ``heads`` (as accumulated by the chain kernel) when given.  Returns a dict name -> gradient
+    with the reference's parameter names and shapes."""
     X = save_slot_views(desc, save, n_points)
-    G = save_slot_views(desc, dz, n_points)
+    G = save_slot_views(desc, dz, n_points, gradient=True)
     e, dv = 3 + 6 * desc.l_xyz, 3 + 6 * desc.l_dir
     sh1, sh2, res = _head_names(desc)
     sem = desc.variant == _capi.VARIANT_SSR and desc.n_classes > 0
     nc = _split_k(n_points)
-    enc, h = X[SAVE_ENC], [X[SAVE_H0 + i] for i in range(8)]        # enc / dir: zero-padded columns, cut from the products
-    # (G slot, X slot, rows, columns): the products with 128 / 256 rows; the first product of a G slot also delivers its bias
-    big = {"t0": (SAVE_H0, SAVE_ENC, 256, 64), "t5e": (SAVE_H0 + 5, SAVE_ENC, 256, 64), "as1": (SAVE_AS1H, SAVE_H0 + 7, 256, 256),
-           "feat": (SAVE_FEAT, SAVE_H0 + 7, 256, 256), "vf": (SAVE_VH, SAVE_FEAT, 128, 256), "vd": (SAVE_VH, SAVE_DIR, 128, 32)}
+    h = [X[SAVE_H0 + i] for i in range(8)]        # enc / dir: zero-padded columns, cut from the products
+    # (G slot, X slot): the products with 128 / 256 rows
+    big = {"t0": (SAVE_H0, SAVE_ENC), "t5e": (SAVE_H0 + 5, SAVE_ENC), "as1": (SAVE_AS1H, SAVE_H0 + 7), "feat": (SAVE_FEAT, SAVE_H0 + 7),
+           "vf": (SAVE_VH, SAVE_FEAT), "vd": (SAVE_VH, SAVE_DIR)}
     for i in range(1, 8):
-        big[f"t{i}"] = (SAVE_H0 + i, SAVE_H0 + i - 1, 256, 256)
+        big[f"t{i}"] = (SAVE_H0 + i, SAVE_H0 + i - 1)
     if sem:
-        big["sem1"] = (SAVE_SEMH, SAVE_H0 + 7, 128, 256)
+        big["sem1"] = (SAVE_SEMH, SAVE_H0 + 7)
     W, B = {}, {}
-    sem2_key = None
-    if ranges is not None:
-        batch, keys, seen = _WgradBatch(n_points, ranges, save), {}, set()
-        for k, (gs, xs, m, n) in big.items():
-            keys[k] = batch.add(G[gs], X[xs], m, n, want_bias=gs not in seen)
-            seen.add(gs)
-        if sem:
-            # semantic_linear.1 (semantic_nerf.py:110): dW[C,128] = d_logits^T . hidden, db = column sums.  d_logits is the
-            # slice d_raw[:, 11:11+C] - neither 16-byte aligned nor 32 columns wide - so it is copied once into a zero-padded
-            # [P, 128 | 256] matrix the split-K kernel can stream; its operand bound is its own (it is not part of dz).
-            c = desc.n_classes
-            mp = 128 if c <= 128 else 256
-            g_sem = d_raw.new_zeros(n_points, mp)
-            g_sem[:, :c] = d_raw[:, BASE_CHANNELS:BASE_CHANNELS + c]
-            r_sem = torch.stack([g_sem.abs().amax().clamp_min(1e-30), ranges[1]])
-            sem2_key = batch.add(g_sem, X[SAVE_SEMH], mp, 128, want_bias=True, ranges=r_sem)
-        batch.run()
-        for k, (gs, xs, m, n) in big.items():
-            W[k] = batch.result(keys[k])
-            if batch.jobs[keys[k]]["boff"] is not None:
-                B[gs] = batch.bias(keys[k])
-    else:
-        for k, (gs, xs, m, n) in big.items():
-            W[k] = _tn(G[gs], X[xs], nc)
-            if gs not in B:
-                B[gs] = _colsum(G[gs], nc)
+    for k, (gs, xs) in big.items():
+        W[k] = _tn(G[gs], X[xs], nc)
+        if gs not in B:
+            B[gs] = _colsum(G[gs], nc)
     out = {}
 
     def lin(name, g, x):
@@ -715,10 +761,7 @@ def mlp_weight_gradients(desc, names, save, dz, d_raw, n_points, endpoint=False,
     if sem:
         out["semantic_linear.0.0.weight"], out["semantic_linear.0.0.bias"] = W["sem1"], B[SAVE_SEMH]
         c = desc.n_classes
-        if sem2_key is not None:
-            out["semantic_linear.1.weight"], out["semantic_linear.1.bias"] = batch.result(sem2_key)[:c], batch.bias(sem2_key)[:c]
-        else:
-            lin("semantic_linear.1", d_raw[:, BASE_CHANNELS:BASE_CHANNELS + c], X[SAVE_SEMH])
+        lin("semantic_linear.1", d_raw[:, BASE_CHANNELS:BASE_CHANNELS + c], X[SAVE_SEMH])
     if heads is None:
         as1h = X[SAVE_AS1H]
         lin("albedo_linear2", dpre[:, 0:3], as1h[:, :128])
@@ -735,7 +778,7 @@ def mlp_weight_gradients(desc, names, save, dz, d_raw, n_points, endpoint=False,
 
 class _FusedMlpFn(torch.autograd.Function):
     """raw = MLP(encode(o + d z), encode(viewdir)) with a HIP forward AND backward: fused split-f16 forward that keeps the
-    activations, MFMA input-gradient chain, split-K MFMA weight gradients (INERF_WGRAD=library: library GEMMs).  Parameters are re-packed on the device
+    activations, MFMA input-gradient chain, split-K MFMA weight gradients.  Parameters are re-packed on the device
     (packing.DevicePacker).  rays / z get no gradient (as in the reference: rays are data, resampled depths are detached)."""
 
     @staticmethod
@@ -755,7 +798,7 @@ class _FusedMlpFn(torch.autograd.Function):
             raw = encode_mlp(d32, packing.device_packer_f32(desc, rays.device)(named), rays.detach(), z_vals.detach(), endpoint)
         # the transposed blob of the backward pass is packed NOW, behind the forward kernel in the queue: at the start of the
         # backward the queue is empty, and its ~25 small launches would each cost a host round trip of GPU idle time
-        packed_bwd = packing.device_packer(desc, True, rays.device)(named) if os.environ.get("INERF_PACK_BWD_EARLY", "1") != "0" else None
+        packed_bwd = packing.device_packer(desc, True, rays.device)(named)
         check_f16_range(status, "training forward", deferrable=True)      # the front-ends read both networks' words once per batch
         ctx.packed_bwd = packed_bwd
         ctx.save_for_backward(raw, save, act_max, *params)
@@ -764,32 +807,15 @@ class _FusedMlpFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_raw):
-        from . import packing
         desc, endpoint, names = ctx.cfg
         raw, save, act_max = ctx.saved_tensors[:3]
-        params = ctx.saved_tensors[3:]
         n, s, ch = raw.shape
         status = _new_status(raw)
-        dz_max = torch.zeros(1, dtype=torch.float32, device=raw.device)
-        packed_bwd = ctx.packed_bwd if ctx.packed_bwd is not None else packing.device_packer(desc, True, raw.device)(dict(zip(names, params)))
         d2 = d_raw.contiguous().view(n * s, ch).float()
-        import os
-        mode = os.environ.get("INERF_WGRAD", "hip")
-        if mode == "hip":          # one C call: chain + weight gradients + reduction + scatter (inerf_mlp_backward)
-            flat = mlp_backward(desc, packed_bwd, raw.view(n * s, ch), d2, save, act_max, endpoint, status)
-            grads = param_views(desc, flat)
-            check_f16_range(status, "training backward")      # read AFTER everything is enqueued: the GPU works through it meanwhile
-            return (None, None, None, None, None, None) + tuple(grads[k] for k in names)
-        # INERF_WGRAD=staged: the round-2 path (chain, then one inerf_mlp_weight_gradient call per product from Python, torch
-        # reductions); =library: library GEMMs for the products (A/B runs)
-        hip_wgrad = mode != "library"
-        dz = mlp_backward_inputs(desc, packed_bwd, raw.view(n * s, ch), d2, save, endpoint, status, dz_max, want_heads=hip_wgrad)
-        heads = None
-        if hip_wgrad:
-            dz, heads = dz
-        ranges = torch.cat([dz_max, act_max]) if hip_wgrad else None
-        grads = mlp_weight_gradients(desc, names, save, dz, d2, n * s, endpoint, ranges, heads)
-        check_f16_range(status, "training backward")      # read AFTER the weight-gradient launches are enqueued: the GPU works through them meanwhile
+        # one C call: chain + weight gradients + reduction + scatter (inerf_mlp_backward)
+        flat = mlp_backward(desc, ctx.packed_bwd, raw.view(n * s, ch), d2, save, act_max, endpoint, status)
+        grads = param_views(desc, flat)
+        check_f16_range(status, "training backward")      # read AFTER everything is enqueued: the GPU works through it meanwhile
         return (None, None, None, None, None, None) + tuple(grads[k] for k in names)
 
 

@@ -44,16 +44,30 @@ def timed(fn):
 
 
 flop = 2 * 659456 * n * s
+p = n * s
 t_inf, _ = timed(lambda: kernels.encode_mlp(desc, pf, rays, z))
 act_max, dz_max = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
 t_fwd, (raw, save) = timed(lambda: kernels.encode_mlp_train(desc, pf, rays, z, act_max=act_max))
-t_bwd, (dz, heads) = timed(lambda: kernels.mlp_backward_inputs(desc, pb, raw.view(n * s, 11), d_raw, save, dz_max=dz_max, want_heads=True))
-t_wl, _ = timed(lambda: kernels.mlp_weight_gradients(desc, names, save, dz, d_raw, n * s))
-t_wg, _ = timed(lambda: kernels.mlp_weight_gradients(desc, names, save, dz, d_raw, n * s, ranges=torch.cat([dz_max, act_max]), heads=heads))
+t_bwd, (dz, heads) = timed(lambda: kernels.mlp_backward_inputs(desc, pb, raw.view(p, 11), d_raw, save, dz_max=dz_max, want_heads=True))
+t_all, _ = timed(lambda: kernels.mlp_backward(desc, pb, raw.view(p, 11), d_raw, save, act_max))
+t_wl, _ = timed(lambda: kernels.mlp_weight_gradients(desc, names, save, dz, d_raw, p, heads=heads))
+
+
+def frag_slot(buf, slot):
+    import ctypes as C
+    off, width = C.c_int64(), C.c_int()
+    _capi.lib().inerf_mlp_save_slot(desc, slot, p, C.byref(off), C.byref(width))
+    return buf[off.value: off.value + (p + 63) // 64 * 64 * 256]
+
+
+s_max = dz[dz.shape[0] - kernels.SAVE_SCALARS:][:1]
+t_one, _ = timed(lambda: kernels.weight_gradient_frag(frag_slot(dz, kernels.SAVE_H0 + 3), frag_slot(save, kernels.SAVE_H0 + 2), s_max, p, want_bias=True))
 gb = save.numel() * 4 / 1e9
-print(f"{n} rays x {s} samples = {n * s} points; activation buffer {gb:.2f} GB")
+saved = (8 * 256 + 256 + 256 + 256 + 128 + 96) * 4 * p / 1e9          # what the training forward writes (h0..h7 fragments, h7 rows, as1h, feat, vh, enc + dir)
+print(f"{n} rays x {s} samples = {p} points; activation buffer {gb:.2f} GB")
 print(f"inference forward        {t_inf:7.3f} ms  {flop / t_inf / 1e9:6.1f} TFLOP/s")
-print(f"training forward (save)  {t_fwd:7.3f} ms  {flop / t_fwd / 1e9:6.1f} TFLOP/s   writes {gb / t_fwd:5.2f} TB/s")
-print(f"input-gradient chain (+ head gradients) {t_bwd:7.3f} ms  {0.89 * flop / t_bwd / 1e9:6.1f} TFLOP/s   reads+writes {2 * gb / t_bwd:5.2f} TB/s (round-1 accounting: activations read + dZ written in full)")
-print(f"weight gradients, library GEMMs {t_wl:7.3f} ms  {flop / t_wl / 1e9:6.1f} TFLOP/s")
-print(f"weight gradients, HIP kernel    {t_wg:7.3f} ms  {flop / t_wg / 1e9:6.1f} TFLOP/s")
+print(f"training forward (save)  {t_fwd:7.3f} ms  {flop / t_fwd / 1e9:6.1f} TFLOP/s   writes {saved / t_fwd:5.2f} TB/s")
+print(f"input-gradient chain (+ head gradients, pre-pass) {t_bwd:7.3f} ms  {0.89 * flop / t_bwd / 1e9:6.1f} TFLOP/s")
+print(f"whole backward, one C call (chain + 13 products + reduction) {t_all:7.3f} ms; weight gradients = {t_all - t_bwd:7.3f} ms  {flop / (t_all - t_bwd) / 1e9:6.1f} TFLOP/s")
+print(f"one 256 x 256 product from fragment slots (incl. the sum over {_capi.lib().inerf_wgrad_grid(p)} partial tiles) {t_one * 1e3:7.1f} us: operands {2 * p * 1024 / t_one / 1e9:5.2f} TB/s")
+print(f"weight gradients, library GEMMs on decoded slots (reference) {t_wl:7.3f} ms")

@@ -429,21 +429,38 @@ def test_weight_gradient_kernel_vs_fp64(p, m, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("p", [1, 31, 33, 5000])
-def test_weight_gradient_forms_of_the_square_product(p, monkeypatch):
-    """256 x 256 products run on the row-coalesced kernel by default and on the lane = point kernel with
-    INERF_WGRAD_FORM=points: both against fp64, down to a single sample point (steps / tiles that are mostly padding)."""
+@pytest.mark.parametrize("p", [1, 15, 17, 63, 65, 1000, 5000, 70001, 131072])
+def test_weight_gradient_from_fragment_slots(p):
+    """The LDS-DMA kernel of the nine 256 x 256 products (both operands FRAGMENT slots, include/inerf.h) and the mixed form
+    (G fragments x row-format X, 64 columns) against fp64 products of what the fragments encode - down to a single sample
+    point (k-blocks and tiles that are mostly padding), ragged counts, more k-blocks than the ring is deep and than the grid
+    is wide; gradients spanning four decades, S a power of two far from 1.  The row-format kernel on the same matrices agrees."""
     from intrinsicnerf_amd import kernels
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(100 + p)
-    G = torch.randn(p, 256, generator=g).to(dev)
-    X = torch.relu(torch.randn(p, 256, generator=g)).to(dev)
-    want_w, want_b = G.double().t() @ X.double(), G.double().sum(0)
-    for form in ("rows", "points"):
-        monkeypatch.setenv("INERF_WGRAD_FORM", form)
-        w, b = kernels.weight_gradient(G, X, 256, 256, want_bias=True)
-        assert float((w.double() - want_w).norm()) <= 2e-6 * float(want_w.norm()), form
-        assert float((b.double() - want_b).norm()) <= 2e-6 * float(want_b.norm()) + 1e-12, form
+    s_max = torch.tensor([2.0 ** -7], device=dev)
+    G = (torch.randn(p, 256, generator=g) * torch.logspace(-4, 0, p)[:, None] * 2.0 ** -7 * 0.9).to(dev)      # |dz| <~ a few S
+    X = torch.relu(torch.randn(p, 256, generator=g) * 3).to(dev)
+    gf = kernels.frag_encode(G, kernels.ACT_SCALE / float(s_max))
+    xf = kernels.frag_encode(X, kernels.ACT_SCALE)
+    Gq, Xq = kernels.frag_decode(gf, p, kernels.ACT_SCALE / float(s_max)).double(), kernels.frag_decode(xf, p, kernels.ACT_SCALE).double()
+    assert float((Gq - G.double()).norm()) <= 1e-6 * float(G.double().norm()) and float((Xq - X.double()).norm()) <= 1e-6 * float(X.double().norm())
+    want_w, want_b = Gq.t() @ Xq, Gq.sum(0)
+    w, b = kernels.weight_gradient_frag(gf, xf, s_max, p, want_bias=True)
+    assert float((w.double() - want_w).norm()) <= 2e-6 * float(want_w.norm())
+    assert float((b.double() - want_b).norm()) <= 2e-6 * float(want_b.norm()) + 1e-12
+    w0 = kernels.weight_gradient_frag(gf, xf, s_max, p)                                         # without the bias sums
+    assert torch.equal(w0, w)
+    # G fragments x 64 columns of row-format X (pts_linears.0 / .5 against the encoding)
+    xr = X[:, 64:128]
+    w64, b64 = kernels.weight_gradient_frag(gf, None, s_max, p, want_bias=True, x_rows=xr, n=64, x_max=X.abs().max().reshape(1))
+    want64 = Gq.t() @ xr.double()
+    assert float((w64.double() - want64).norm()) <= 2e-6 * float(want64.norm())
+    assert float((b64.double() - want_b).norm()) <= 2e-6 * float(want_b.norm()) + 1e-12
+    # the row-format kernel (lane = point form) on the same 256 x 256 product
+    wr, br = kernels.weight_gradient(G, X, 256, 256, want_bias=True)
+    assert float((wr.double() - want_w).norm()) <= 4e-6 * float(want_w.norm())
+    assert float((br.double() - want_b).norm()) <= 4e-6 * float(want_b.norm()) + 1e-12
 
 
 @pytest.mark.gpu
@@ -586,12 +603,14 @@ def test_short_training_run_matches_torch_layers(monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant,c,endpoint", [("object", 0, False), ("ssr", 28, False), ("ssr", 5, True), ("ssr", 150, False)])
-def test_one_call_backward_equals_the_staged_one(variant, c, endpoint, monkeypatch):
-    """inerf_mlp_backward (chain + every weight-gradient product + reduction + scatter in ONE C call, the default since round 3)
-    against the round-2 path that drives the same kernels from Python (INERF_WGRAD=staged): the same numbers up to the
-    summation order of the workgroups' partial tiles; plus the entry's own contract (workspace check, empty batch)."""
+def test_one_call_backward_equals_library_products_of_its_own_buffers(variant, c, endpoint, monkeypatch):
+    """inerf_mlp_backward (chain + every weight-gradient product + reduction + scatter in ONE C call) against the same step
+    taken apart: the chain alone (inerf_mlp_backward_inputs), its fragment / row slots decoded, every product as a library GEMM
+    in fp64 (kernels.mlp_weight_gradients).  Pins the fragment formats of both producers, the LDS-DMA kernel, the mixed-format
+    products, the bias sums and the scatter into the reference's parameter layout; plus the entry's own contract (workspace
+    check, empty batch)."""
     import ctypes as C
-    from intrinsicnerf_amd import _capi, kernels, object_level as ol, ssr
+    from intrinsicnerf_amd import _capi, kernels, object_level as ol, packing, ssr
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(3)
     sd = oracle.lcg_state_dict(variant, c, seed=29, sigma_gain_log2=3, freq_decay=True)
@@ -602,23 +621,42 @@ def test_one_call_backward_equals_the_staged_one(variant, c, endpoint, monkeypat
         embed, ch = ssr.get_embedder(10, 0, scalar_factor=10); embed_d, ch_d = ssr.get_embedder(4, 0, scalar_factor=1)
         net = ssr.Semantic_NeRF(c > 0, c, D=8, W=256, input_ch=ch, output_ch=5, skips=[4], input_ch_views=ch_d, use_viewdirs=True).to(dev)
     net.load_state_dict(sd)
-    n, s = 300, 48
+    n, s = 300, 47                      # 14 100 points: a ragged last tile
     d = torch.randn(n, 3, generator=g)
     rays = torch.cat([torch.rand(n, 3, generator=g) * 2 - 1, d, torch.zeros(n, 2), d / d.norm(dim=-1, keepdim=True)], -1).to(dev)
     z = torch.sort(torch.rand(n, s, generator=g) * 3 + 0.5, -1)[0].to(dev)
-    cot = torch.randn(n, s, 11 + c + (128 if endpoint else 0), generator=g).to(dev)
+    chn = 11 + c + (128 if endpoint else 0)
+    cot = (torch.randn(n, s, chn, generator=g) * torch.logspace(-2, 1, n)[:, None, None] * 2.0 ** -9).to(dev)      # S far from 1
     desc = net.fused_desc()
     desc.xyz_div = embed.scalar_factor
-    out = {}
-    for mode in ("hip", "staged"):
-        monkeypatch.setenv("INERF_WGRAD", mode)
-        net.zero_grad()
-        raw = kernels.mlp_train(desc, net, rays, z, endpoint)
-        (raw * cot).sum().backward()
-        out[mode] = {k: p.grad.clone() for k, p in net.named_parameters()}
-    for k in out["hip"]:
-        a, b = out["hip"][k].double(), out["staged"][k].double()
-        assert a.shape == b.shape and float((a - b).norm()) <= 2e-6 * float(b.norm()) + 1e-12, k
+    net.zero_grad()
+    raw = kernels.mlp_train(desc, net, rays, z, endpoint)
+    (raw * cot).sum().backward()
+    got = {k: p.grad.clone() for k, p in net.named_parameters()}
+    # the same step taken apart
+    d16 = _capi.NetDesc(desc.variant, desc.n_classes, desc.l_xyz, desc.l_dir, desc.xyz_div, _capi.PREC_F16X3)
+    named = dict(net.named_parameters())
+    names = tuple(name for name, _ in packing.tensor_table(d16))
+    pf, pb = packing.device_packer(d16, False, dev)(named), packing.device_packer(d16, True, dev)(named)
+    with torch.no_grad():
+        raw2, save = kernels.encode_mlp_train(d16, pf, rays, z, endpoint)
+        d2 = cot.reshape(n * s, chn).contiguous()
+        dz, heads = kernels.mlp_backward_inputs(d16, pb, raw2.view(n * s, chn), d2, save, endpoint, want_heads=True)
+        s_max = float(dz[dz.shape[0] - kernels.SAVE_SCALARS])
+        assert s_max > 0 and s_max == 2.0 ** round(np.log2(s_max)) and s_max < 1.0, s_max
+        X = kernels.save_slot_views(d16, save, n * s)
+        G = kernels.save_slot_views(d16, dz, n * s, gradient=True)
+        want = kernels.mlp_weight_gradients(d16, names, save, dz, d2, n * s, endpoint, heads)
+        # fp64 products of the decoded slots for the square layers (the library's fp32 GEMMs are 1e-6 themselves)
+        for i in range(1, 8):
+            w64 = (G[kernels.SAVE_H0 + i].double().t() @ X[kernels.SAVE_H0 + i - 1].double())
+            name = f"pts_linears.{i}.weight"
+            ref = w64 if i != 5 else torch.cat([want[name][:, :63].double(), w64], 1)
+            assert float((got[name].double() - ref).norm()) <= 3e-6 * float(ref.norm()), name
+    assert torch.equal(raw.detach(), raw2)
+    for k in got:
+        a, b = got[k].double(), want[k].double()
+        assert a.shape == b.shape and float((a - b).norm()) <= 2e-5 * float(b.norm()) + 1e-12, (k, float((a - b).norm()), float(b.norm()))
     lib = _capi.lib()
     d16 = _capi.NetDesc(desc.variant, desc.n_classes, desc.l_xyz, desc.l_dir, desc.xyz_div, _capi.PREC_F16X3)
     n_params = lib.inerf_param_floats(d16)
