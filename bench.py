@@ -262,6 +262,11 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:       # device_id binds the communicator to this rank's GPU up front (eager RCCL init; no device guessing in barrier())
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    # Host-side rendezvous for the END of the run: rank 0 spends minutes in the CPU oracle (parity, cpu_baseline) while the others
+    # have nothing left to do.  Waiting for it in an RCCL barrier would spin a GPU kernel per idle rank (and trip the collective
+    # watchdog); on a gloo group the idle ranks sleep in a socket read.
+    import datetime
+    side = dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=45)) if world > 1 else None
 
     import __graft_entry__
     __graft_entry__.build()
@@ -380,7 +385,22 @@ def main():
     for _ in range(20):
         st.item()
     sync_ms = (time.perf_counter() - t1) / 20 * 1e3
+    per_rank = None
+    if world > 1:       # what every rank's band cost (a sub-6x result must be diagnosable from the JSON line alone)
+        mine = torch.tensor([wall_ms, gpu_ms, band_wall, band_gpu, gather_ms], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        every = torch.stack(every).cpu()
+        per_rank = {"rays_per_rank": n_local,
+                    "render_wall_ms": every[:, 0].tolist(), "render_gpu_ms": every[:, 1].tolist(),
+                    "render_gpu_ms_min_max": [float(every[:, 1].min()), float(every[:, 1].max())],
+                    "render_non_kernel_frac_max": float(((every[:, 0] - every[:, 1]) / every[:, 0]).max()),
+                    "gather_ms": every[:, 4].tolist(),
+                    "step_minus_slowest_render_ms": ms_per_step - float(every[:, 0].max()),
+                    "note": "one entry per rank: this rank's band of the frame through the front-end (wall and HIP events), and its "
+                            "all-gather alone; step - slowest render = what the collective and the rendezvous add per frame"}
     frame_costs = {
+        "per_rank": per_rank,
         "render_wall_ms": wall_ms, "render_gpu_ms": gpu_ms, "non_kernel_ms": wall_ms - gpu_ms,
         "non_kernel_frac": (wall_ms - gpu_ms) / wall_ms,
         "band_80000_rays": {"wall_ms": band_wall, "gpu_ms": band_gpu, "non_kernel_frac": (band_wall - band_gpu) / band_wall},
@@ -435,23 +455,33 @@ def main():
     prec = _capi.default_precision()
     f16 = prec == _capi.PREC_F16X3
     roofline, (z_coarse, coarse_launch_ms) = kernel_roofline(prec, max(1, args.steps))
-    roofline_f32 = roofline if prec == _capi.PREC_F32 else kernel_roofline(_capi.PREC_F32, 1)[0]
+    roofline_f32 = roofline if prec == _capi.PREC_F32 else (kernel_roofline(_capi.PREC_F32, max(1, args.steps))[0] if not args.no_extras else None)
 
     extras = rank == 0 and world == 1 and not args.no_extras
-    # the same frame through the product front-end with the exact-fp32 MFMA kernel, for reference (one timed step)
-    exact = None
+    # the same frames through the product front-end with the exact-fp32 MFMA kernel: the figure under the strictest reading of
+    # "fp32" (no split operands anywhere), measured like `value` - one warm-up, then --steps frames between two fences
+    exact = strict = None
     if prec != _capi.PREC_F32 and not args.no_extras:
         with _capi.forced_precision(_capi.PREC_F32):
             step(); fence()
             t1 = time.perf_counter()
-            step(); fence()
+            for _ in range(args.steps):
+                step()
+            fence()
             dt32 = time.perf_counter() - t1
         if world > 1:
             t = torch.tensor([dt32], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt32 = float(t.item())
-        exact = {"value": n_total / dt32, "unit": "rays/s", "ms_per_step": dt32 * 1e3, "steps": 1,
-                 "note": "whole path with INERF_PRECISION=f32 (v_mfma_f32_32x32x2_f32 everywhere)"}
+        exact = {"value": n_total * args.steps / dt32, "unit": "rays/s", "ms_per_step": dt32 / args.steps * 1e3, "steps": args.steps,
+                 "note": "whole path with INERF_PRECISION=f32 (v_mfma_f32_32x32x2_f32 everywhere), timed like `value`"}
+        strict = {"value": exact["value"], "unit": "rays/s", "frac": roofline_f32["frac"], "peak": roofline_f32["peak"],
+                  "achieved": roofline_f32["achieved"], "steps": args.steps, "launches_timed": roofline_f32["launches_timed"],
+                  "note": "exact-fp32 arithmetic end to end: rays/s of the whole path and its MLP kernel against the 157.3 TFLOP/s "
+                          "fp32-MFMA peak (the same numbers as exact_f32_path / roofline_f32_kernel)"}
+    elif prec == _capi.PREC_F32:
+        strict = {"value": rays_per_s, "unit": "rays/s", "frac": roofline["frac"], "peak": roofline["peak"], "achieved": roofline["achieved"],
+                  "steps": args.steps, "launches_timed": roofline["launches_timed"], "note": "the run itself is exact fp32 (INERF_PRECISION=f32)"}
 
     # what the f16x3 range guard costs when it trips (chunk-granular).  The frame is rendered in the reference's
     # default chunks of 32768 rays (run_nerf.py:559) with a fine network that leaves the split's activation range only in a
@@ -657,6 +687,8 @@ def main():
     # ---- CPU oracle on the sampled rays of the timed frame: cpu_baseline (its fp32 run, timed) + parity (fp32 and fp64) ----
     cpu = parity = None
     problems = []
+    if rank == 0 and os.environ.get("INERF_BENCH_INJECT_FAILURE") == "1":        # (tests the N > 1 failure path: every rank must exit non-zero, promptly)
+        problems.append("injected failure (INERF_BENCH_INJECT_FAILURE=1)")
     if rank == 0 and not args.no_cpu_baseline:
         from oracle import stagewise
         o32, quick = cpu_oracle_run(rays_s, sd_c, sd_f)                 # the parity reference; its timing is the "quick" CPU figure
@@ -696,8 +728,14 @@ def main():
             e2e[fk] = stagewise.psnr_delta_db(hip, o32[ok].numpy(), o64[ok].numpy(), detail=True)
             staged[fk] = stagewise.psnr_delta_db(got[ok].reshape(o32[ok].shape), o32[ok].numpy(), o64[ok].numpy())
             own[fk] = stagewise.psnr_delta_db(o32[ok].numpy(), o64[ok].numpy(), o64[ok].numpy())
-        parity["psnr_delta_db"] = max(abs(v["delta_db"]) for v in e2e.values())
-        parity["psnr_delta_db_systematic"] = max(abs(v["systematic_db"]) for v in e2e.values())
+        # PSNR in the reference is computed on rgb (run_nerf_helpers.py:11-12, run_nerf.py:976-985): that map first, with the
+        # sampling sigma of this 4 077-ray estimate next to it; the other maps per_map
+        parity["psnr_delta_db_rgb"] = e2e["rgb_map"]["delta_db"]
+        parity["psnr_delta_db_rgb_sampling_sigma"] = e2e["rgb_map"].get("sampling_sigma_db")
+        parity["psnr_delta_db_rgb_systematic"] = e2e["rgb_map"]["systematic_db"]
+        parity["psnr_delta_db_rgb_fine_pass_on_reference_depths"] = staged["rgb_map"]
+        parity["psnr_delta_db_max_over_maps"] = max(abs(v["delta_db"]) for v in e2e.values())
+        parity["psnr_delta_db_systematic_max_over_maps"] = max(abs(v["systematic_db"]) for v in e2e.values())
         parity["psnr_delta_db_per_map"] = e2e
         parity["psnr_delta_db_fine_pass_on_reference_depths"] = staged
         parity["psnr_oracle_fp32_vs_fp64_db"] = own
@@ -722,15 +760,22 @@ def main():
                                    "(seeds 0/1) with the density head calibrated so that acc spans (0, 1]",
                        "rays_per_step": n_total, "parallelism": f"ray-sharded x{world}",
                        "gather": "all_gather of 12 floats/ray" if world > 1 else "none"},
-            "roofline": roofline, "roofline_f32_kernel": roofline_f32, "exact_f32_path": exact, "parity": parity,
+            "roofline": roofline, "strict_fp32": strict, "roofline_f32_kernel": roofline_f32, "exact_f32_path": exact, "parity": parity,
             "configs": configs, "frame_costs": frame_costs, "f16_range_fallback": fallback, "train_step": train, "cpu_baseline": cpu}))
         sys.stdout.flush()
+    n_bad = len(problems)
     if world > 1:
-        if not problems:
-            dist.barrier()            # the other ranks wait here while rank 0 runs the CPU oracle: nobody tears the job down under it
+        # every rank learns rank 0's verdict and all leave together, with the same exit code (round 3: a parity failure made rank 0
+        # skip a barrier the others were in - a collective-watchdog timeout instead of the message below).  Host-side group: the
+        # idle ranks sleep here while rank 0 is in the CPU oracle.
+        verdict = torch.tensor([n_bad], dtype=torch.int64)
+        dist.broadcast(verdict, 0, group=side)
+        n_bad = int(verdict.item())
         dist.destroy_process_group()
     if problems:
         raise SystemExit("bench.py: the timed frame does NOT match the oracle:\n" + "\n".join(problems))
+    if n_bad:
+        raise SystemExit(f"bench.py: rank 0 reports {n_bad} parity violation(s) of the timed frame")
 
 
 if __name__ == "__main__":

@@ -32,7 +32,7 @@ struct BwdParams {
     const float* save;      // activations kept by the training forward
     float* dz;              // out: pre-activation gradients, same slot layout
     float* dz_max;          // out: max |dz| over every ROW-format slot (caller zeroes it): the row-format weight-gradient kernel's operand scale
-    const float* s_max;     // in: S, the largest per-point normaliser of the batch (k_head_scale): fragments hold kActScale * dz / S
+    const float* s_max;     // in: S, the largest per-point normaliser of the batch (k_head_scale): fragments hold kGradFragScale * dz / S
     float* head_partial;    // out, optional: [grid][kHeadFloats] weight / bias gradients of the 1-4-row heads, per workgroup
     int32_t* status;
     int64_t off[SAVE_SLOTS];
@@ -68,21 +68,37 @@ struct NoAlpha {};
 struct DzDst {
     __amdgpu_buffer_rsrc_t rsrc;      // the layer's dZ slot: n_tiles * kFragTileBytes (whole tiles: padding points carry zeros)
     unsigned voff;                    // bytes: tile * kFragTileBytes + (first channel block of this wave) * 2 * kFragBytes + lane * 16
-    const float* frow;                // LDS: per-point factor s_p / S of point 4 * (lane >> 5), row stride kRowH / 2 floats
+    const float* frow;                // LDS: per-point factor (kGradFragScale / kActScale) s_p / S of point 4 * (lane >> 5), row stride kRowH / 2 floats
 };
+// B operand of bwd_store's transposing MFMAs (see DzDst): lane (j = lane & 31, kg = lane >> 5) holds Sel[8 kg + m][j], m = 0..7,
+// per k-block - in the k order of the ACCUMULATOR registers (planes_to_frag's operands come from LDS in channel order).  Rebuilt
+// by every epilogue from a laundered lane index: as a loop invariant it would occupy eight registers for the whole kernel,
+// which sits at its 256.
+__device__ __forceinline__ Selector accumulator_selector(int lane) {
+    asm volatile("" : "+v"(lane));
+    Selector sel;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+            sel.k[kb][m] = (16 * kb + 8 * (m >> 2) + 4 * (lane >> 5) + (m & 3)) == (lane & 31) ? (_Float16)1.0f : (_Float16)0.0f;
+    return sel;
+}
+
 template <int RB, bool BITS = false, typename AlphaAcc = NoAlpha>
 __device__ __forceinline__ void bwd_store(const f32x16 (&am)[RB][2], float inv,
                                           const f32x4 (*acts)[2][4] /* [RB][2][4] saved activations of this lane's values (requested
                                                                        before the GEMM; zero for points beyond the end), or nullptr */,
                                           const f32x4 (*extra)[4] /* [RB][4] or nullptr */, float ex0, float ex1,
                                           _Float16* dl /* plane_hi + (lane&31)*kRowH + 4h + dcol + chan0 */, f16x2& amax2,
-                                          const DzDst& dst, const Selector& sel, float s0, float s1,
+                                          const DzDst& dst, int lane, float s0, float s1,
                                           bool valid0, bool valid1, float& gmax,
                                           u32x2 mask_bits /* BITS: this lane's words of the layer (layout.h) */,
                                           AlphaAcc& alpha_acc /* f32x4[RB][4]: += (true d sigma of the point) * saved activation; by
                                                                  reference and selected at compile time - through a pointer-or-null
                                                                  argument the accumulators lived in scratch memory */) {
     constexpr bool kAlpha = !std::is_same<AlphaAcc, NoAlpha>::value;
+    const Selector sel = accumulator_selector(lane);
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
 #pragma unroll
@@ -141,12 +157,20 @@ __device__ __forceinline__ void bwd_store(const f32x16 (&am)[RB][2], float inv,
                     const int r = 8 * q + 2 * i;                             // point (r & 3) + 8 (r >> 2) (+ 4 (lane >> 5): in frow)
                     f16x2 h2, l2;
                     split_pair(tr[r] * fr[((r & 3) + 8 * (r >> 2)) * (kRowH / 2)], tr[r + 1] * fr[(((r + 1) & 3) + 8 * ((r + 1) >> 2)) * (kRowH / 2)], h2, l2);
+                    // range check of the fragment values: the conversion saturates at 65504, above the kF16Safe the kernel's
+                    // running maximum is compared with at its end
+                    amax2 = __builtin_elementwise_max(amax2, __builtin_bit_cast(f16x2, __builtin_bit_cast(unsigned, h2) & 0x7FFF7FFFu));
                     oh[i] = __builtin_bit_cast(unsigned, h2);
                     ol[i] = __builtin_bit_cast(unsigned, l2);
                 }
                 // (whole offset in the VGPR operand: a 16-byte buffer store with a register SGPR offset gets no hazard wait state, tests/test_isa_audit_cpu.py)
                 __builtin_amdgcn_raw_buffer_store_b128(oh, dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, rb, 0)), 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(ol, dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, rb, 1)), 0, 0);
+                {   // pinned: left free, the compiler keeps the partial maxima alive across the stores (spilled) and folds them in later
+                    unsigned a = __builtin_bit_cast(unsigned, amax2);
+                    asm volatile("" : "+v"(a));
+                    amax2 = __builtin_bit_cast(f16x2, a);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -254,7 +278,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
     const _Float16* const xr = xw + 8 * (lane >> 5);              // wide GEMM operand reads (+ column)
     _Float16* const xd = xw + 4 * (lane >> 5) + WCH * wave;       // wide stores: this wave's channels (+ column)
     auto ptf = [&](int pt) { return reinterpret_cast<float*>(ldsb + pt * kRowH); };   // per-point scratch in the enc columns:
-                                                                                      // [0..7] head gradients / s, [8] s, [9] 1/s, [10] s / S
+                                                                                      // [0..7] head gradients / s, [8] s, [9] 1/s, [10] (kGradFragScale / kActScale) s / S
     WeightBuf wb;
     wb.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wts), 0, L.total_floats * 4, 0x00020000);
     wb.voff = lane * 16;
@@ -265,13 +289,6 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
 
     WidePreH<RB> preA, preB;
     prefetch_w<RB, KS>(preA, wb, frag(L.views_t, 8));
-    Selector sel;                          // see DzDst: lane (j = lane & 31, kg = lane >> 5) holds Sel[8 kg + m][j], m = 0..7, per k-block
-                                           // (k order of the ACCUMULATOR registers; planes_to_frag's operands come from LDS in channel order)
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int m = 0; m < 8; ++m)
-            sel.k[kb][m] = (16 * kb + 8 * (m >> 2) + 4 * (lane >> 5) + (m & 3)) == (lane & 31) ? (_Float16)1.0f : (_Float16)0.0f;
     // Rows of the activation / gradient slots are reached through buffer descriptors (wave-uniform, in SGPRs) + ONE 32-bit
     // per-thread offset per stage + a wave-uniform tile offset: with 64-bit per-thread pointers every stage kept four address
     // registers alive across the tile loop (spilled in the eight-wave form).  The range check also replaces the `valid` tests:
@@ -352,7 +369,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
             for (int k = 0; k < 8; ++k) f[k] = dp[k] * is;
             f[8] = s;
             f[9] = is;
-            f[10] = s * inv_smax;          // (a point without gradient has s = 1 and only zeros to scale)
+            f[10] = s * inv_smax * (kGradFragScale / kActScale);          // (a point without gradient has s = 1 and only zeros to scale)
         }
         STAMP();
         __syncthreads();
@@ -406,6 +423,8 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
         __syncthreads();
         STAMP();
 
+        int lane_t = lane;
+        asm volatile("" : "+v"(lane_t));
         const int pt0 = tile * kPts + (lane & 31);
         const bool valid0 = pt0 < p.n_points, valid1 = pt0 + 32 < p.n_points;
         const float s0 = ptf(lane & 31)[8], s1 = ptf((lane & 31) + 32)[8];
@@ -432,7 +451,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
             prefetch_w<RB, KS>(preA, wb, frag(L.feat_t, 16));
             prefetch_w<RB, KS>(preB, wb, frag(L.as1_t, 16));
             NoAlpha none;
-            bwd_store<RB>(am, inv, nullptr, nullptr, 0.0f, 0.0f, xd + kColB, amax2, dz_dst(SAVE_FEAT), sel, s0, s1, valid0, valid1, gmax,
+            bwd_store<RB>(am, inv, nullptr, nullptr, 0.0f, 0.0f, xd + kColB, amax2, dz_dst(SAVE_FEAT), lane, s0, s1, valid0, valid1, gmax,
                          u32x2{0u, 0u}, none);
         }
         STAMP();
@@ -477,8 +496,8 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
             FragDst d;
             d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dz + p.off[SAVE_AS1H], 0, (int)((unsigned)p.n_tiles * (unsigned)kFragTileBytes), 0x00020000);
             d.voff = (unsigned)tile * (unsigned)kFragTileBytes + (unsigned)(WCH / 32 * wave) * (2u * kFragBytes) + (unsigned)lane * 16u;
-            planes_to_frag<RB, kRowH, kPlaneH, true>(xr + kColA + WCH * wave, plane_selector(lane), d,
-                                                     reinterpret_cast<const float*>(ldsb) + 10 + 4 * (lane >> 5) * (kRowH / 2), kRowH / 2);
+            planes_to_frag<RB, kRowH, kPlaneH, true>(xr + kColA + WCH * wave, plane_selector(lane_t), d,
+                                                     reinterpret_cast<const float*>(ldsb) + 10 + 4 * (lane >> 5) * (kRowH / 2), kRowH / 2, &amax2);
         }
 
         // ---------------- d h7 = W_feat^T d feature + W_as1^T dZ_as1 (+ W_sem1^T dZ_semh) + w_alpha d sigma ----------------
@@ -544,7 +563,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
             STAMP();
             __syncthreads();                 // every wave is done reading A and B
             STAMP();
-            bwd_store<RB>(am, inv, h7v, aw, e0, e1, xd + kColA, amax2, dz_dst(SAVE_H7), sel, s0, s1, valid0, valid1, gmax,
+            bwd_store<RB>(am, inv, h7v, aw, e0, e1, xd + kColA, amax2, dz_dst(SAVE_H7), lane, s0, s1, valid0, valid1, gmax,
                          u32x2{0u, 0u}, halpha);       // (accumulated whether or not `heads`)
         }
         STAMP();
@@ -565,7 +584,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
             if (l > 1) prefetch_w<RB, KS>(preA, wb, frag(L.trunk_t[l - 1], 16));
             else       prefetch_w<RB, KS>(preA, wb, frag(L.views_t, 8));
             NoAlpha none;
-            bwd_store<RB, true>(am, inv, nullptr, nullptr, 0.0f, 0.0f, xd + dst, amax2, dz_dst(SAVE_H0 + l - 1), sel, s0, s1, valid0, valid1,
+            bwd_store<RB, true>(am, inv, nullptr, nullptr, 0.0f, 0.0f, xd + dst, amax2, dz_dst(SAVE_H0 + l - 1), lane, s0, s1, valid0, valid1,
                                gmax, mbits, none);
             STAMP();
             __syncthreads();
@@ -626,6 +645,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
         }
     }
     const float amax_all = fmaxf((float)amax2[0], (float)amax2[1]);
+    // (amax2 covers the fragment values too: one beyond f16's range was saturated, not stored - the same verdict as for an operand of the chain)
     if (p.status && __any(!(amax_all <= kF16Safe)) && lane == 0) atomicOr(p.status, INERF_STATUS_F16_RANGE);
     if (p.dz_max) {                       // non-negative floats order like their bit patterns
 #pragma unroll

@@ -261,7 +261,8 @@ __device__ __forceinline__ unsigned frag_off(int kb, int cb, int plane) { return
 template <int NB, int ROW, int PLANE, bool SCALED = false>
 __device__ __forceinline__ void planes_to_frag(const _Float16* xa /* plane_hi + (lane & 31) * ROW + 8 * (lane >> 5) + first column */,
                                                const Selector& sel, const FragDst& dst,
-                                               const float* fscale = nullptr /* LDS: factor of point 4 * (lane >> 5) */, int fstride = 0) {
+                                               const float* fscale = nullptr /* LDS: factor of point 4 * (lane >> 5) */, int fstride = 0,
+                                               f16x2* amax2 = nullptr /* SCALED: running packed max of |hi| (range check at the kernel's end) */) {
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb)
 #pragma unroll
@@ -301,6 +302,7 @@ __device__ __forceinline__ void planes_to_frag(const _Float16* xa /* plane_hi + 
                         const int r = 8 * q + 2 * i;
                         f16x2 h2, l2;
                         split_pair(t[r] * fs[((r & 3) + 8 * (r >> 2)) * fstride], t[r + 1] * fs[(((r + 1) & 3) + 8 * ((r + 1) >> 2)) * fstride], h2, l2);
+                        *amax2 = __builtin_elementwise_max(*amax2, __builtin_bit_cast(f16x2, __builtin_bit_cast(unsigned, h2) & 0x7FFF7FFFu));
                         oh[i] = __builtin_bit_cast(unsigned, h2);
                         ol[i] = __builtin_bit_cast(unsigned, l2);
                     }

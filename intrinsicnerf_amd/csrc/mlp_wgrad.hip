@@ -29,7 +29,7 @@ struct WgradParams {
     const float* G;          // [P, ldg] (pointer to the first used column)
     const float* X;          // [P, ldx]
     const float* ranges;     // device: {gmax, xmax}: upper bounds of |G| and |X| (GFRAG: [1] only)
-    const float* s_max;      // GFRAG: G is a fragment slot holding kActScale * dz / S; device: S (layout.h)
+    const float* s_max;      // GFRAG: G is a fragment slot holding kGradFragScale * dz / S; device: S (layout.h)
     float* partial;          // workgroup g writes its M x N tile at partial + g * partial_stride
     float* bias_partial;     // optional: workgroup g writes its column sums of G at bias_partial + g * partial_stride
     int64_t partial_stride;  // floats
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
     auto pow2_for = [](float m) { int e; if (!(m > 0.0f) || !(m < 3.0e38f)) return 1.0f; frexpf(m, &e); return ldexpf(1.0f, 14 - e); };
     auto uniform = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
     const float sx = uniform(pow2_for(p.ranges[1]));       // wave-uniform: scalar registers
-    const float sg = GFRAG ? uniform(kActScale / fmaxf(p.s_max[0], kMinGradScale)) : uniform(pow2_for(p.ranges[0]));
+    const float sg = GFRAG ? uniform(kGradFragScale / fmaxf(p.s_max[0], kMinGradScale)) : uniform(pow2_for(p.ranges[0]));
 
     // identity operands of the transposer: B[k][n] = (n == k) resp. (n == k + 16); lane n holds k = 8 * lh + i
     f16x8 id0, id1;
@@ -305,7 +305,7 @@ constexpr int kFragStageBytes = 2 * kFragKbBytes;               // G | X of one 
 static_assert(kFragStages >= 3 && kFragStages <= 5, "ring depth");
 
 struct WgradFragParams {
-    const void* G;           // fragment slot of dZ: kActScale * dz / S
+    const void* G;           // fragment slot of dZ: kGradFragScale * dz / S
     const void* X;           // fragment slot of activations: kActScale * h
     const float* s_max;      // device: S
     float* partial;          // workgroup g writes its 256 x 256 tile at partial + g * partial_stride
@@ -404,10 +404,10 @@ __global__ __launch_bounds__(512, 1) void k_mlp_wgrad_frag(const WgradFragParams
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
             const float both = bias_sum[rb] + __shfl_xor(bias_sum[rb], 32);
-            if (lh == 0) p.bias_partial[(size_t)blockIdx.x * p.partial_stride + 32 * (rb0 + rb) + lp] = both * (s * (1.0f / kActScale));
+            if (lh == 0) p.bias_partial[(size_t)blockIdx.x * p.partial_stride + 32 * (rb0 + rb) + lp] = both * (s * (1.0f / kGradFragScale));
         }
     }
-    const float back = s * (1.0f / (kActScale * kActScale));
+    const float back = s * (1.0f / (kGradFragScale * kActScale));
     float* out = p.partial + (size_t)blockIdx.x * p.partial_stride;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)

@@ -466,6 +466,7 @@ def render_rays_fused(desc, packed_coarse, packed_fine, rays, n_samples, n_impor
 # ---------------------------------------------------------------------------------------------------------------------
 (SAVE_ENC, SAVE_DIR, SAVE_H0, SAVE_AS1H, SAVE_FEAT, SAVE_VH, SAVE_SEMH, SAVE_DPRE, SAVE_H7R, SAVE_SLOTS) = (0, 1, 2, 10, 11, 12, 13, 14, 15, 16)
 ACT_SCALE = 8.0                 # activations travel as f16 hi/lo of 8 * value (csrc/layout.h kActScale)
+GRAD_FRAG_SCALE = 1024.0        # fragment slots of a gradient buffer hold 1024 * dz / S (csrc/layout.h kGradFragScale)
 SAVE_SCALARS = 64               # floats behind the slots and the mask area; [0] of a gradient buffer: S (include/inerf.h)
 
 
@@ -514,7 +515,7 @@ def save_slot_views(desc, buf, n_points, gradient=False):
             if gradient:
                 if s is None:
                     s = buf[buf.shape[0] - SAVE_SCALARS].clamp_min(2.0 ** -100)
-                views.append(frag_decode(frag, n_points, 1.0) * (s / ACT_SCALE))
+                views.append(frag_decode(frag, n_points, 1.0) * (s / GRAD_FRAG_SCALE))
             else:
                 views.append(frag_decode(frag, n_points, ACT_SCALE))
         else:
@@ -690,7 +691,7 @@ def weight_gradient(g, x, m, n, ranges=None, want_bias=False):
 
 def weight_gradient_frag(g_frag, x_frag, s_max, n_points, want_bias=False, x_rows=None, n=256, x_max=None):
     """G^T X with G a FRAGMENT slot of a gradient buffer (256 channels, ``s_max``: float32[1] device tensor S - the slot holds
-    8 * dz / S) through the HIP split-K kernels: against ``x_frag``, a FRAGMENT slot of activations (LDS-DMA kernel, 256 x 256),
+    GRAD_FRAG_SCALE * dz / S) through the HIP split-K kernels: against ``x_frag``, a FRAGMENT slot of activations (LDS-DMA kernel, 256 x 256),
     or, with ``x_rows`` ([n_points, >= n] fp32 rows, ``x_max`` = float32[1] bound of |x|), against row-format activations."""
     lib = _capi.lib()
     grid = lib.inerf_wgrad_grid(n_points)

@@ -439,11 +439,11 @@ def test_weight_gradient_from_fragment_slots(p):
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(100 + p)
     s_max = torch.tensor([2.0 ** -7], device=dev)
-    G = (torch.randn(p, 256, generator=g) * torch.logspace(-4, 0, p)[:, None] * 2.0 ** -7 * 0.9).to(dev)      # |dz| <~ a few S
+    G = (torch.randn(p, 256, generator=g) * torch.logspace(0, -4, p)[:, None] * 2.0 ** -7 * 0.9).to(dev)      # |dz| <~ a few S
     X = torch.relu(torch.randn(p, 256, generator=g) * 3).to(dev)
-    gf = kernels.frag_encode(G, kernels.ACT_SCALE / float(s_max))
+    gf = kernels.frag_encode(G, kernels.GRAD_FRAG_SCALE / float(s_max))
     xf = kernels.frag_encode(X, kernels.ACT_SCALE)
-    Gq, Xq = kernels.frag_decode(gf, p, kernels.ACT_SCALE / float(s_max)).double(), kernels.frag_decode(xf, p, kernels.ACT_SCALE).double()
+    Gq, Xq = kernels.frag_decode(gf, p, kernels.GRAD_FRAG_SCALE / float(s_max)).double(), kernels.frag_decode(xf, p, kernels.ACT_SCALE).double()
     assert float((Gq - G.double()).norm()) <= 1e-6 * float(G.double().norm()) and float((Xq - X.double()).norm()) <= 1e-6 * float(X.double().norm())
     want_w, want_b = Gq.t() @ Xq, Gq.sum(0)
     w, b = kernels.weight_gradient_frag(gf, xf, s_max, p, want_bias=True)

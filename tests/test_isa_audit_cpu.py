@@ -103,6 +103,6 @@ def test_training_kernels_stay_out_of_scratch(tmp_path):
     chain = bytes_of("k_mlp_dgrad")
     assert len(chain) == 2, sorted(chain)
     assert chain["_ZN5inerf11k_mlp_dgradILb0ELi8EEEvNS_9BwdParamsE"] == 0
-    assert chain["_ZN5inerf11k_mlp_dgradILb1ELi8EEEvNS_9BwdParamsE"] <= 64          # (round 3: 112)
+    assert chain["_ZN5inerf11k_mlp_dgradILb1ELi8EEEvNS_9BwdParamsE"] <= 80          # (round 3: 112; the 1-4-row heads' accumulators of one VALU stage)
     wgrad = bytes_of("k_mlp_wgrad")
     assert len(wgrad) >= 9 and all(v == 0 for v in wgrad.values()), wgrad
