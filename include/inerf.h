@@ -155,9 +155,9 @@ int inerf_encode_mlp_ws(const inerf_net_desc* net, const float* packed_weights, 
  *               byte offset = (((tile * 4 + kb) * 8 + cb) * 2 + (0: hi, 1: lo)) * 1024 + lane * 16 + 2 * i      (i = 0..7)
  *               channel = 32 cb + (lane & 31),  point = 64 tile + 32 (kb >> 1) + (i & 3) + 8 ((i >> 2) + 2 (kb & 1)) + 4 (lane >> 5)
  *             (lane = channel, 8 k-values = 8 points: one 16-byte operand slot of v_mfma_f32_32x32x16_f16; the point order
- *             inside a block is the accumulator's register order).  save: 2..9 with scale 8; dz: 2..11 with scale 1024 / S, S =
- *             the float at element inerf_mlp_save_floats() - 64 of dz (the largest per-point normaliser of the batch, a
- *             power of two, written by inerf_mlp_backward_inputs; |dz| beyond 64 S raises INERF_STATUS_F16_RANGE).  Padding points of the last tile hold a copy of the last
+ *             inside a block is the accumulator's register order).  save: 2..9 with scale 8; dz: 2..11 with scale 256 / S, S =
+ *             the float at element inerf_mlp_save_floats() - 64 of dz (the power of two above the batch's largest |d_raw|
+ *             entry, written by inerf_mlp_backward_inputs; |dz| beyond ~230 S raises INERF_STATUS_F16_RANGE).  Padding points of the last tile hold a copy of the last
  *             point (save) / zeros (dz).  Same 4 bytes per element as fp32; the producers write whole fragments and
  *             inerf_mlp_weight_gradient_frag moves them HBM -> LDS by DMA, without a register or a conversion in between.
  * Behind the slots `save` carries the ReLU masks of h0..h6 as bits (14 336 bytes per 64-point tile, written by

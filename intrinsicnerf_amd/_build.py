@@ -52,11 +52,21 @@ def built_digest(lib_path=None):
     return data[i + len(DIGEST_MARK): i + len(DIGEST_MARK) + 64].decode("ascii", "replace") if i >= 0 else ""
 
 
+def sources_present():
+    """False in a deployment that ships the built library without ``csrc/`` (or without some header): nothing to compare with."""
+    return all(os.path.exists(p) for p in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS)
+
+
 def _stale(lib_path=None):
     """True when ``lib_path`` (default: the in-tree library) is missing or was built from other sources / flags than the
-    tree holds now.  Content-based: kernel edits, flag edits in this file and reordered mtimes are all caught."""
+    tree holds now.  Content-based: kernel edits, flag edits in this file and reordered mtimes are all caught.  A tree without
+    its sources cannot judge: an existing library is then taken as it is (the binding still checks its ABI number)."""
     lib_path = lib_path or LIB_PATH
-    return not os.path.exists(lib_path) or built_digest(lib_path) != source_digest()
+    if not os.path.exists(lib_path):
+        return True
+    if not sources_present():
+        return False
+    return built_digest(lib_path) != source_digest()
 
 
 def have_hipcc():

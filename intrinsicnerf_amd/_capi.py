@@ -113,6 +113,11 @@ def lib():
             else:
                 raise RuntimeError(f"{LIB_PATH} was built from different sources (digest {_build.built_digest()[:12]}, tree "
                                    f"{_build.source_digest()[:12]}) and hipcc is not available to rebuild it")
+        if path != LIB_PATH and _build.sources_present() and _build.built_digest(path) != _build.source_digest():
+            # an override library is loaded as asked for (the ABI number below is its only guard) - but never silently
+            import warnings
+            warnings.warn(f"INERF_LIB_OVERRIDE={path}: built from other sources than this tree (digest "
+                          f"{_build.built_digest(path)[:12] or 'none'}, tree {_build.source_digest()[:12]})")
         handle = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)          # AttributeError here = header/library mismatch

@@ -361,25 +361,14 @@ int device_cus() {
     return n;
 }
 
-// Tile shape: 64-point tiles, one workgroup per CU (default; measured 129.2 TFLOP/s) or 32-point
-// tiles, two workgroups per CU (124.8 TFLOP/s: the second workgroup hides barriers/epilogues but
-// doubles the weight stream and halves the skinny-GEMM parallelism).  INERF_TILE_POINTS=64|32
-// selects for A/B measurements.
-int stagger_units(int n_tiles, int grid) {
-    if (n_tiles < 4 * grid) return 0;
-    const char* e = getenv("INERF_TRAIN_STAGGER");
-    const int u = e ? atoi(e) : 4;
-    return u < 0 ? 0 : (u > 64 ? 64 : u);
-}
+// Staggered start of the chain's workgroups (mlp_common.h stagger_start): four units of 2 048 cycles per step of the
+// eight-step pattern, none for launches with fewer than four tiles per workgroup.
+int stagger_units(int n_tiles, int grid) { return n_tiles < 4 * grid ? 0 : 4; }
 
-int tile_blocks() {
-    static int pb = 0;
-    if (pb == 0) {
-        const char* e = getenv("INERF_TILE_POINTS");
-        pb = (e && atoi(e) == 32) ? 1 : 2;
-    }
-    return pb;
-}
+// Tile shape of the exact-fp32 kernel: 64-point tiles, one workgroup per CU (129.2 TFLOP/s).  (A 32-point-tile form with two
+// workgroups per CU measured 124.8 - the second workgroup hides barriers and epilogues but doubles the weight stream and halves
+// the skinny-GEMM parallelism; its template instance is no longer selectable at run time.)
+int tile_blocks() { return 2; }
 
 int record(hipError_t e) {
     if (e == hipSuccess) return INERF_OK;

@@ -31,7 +31,7 @@ struct MlpParams {
 
 // Staggered start of the input-gradient chain.  Every workgroup walks the same stages at the same pace, so the whole chip asks HBM for the same kind of rows at the same moment - 64 KB per CU x 256 CUs is
 // 6 000 cycles of HBM whatever the kernel does meanwhile.  A start offset of ((b ^ (b >> 3)) & 7) x units x 2 048 cycles spreads
-// those bursts over an eighth of a tile each: chain 2.20 -> 2.04 ms on 393 216 points.  INERF_TRAIN_STAGGER=<units> (0: off).
+// those bursts over an eighth of a tile each: chain 2.20 -> 2.04 ms on 393 216 points.
 // (No effect on the training forward, whose two workgroups per CU drift apart by themselves: 2.13 vs 2.12 ms.)
 #ifdef __HIPCC__
 __device__ __forceinline__ void stagger_start(int units) {

@@ -261,38 +261,57 @@ __device__ __forceinline__ unsigned frag_off(int kb, int cb, int plane) { return
 template <int NB, int ROW, int PLANE, bool SCALED = false>
 __device__ __forceinline__ void planes_to_frag(const _Float16* xa /* plane_hi + (lane & 31) * ROW + 8 * (lane >> 5) + first column */,
                                                const Selector& sel, const FragDst& dst,
-                                               const float* fscale = nullptr /* LDS: factor of point 4 * (lane >> 5) */, int fstride = 0,
-                                               f16x2* amax2 = nullptr /* SCALED: running packed max of |hi| (range check at the kernel's end) */) {
+                                               const float* fscale = nullptr /* LDS: factor of point 4 * (lane >> 5) */, int fstride = 0) {
+    const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int cb = 0; cb < NB; ++cb)
+    for (int cb = 0; cb < NB; ++cb) {
+        // both point halves of a channel block together: eight operand reads, then eight MFMAs on four independent accumulators,
+        // then the conversions and stores - one block at a time was a chain of exposed latencies (LDS, matrix core, LDS, ...)
+        f16x8 ah[2][2], al[2][2];          // [pb][k-block]
 #pragma unroll
         for (int pb = 0; pb < 2; ++pb) {
             const _Float16* src = xa + pb * 32 * ROW + 32 * cb;
-            const f16x8 ah0 = *reinterpret_cast<const f16x8*>(src), ah1 = *reinterpret_cast<const f16x8*>(src + 16);
-            const f16x8 al0 = *reinterpret_cast<const f16x8*>(src + PLANE), al1 = *reinterpret_cast<const f16x8*>(src + PLANE + 16);
-            const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-            if constexpr (!SCALED) {
-                f32x16 th = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, sel.k[0], zero, 0, 0, 0);
-                f32x16 tl = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, sel.k[0], zero, 0, 0, 0);
-                th = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, sel.k[1], th, 0, 0, 0);
-                tl = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, sel.k[1], tl, 0, 0, 0);
+            ah[pb][0] = *reinterpret_cast<const f16x8*>(src);          ah[pb][1] = *reinterpret_cast<const f16x8*>(src + 16);
+            al[pb][0] = *reinterpret_cast<const f16x8*>(src + PLANE);  al[pb][1] = *reinterpret_cast<const f16x8*>(src + PLANE + 16);
+        }
+        if constexpr (!SCALED) {
+            f32x16 th[2], tl[2];
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                th[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[pb][0], sel.k[0], zero, 0, 0, 0);
+                tl[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[pb][0], sel.k[0], zero, 0, 0, 0);
+            }
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                th[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[pb][1], sel.k[1], th[pb], 0, 0, 0);
+                tl[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[pb][1], sel.k[1], tl[pb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     u32x4 oh, ol;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        oh[i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(th[8 * q + 2 * i], th[8 * q + 2 * i + 1]));
-                        ol[i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(tl[8 * q + 2 * i], tl[8 * q + 2 * i + 1]));
+                        oh[i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(th[pb][8 * q + 2 * i], th[pb][8 * q + 2 * i + 1]));
+                        ol[i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(tl[pb][8 * q + 2 * i], tl[pb][8 * q + 2 * i + 1]));
                     }
                     // (whole offset in the VGPR operand: a 16-byte buffer store with a register SGPR offset gets no hazard wait state, tests/test_isa_audit_cpu.py)
                     __builtin_amdgcn_raw_buffer_store_b128(oh, dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, cb, 0)), 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b128(ol, dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, cb, 1)), 0, 0);
                 }
-            } else {
-                f32x16 t = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, sel.k[0], zero, 0, 0, 0);
-                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, sel.k[1], t, 0, 0, 0);
-                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, sel.k[0], t, 0, 0, 0);
-                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, sel.k[1], t, 0, 0, 0);
+        } else {
+            f32x16 t[2];
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) t[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[pb][0], sel.k[0], zero, 0, 0, 0);
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) t[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[pb][1], sel.k[1], t[pb], 0, 0, 0);
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) t[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[pb][0], sel.k[0], t[pb], 0, 0, 0);
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) t[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[pb][1], sel.k[1], t[pb], 0, 0, 0);
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
                 const float* fs = fscale + pb * 32 * fstride;
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
@@ -301,8 +320,7 @@ __device__ __forceinline__ void planes_to_frag(const _Float16* xa /* plane_hi + 
                     for (int i = 0; i < 4; ++i) {
                         const int r = 8 * q + 2 * i;
                         f16x2 h2, l2;
-                        split_pair(t[r] * fs[((r & 3) + 8 * (r >> 2)) * fstride], t[r + 1] * fs[(((r + 1) & 3) + 8 * ((r + 1) >> 2)) * fstride], h2, l2);
-                        *amax2 = __builtin_elementwise_max(*amax2, __builtin_bit_cast(f16x2, __builtin_bit_cast(unsigned, h2) & 0x7FFF7FFFu));
+                        split_pair(t[pb][r] * fs[((r & 3) + 8 * (r >> 2)) * fstride], t[pb][r + 1] * fs[(((r + 1) & 3) + 8 * ((r + 1) >> 2)) * fstride], h2, l2);
                         oh[i] = __builtin_bit_cast(unsigned, h2);
                         ol[i] = __builtin_bit_cast(unsigned, l2);
                     }
@@ -310,8 +328,9 @@ __device__ __forceinline__ void planes_to_frag(const _Float16* xa /* plane_hi + 
                     __builtin_amdgcn_raw_buffer_store_b128(ol, dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, cb, 1)), 0, 0);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // word = (word << 1) | (v > 0) in two instructions.  v > 0 <=> its bit pattern, read as a signed integer, is > 0 (-0.0 is

@@ -16,6 +16,11 @@ read during capture; they are collected (kernels.captured_status) and read betwe
 f16's range never reaches the optimizer: it is re-run eagerly (where the front-end's own fallback evaluates it with torch
 layers) from the same RNG state.  Random draws inside the step (jitter, noise) use torch's graph-safe generator and advance
 on every replay.
+
+Learning-rate schedules: both reference trainers write ``param_group['lr'] = new_lrate`` every iteration (run_nerf.py:1024-1027,
+trainer.py:1006-1009).  A Python float would be baked into graph B's kernels at capture time, so every group's rate lives in a
+DEVICE tensor that the captured Adam reads; ``__call__`` notices a rate the trainer wrote into the group (any float, or another
+tensor), copies its value into that tensor and puts the tensor back - the reference's decay lines work unchanged.
 """
 import torch
 
@@ -43,6 +48,13 @@ class GraphedTrainStep:
             if isinstance(st.get("step"), torch.Tensor) and st["step"].device != dev:
                 st["step"] = st["step"].to(dev)
         self.params = [p for g in optimizer.param_groups for p in g["params"]]
+        # one device scalar per group: what the captured optimizer kernels read as the learning rate (see the module docstring)
+        self._lr = []
+        for group in optimizer.param_groups:
+            lr = group["lr"]
+            t = lr.detach().to(dev, torch.float32).clone() if isinstance(lr, torch.Tensor) else torch.tensor(float(lr), dtype=torch.float32, device=dev)
+            group["lr"] = t
+            self._lr.append(t)
         # Eager warm-up on a side stream (allocator pools, the optimizer's lazily created state - a state created DURING capture
         # would be re-zeroed by every replay).  It must leave no trace: parameters, optimizer state and the RNG are put back.
         keep_p = [p.detach().clone() for p in self.params]
@@ -80,7 +92,26 @@ class GraphedTrainStep:
                 optimizer.step()
         finally:
             kernels.captured_status = saved
+        # the gradient tensors graph A writes (owned by its pool): what p.grad must point at whenever the caller looks
+        self._grads = [p.grad for p in self.params]
         self.fallbacks = 0
+
+    def set_lr(self, lr, group=None):
+        """Learning rate of ``group`` (index; default: every group) for the following steps.  Equivalent to the reference's
+        ``param_group['lr'] = lr``, which ``__call__`` also honours."""
+        for i, t in enumerate(self._lr):
+            if group is None or group == i:
+                t.fill_(float(lr))
+
+    def _sync_lr(self):
+        for group, t in zip(self.opt.param_groups, self._lr):
+            cur = group["lr"]
+            if cur is not t:                              # the trainer assigned a new rate (run_nerf.py:1026-1027, trainer.py:1008-1009)
+                if isinstance(cur, torch.Tensor):
+                    t.copy_(cur.detach().reshape(()))
+                else:
+                    t.fill_(float(cur))
+                group["lr"] = t
 
     def _eager_step(self):
         self.opt.zero_grad(set_to_none=True)
@@ -96,6 +127,7 @@ class GraphedTrainStep:
             if dst.shape != src.shape:
                 raise ValueError(f"input of shape {tuple(src.shape)}, the graph was captured for {tuple(dst.shape)}")
             dst.copy_(src, non_blocking=True)
+        self._sync_lr()
         dev = self.static[0].device
         rng = torch.cuda.get_rng_state(dev) if self.status is not None else None
         self.graph_a.replay()
@@ -104,8 +136,16 @@ class GraphedTrainStep:
             # same random draws, eagerly - the front-end's own handler evaluates it with torch layers (object_level.render_rays).
             torch.cuda.set_rng_state(rng, dev)
             self.fallbacks += 1
-            loss = self._eager_step()
+            loss = self._eager_step()                     # (re-binds every p.grad to a fresh eager tensor)
             self.loss.copy_(loss.detach())
+            with torch.no_grad():                         # ... back to the graph's own gradient tensors, holding this step's values: a caller
+                for p, g in zip(self.params, self._grads):      # that clips or logs p.grad keeps seeing what the last step used
+                    if g is not None:
+                        if p.grad is not None:
+                            g.copy_(p.grad)
+                        else:
+                            g.zero_()
+                        p.grad = g
             return self.loss
         self.graph_b.replay()
         return self.loss

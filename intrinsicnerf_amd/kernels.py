@@ -178,7 +178,7 @@ def check_f16_range(status, what, deferrable=False):
     if _capturing():
         _defer_to_graph_owner([status.reshape(1)])
         return
-    if deferrable and _deferred is not None and os.environ.get("INERF_EAGER_RANGE_CHECKS", "0") == "0":      # (A/B switch)
+    if deferrable and _deferred is not None:
         _deferred.words.append(status.reshape(1))
         _deferred.tags.append(_deferred.tag)
         return
@@ -466,7 +466,7 @@ def render_rays_fused(desc, packed_coarse, packed_fine, rays, n_samples, n_impor
 # ---------------------------------------------------------------------------------------------------------------------
 (SAVE_ENC, SAVE_DIR, SAVE_H0, SAVE_AS1H, SAVE_FEAT, SAVE_VH, SAVE_SEMH, SAVE_DPRE, SAVE_H7R, SAVE_SLOTS) = (0, 1, 2, 10, 11, 12, 13, 14, 15, 16)
 ACT_SCALE = 8.0                 # activations travel as f16 hi/lo of 8 * value (csrc/layout.h kActScale)
-GRAD_FRAG_SCALE = 1024.0        # fragment slots of a gradient buffer hold 1024 * dz / S (csrc/layout.h kGradFragScale)
+GRAD_FRAG_SCALE = 256.0         # fragment slots of a gradient buffer hold 256 * dz / S (csrc/layout.h kGradFragScale)
 SAVE_SCALARS = 64               # floats behind the slots and the mask area; [0] of a gradient buffer: S (include/inerf.h)
 
 

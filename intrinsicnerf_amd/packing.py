@@ -175,10 +175,9 @@ class DevicePacker:
 
     def __call__(self, named_params):
         """``named_params``: dict name -> tensor (parameters or a state dict) on this packer's device."""
-        import os
-        if self.hip is not None and os.environ.get("INERF_REPACK", "hip") != "torch":
+        if self.hip is not None:
             return self._repack_hip(named_params)
-        return self._repack_torch(named_params)
+        return self._repack_torch(named_params)        # (CPU tensors: the tests of the map itself)
 
     def _repack_hip(self, named_params):
         """One memset + three kernels of the library (inerf_repack) that read the parameters where they live."""
@@ -249,10 +248,13 @@ class DevicePackerF32:
         if not torch.equal(src, src.round()) or float(src.min()) < 0 or float(src.max()) > flat + 1:
             raise RuntimeError("the fp32 blob is not a permutation of the parameters: DevicePackerF32 does not apply")
         self.src = src.to(torch.int64).to(device)
+        # the two constants the index map refers to besides the parameters, resident on the device: built per call they were a
+        # pageable host-to-device copy - a host synchronisation per INERF_PRECISION=f32 training forward, and illegal under stream capture
+        self.prefix = torch.tensor([0.0, 1.0], dtype=torch.float32, device=device)
 
     def __call__(self, named_params):
-        flat = torch.cat([named_params[k].detach().reshape(-1).float() for k in self.names])
-        return torch.cat([flat.new_tensor([0.0, 1.0]), flat])[self.src]
+        flat = torch.cat([self.prefix] + [named_params[k].detach().reshape(-1).float() for k in self.names])
+        return flat[self.src]
 
 
 def device_packer_f32(desc, device):

@@ -102,6 +102,19 @@ class Semantic_NeRF(nn.Module):
         return torch.cat(parts, -1)
 
 
+_told_unfused = False
+
+
+def _unfused_notice(what):
+    """Said once per process (the object-level front-end's staged branch does the same for foreign networks)."""
+    global _told_unfused
+    if not _told_unfused:
+        import warnings
+        warnings.warn(f"{what}: network / encoders outside the fused kernels' architecture (D=8, W=256, skips=[4], multires<=10, "
+                      "multires_views<=4): HIP sampling and compositing, the networks through their torch forward.")
+        _told_unfused = True
+
+
 def _fusable(fn, embed_fn, embeddirs_fn):
     if not hasattr(fn, "fused_desc"):
         return None
@@ -119,8 +132,9 @@ def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64
     any callable on the embedded tensor (called as the reference does).  ``show_endpoint`` is what the
     reference expresses as ``lambda x: net(x, self.endpoint_feat)`` (trainer.py:770)."""
     desc = _fusable(fn, embed_fn, embeddirs_fn) if viewdirs is not None else None
-    if desc is None:
-        return _run_network_torch(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk)
+    if desc is None:         # any other callable / architecture: called as the reference calls it (model_utils.py:19-35)
+        call = (lambda x: fn(x, True)) if show_endpoint else fn          # trainer.py:770
+        return _run_network_torch(inputs, viewdirs, call, embed_fn, embeddirs_fn, netchunk)
     if _wants_grad(fn):      # training step: the layers go through torch autograd (object_level._training_path_notice)
         _training_path_notice("run_network")
         call = (lambda x: fn(x, True)) if show_endpoint else fn          # trainer.py:770
@@ -384,9 +398,14 @@ class SSRRenderMixin:
         if ray_batch.shape[-1] <= 8:
             raise NotImplementedError("volumetric_rendering needs view directions (use_viewdirs: true in every config)")
         desc = _fusable(self.ssr_net_coarse, self.embed_fn, self.embeddirs_fn)
-        if desc is None or (self.N_importance > 0 and _fusable(self.ssr_net_fine, self.embed_fn, self.embeddirs_fn) is None):
-            raise NotImplementedError("networks / encoders outside the fused kernel's architecture (D=8, W=256, "
-                                      "skips=[4], multires<=10, multires_views<=4); there is no eager fallback")
+        if desc is not None and self.N_importance > 0 and _fusable(self.ssr_net_fine, self.embed_fn, self.embeddirs_fn) is None:
+            desc = None
+        if desc is None:
+            # The reference builds whatever netdepth / netwidth the YAML says (trainer.py:811-846) and calls it
+            # (model_utils.py:19-35).  Outside the fused kernels' architecture (D=8, W=256, skips=[4], multires<=10,
+            # multires_views<=4) the path runs STAGED, like object_level.render_rays does for a user-supplied network:
+            # sampling and compositing on the HIP kernels (with their HIP backward), the networks through their own forward.
+            _unfused_notice("volumetric_rendering")
         training = bool(self.training)
         t_vals = torch.linspace(0., 1., steps=self.N_samples, device=dev)
         # RNG draws in the reference's order: t_rand (:744), coarse noise (model_utils.py:70), u (rays.py:197), fine noise
@@ -411,7 +430,9 @@ class SSRRenderMixin:
             kernels.check_f16_range(res.pop("status", None), "volumetric_rendering", deferrable=t_rand is None and noise_c is None)
             return res
 
-        if _wants_grad(self.ssr_net_coarse, self.ssr_net_fine):
+        if desc is None:
+            o = self._staged(ray_batch, t_vals, t_rand, noise_c, u, noise_f, ep, None)
+        elif _wants_grad(self.ssr_net_coarse, self.ssr_net_fine):
             _training_path_notice("volumetric_rendering")
             td = _train_desc(desc)
             if td is None:

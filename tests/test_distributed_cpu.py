@@ -1,4 +1,4 @@
-"""CPU, world_size 2 over gloo: ray sharding + the all-gather of rendered maps (the N > 1 path of bench.py)."""
+"""CPU, world_size 2 and 8 over gloo: ray sharding + the all-gather of rendered maps (the N > 1 path of bench.py)."""
 import os
 import socket
 
@@ -44,6 +44,49 @@ def _ssr_worker(rank, world, port, n_total, out_dir):
     full = idist.render_sharded(render, rays, layout)
     torch.save({k: v.clone() for k, v in full.items()}, os.path.join(out_dir, f"ssr{rank}.pt"))
     dist.destroy_process_group()
+
+
+def _frame_worker(rank, world, port, n_total, ssr_classes, out_dir):
+    """One rank of a full-size frame through distributed.render_sharded: the band's maps are cheap functions of the global ray
+    index (the first float of the ray row), so the gathered frame can be checked exactly without rendering anything."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from intrinsicnerf_amd import distributed as idist
+    layout = idist.OBJECT_MAP_LAYOUT if ssr_classes < 0 else idist.ssr_map_layout(ssr_classes)
+    rays = torch.zeros(n_total, 11)
+    rays[:, 0] = torch.arange(n_total, dtype=torch.float32)
+    seen = {}
+
+    def render(band):
+        seen["rows"] = (int(band[0, 0]), band.shape[0])
+        t = band[:, 0]
+        return {k: (t[:, None] + 0.125 * (i + 1) + torch.arange(w)[None, :]) if w > 1 else t + 0.125 * (i + 1) for i, (k, w) in enumerate(layout)}
+
+    full = idist.render_sharded(render, rays, layout)
+    t = rays[:, 0]
+    ok = all(torch.equal(full[k], (t[:, None] + 0.125 * (i + 1) + torch.arange(w)[None, :]) if w > 1 else t + 0.125 * (i + 1))
+             for i, (k, w) in enumerate(layout))
+    torch.save({"ok": ok, "band": seen["rows"], "keys": sorted(full)}, os.path.join(out_dir, f"frame{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total,ssr_classes", [(640000, -1), (76800, 28), (76801, 28)])
+def test_eight_rank_full_frames(tmp_path, n_total, ssr_classes):
+    """BASELINE configs[2] / [4] at the driver's largest scale: the 800x800 object frame (12 floats per ray) and the 320x240 SSR
+    frame (26 + 2C floats per ray, C = 28) tiled over EIGHT ranks - contiguous bands that cover the frame, every rank ends up
+    with the identical full frame; 76 801 rays: the ragged path (bands differ by one ray)."""
+    from intrinsicnerf_amd import distributed as idist
+    world = 8
+    mp.spawn(_frame_worker, args=(world, _free_port(), n_total, ssr_classes, str(tmp_path)), nprocs=world, join=True)
+    covered = 0
+    for r in range(world):
+        rec = torch.load(os.path.join(tmp_path, f"frame{r}.pt"))
+        assert rec["ok"], f"rank {r}: gathered frame differs"
+        b, e = idist.shard_bounds(n_total, r, world)
+        assert rec["band"] == (b, e - b)
+        covered += e - b
+    assert covered == n_total
 
 
 @pytest.mark.parametrize("n_total", [12, 13])

@@ -233,14 +233,6 @@ def test_deferred_range_checks_read_the_status_words_once():
             if j == 3:
                 kernels.check_f16_range(word, f"chunk {j} (fine pass)", deferrable=True)       # two words of one chunk
     assert block.tripped == [1, 3, 4]
-    # INERF_EAGER_RANGE_CHECKS=1: every check reads its word at once, block or not (A/B switch for the deferred reads)
-    os.environ["INERF_EAGER_RANGE_CHECKS"] = "1"
-    try:
-        with pytest.raises(FloatingPointError, match="chunk 1"):
-            with kernels.deferred_range_checks("frame"):
-                kernels.check_f16_range(bad, "chunk 1", deferrable=True)
-    finally:
-        del os.environ["INERF_EAGER_RANGE_CHECKS"]
     assert kernels._deferred is None
     # the whole-frame retry switches the default precision for its duration only
     before = _capi.default_precision()

@@ -52,7 +52,11 @@ def test_graphed_step_equals_the_eager_step(perturb, monkeypatch):
                 step = graphs.GraphedTrainStep(loss_fn, (batches[0], targets[0]), opt)      # its warm-up steps must leave no trace
                 assert step.status is not None, "the step's f16 range words must be part of the graph"
             torch.manual_seed(5)
-            for r, t in zip(batches, targets):
+            for it, (r, t) in enumerate(zip(batches, targets)):
+                # the reference's schedule: a new rate written into the group every iteration (run_nerf.py:1023-1027, trainer.py:1005-1009).
+                # A steep one, so that a rate baked into the captured optimizer at its capture-time value would show in the parameters
+                for group in opt.param_groups:
+                    group["lr"] = 1e-4 * (0.1 ** (it / 2.0))
                 if mode == "eager":
                     opt.zero_grad(set_to_none=True)
                     loss = loss_fn(r, t)
@@ -63,6 +67,7 @@ def test_graphed_step_equals_the_eager_step(perturb, monkeypatch):
                 losses.append(float(loss))
         if mode == "graph":
             assert step.fallbacks == 0
+            assert all(float(g["lr"]) == pytest.approx(1e-4 * 0.1 ** 1.5, rel=1e-6) for g in opt.param_groups)
         results[mode] = (losses, [p.detach().clone() for p in list(net_c.parameters()) + list(net_f.parameters())])
     assert np.isfinite(results["graph"][0]).all()
     if perturb == 0.0:          # no random draws: the replayed graphs ARE the eager step
@@ -94,6 +99,9 @@ def test_a_batch_outside_the_f16_range_does_not_reach_the_optimizer_through_the_
         loss = step(r, t)
     assert step.fallbacks == 1, "the graph's range word must have sent this batch to the eager path"
     assert torch.isfinite(loss).all()
+    # the eager re-run re-binds p.grad; afterwards p.grad must again be the tensors the graph writes, holding that step's gradients
+    params = list(net_c.parameters()) + list(net_f.parameters())
+    assert all(p.grad is g for p, g in zip(step.params, step._grads)) and all(torch.isfinite(p.grad).all() for p in params)
     assert all(torch.isfinite(p).all() for p in list(net_c.parameters()) + list(net_f.parameters()))
 
 

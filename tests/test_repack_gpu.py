@@ -30,10 +30,8 @@ def test_hip_repack_is_bit_identical_to_the_host_packer(variant, c, monkeypatch)
             host = packing.pack_state_dict_bwd(desc, sd) if backward else packing.pack_state_dict(desc, sd)
             packer = packing.DevicePacker(desc, backward, dev)
             assert packer.hip is not None
-            monkeypatch.setenv("INERF_REPACK", "hip")
-            got = packer(sd_dev)
-            monkeypatch.setenv("INERF_REPACK", "torch")
-            twin = packer(sd_dev)
+            got = packer(sd_dev)                       # the library's inerf_repack
+            twin = packer._repack_torch(sd_dev)        # its framework twin (what CPU tensors take)
             torch.cuda.synchronize()
             assert torch.equal(host.view(torch.int32), got.cpu().view(torch.int32)), (variant, c, seed, backward, "hip vs host")
             differing = int((twin.view(torch.int16) != got.view(torch.int16)).sum())
