@@ -152,14 +152,14 @@ inline NetLayout make_layout(const inerf_net_desc& net) {
 //     4 bytes per element as fp32.  The point order inside a k-block is the accumulator's register order - the same for the
 //     activations and the gradients, and the one the row-format kernel's transposing MFMAs produce - so products may mix
 //     formats (G fragments x row-format X).
-//     Scales: activations are stored as kActScale * h (the forward's own LDS planes); gradients as kGradFragScale * dZ / S, S =
-//     a power of two >= the largest per-point normaliser of the chain (the power of two above max |d_raw|; mlp_bwd.hip).  The weight-
-//     gradient products need ONE scale per slot (a sum over points cannot be re-scaled per point), and f16 has 30 binades for
-//     values that span 13 binades between the points of a batch and ~10 between a point's head and trunk gradients: the
-//     scale puts the typical maximum (|dZ| ~ S) at 2^8 and leaves 2^8 of headroom before f16 overflows - a hidden gradient more
-//     than ~230 x its point's largest head gradient raises INERF_STATUS_F16_RANGE like any other range violation of the path.
+//     Activations are stored split, as kActScale * h (the forward's own LDS planes: their range is the kernel's guard).  Gradients
+//     have no scale that is known before the whole batch has been walked (a sum over points cannot be re-scaled per point, and
+//     f16's 30 binades do not hold 13 binades between the points of a batch times ~16 between the layers of the chain at any
+//     fixed scale: a first version that split them in the producer lost 6 bits in the lower trunk layers): the gradient slots
+//     hold fp32 in the SAME operand order - where the split format has a k-block's hi | lo fragments they have the lane's points
+//     0..3 | 4..7 - and the consumer splits them in registers with the batch's max |dz| in hand, after the same LDS-DMA.
 //   activation buffer: ENC, DIR, AS1H, FEAT, VH, SEMH, H7R rows; H0..H7 fragments (H7 in both formats: the chain reads its rows);
-//   gradient buffer:   VH, SEMH, DPRE rows; H0..H7, AS1H, FEAT fragments (8 floats per point of DPRE: albedo 3, shading 1,
+//   gradient buffer:   VH, SEMH, DPRE rows; H0..H7, AS1H, FEAT fp32 fragments (8 floats per point of DPRE: albedo 3, shading 1,
 //                      residual 3, sigma 1); ENC, DIR, H7R unused.
 enum SaveSlot {
     SAVE_ENC = 0,      // 64  encoded position (63 + zero pad)
@@ -215,11 +215,8 @@ constexpr int kReluBitLayers = 7;
 constexpr int kReluBitTileBytes = kReluBitLayers * 4 * 64 * 8;      // 14,336 B per 64-point tile
 inline int64_t relu_bits_offset(const inerf_net_desc& net, int64_t n_points) { return save_offset(net, SAVE_SLOTS, n_points); }
 inline int64_t relu_bits_floats(int64_t n_points) { return (n_points + kTilePoints - 1) / kTilePoints * (kReluBitTileBytes / 4); }
-// Behind the mask area: 64 floats of per-evaluation scalars.  [0] of the GRADIENT buffer = S, the scale of the chain's
-// fragments (see above), written by the pre-pass of inerf_mlp_backward_inputs and read by every consumer of its fragments.
+// Behind the mask area: 64 floats of per-evaluation scalars (reserved).
 constexpr int kSaveScalars = 64;
-constexpr float kGradFragScale = 256.0f;        // fragments of the gradient buffer hold kGradFragScale * dz / S  (= kActScale * 32)
-constexpr float kMinGradScale = 0x1p-100f;      // floor of S (keeps 1 / S finite when every gradient of a batch underflows)
 inline int64_t save_scalars_offset(const inerf_net_desc& net, int64_t n_points) { return relu_bits_offset(net, n_points) + relu_bits_floats(n_points); }
 inline int64_t save_total_floats(const inerf_net_desc& net, int64_t n_points) {
     return save_scalars_offset(net, n_points) + kSaveScalars;

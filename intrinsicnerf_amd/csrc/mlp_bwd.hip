@@ -31,8 +31,7 @@ struct BwdParams {
     const float* d_raw;     // [P, channels]
     const float* save;      // activations kept by the training forward
     float* dz;              // out: pre-activation gradients, same slot layout
-    float* dz_max;          // out: max |dz| over the ROW-format slots (VH, SEMH; caller zeroes it): the row-format weight-gradient kernel's operand scale
-    const float* s_max;     // in: S >= every point's normaliser (k_grad_bound): fragments hold kGradFragScale * dz / S
+    float* dz_max;          // out: max |dz| over every slot (caller zeroes it): the weight-gradient kernels' operand scale
     float* head_partial;    // out, optional: [grid][kHeadFloats] weight / bias gradients of the 1-4-row heads, per workgroup
     int32_t* status;
     int64_t off[SAVE_SLOTS];
@@ -55,21 +54,22 @@ constexpr int kHeadRes = 0, kHeadAs2 = 384, kHeadAlpha = 1408, kHeadBias = 1664,
 // activation, hi/lo split into LDS (normalised, kActScale domain) and the true gradient to global memory
 struct NoAlpha {};
 
-// Where a layer's dZ goes: a FRAGMENT slot (layout.h SaveSlot) - the operand fragments of the weight-gradient product
-// dW = dZ^T X, lane = channel, 8 k-values = 8 sample points.  The accumulator layout (lane = point, 16 registers = 4 + 4 + 4 + 4
-// channels) is the transpose of that, and it stores badly anyway (a 16-byte piece per lane is 32 bytes per point and instruction:
-// measured 1.2-1.5 x write amplification, the 512 partial-line transactions per wave and layer were most of an epilogue's 10 000
-// cycles).  So the block is transposed by the matrix core: with the block's f16 hi / lo halves - which the epilogue has anyway -
-// as the A operand (row = point, k = the lane's channels) and a 0/1 selection matrix as B, D'[point][channel] = hi + lo comes
-// back with lane = CHANNEL, registers = points.  Before that each point's halves are brought from its own normalisation to the
-// batch's (a power of two: its normaliser over the largest, times the fragments' gain - in accumulator layout a lane holds ONE
-// point, so this is a packed multiply by a per-lane constant); hi and lo are transposed separately and leave as four 1 KB
-// fragments per block - one 16-byte store per lane and fragment, every 128-byte line complete.  4 MFMAs per 32 x 32 block, +8 %
-// of a layer's matrix work.  Until round 4 the transposed block left as fp32 rows and the weight-gradient kernel re-split it.
+// Where a layer's dZ goes: a FRAGMENT slot (layout.h SaveSlot) - the values in the operand order of the weight-gradient
+// product dW = dZ^T X (lane = channel, 8 k-values = 8 sample points), as fp32: gradients have no scale that is known before the
+// whole batch has been walked, so they are split into f16 hi / lo by their CONSUMER, with the batch's max |dz| in hand.
+// The accumulator layout (lane = point, 16 registers = 4 + 4 + 4 + 4 channels) is the transpose of that order, and it stores
+// badly anyway (a 16-byte piece per lane is 32 bytes per point and instruction: measured 1.2-1.5 x write amplification, the 512
+// partial-line transactions per wave and layer were most of an epilogue's 10 000 cycles).  So the block is transposed by the
+// matrix core: with the block's f16 hi / lo halves - which the epilogue has anyway - as the A operand (row = point, k = the
+// lane's channels) and a 0/1 selection matrix as B (B[k][j] = 1/kActScale where channel(k) == j), D'[point][channel] = hi + lo
+// comes back with lane = CHANNEL, registers = points; scaled back by each point's normaliser it leaves as four 1 KB pieces per
+// block (two per 16-point k-block: points 0..3 | 4..7 of every lane's eight) - one 16-byte store per lane and piece, every
+// 128-byte line complete.  hi + lo carry 22 bits - exactly what the weight-gradient kernel keeps of a dZ value when it splits
+// it.  4 MFMAs per 32 x 32 block, +8 % of a layer's matrix work.
 struct DzDst {
     __amdgpu_buffer_rsrc_t rsrc;      // the layer's dZ slot: n_tiles * kFragTileBytes (whole tiles: padding points carry zeros)
     unsigned voff;                    // bytes: tile * kFragTileBytes + (first channel block of this wave) * 2 * kFragBytes + lane * 16
-    f16x4 f4[2];                      // (kGradFragScale / kActScale) s_p / S of this lane's two points (lane & 31, + 32), four times each
+    const float* srow;                // LDS: per-point scale s_p of point 4 * (lane >> 5), row stride kRowH / 2 floats
 };
 // B operand of bwd_store's transposing MFMAs (see DzDst): lane (j = lane & 31, kg = lane >> 5) holds Sel[8 kg + m][j], m = 0..7,
 // per k-block - in the k order of the ACCUMULATOR registers (planes_to_frag's operands come from LDS in channel order).  Rebuilt
@@ -82,7 +82,7 @@ __device__ __forceinline__ Selector accumulator_selector(int lane) {
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int m = 0; m < 8; ++m)
-            sel.k[kb][m] = (16 * kb + 8 * (m >> 2) + 4 * (lane >> 5) + (m & 3)) == (lane & 31) ? (_Float16)1.0f : (_Float16)0.0f;
+            sel.k[kb][m] = (16 * kb + 8 * (m >> 2) + 4 * (lane >> 5) + (m & 3)) == (lane & 31) ? (_Float16)(1.0f / kActScale) : (_Float16)0.0f;
     return sel;
 }
 
@@ -93,7 +93,7 @@ __device__ __forceinline__ void bwd_store(const f32x16 (&am)[RB][2], float inv,
                                           const f32x4 (*extra)[4] /* [RB][4] or nullptr */, float ex0, float ex1,
                                           _Float16* dl /* plane_hi + (lane&31)*kRowH + 4h + dcol + chan0 */, f16x2& amax2,
                                           const DzDst& dst, int lane, float s0, float s1,
-                                          bool valid0, bool valid1,
+                                          bool valid0, bool valid1, float& gmax,
                                           u32x2 mask_bits /* BITS: this lane's words of the layer (layout.h) */,
                                           AlphaAcc& alpha_acc /* f32x4[RB][4]: += (true d sigma of the point) * saved activation; by
                                                                  reference and selected at compile time - through a pointer-or-null
@@ -107,6 +107,7 @@ __device__ __forceinline__ void bwd_store(const f32x16 (&am)[RB][2], float inv,
             const bool valid = pb == 0 ? valid0 : valid1;
             const int bits16 = valid ? (int)(mask_bits[rb] >> (16 * (1 - pb))) : 0;     // points beyond the end carry no gradient
             const float ex = pb == 0 ? ex0 : ex1;
+            const float back = (pb == 0 ? s0 : s1) * (1.0f / kActScale);
             f16x4 hi_g[4], lo_g[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -134,36 +135,34 @@ __device__ __forceinline__ void bwd_store(const f32x16 (&am)[RB][2], float inv,
                 _Float16* d = dl + pb * 32 * kRowH + 32 * rb + 8 * g;
                 *reinterpret_cast<f16x4*>(d) = hi_g[g];
                 *reinterpret_cast<f16x4*>(d + kPlaneH) = lo_g[g];
+                // invalid points carry zeros: no need to exclude them from the running maximum
+                gmax = fmaxf(gmax, fmaxf(fmaxf(fabsf(t[0]), fabsf(t[1])), fmaxf(fabsf(t[2]), fabsf(t[3]))) * back);
             }
-            // Fragment values: this lane's point has ONE factor (its normaliser over the batch's, times the fragments' gain: a
-            // power of two), so the f16 halves are scaled as they are - two packed multiplies per four values, exact unless a
-            // point far below the batch's largest gradient flushes towards zero - and transposed separately (see DzDst):
-            // D'[point][channel] = sum_k A[point][k] Sel[k][channel], two k-blocks of 16 channels, hi and lo each.  The products
-            // are f16 x 1.0: exact, and any rounding mode converts them back.  (A scaled half beyond f16's range would be an inf
-            // here; the kernel's final range check is on max |half| x gain, so such a launch is always flagged.)
-            const f16x4 f4 = pb == 0 ? dst.f4[0] : dst.f4[1];
-            const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-            f32x16 trh = zero, trl = zero;
+            // transpose (see DzDst): D'[point][channel] = sum_k A[point][k] Sel[k][channel], hi then lo, two k-blocks of 16 channels
+            f32x16 tr = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
-                const f16x4 h0 = hi_g[2 * kb] * f4, h1 = hi_g[2 * kb + 1] * f4, l0 = lo_g[2 * kb] * f4, l1 = lo_g[2 * kb + 1] * f4;
-                const f16x8 ah = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-                const f16x8 al = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
-                trh = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, sel.k[kb], trh, 0, 0, 0);
-                trl = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, sel.k[kb], trl, 0, 0, 0);
+                const f16x8 ah = {hi_g[2 * kb][0], hi_g[2 * kb][1], hi_g[2 * kb][2], hi_g[2 * kb][3],
+                                  hi_g[2 * kb + 1][0], hi_g[2 * kb + 1][1], hi_g[2 * kb + 1][2], hi_g[2 * kb + 1][3]};
+                const f16x8 al = {lo_g[2 * kb][0], lo_g[2 * kb][1], lo_g[2 * kb][2], lo_g[2 * kb][3],
+                                  lo_g[2 * kb + 1][0], lo_g[2 * kb + 1][1], lo_g[2 * kb + 1][2], lo_g[2 * kb + 1][3]};
+                tr = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, sel.k[kb], tr, 0, 0, 0);
+                tr = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, sel.k[kb], tr, 0, 0, 0);
             }
+            const float* sr = dst.srow + pb * 32 * (kRowH / 2);
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                u32x4 oh, ol;
+            for (int q = 0; q < 2; ++q)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    oh[i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(trh[8 * q + 2 * i], trh[8 * q + 2 * i + 1]));
-                    ol[i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(trl[8 * q + 2 * i], trl[8 * q + 2 * i + 1]));
+                for (int j = 0; j < 2; ++j) {
+                    f32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 8 * q + 4 * j + i;                     // point (r & 3) + 8 (r >> 2) (+ 4 (lane >> 5): in srow)
+                        v[i] = tr[r] * sr[((r & 3) + 8 * (r >> 2)) * (kRowH / 2)];
+                    }
+                    // (whole offset in the VGPR operand: a 16-byte buffer store with a register SGPR offset gets no hazard wait state, tests/test_isa_audit_cpu.py)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, rb, j)), 0, 0);
                 }
-                // (whole offset in the VGPR operand: a 16-byte buffer store with a register SGPR offset gets no hazard wait state, tests/test_isa_audit_cpu.py)
-                __builtin_amdgcn_raw_buffer_store_b128(oh, dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, rb, 0)), 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(ol, dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, rb, 1)), 0, 0);
-            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -228,28 +227,6 @@ __device__ __forceinline__ float head_gradients(const BwdParams& p, int gp, bool
     return s;
 }
 
-// S, the scale of the chain's fragment outputs: a power of two that is >= every point's normaliser.  A point's head gradients
-// are bounded by the largest |d_raw| entry of the batch (sigmoid' <= 1/4, |albedo|, |shading| <= 1: each of the eight is at most
-// that entry; sigma, logits and endpoint feature ARE entries), so S = the power of two above max |d_raw| - one coalesced pass
-// over d_raw (a few microseconds) instead of evaluating every point's heads twice.  It may exceed the largest normaliser by a
-// few binades (when the largest entries meet small sigmoid' factors): that much of the fragments' 2^5 gain is then unused.
-__global__ __launch_bounds__(256) void k_grad_bound(const float* __restrict__ d_raw, int64_t n, float* __restrict__ s_max) {
-    float m = 0.0f;
-    const int64_t n4 = n >> 2;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(d_raw) + i);
-        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-    }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(d_raw[4 * n4 + threadIdx.x]));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0 && m > 0.0f && m < 3.0e38f) {      // the same normaliser rule as head_gradients: 2^e with m < 2^e
-        int e;
-        frexpf(m, &e);
-        atomicMax(reinterpret_cast<unsigned int*>(s_max), __builtin_bit_cast(unsigned int, ldexpf(1.0f, e)));
-    }
-}
-
 // NW waves per workgroup: 4 (each wave 64 channels = RB 2 row blocks; one wave per SIMD) or 8 (32 channels each; TWO waves per
 // SIMD, so one wave's epilogue / VALU stage / memory wait runs under the other's MFMAs - with one wave per SIMD a tile was
 // 63 k cycles of MFMA in 192 k).  Same tile, same LDS, same packed weights (an 8-wave wave takes one of the two row blocks of
@@ -274,7 +251,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
     const _Float16* const xr = xw + 8 * (lane >> 5);              // wide GEMM operand reads (+ column)
     _Float16* const xd = xw + 4 * (lane >> 5) + WCH * wave;       // wide stores: this wave's channels (+ column)
     auto ptf = [&](int pt) { return reinterpret_cast<float*>(ldsb + pt * kRowH); };   // per-point scratch in the enc columns:
-                                                                                      // [0..7] head gradients / s, [8] s, [9] 1/s, [10] (kGradFragScale / kActScale) s / S
+                                                                                      // [0..7] head gradients / s, [8] s, [9] 1/s
     WeightBuf wb;
     wb.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wts), 0, L.total_floats * 4, 0x00020000);
     wb.voff = lane * 16;
@@ -330,9 +307,6 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
 #else
 #define STAMP() do { } while (0)
 #endif
-    // S: a power of two >= the batch's largest per-point normaliser (k_grad_bound); the floor keeps 1 / S finite for batches whose
-    // gradients are all below 2^-100 (the consumers apply the same floor)
-    const float inv_smax = 1.0f / fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.s_max[0]))), kMinGradScale);
     stagger_start(p.stagger);
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         STAMP();
@@ -365,7 +339,6 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
             for (int k = 0; k < 8; ++k) f[k] = dp[k] * is;
             f[8] = s;
             f[9] = is;
-            f[10] = s * inv_smax * (kGradFragScale / kActScale);          // (a point without gradient has s = 1 and only zeros to scale)
         }
         STAMP();
         __syncthreads();
@@ -424,13 +397,11 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
         const int pt0 = tile * kPts + (lane & 31);
         const bool valid0 = pt0 < p.n_points, valid1 = pt0 + 32 < p.n_points;
         const float s0 = ptf(lane & 31)[8], s1 = ptf((lane & 31) + 32)[8];
-        const _Float16 fh0 = (_Float16)ptf(lane & 31)[10], fh1 = (_Float16)ptf((lane & 31) + 32)[10];
-        const f16x4 f4_0 = {fh0, fh0, fh0, fh0}, f4_1 = {fh1, fh1, fh1, fh1};
         auto dz_dst = [&](int slot) {                 // 256-wide slots only (every layer this kernel runs on the matrix core)
             DzDst d;
             d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dz + p.off[slot], 0, (int)((unsigned)p.n_tiles * (unsigned)kFragTileBytes), 0x00020000);
             d.voff = (unsigned)tile * (unsigned)kFragTileBytes + (unsigned)(WCH / 32 * wave) * (2u * kFragBytes) + (unsigned)lane * 16u;
-            d.f4[0] = f4_0; d.f4[1] = f4_1;
+            d.srow = reinterpret_cast<const float*>(ldsb) + 8 + 4 * (lane >> 5) * (kRowH / 2);
             return d;
         };
         f32x16 am[RB][2];
@@ -449,7 +420,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
             prefetch_w<RB, KS>(preA, wb, frag(L.feat_t, 16));
             prefetch_w<RB, KS>(preB, wb, frag(L.as1_t, 16));
             NoAlpha none;
-            bwd_store<RB>(am, inv, nullptr, nullptr, 0.0f, 0.0f, xd + kColB, amax2, dz_dst(SAVE_FEAT), lane, s0, s1, valid0, valid1,
+            bwd_store<RB>(am, inv, nullptr, nullptr, 0.0f, 0.0f, xd + kColB, amax2, dz_dst(SAVE_FEAT), lane, s0, s1, valid0, valid1, gmax,
                          u32x2{0u, 0u}, none);
         }
         STAMP();
@@ -482,6 +453,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
                 for (int cc = 0; cc < 4; ++cc) v[cc] = act[cc] > 0.0f ? v[cc] : 0.0f;
                 split_store4(ldsb + rows.st[i / HALF][0] + (i % HALF) * AS_STEP * kRowH, ldsb + rows.st[i / HALF][1] + (i % HALF) * AS_STEP * kRowH,
                              v, amax2);
+                gmax = fmaxf(gmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) * f[8]);
                 if (i & 1) __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -494,8 +466,8 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
             FragDst d;
             d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dz + p.off[SAVE_AS1H], 0, (int)((unsigned)p.n_tiles * (unsigned)kFragTileBytes), 0x00020000);
             d.voff = (unsigned)tile * (unsigned)kFragTileBytes + (unsigned)(WCH / 32 * wave) * (2u * kFragBytes) + (unsigned)lane * 16u;
-            planes_to_frag<RB, kRowH, kPlaneH, true>(xr + kColA + WCH * wave, plane_selector(lane_t), d,
-                                                     reinterpret_cast<const float*>(ldsb) + 10 + 4 * (lane >> 5) * (kRowH / 2), kRowH / 2);
+            planes_to_frag<RB, kRowH, kPlaneH, true>(xr + kColA + WCH * wave, plane_selector(lane_t, 1.0f / kActScale), d,
+                                                     reinterpret_cast<const float*>(ldsb) + 8 + 4 * (lane >> 5) * (kRowH / 2), kRowH / 2);
         }
 
         // ---------------- d h7 = W_feat^T d feature + W_as1^T dZ_as1 (+ W_sem1^T dZ_semh) + w_alpha d sigma ----------------
@@ -561,7 +533,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
             STAMP();
             __syncthreads();                 // every wave is done reading A and B
             STAMP();
-            bwd_store<RB>(am, inv, h7v, aw, e0, e1, xd + kColA, amax2, dz_dst(SAVE_H7), lane, s0, s1, valid0, valid1,
+            bwd_store<RB>(am, inv, h7v, aw, e0, e1, xd + kColA, amax2, dz_dst(SAVE_H7), lane, s0, s1, valid0, valid1, gmax,
                          u32x2{0u, 0u}, halpha);       // (accumulated whether or not `heads`)
         }
         STAMP();
@@ -583,7 +555,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
             else       prefetch_w<RB, KS>(preA, wb, frag(L.views_t, 8));
             NoAlpha none;
             bwd_store<RB, true>(am, inv, nullptr, nullptr, 0.0f, 0.0f, xd + dst, amax2, dz_dst(SAVE_H0 + l - 1), lane, s0, s1, valid0, valid1,
-                               mbits, none);
+                               gmax, mbits, none);
             STAMP();
             __syncthreads();
             STAMP();
@@ -643,8 +615,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
         }
     }
     const float amax_all = fmaxf((float)amax2[0], (float)amax2[1]);
-    // (x the fragments' gain: a fragment value is a normalised half times at most that - checked here, conservatively, instead of per value)
-    if (p.status && __any(!(amax_all * (kGradFragScale / kActScale) <= kF16Safe)) && lane == 0) atomicOr(p.status, INERF_STATUS_F16_RANGE);
+    if (p.status && __any(!(amax_all <= kF16Safe)) && lane == 0) atomicOr(p.status, INERF_STATUS_F16_RANGE);
     if (p.dz_max) {                       // non-negative floats order like their bit patterns
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o));
@@ -685,16 +656,6 @@ extern "C" int inerf_mlp_backward_inputs(const inerf_net_desc* net, const float*
     p.channels = INERF_BASE_CHANNELS + p.n_classes + (p.endpoint ? INERF_ENDPOINT_DIM : 0);
     const int grid = p.n_tiles < device_cus() ? p.n_tiles : device_cus();
     p.stagger = stagger_units(p.n_tiles, grid);
-    // S, the scale of the chain's fragment outputs (layout.h SaveSlot), lives behind the slots of the gradient buffer
-    float* s_max = dz_out + save_scalars_offset(*net, n_points);
-    p.s_max = s_max;
-    hipError_t e0 = hipMemsetAsync(s_max, 0, sizeof(float), (hipStream_t)stream);
-    if (e0 != hipSuccess) return record(e0);
-    {
-        const int64_t n = n_points * (int64_t)p.channels;
-        const int64_t blocks = (n / 4 + 255) / 256;
-        hipLaunchKernelGGL(k_grad_bound, dim3((unsigned)(blocks < 2048 ? (blocks > 0 ? blocks : 1) : 2048)), dim3(256), 0, (hipStream_t)stream, d_raw, n, s_max);
-    }
     // eight waves per workgroup (two per SIMD, 32 channels each)
     void (*kern)(const BwdParams) = ssr ? k_mlp_dgrad<true, 8> : k_mlp_dgrad<false, 8>;
     static PerDeviceOnce attr_set[2];

@@ -255,9 +255,10 @@ struct FragDst {
 };
 __device__ __forceinline__ unsigned frag_off(int kb, int cb, int plane) { return (unsigned)((kb * 8 + cb) * 2 + plane) * kFragBytes; }
 
-// NB: 32-channel blocks of this wave (consecutive, starting at the column `xa` points at).  SCALED: every point's values are
-// multiplied by fscale[point * fstride] (powers of two: the chain's per-point normaliser over the largest one) before they are
-// converted - hi and lo are transposed into ONE accumulator (their exact sum, 22 bits) and split again after the scaling.
+// NB: 32-channel blocks of this wave (consecutive, starting at the column `xa` points at).  SCALED (the chain's gradient slots):
+// hi and lo are transposed into ONE accumulator (their exact sum, 22 bits), every point's values are multiplied by
+// fscale[point * fstride] (the chain's per-point normaliser) and leave as fp32 in the same operand order - two 1 KB pieces per
+// 16-point k-block (points 0..3 | 4..7 of a lane's eight) where the split format has its hi | lo fragments.
 template <int NB, int ROW, int PLANE, bool SCALED = false>
 __device__ __forceinline__ void planes_to_frag(const _Float16* xa /* plane_hi + (lane & 31) * ROW + 8 * (lane >> 5) + first column */,
                                                const Selector& sel, const FragDst& dst,
@@ -314,19 +315,17 @@ __device__ __forceinline__ void planes_to_frag(const _Float16* xa /* plane_hi + 
             for (int pb = 0; pb < 2; ++pb) {
                 const float* fs = fscale + pb * 32 * fstride;
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    u32x4 oh, ol;
+                for (int q = 0; q < 2; ++q)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int r = 8 * q + 2 * i;
-                        f16x2 h2, l2;
-                        split_pair(t[pb][r] * fs[((r & 3) + 8 * (r >> 2)) * fstride], t[pb][r + 1] * fs[(((r + 1) & 3) + 8 * ((r + 1) >> 2)) * fstride], h2, l2);
-                        oh[i] = __builtin_bit_cast(unsigned, h2);
-                        ol[i] = __builtin_bit_cast(unsigned, l2);
+                    for (int j = 0; j < 2; ++j) {
+                        f32x4 v;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int r = 8 * q + 4 * j + i;
+                            v[i] = t[pb][r] * fs[((r & 3) + 8 * (r >> 2)) * fstride];
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, cb, j)), 0, 0);
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(oh, dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, cb, 0)), 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(ol, dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, cb, 1)), 0, 0);
-                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);

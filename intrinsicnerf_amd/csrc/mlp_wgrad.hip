@@ -11,9 +11,10 @@
 // The operands of that MFMA must hold, per lane, 8 consecutive k (= points) of one channel, while the network
 // kernels work point-major.  Two kernels:
 //   * k_mlp_wgrad_frag - the nine 256 x 256 products of a network (90 % of the operand bytes): both operands arrive as
-//     FRAGMENT slots, i.e. already split and already in operand order (the producers transpose with the matrix core and
-//     store whole 1 KB fragments).  The kernel is a ring of LDS stages filled by LDS-DMA (buffer_load ... lds: no registers,
-//     no conversion, no VALU) and 24 MFMAs per wave and 16-point k-block; bound by HBM.
+//     FRAGMENT slots, i.e. in operand order (the producers transpose with the matrix core and store whole 1 KB pieces) - the
+//     activations already split into f16 hi / lo, the gradients as fp32 (their scale is only known now).  The kernel is a ring
+//     of LDS stages filled by LDS-DMA (buffer_load ... lds: no row registers, no transposition), a three-instruction split of
+//     the wave's own G operands, and 24 MFMAs per wave and 16-point k-block; bound by HBM.
 //   * k_mlp_wgrad - every other shape (operands 32..128 wide, or 128 rows): row-format X (and G, unless it is a fragment
 //     slot) transposed inside the kernel by the matrix core: an MFMA of a [32 points x 16 channels] fragment (lane = point,
 //     8 consecutive channels: a natural 32-byte read of a point's row) with an identity matrix returns that block in
@@ -28,8 +29,7 @@ namespace inerf {
 struct WgradParams {
     const float* G;          // [P, ldg] (pointer to the first used column)
     const float* X;          // [P, ldx]
-    const float* ranges;     // device: {gmax, xmax}: upper bounds of |G| and |X| (GFRAG: [1] only)
-    const float* s_max;      // GFRAG: G is a fragment slot holding kGradFragScale * dz / S; device: S (layout.h)
+    const float* ranges;     // device: {gmax, xmax}: upper bounds of |G| and |X|
     float* partial;          // workgroup g writes its M x N tile at partial + g * partial_stride
     float* bias_partial;     // optional: workgroup g writes its column sums of G at bias_partial + g * partial_stride
     int64_t partial_stride;  // floats
@@ -85,8 +85,8 @@ __device__ __forceinline__ float transpose_block(f16x8 g0, f16x8 g1, f16x8 id0, 
 // M = 256 runs as 8 waves of <= 256 registers (128 of them accumulators): two waves per SIMD, so that one wave's loads and
 // conversions overlap the other's MFMAs.  (With 4 waves x 64 rows - 256 accumulator registers per lane - prefetching the
 // next tile spilled and was 20 % slower than not prefetching at all.)
-// GFRAG: G is a fragment slot (this wave's 32 channels = channel block `wave`): its operands are loaded as they are, one
-// 16-byte request per lane, k-block and plane.
+// GFRAG: G is a (fp32) fragment slot of the gradient buffer (this wave's 32 channels = channel block `wave`): its operands are
+// loaded in operand order - two 16-byte requests per lane and k-block - and only split.
 template <int NW, int CB, bool GFRAG = false>
 __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
     static_assert(!GFRAG || NW == 8, "fragment slots are 256 channels wide");
@@ -98,8 +98,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
     // powers of two that bring the operands' bounds into [2^13, 2^14) (f16 hi/lo split range)
     auto pow2_for = [](float m) { int e; if (!(m > 0.0f) || !(m < 3.0e38f)) return 1.0f; frexpf(m, &e); return ldexpf(1.0f, 14 - e); };
     auto uniform = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
-    const float sx = uniform(pow2_for(p.ranges[1]));       // wave-uniform: scalar registers
-    const float sg = GFRAG ? uniform(kGradFragScale / fmaxf(p.s_max[0], kMinGradScale)) : uniform(pow2_for(p.ranges[0]));
+    const float sg = uniform(pow2_for(p.ranges[0])), sx = uniform(pow2_for(p.ranges[1]));       // wave-uniform: scalar registers
 
     // identity operands of the transposer: B[k][n] = (n == k) resp. (n == k + 16); lane n holds k = 8 * lh + i
     f16x8 id0, id1;
@@ -131,7 +130,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, (int)((unsigned)p.n_points * (unsigned)p.ldx * 4u), 0x00020000);
     const unsigned g_voff0 = (unsigned)(lp * p.ldg + 32 * wave + 8 * lh) * 4u, x_voff0 = (unsigned)(lp * p.ldx + 8 * lh) * 4u;
     float xraw[XS][2][2][8], graw[GFRAG ? 1 : 2][2][8];
-    f16x8 gfr[GFRAG ? 2 : 1][2][2];           // GFRAG: [point half][k-block][hi | lo]
+    f32x4 gfr[GFRAG ? 2 : 1][2][2];           // GFRAG: [point half][k-block][points 0..3 | 4..7 of the lane's eight]
     auto opaque = [](unsigned v) { asm volatile("" : "+v"(v)); return v; };      // keeps `voff + constant` an immediate, not a hoisted register
     auto load_x = [&](int tile, int ph) {
 #pragma unroll
@@ -149,8 +148,8 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
-                for (int plane = 0; plane < 2; ++plane)
-                    gfr[ph][q][plane] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, (int)(voff + frag_off(2 * ph + q, wave, plane)), 0, 0));
+                for (int j = 0; j < 2; ++j)
+                    gfr[ph][q][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, (int)(voff + frag_off(2 * ph + q, wave, j)), 0, 0));
         } else {
             const unsigned voff = opaque(g_voff0 + (unsigned)(tile * kTilePoints + 32 * ph) * (unsigned)p.ldg * 4u);
 #pragma unroll
@@ -203,16 +202,14 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
         for (int ph = 0; ph < 2; ++ph) {
             f16x8 gh[2], gl[2];                // [q]
             if constexpr (GFRAG) {
-                const f16x2 ones = {(_Float16)1.0f, (_Float16)1.0f};
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    gh[q] = gfr[ph][q][0];
-                    gl[q] = gfr[ph][q][1];
+                    float v[8];
 #pragma unroll
-                    for (int i = 0; i < 8; i += 2) {       // v_dot2_f32_f16: exact products, fp32 sums
-                        bias_sum = __builtin_amdgcn_fdot2(f16x2{gh[q][i], gh[q][i + 1]}, ones, bias_sum, false);
-                        bias_sum = __builtin_amdgcn_fdot2(f16x2{gl[q][i], gl[q][i + 1]}, ones, bias_sum, false);
-                    }
+                    for (int i = 0; i < 4; ++i) { v[i] = gfr[ph][q][0][i]; v[4 + i] = gfr[ph][q][1][i]; }
+                    split8(v, sg, gh[q], gl[q]);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) bias_sum += v[i] * sg;            // (in units of 1 / sg, like the other form's)
                 }
             } else {
                 f16x8 h0, l0, h1, l1;
@@ -285,17 +282,19 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
 // ---------------------------------------------------------------------------------------------------------------------
 // 256 x 256 products (nine of a network's thirteen, 90 % of the weight-gradient bytes): both operands are FRAGMENT slots.
 //
-// Per 16-point k-block a slot holds 16 fragments of 1 KB ([32-channel block][hi | lo], layout.h), contiguous: one LDS stage =
-// 16 KB of G + 16 KB of X.  A ring of kFragStages stages is filled by LDS-DMA - `buffer_load_dwordx4 ... lds` moves a fragment
-// from HBM to LDS in one instruction, lane l's 16 bytes to byte 16 l of the destination, which is exactly where the lane that
-// contracts reads its operand slot (conflict-free by construction) - so the loads need no registers, nothing is converted and
-// the VALU idles; up to kFragStages - 1 stages (96 KB per CU) are in flight while one is contracted.  Eight waves: wave w
+// Per 16-point k-block a slot holds 16 pieces of 1 KB ([32-channel block][hi | lo] - gradients: [points 0..3 | 4..7], fp32 -,
+// layout.h), contiguous: one LDS stage = 16 KB of G + 16 KB of X.  A ring of kFragStages stages is filled by LDS-DMA -
+// `buffer_load_dwordx4 ... lds` moves a piece from HBM to LDS in one instruction, lane l's 16 bytes to byte 16 l of the
+// destination, which is exactly where the lane that contracts reads its operand slot (conflict-free by construction) - so the
+// loads need no registers and nothing is transposed; X is consumed as it lands, a wave's own G operands (two blocks) are split
+// into f16 hi / lo with the batch's max |dz| as scale (16 three-instruction splits per k-block against 24 MFMAs); up to
+// kFragStages - 1 stages (96 KB per CU) are in flight while one is contracted.  Eight waves: wave w
 // requests fragments 4 (w & 3) .. + 3 of G (w < 4) or X (w >= 4) of every stage and contracts rows 64 (w & 3) .. + 63 x columns
 // 128 (w >> 2) .. + 127 (2 x 4 accumulator blocks; 12 operand reads and 24 MFMAs per k-block).
 // Synchronisation per stage: every wave waits for ITS OWN requests of the stage (counted vmcnt: the younger stages stay in
 // flight), then one raw s_barrier - behind it every wave's fragments of the stage have landed, and every wave has finished
 // reading the stage before, whose buffer is the one re-filled next.  (A __syncthreads() would drain vmcnt to 0.)
-// The column sums of G (the bias gradient) come from the operands the waves 0..3 read anyway (v_dot2_f32_f16 with ones).
+// The column sums of G (the bias gradient) come from the operands the waves 0..3 read anyway.
 // ---------------------------------------------------------------------------------------------------------------------
 #ifndef INERF_WGRAD_FRAG_STAGES
 #define INERF_WGRAD_FRAG_STAGES 4
@@ -305,9 +304,9 @@ constexpr int kFragStageBytes = 2 * kFragKbBytes;               // G | X of one 
 static_assert(kFragStages >= 3 && kFragStages <= 5, "ring depth");
 
 struct WgradFragParams {
-    const void* G;           // fragment slot of dZ: kGradFragScale * dz / S
-    const void* X;           // fragment slot of activations: kActScale * h
-    const float* s_max;      // device: S
+    const void* G;           // fragment slot of dZ: fp32 in operand order
+    const void* X;           // fragment slot of activations: f16 hi / lo of kActScale * h
+    const float* ranges;     // device: {gmax, ...}: upper bound of |G|
     float* partial;          // workgroup g writes its 256 x 256 tile at partial + g * partial_stride
     float* bias_partial;     // optional: ... its column sums of G
     int64_t partial_stride;  // floats
@@ -343,16 +342,32 @@ __global__ __launch_bounds__(512, 1) void k_mlp_wgrad_frag(const WgradFragParams
         for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.0f;
-    float bias_sum[2] = {0.0f, 0.0f};          // waves 0..3: this lane's channel of row block rb, its k-half's points
-    const f16x2 ones = {(_Float16)1.0f, (_Float16)1.0f};
+    float bias_sum[2] = {0.0f, 0.0f};          // waves 0..3: this lane's channel of row block rb, its k-half's points (units of 1 / sg)
+    auto pow2_for = [](float m) { int e; if (!(m > 0.0f) || !(m < 3.0e38f)) return 1.0f; frexpf(m, &e); return ldexpf(1.0f, 14 - e); };
+    const float sg = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pow2_for(p.ranges[0]))));
     auto contract = [&](int buf) {
         const char* gset = ldsw + buf * kFragStageBytes + lane * 16;
         const char* xset = gset + kFragKbBytes;
         auto frag = [&](const char* set, int block, int plane) { return *reinterpret_cast<const f16x8*>(set + (block * 2 + plane) * kFragBytes); };
         f16x8 gh[2], gl[2], xh[2], xl[2];
+        f32x4 graw[2][2];
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) { gh[rb] = frag(gset, rb0 + rb, 0); gl[rb] = frag(gset, rb0 + rb, 1); }
+        for (int rb = 0; rb < 2; ++rb) {
+            graw[rb][0] = *reinterpret_cast<const f32x4*>(gset + ((rb0 + rb) * 2 + 0) * kFragBytes);
+            graw[rb][1] = *reinterpret_cast<const f32x4*>(gset + ((rb0 + rb) * 2 + 1) * kFragBytes);
+        }
         xh[0] = frag(xset, cb0, 0); xl[0] = frag(xset, cb0, 1);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v[i] = graw[rb][0][i]; v[4 + i] = graw[rb][1][i]; }
+            split8(v, sg, gh[rb], gl[rb]);
+            if (wave < 4 && p.bias_partial) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) bias_sum[rb] += v[i] * sg;
+            }
+        }
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {     // X operands one read ahead of their MFMAs, fenced (unfenced, the scheduler hoists every read to the top)
             if (cb + 1 < 4) { xh[(cb + 1) & 1] = frag(xset, cb0 + cb + 1, 0); xl[(cb + 1) & 1] = frag(xset, cb0 + cb + 1, 1); }
@@ -364,15 +379,6 @@ __global__ __launch_bounds__(512, 1) void k_mlp_wgrad_frag(const WgradFragParams
                 acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl[rb], xh[cb & 1], acc[rb][cb], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-        }
-        if (wave < 4 && p.bias_partial) {
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                for (int i = 0; i < 8; i += 2) {
-                    bias_sum[rb] = __builtin_amdgcn_fdot2(f16x2{gh[rb][i], gh[rb][i + 1]}, ones, bias_sum[rb], false);
-                    bias_sum[rb] = __builtin_amdgcn_fdot2(f16x2{gl[rb][i], gl[rb][i + 1]}, ones, bias_sum[rb], false);
-                }
         }
     };
 
@@ -399,15 +405,14 @@ __global__ __launch_bounds__(512, 1) void k_mlp_wgrad_frag(const WgradFragParams
     }
 
     // ---- this workgroup's partial tile and its column sums of G ----
-    const float s = fmaxf(p.s_max[0], kMinGradScale);
     if (p.bias_partial && wave < 4) {          // the two lane halves hold complementary points of the same channel
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
             const float both = bias_sum[rb] + __shfl_xor(bias_sum[rb], 32);
-            if (lh == 0) p.bias_partial[(size_t)blockIdx.x * p.partial_stride + 32 * (rb0 + rb) + lp] = both * (s * (1.0f / kGradFragScale));
+            if (lh == 0) p.bias_partial[(size_t)blockIdx.x * p.partial_stride + 32 * (rb0 + rb) + lp] = both / sg;
         }
     }
-    const float back = s * (1.0f / (kGradFragScale * kActScale));
+    const float back = 1.0f / (sg * kActScale);
     float* out = p.partial + (size_t)blockIdx.x * p.partial_stride;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
@@ -478,38 +483,39 @@ extern "C" int inerf_mlp_weight_gradient(const float* G, int ldg, const float* X
     if ((ldg & 3) || (ldx & 3) || (((uintptr_t)G | (uintptr_t)X) & 15)) return INERF_E_INVALID;      // 16-byte row pieces
     if (partial_stride < (int64_t)M * N) return INERF_E_INVALID;
     WgradParams p;
-    p.G = G; p.X = X; p.ranges = ranges; p.s_max = nullptr; p.partial = partial; p.bias_partial = bias_partial; p.partial_stride = partial_stride;
+    p.G = G; p.X = X; p.ranges = ranges; p.partial = partial; p.bias_partial = bias_partial; p.partial_stride = partial_stride;
     p.ldg = ldg; p.ldx = ldx; p.n_points = (int)n_points; p.M = M; p.N = N;
     p.n_tiles = (int)((n_points + kTilePoints - 1) / kTilePoints);
     return launch_rows(p, false, stream);
 }
 
-// G: a FRAGMENT slot of the gradient buffer (256 channels; s_max: the device float S that buffer carries, layout.h); X: rows.
-extern "C" int inerf_mlp_weight_gradient_gfrag(const void* G_frag, const float* s_max, const float* X, int ldx, int64_t n_points, int N,
+// G: a (fp32) FRAGMENT slot of the gradient buffer (256 channels); X: rows.  ranges: device {gmax, xmax} as above.
+extern "C" int inerf_mlp_weight_gradient_gfrag(const void* G_frag, const float* X, int ldx, int64_t n_points, int N,
                                                const float* ranges, float* partial, float* bias_partial, int64_t partial_stride,
                                                void* stream) {
     using namespace inerf;
-    if (!G_frag || !s_max || !X || !ranges || !partial || n_points <= 0 || ldx < N) return INERF_E_INVALID;
+    if (!G_frag || !X || !ranges || !partial || n_points <= 0 || ldx < N) return INERF_E_INVALID;
     if (n_points > kMaxTrainPoints) return INERF_E_UNSUPPORTED;
     if ((ldx & 3) || (((uintptr_t)G_frag | (uintptr_t)X) & 15)) return INERF_E_INVALID;
     if (partial_stride < (int64_t)kWidth * N) return INERF_E_INVALID;
     WgradParams p;
-    p.G = static_cast<const float*>(G_frag); p.X = X; p.ranges = ranges; p.s_max = s_max; p.partial = partial; p.bias_partial = bias_partial;
+    p.G = static_cast<const float*>(G_frag); p.X = X; p.ranges = ranges; p.partial = partial; p.bias_partial = bias_partial;
     p.partial_stride = partial_stride;
     p.ldg = kWidth; p.ldx = ldx; p.n_points = (int)n_points; p.M = kWidth; p.N = N;
     p.n_tiles = (int)((n_points + kTilePoints - 1) / kTilePoints);
     return launch_rows(p, true, stream);
 }
 
-// Both operands FRAGMENT slots (256 x 256): G of the gradient buffer, X of the activation buffer, on the same n_points.
-extern "C" int inerf_mlp_weight_gradient_frag(const void* G_frag, const void* X_frag, const float* s_max, int64_t n_points,
+// Both operands FRAGMENT slots (256 x 256): G of the gradient buffer (fp32), X of the activation buffer (split), on the same
+// n_points.  ranges: device {gmax, ...}: an upper bound of |G| (the dz_max of inerf_mlp_backward_inputs).
+extern "C" int inerf_mlp_weight_gradient_frag(const void* G_frag, const void* X_frag, const float* ranges, int64_t n_points,
                                               float* partial, float* bias_partial, int64_t partial_stride, void* stream) {
     using namespace inerf;
-    if (!G_frag || !X_frag || !s_max || !partial || n_points <= 0) return INERF_E_INVALID;
+    if (!G_frag || !X_frag || !ranges || !partial || n_points <= 0) return INERF_E_INVALID;
     if (n_points > kMaxTrainPoints) return INERF_E_UNSUPPORTED;
     if ((((uintptr_t)G_frag | (uintptr_t)X_frag) & 15) || partial_stride < (int64_t)kWidth * kWidth) return INERF_E_INVALID;
     WgradFragParams p;
-    p.G = G_frag; p.X = X_frag; p.s_max = s_max; p.partial = partial; p.bias_partial = bias_partial; p.partial_stride = partial_stride;
+    p.G = G_frag; p.X = X_frag; p.ranges = ranges; p.partial = partial; p.bias_partial = bias_partial; p.partial_stride = partial_stride;
     p.n_kb = (int)((n_points + kTilePoints - 1) / kTilePoints) * 4;
     const int grid = inerf_wgrad_grid(n_points);
     constexpr int lds = kFragStages * kFragStageBytes;

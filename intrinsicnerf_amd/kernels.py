@@ -466,13 +466,12 @@ def render_rays_fused(desc, packed_coarse, packed_fine, rays, n_samples, n_impor
 # ---------------------------------------------------------------------------------------------------------------------
 (SAVE_ENC, SAVE_DIR, SAVE_H0, SAVE_AS1H, SAVE_FEAT, SAVE_VH, SAVE_SEMH, SAVE_DPRE, SAVE_H7R, SAVE_SLOTS) = (0, 1, 2, 10, 11, 12, 13, 14, 15, 16)
 ACT_SCALE = 8.0                 # activations travel as f16 hi/lo of 8 * value (csrc/layout.h kActScale)
-GRAD_FRAG_SCALE = 256.0         # fragment slots of a gradient buffer hold 256 * dz / S (csrc/layout.h kGradFragScale)
-SAVE_SCALARS = 64               # floats behind the slots and the mask area; [0] of a gradient buffer: S (include/inerf.h)
+SAVE_SCALARS = 64               # floats behind the slots and the mask area (reserved; include/inerf.h)
 
 
-def frag_decode(frag, n_points, scale):
-    """A 256-wide FRAGMENT slot (include/inerf.h: f16 hi/lo operand fragments of the weight-gradient products; ``frag``: its
-    elements as a float32 or float16 tensor) -> the fp32 [n_points, 256] matrix it encodes: (hi + lo) / scale."""
+def frag_decode(frag, n_points, scale=ACT_SCALE):
+    """A 256-wide FRAGMENT slot of an ACTIVATION buffer (include/inerf.h: f16 hi/lo operand fragments of the weight-gradient
+    products; ``frag``: its elements as a float32 or float16 tensor) -> the fp32 [n_points, 256] matrix it encodes: (hi + lo) / scale."""
     h = frag.view(torch.float16) if frag.dtype != torch.float16 else frag
     tiles = h.numel() // (64 * 256 * 2)
     # [tile, pb, q, cb, plane, h, c, i_hi, i_lo]: point = 32 pb + 16 q + 8 i_hi + 4 h + i_lo, channel = 32 cb + c
@@ -482,10 +481,10 @@ def frag_decode(frag, n_points, scale):
     return v[:n_points] / scale
 
 
-def frag_encode(rows, scale):
+def frag_encode(rows, scale=ACT_SCALE):
     """fp32 [n_points, 256] -> the FRAGMENT slot of ``frag_decode`` (float16 tensor of 64 * ceil(n / 64) * 512 halfs): hi = f16
-    of scale * value rounded towards zero, lo = f16(scale * value - hi); padding points are zero.  What the training kernels'
-    epilogues emit, restated with torch for the tests of the weight-gradient kernel."""
+    of scale * value rounded towards zero, lo = f16(scale * value - hi); padding points are zero.  What the training forward's
+    epilogue emits, restated with torch for the tests of the weight-gradient kernel."""
     n = rows.shape[0]
     tiles = (n + 63) // 64
     v = torch.zeros(tiles * 64, 256, dtype=torch.float32, device=rows.device)
@@ -500,24 +499,36 @@ def frag_encode(rows, scale):
     return both.permute(1, 2, 3, 7, 0, 5, 8, 4, 6).contiguous().view(-1)     # [tile, pb, q, cb, plane, h, c, i_hi, i_lo]
 
 
+def grad_frag_decode(frag, n_points):
+    """A 256-wide FRAGMENT slot of a GRADIENT buffer (fp32 in the same operand order: where the split format has a k-block's
+    hi | lo pieces this one has the lane's points 0..3 | 4..7) -> the fp32 [n_points, 256] matrix."""
+    tiles = frag.numel() // (64 * 256)
+    v = frag.view(tiles, 2, 2, 8, 2, 2, 32, 4)                               # [tile, pb, q, cb, j = i_hi, h, c, i_lo]
+    return v.permute(0, 1, 2, 4, 5, 7, 3, 6).reshape(tiles * 64, 256)[:n_points]       # -> [tile, pb, q, i_hi, h, i_lo, cb, c]
+
+
+def grad_frag_encode(rows):
+    """fp32 [n_points, 256] -> the gradient-buffer FRAGMENT slot of ``grad_frag_decode`` (padding points zero)."""
+    n = rows.shape[0]
+    tiles = (n + 63) // 64
+    v = torch.zeros(tiles * 64, 256, dtype=torch.float32, device=rows.device)
+    v[:n] = rows.float()
+    v = v.view(tiles, 2, 2, 2, 2, 4, 8, 32)                                  # [tile, pb, q, i_hi, h, i_lo, cb, c]
+    return v.permute(0, 1, 2, 6, 3, 4, 7, 5).contiguous().view(-1)           # [tile, pb, q, cb, i_hi, h, c, i_lo]
+
+
 def save_slot_views(desc, buf, n_points, gradient=False):
     """The [n_points, width] matrices of an activation buffer (``gradient``: of a buffer of pre-activation gradients;
     include/inerf.h: slot list).  Row-format slots are views; FRAGMENT slots are decoded into new fp32 tensors."""
     views = []
     lib = _capi.lib()
     off, width = C.c_int64(), C.c_int()
-    s = None
     for slot in range(SAVE_SLOTS):
         _capi.check(lib.inerf_mlp_save_slot(desc, slot, n_points, C.byref(off), C.byref(width)), "inerf_mlp_save_slot")
         if lib.inerf_mlp_save_slot_is_fragment(slot, 1 if gradient else 0) == 1:
             padded = (n_points + 63) // 64 * 64
             frag = buf[off.value: off.value + padded * width.value]
-            if gradient:
-                if s is None:
-                    s = buf[buf.shape[0] - SAVE_SCALARS].clamp_min(2.0 ** -100)
-                views.append(frag_decode(frag, n_points, 1.0) * (s / GRAD_FRAG_SCALE))
-            else:
-                views.append(frag_decode(frag, n_points, ACT_SCALE))
+            views.append(grad_frag_decode(frag, n_points) if gradient else frag_decode(frag, n_points))
         else:
             views.append(buf[off.value: off.value + n_points * width.value].view(n_points, width.value))
     return views
@@ -689,23 +700,23 @@ def weight_gradient(g, x, m, n, ranges=None, want_bias=False):
     return (b.result(k), b.bias(k)) if want_bias else b.result(k)
 
 
-def weight_gradient_frag(g_frag, x_frag, s_max, n_points, want_bias=False, x_rows=None, n=256, x_max=None):
-    """G^T X with G a FRAGMENT slot of a gradient buffer (256 channels, ``s_max``: float32[1] device tensor S - the slot holds
-    GRAD_FRAG_SCALE * dz / S) through the HIP split-K kernels: against ``x_frag``, a FRAGMENT slot of activations (LDS-DMA kernel, 256 x 256),
-    or, with ``x_rows`` ([n_points, >= n] fp32 rows, ``x_max`` = float32[1] bound of |x|), against row-format activations."""
+def weight_gradient_frag(g_frag, x_frag, ranges, n_points, want_bias=False, x_rows=None, n=256):
+    """G^T X with G a FRAGMENT slot of a gradient buffer (256 channels, fp32 in operand order) through the HIP split-K kernels:
+    against ``x_frag``, a FRAGMENT slot of activations (split f16; the LDS-DMA kernel, 256 x 256), or, with ``x_rows``
+    ([n_points, >= n] fp32 rows), against row-format activations.  ``ranges``: float32[2] device tensor, upper bounds of |G|
+    and |X|."""
     lib = _capi.lib()
     grid = lib.inerf_wgrad_grid(n_points)
     total = 256 * n + (256 if want_bias else 0)
-    buf = _new(s_max, grid, total)
+    buf = _new(ranges, grid, total)
     base = buf.data_ptr()
     bias = C.c_void_p(base + 4 * 256 * n) if want_bias else None
-    with torch.cuda.device(s_max.device):
+    with torch.cuda.device(ranges.device):
         if x_rows is None:
-            rc = lib.inerf_mlp_weight_gradient_frag(_ptr(g_frag), _ptr(x_frag), _ptr(s_max), n_points, C.c_void_p(base), bias, total, _stream(s_max))
+            rc = lib.inerf_mlp_weight_gradient_frag(_ptr(g_frag), _ptr(x_frag), _ptr(ranges), n_points, C.c_void_p(base), bias, total, _stream(ranges))
         else:
-            ranges = torch.cat([torch.zeros_like(x_max), x_max])
-            rc = lib.inerf_mlp_weight_gradient_gfrag(_ptr(g_frag), _ptr(s_max), C.c_void_p(x_rows.data_ptr()), x_rows.stride(0), n_points, n,
-                                                     _ptr(ranges), C.c_void_p(base), bias, total, _stream(s_max))
+            rc = lib.inerf_mlp_weight_gradient_gfrag(_ptr(g_frag), C.c_void_p(x_rows.data_ptr()), x_rows.stride(0), n_points, n,
+                                                     _ptr(ranges), C.c_void_p(base), bias, total, _stream(ranges))
     _capi.check(rc, "inerf_mlp_weight_gradient_frag")
     sums = buf.sum(0)
     w = sums[:256 * n].view(256, n)

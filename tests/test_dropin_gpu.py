@@ -261,14 +261,19 @@ def test_ssr_trainer_with_another_netwidth_runs_staged():
     torch.manual_seed(3)
     t.create_ssr()
     assert t.ssr_net_coarse.fused_desc() is None and t.ssr_net_coarse.pts_linears[1].weight.shape == (128, 128)
-    with torch.no_grad():       # default init has every density negative: a density head that straddles zero on this camera
-        for net in (t.ssr_net_coarse, t.ssr_net_fine):
-            net.alpha_linear.weight.mul_(256.0)
-            net.alpha_linear.bias.add_(1.0)
     H, W = 240, 320
     fx = W / 2.0 / np.tan(np.deg2rad(45.0))
     rays = ssr.create_rays(1, torch.eye(4)[None], H, W, fx, fx, (W - 1.0) / 2.0, (H - 1.0) / 2.0, 0.1, 10.0).reshape(-1, 11)
     sub = rays[torch.arange(0, H * W, 301)].contiguous()
+    with torch.no_grad():       # default init leaves the density near zero and of one sign: a density head that straddles zero on this camera
+        z = torch.linspace(0.1, 10.0, 64)
+        pts = (sub[:, None, 0:3] + sub[:, None, 3:6] * z[None, :, None]).reshape(-1, 3)
+        emb = torch.cat([t.embed_fn(pts), t.embeddirs_fn(sub[:, None, 8:11].expand(-1, 64, -1).reshape(-1, 3))], -1).to(dev)
+        for net in (t.ssr_net_coarse, t.ssr_net_fine):
+            sigma = net(emb)[:, 3]
+            gain = 0.5 / float(sigma.std())
+            net.alpha_linear.weight.mul_(gain)
+            net.alpha_linear.bias.copy_((net.alpha_linear.bias - sigma.median()) * gain)
     t.training = False
     t.ssr_net_coarse.eval(); t.ssr_net_fine.eval()
     with warnings.catch_warnings():
