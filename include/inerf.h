@@ -149,18 +149,20 @@ int inerf_encode_mlp_ws(const inerf_net_desc* net, const float* packed_weights, 
  *   14 (dz only) head pre-activation gradients 8: albedo 3, shading 1, residual 3, sigma 1 | 15 (save only) h7 again.
  * Two slot formats:
  *   ROWS      a row-major fp32 [n_points, width] matrix.  save: 0, 1, 10, 11, 12, 13, 15; dz: 12, 13, 14.
- *   FRAGMENTS the operands of the nine 256 x 256 weight-gradient products dW = dZ^T X in the order the matrix core consumes
- *             them, in 1 KB pieces; with kb = 16-point block of the tile (0..3), cb = 32-channel block, j = 0 | 1:
- *               byte offset of a piece = (((tile * 4 + kb) * 8 + cb) * 2 + j) * 1024,  lane l at + 16 l
- *               channel = 32 cb + (l & 31),  point(i) = 64 tile + 32 (kb >> 1) + (i & 3) + 8 ((i >> 2) + 2 (kb & 1)) + 4 (l >> 5)
- *             (lane = channel, i = 0..7: the 8 k-values of one operand slot of v_mfma_f32_32x32x16_f16; the point order
+ *   FRAGMENTS the operands of the nine 256 x 256 weight-gradient products dW = dZ^T X exactly as the matrix core consumes
+ *             them: every value v is stored as f16 hi = f16(v') (towards zero) and f16 lo = f16(v' - hi) in 1 KB fragments
+ *             [32 channels x 16 points]; with kb = 16-point block of the tile (0..3), cb = 32-channel block:
+ *               byte offset = (((tile * 4 + kb) * 8 + cb) * 2 + (0: hi, 1: lo)) * 1024 + lane * 16 + 2 * i      (i = 0..7)
+ *               channel = 32 cb + (lane & 31),  point = 64 tile + 32 (kb >> 1) + (i & 3) + 8 ((i >> 2) + 2 (kb & 1)) + 4 (lane >> 5)
+ *             (lane = channel, 8 k-values = 8 points: one 16-byte operand slot of v_mfma_f32_32x32x16_f16; the point order
  *             inside a block is the accumulator's register order).
- *             save, slots 2..9 (activations, already SPLIT): piece j = 0 holds f16 hi = f16(8 v) (towards zero), j = 1
- *             f16 lo = f16(8 v - hi), eight halves per lane, i = 0..7.
- *             dz, slots 2..11 (gradients, fp32 - their scale is only known when the whole batch has been walked, so their
- *             consumer splits them): piece j holds the lane's points i = 4 j .. 4 j + 3 as four floats.
- *             Padding points of the last tile hold a copy of the last point (save) / zeros (dz).  4 bytes per element either
- *             way; the producers write whole pieces and inerf_mlp_weight_gradient_frag moves them HBM -> LDS by DMA.
+ *             save, slots 2..9: v' = 8 v (the forward kernel's own operand halves).
+ *             dz, slots 2..11: v' = 8 v / s_p, s_p = the point's NORMALISER (the power of two above its largest head
+ *             gradient; the chain works on normalised gradients, so these halves keep 22 bits whatever a point's gradient
+ *             scale) - the normalisers are the first 64 * ceil(n_points / 64) floats of slot 0 of dz, and the weight-gradient
+ *             kernels multiply them back in when they bring a fragment to the batch's max |dz|.
+ *             Padding points of the last tile hold a copy of the last point (save) / zeros (dz).  Same 4 bytes per element as
+ *             fp32; the producers write whole fragments and inerf_mlp_weight_gradient_frag moves them HBM -> LDS by DMA.
  * Behind the slots `save` carries the ReLU masks of h0..h6 as bits (14 336 bytes per 64-point tile, written by
  * inerf_encode_mlp_train and read by inerf_mlp_backward_inputs in place of the activations; layout private to the
  * two kernels) and 64 scalars: always pass a buffer that inerf_encode_mlp_train itself filled, of inerf_mlp_save_floats() floats.
@@ -211,13 +213,13 @@ int inerf_mlp_backward_grid(int64_t n_points);
 int inerf_wgrad_grid(int64_t n_points);
 int inerf_mlp_weight_gradient(const float* G, int ldg, const float* X, int ldx, int64_t n_points, int M, int N,
                               const float* ranges, float* partial, float* bias_partial, int64_t partial_stride, void* stream);
-/* The same with G a FRAGMENT slot of the gradient buffer (M = 256; fp32 in operand order, see above) and X row-format:
- * N in {64} (the encoding columns of pts_linears.0 / .5).  ranges as above. */
-int inerf_mlp_weight_gradient_gfrag(const void* G_frag, const float* X, int ldx, int64_t n_points, int N,
+/* The same with G a FRAGMENT slot of the gradient buffer (M = 256) - g_scale: the points' normalisers, slot 0 of that buffer,
+ * see above - and X row-format: N in {64} (the encoding columns of pts_linears.0 / .5).  ranges as above (of the TRUE |dz|). */
+int inerf_mlp_weight_gradient_gfrag(const void* G_frag, const float* g_scale, const float* X, int ldx, int64_t n_points, int N,
                                     const float* ranges, float* partial, float* bias_partial, int64_t partial_stride, void* stream);
 /* ... and with BOTH operands FRAGMENT slots (256 x 256: G of the gradient buffer, X of the activation buffer, same points):
- * a ring of LDS stages filled by LDS-DMA - bound by HBM bandwidth.  ranges[0]: an upper bound of |G|. */
-int inerf_mlp_weight_gradient_frag(const void* G_frag, const void* X_frag, const float* ranges, int64_t n_points,
+ * a ring of LDS stages filled by LDS-DMA - bound by HBM bandwidth.  ranges[0]: an upper bound of the true |dz|. */
+int inerf_mlp_weight_gradient_frag(const void* G_frag, const float* g_scale, const void* X_frag, const float* ranges, int64_t n_points,
                                    float* partial, float* bias_partial, int64_t partial_stride, void* stream);
 
 /* The network's whole backward pass in ONE call: the input-gradient chain, every weight-gradient product (split-K launches,

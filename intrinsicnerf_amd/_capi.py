@@ -72,8 +72,8 @@ SYMBOLS = {
     "inerf_mlp_backward_grid": (_I, [_L]),
     "inerf_wgrad_grid": (_I, [_L]),
     "inerf_mlp_weight_gradient": (_I, [_P, _I, _P, _I, _L, _I, _I, _P, _P, _P, _L, _P]),
-    "inerf_mlp_weight_gradient_gfrag": (_I, [_P, _P, _I, _L, _I, _P, _P, _P, _L, _P]),
-    "inerf_mlp_weight_gradient_frag": (_I, [_P, _P, _P, _L, _P, _P, _L, _P]),
+    "inerf_mlp_weight_gradient_gfrag": (_I, [_P, _P, _P, _I, _L, _I, _P, _P, _P, _L, _P]),
+    "inerf_mlp_weight_gradient_frag": (_I, [_P, _P, _P, _P, _L, _P, _P, _L, _P]),
     "inerf_mlp_save_slot_is_fragment": (_I, [_I, _I]),
     "inerf_param_floats": (_L, [C.POINTER(NetDesc)]),
     "inerf_mlp_backward_workspace_bytes": (_L, [C.POINTER(NetDesc), _L]),

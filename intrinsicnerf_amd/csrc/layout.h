@@ -152,14 +152,16 @@ inline NetLayout make_layout(const inerf_net_desc& net) {
 //     4 bytes per element as fp32.  The point order inside a k-block is the accumulator's register order - the same for the
 //     activations and the gradients, and the one the row-format kernel's transposing MFMAs produce - so products may mix
 //     formats (G fragments x row-format X).
-//     Activations are stored split, as kActScale * h (the forward's own LDS planes: their range is the kernel's guard).  Gradients
-//     have no scale that is known before the whole batch has been walked (a sum over points cannot be re-scaled per point, and
-//     f16's 30 binades do not hold 13 binades between the points of a batch times ~16 between the layers of the chain at any
-//     fixed scale: a first version that split them in the producer lost 6 bits in the lower trunk layers): the gradient slots
-//     hold fp32 in the SAME operand order - where the split format has a k-block's hi | lo fragments they have the lane's points
-//     0..3 | 4..7 - and the consumer splits them in registers with the batch's max |dz| in hand, after the same LDS-DMA.
+//     Scales: activations are stored as kActScale * h (the forward's own LDS planes: their range is the kernel's guard).
+//     Gradients have no scale that is known before the whole batch has been walked, and a sum over points cannot be re-scaled
+//     per point afterwards; f16's 30 binades do not hold 13 binades between the points of a batch times ~16 between the layers
+//     of the chain at any fixed scale (a first version that split the true dz in the producer lost 6 bits in the lower trunk
+//     layers).  So the gradient slots hold the chain's own NORMALISED halves - kActScale * dZ / s_p, s_p the point's normaliser
+//     (a power of two): 22 bits whatever the point's scale, straight from the chain's LDS planes - and the normalisers travel
+//     beside them (SAVE_ENC of the gradient buffer: one float per point); the consumer multiplies them back in when it brings
+//     its own operands to the batch's max |dz| (~50 VALU instructions per fragment pair, beside 24 MFMAs per k-block).
 //   activation buffer: ENC, DIR, AS1H, FEAT, VH, SEMH, H7R rows; H0..H7 fragments (H7 in both formats: the chain reads its rows);
-//   gradient buffer:   VH, SEMH, DPRE rows; H0..H7, AS1H, FEAT fp32 fragments (8 floats per point of DPRE: albedo 3, shading 1,
+//   gradient buffer:   VH, SEMH, DPRE rows; H0..H7, AS1H, FEAT fragments; ENC: the normalisers (8 floats per point of DPRE: albedo 3, shading 1,
 //                      residual 3, sigma 1); ENC, DIR, H7R unused.
 enum SaveSlot {
     SAVE_ENC = 0,      // 64  encoded position (63 + zero pad)

@@ -54,22 +54,24 @@ constexpr int kHeadRes = 0, kHeadAs2 = 384, kHeadAlpha = 1408, kHeadBias = 1664,
 // activation, hi/lo split into LDS (normalised, kActScale domain) and the true gradient to global memory
 struct NoAlpha {};
 
-// Where a layer's dZ goes: a FRAGMENT slot (layout.h SaveSlot) - the values in the operand order of the weight-gradient
-// product dW = dZ^T X (lane = channel, 8 k-values = 8 sample points), as fp32: gradients have no scale that is known before the
-// whole batch has been walked, so they are split into f16 hi / lo by their CONSUMER, with the batch's max |dz| in hand.
-// The accumulator layout (lane = point, 16 registers = 4 + 4 + 4 + 4 channels) is the transpose of that order, and it stores
-// badly anyway (a 16-byte piece per lane is 32 bytes per point and instruction: measured 1.2-1.5 x write amplification, the 512
-// partial-line transactions per wave and layer were most of an epilogue's 10 000 cycles).  So the block is transposed by the
-// matrix core: with the block's f16 hi / lo halves - which the epilogue has anyway - as the A operand (row = point, k = the
-// lane's channels) and a 0/1 selection matrix as B (B[k][j] = 1/kActScale where channel(k) == j), D'[point][channel] = hi + lo
-// comes back with lane = CHANNEL, registers = points; scaled back by each point's normaliser it leaves as four 1 KB pieces per
-// block (two per 16-point k-block: points 0..3 | 4..7 of every lane's eight) - one 16-byte store per lane and piece, every
-// 128-byte line complete.  hi + lo carry 22 bits - exactly what the weight-gradient kernel keeps of a dZ value when it splits
-// it.  4 MFMAs per 32 x 32 block, +8 % of a layer's matrix work.
+// Where a layer's dZ goes: a FRAGMENT slot (layout.h SaveSlot) - the operand fragments of the weight-gradient product
+// dW = dZ^T X, lane = channel, 8 k-values = 8 sample points.  The accumulator layout (lane = point, 16 registers = 4 + 4 + 4 + 4
+// channels) is the transpose of that, and it stores badly anyway (a 16-byte piece per lane is 32 bytes per point and instruction:
+// measured 1.2-1.5 x write amplification, the 512 partial-line transactions per wave and layer were most of an epilogue's
+// 10 000 cycles).  So the block is transposed by the matrix core: with the block's f16 hi / lo halves - which the epilogue has
+// anyway - as the A operand (row = point, k = the lane's channels) and a 0/1 selection matrix as B, D'[point][channel] comes back
+// with lane = CHANNEL, registers = points - hi and lo separately, and as they are: the NORMALISED values (kActScale * dz / s_p),
+// whose range is this kernel's guard, so that they fit f16 with their full 22 bits whatever the point's gradient scale.  The
+// products are f16 x 1.0: exact, and any rounding mode converts them back.  They leave as four 1 KB fragments per block - one
+// 16-byte store per lane and fragment, every 128-byte line complete.  The normalisers s_p (4 bytes per point, SAVE_ENC of
+// the gradient buffer) travel beside them: the weight-gradient kernels, which know the batch's max |dz| by then, multiply them
+// back in when they bring a fragment to their own scale.  4 MFMAs per 32 x 32 block, +8 % of a layer's matrix work.
+// (Rounds 2-3: the transposed block left as fp32 rows, scaled back per value from LDS; a first fragment version split the true
+// dz in the producer with a scale guessed from d_raw and lost 6 bits in the lower trunk layers - f16's 30 binades do not hold
+// 13 binades between the points of a batch times ~16 between the layers of the chain.)
 struct DzDst {
     __amdgpu_buffer_rsrc_t rsrc;      // the layer's dZ slot: n_tiles * kFragTileBytes (whole tiles: padding points carry zeros)
     unsigned voff;                    // bytes: tile * kFragTileBytes + (first channel block of this wave) * 2 * kFragBytes + lane * 16
-    const float* srow;                // LDS: per-point scale s_p of point 4 * (lane >> 5), row stride kRowH / 2 floats
 };
 // B operand of bwd_store's transposing MFMAs (see DzDst): lane (j = lane & 31, kg = lane >> 5) holds Sel[8 kg + m][j], m = 0..7,
 // per k-block - in the k order of the ACCUMULATOR registers (planes_to_frag's operands come from LDS in channel order).  Rebuilt
@@ -82,7 +84,7 @@ __device__ __forceinline__ Selector accumulator_selector(int lane) {
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int m = 0; m < 8; ++m)
-            sel.k[kb][m] = (16 * kb + 8 * (m >> 2) + 4 * (lane >> 5) + (m & 3)) == (lane & 31) ? (_Float16)(1.0f / kActScale) : (_Float16)0.0f;
+            sel.k[kb][m] = (16 * kb + 8 * (m >> 2) + 4 * (lane >> 5) + (m & 3)) == (lane & 31) ? (_Float16)1.0f : (_Float16)0.0f;
     return sel;
 }
 
@@ -138,31 +140,30 @@ __device__ __forceinline__ void bwd_store(const f32x16 (&am)[RB][2], float inv,
                 // invalid points carry zeros: no need to exclude them from the running maximum
                 gmax = fmaxf(gmax, fmaxf(fmaxf(fabsf(t[0]), fabsf(t[1])), fmaxf(fabsf(t[2]), fabsf(t[3]))) * back);
             }
-            // transpose (see DzDst): D'[point][channel] = sum_k A[point][k] Sel[k][channel], hi then lo, two k-blocks of 16 channels
-            f32x16 tr = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            // transpose (see DzDst): D'[point][channel] = sum_k A[point][k] Sel[k][channel], two k-blocks of 16 channels, hi and lo each
+            const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            f32x16 trh = zero, trl = zero;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 const f16x8 ah = {hi_g[2 * kb][0], hi_g[2 * kb][1], hi_g[2 * kb][2], hi_g[2 * kb][3],
                                   hi_g[2 * kb + 1][0], hi_g[2 * kb + 1][1], hi_g[2 * kb + 1][2], hi_g[2 * kb + 1][3]};
                 const f16x8 al = {lo_g[2 * kb][0], lo_g[2 * kb][1], lo_g[2 * kb][2], lo_g[2 * kb][3],
                                   lo_g[2 * kb + 1][0], lo_g[2 * kb + 1][1], lo_g[2 * kb + 1][2], lo_g[2 * kb + 1][3]};
-                tr = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, sel.k[kb], tr, 0, 0, 0);
-                tr = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, sel.k[kb], tr, 0, 0, 0);
+                trh = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, sel.k[kb], trh, 0, 0, 0);
+                trl = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, sel.k[kb], trl, 0, 0, 0);
             }
-            const float* sr = dst.srow + pb * 32 * (kRowH / 2);
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
+            for (int q = 0; q < 2; ++q) {
+                u32x4 oh, ol;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    f32x4 v;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int r = 8 * q + 4 * j + i;                     // point (r & 3) + 8 (r >> 2) (+ 4 (lane >> 5): in srow)
-                        v[i] = tr[r] * sr[((r & 3) + 8 * (r >> 2)) * (kRowH / 2)];
-                    }
-                    // (whole offset in the VGPR operand: a 16-byte buffer store with a register SGPR offset gets no hazard wait state, tests/test_isa_audit_cpu.py)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, rb, j)), 0, 0);
+                for (int i = 0; i < 4; ++i) {
+                    oh[i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(trh[8 * q + 2 * i], trh[8 * q + 2 * i + 1]));
+                    ol[i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(trl[8 * q + 2 * i], trl[8 * q + 2 * i + 1]));
                 }
+                // (whole offset in the VGPR operand: a 16-byte buffer store with a register SGPR offset gets no hazard wait state, tests/test_isa_audit_cpu.py)
+                __builtin_amdgcn_raw_buffer_store_b128(oh, dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, rb, 0)), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(ol, dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, rb, 1)), 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -339,6 +340,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
             for (int k = 0; k < 8; ++k) f[k] = dp[k] * is;
             f[8] = s;
             f[9] = is;
+            p.dz[p.off[SAVE_ENC] + gp] = s;        // the point's normaliser, beside the fragments (padding points: 1, with all-zero fragments)
         }
         STAMP();
         __syncthreads();
@@ -401,7 +403,6 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
             DzDst d;
             d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dz + p.off[slot], 0, (int)((unsigned)p.n_tiles * (unsigned)kFragTileBytes), 0x00020000);
             d.voff = (unsigned)tile * (unsigned)kFragTileBytes + (unsigned)(WCH / 32 * wave) * (2u * kFragBytes) + (unsigned)lane * 16u;
-            d.srow = reinterpret_cast<const float*>(ldsb) + 8 + 4 * (lane >> 5) * (kRowH / 2);
             return d;
         };
         f32x16 am[RB][2];
@@ -466,8 +467,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
             FragDst d;
             d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dz + p.off[SAVE_AS1H], 0, (int)((unsigned)p.n_tiles * (unsigned)kFragTileBytes), 0x00020000);
             d.voff = (unsigned)tile * (unsigned)kFragTileBytes + (unsigned)(WCH / 32 * wave) * (2u * kFragBytes) + (unsigned)lane * 16u;
-            planes_to_frag<RB, kRowH, kPlaneH, true>(xr + kColA + WCH * wave, plane_selector(lane_t, 1.0f / kActScale), d,
-                                                     reinterpret_cast<const float*>(ldsb) + 8 + 4 * (lane >> 5) * (kRowH / 2), kRowH / 2);
+            planes_to_frag<RB, kRowH, kPlaneH>(xr + kColA + WCH * wave, plane_selector(lane_t), d);
         }
 
         // ---------------- d h7 = W_feat^T d feature + W_as1^T dZ_as1 (+ W_sem1^T dZ_semh) + w_alpha d sigma ----------------

@@ -255,14 +255,10 @@ struct FragDst {
 };
 __device__ __forceinline__ unsigned frag_off(int kb, int cb, int plane) { return (unsigned)((kb * 8 + cb) * 2 + plane) * kFragBytes; }
 
-// NB: 32-channel blocks of this wave (consecutive, starting at the column `xa` points at).  SCALED (the chain's gradient slots):
-// hi and lo are transposed into ONE accumulator (their exact sum, 22 bits), every point's values are multiplied by
-// fscale[point * fstride] (the chain's per-point normaliser) and leave as fp32 in the same operand order - two 1 KB pieces per
-// 16-point k-block (points 0..3 | 4..7 of a lane's eight) where the split format has its hi | lo fragments.
-template <int NB, int ROW, int PLANE, bool SCALED = false>
+// NB: 32-channel blocks of this wave (consecutive, starting at the column `xa` points at).
+template <int NB, int ROW, int PLANE>
 __device__ __forceinline__ void planes_to_frag(const _Float16* xa /* plane_hi + (lane & 31) * ROW + 8 * (lane >> 5) + first column */,
-                                               const Selector& sel, const FragDst& dst,
-                                               const float* fscale = nullptr /* LDS: factor of point 4 * (lane >> 5) */, int fstride = 0) {
+                                               const Selector& sel, const FragDst& dst) {
     const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) {
@@ -275,59 +271,31 @@ __device__ __forceinline__ void planes_to_frag(const _Float16* xa /* plane_hi + 
             ah[pb][0] = *reinterpret_cast<const f16x8*>(src);          ah[pb][1] = *reinterpret_cast<const f16x8*>(src + 16);
             al[pb][0] = *reinterpret_cast<const f16x8*>(src + PLANE);  al[pb][1] = *reinterpret_cast<const f16x8*>(src + PLANE + 16);
         }
-        if constexpr (!SCALED) {
-            f32x16 th[2], tl[2];
+        f32x16 th[2], tl[2];
 #pragma unroll
-            for (int pb = 0; pb < 2; ++pb) {
-                th[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[pb][0], sel.k[0], zero, 0, 0, 0);
-                tl[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[pb][0], sel.k[0], zero, 0, 0, 0);
-            }
-#pragma unroll
-            for (int pb = 0; pb < 2; ++pb) {
-                th[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[pb][1], sel.k[1], th[pb], 0, 0, 0);
-                tl[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[pb][1], sel.k[1], tl[pb], 0, 0, 0);
-            }
-#pragma unroll
-            for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    u32x4 oh, ol;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        oh[i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(th[pb][8 * q + 2 * i], th[pb][8 * q + 2 * i + 1]));
-                        ol[i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(tl[pb][8 * q + 2 * i], tl[pb][8 * q + 2 * i + 1]));
-                    }
-                    // (whole offset in the VGPR operand: a 16-byte buffer store with a register SGPR offset gets no hazard wait state, tests/test_isa_audit_cpu.py)
-                    __builtin_amdgcn_raw_buffer_store_b128(oh, dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, cb, 0)), 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(ol, dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, cb, 1)), 0, 0);
-                }
-        } else {
-            f32x16 t[2];
-#pragma unroll
-            for (int pb = 0; pb < 2; ++pb) t[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[pb][0], sel.k[0], zero, 0, 0, 0);
-#pragma unroll
-            for (int pb = 0; pb < 2; ++pb) t[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[pb][1], sel.k[1], t[pb], 0, 0, 0);
-#pragma unroll
-            for (int pb = 0; pb < 2; ++pb) t[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[pb][0], sel.k[0], t[pb], 0, 0, 0);
-#pragma unroll
-            for (int pb = 0; pb < 2; ++pb) t[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[pb][1], sel.k[1], t[pb], 0, 0, 0);
-#pragma unroll
-            for (int pb = 0; pb < 2; ++pb) {
-                const float* fs = fscale + pb * 32 * fstride;
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        f32x4 v;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int r = 8 * q + 4 * j + i;
-                            v[i] = t[pb][r] * fs[((r & 3) + 8 * (r >> 2)) * fstride];
-                        }
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, cb, j)), 0, 0);
-                    }
-            }
+        for (int pb = 0; pb < 2; ++pb) {
+            th[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[pb][0], sel.k[0], zero, 0, 0, 0);
+            tl[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[pb][0], sel.k[0], zero, 0, 0, 0);
         }
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            th[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[pb][1], sel.k[1], th[pb], 0, 0, 0);
+            tl[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[pb][1], sel.k[1], tl[pb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                u32x4 oh, ol;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    oh[i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(th[pb][8 * q + 2 * i], th[pb][8 * q + 2 * i + 1]));
+                    ol[i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(tl[pb][8 * q + 2 * i], tl[pb][8 * q + 2 * i + 1]));
+                }
+                // (whole offset in the VGPR operand: a 16-byte buffer store with a register SGPR offset gets no hazard wait state, tests/test_isa_audit_cpu.py)
+                __builtin_amdgcn_raw_buffer_store_b128(oh, dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, cb, 0)), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(ol, dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, cb, 1)), 0, 0);
+            }
         __builtin_amdgcn_sched_barrier(0);
     }
 }

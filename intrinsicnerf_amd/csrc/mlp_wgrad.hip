@@ -11,10 +11,11 @@
 // The operands of that MFMA must hold, per lane, 8 consecutive k (= points) of one channel, while the network
 // kernels work point-major.  Two kernels:
 //   * k_mlp_wgrad_frag - the nine 256 x 256 products of a network (90 % of the operand bytes): both operands arrive as
-//     FRAGMENT slots, i.e. in operand order (the producers transpose with the matrix core and store whole 1 KB pieces) - the
-//     activations already split into f16 hi / lo, the gradients as fp32 (their scale is only known now).  The kernel is a ring
-//     of LDS stages filled by LDS-DMA (buffer_load ... lds: no row registers, no transposition), a three-instruction split of
-//     the wave's own G operands, and 24 MFMAs per wave and 16-point k-block; bound by HBM.
+//     FRAGMENT slots, i.e. split into f16 hi / lo and in operand order (the producers transpose with the matrix core and
+//     store whole 1 KB fragments) - the activations at the forward's fixed scale, the gradients NORMALISED per point, with
+//     the points' normalisers beside them (their common scale is only known now).  The kernel is a ring of LDS stages filled
+//     by LDS-DMA (buffer_load ... lds: no row registers, no transposition), a re-scaling of the wave's own G operands to the
+//     batch's max |dz|, and 24 MFMAs per wave and 16-point k-block; bound by HBM.
 //   * k_mlp_wgrad - every other shape (operands 32..128 wide, or 128 rows): row-format X (and G, unless it is a fragment
 //     slot) transposed inside the kernel by the matrix core: an MFMA of a [32 points x 16 channels] fragment (lane = point,
 //     8 consecutive channels: a natural 32-byte read of a point's row) with an identity matrix returns that block in
@@ -30,6 +31,7 @@ struct WgradParams {
     const float* G;          // [P, ldg] (pointer to the first used column)
     const float* X;          // [P, ldx]
     const float* ranges;     // device: {gmax, xmax}: upper bounds of |G| and |X|
+    const float* g_scale;    // GFRAG: the points' normalisers s_p (64 * n_tiles floats): G's fragments hold kActScale * dz / s_p
     float* partial;          // workgroup g writes its M x N tile at partial + g * partial_stride
     float* bias_partial;     // optional: workgroup g writes its column sums of G at bias_partial + g * partial_stride
     int64_t partial_stride;  // floats
@@ -85,8 +87,9 @@ __device__ __forceinline__ float transpose_block(f16x8 g0, f16x8 g1, f16x8 id0, 
 // M = 256 runs as 8 waves of <= 256 registers (128 of them accumulators): two waves per SIMD, so that one wave's loads and
 // conversions overlap the other's MFMAs.  (With 4 waves x 64 rows - 256 accumulator registers per lane - prefetching the
 // next tile spilled and was 20 % slower than not prefetching at all.)
-// GFRAG: G is a (fp32) fragment slot of the gradient buffer (this wave's 32 channels = channel block `wave`): its operands are
-// loaded in operand order - two 16-byte requests per lane and k-block - and only split.
+// GFRAG: G is a fragment slot of the gradient buffer (this wave's 32 channels = channel block `wave`): its operands are loaded
+// in operand order - two 16-byte requests per lane and k-block, plus the eight points' normalisers - and brought to this
+// product's scale (hi + lo, times s_p, split again).
 template <int NW, int CB, bool GFRAG = false>
 __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
     static_assert(!GFRAG || NW == 8, "fragment slots are 256 channels wide");
@@ -130,7 +133,10 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, (int)((unsigned)p.n_points * (unsigned)p.ldx * 4u), 0x00020000);
     const unsigned g_voff0 = (unsigned)(lp * p.ldg + 32 * wave + 8 * lh) * 4u, x_voff0 = (unsigned)(lp * p.ldx + 8 * lh) * 4u;
     float xraw[XS][2][2][8], graw[GFRAG ? 1 : 2][2][8];
-    f32x4 gfr[GFRAG ? 2 : 1][2][2];           // GFRAG: [point half][k-block][points 0..3 | 4..7 of the lane's eight]
+    f16x8 gfr[GFRAG ? 2 : 1][2][2];           // GFRAG: [point half][k-block][hi | lo]
+    f32x4 gsc[GFRAG ? 2 : 1][2][2];           // ... and the normalisers of the lane's points 0..3 | 4..7
+    const __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GFRAG ? p.g_scale : p.G), 0,
+                                                                             GFRAG ? p.n_tiles * kTilePoints * 4 : 0, 0x00020000);
     auto opaque = [](unsigned v) { asm volatile("" : "+v"(v)); return v; };      // keeps `voff + constant` an immediate, not a hoisted register
     auto load_x = [&](int tile, int ph) {
 #pragma unroll
@@ -148,8 +154,12 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    gfr[ph][q][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, (int)(voff + frag_off(2 * ph + q, wave, j)), 0, 0));
+                for (int j = 0; j < 2; ++j) {
+                    gfr[ph][q][j] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, (int)(voff + frag_off(2 * ph + q, wave, j)), 0, 0));
+                    // points 16 (4 tile + 2 ph + q) + 4 (lane >> 5) + 8 j + 0..3 (layout.h frag_point)
+                    gsc[ph][q][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                        s_rsrc, (int)opaque((unsigned)(tile * kTilePoints + 32 * ph + 16 * q + 4 * lh + 8 * j) * 4u), 0, 0));
+                }
         } else {
             const unsigned voff = opaque(g_voff0 + (unsigned)(tile * kTilePoints + 32 * ph) * (unsigned)p.ldg * 4u);
 #pragma unroll
@@ -206,10 +216,11 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
                 for (int q = 0; q < 2; ++q) {
                     float v[8];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { v[i] = gfr[ph][q][0][i]; v[4 + i] = gfr[ph][q][1][i]; }
-                    split8(v, sg, gh[q], gl[q]);
+                    for (int i = 0; i < 8; ++i)
+                        v[i] = ((float)gfr[ph][q][0][i] + (float)gfr[ph][q][1][i]) * (gsc[ph][q][i >> 2][i & 3] * (sg * (1.0f / kActScale)));
+                    split8(v, 1.0f, gh[q], gl[q]);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) bias_sum += v[i] * sg;            // (in units of 1 / sg, like the other form's)
+                    for (int i = 0; i < 8; ++i) bias_sum += v[i];            // (in units of 1 / sg, like the other form's)
                 }
             } else {
                 f16x8 h0, l0, h1, l1;
@@ -282,13 +293,15 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
 // ---------------------------------------------------------------------------------------------------------------------
 // 256 x 256 products (nine of a network's thirteen, 90 % of the weight-gradient bytes): both operands are FRAGMENT slots.
 //
-// Per 16-point k-block a slot holds 16 pieces of 1 KB ([32-channel block][hi | lo] - gradients: [points 0..3 | 4..7], fp32 -,
-// layout.h), contiguous: one LDS stage = 16 KB of G + 16 KB of X.  A ring of kFragStages stages is filled by LDS-DMA -
-// `buffer_load_dwordx4 ... lds` moves a piece from HBM to LDS in one instruction, lane l's 16 bytes to byte 16 l of the
+// Per 16-point k-block a slot holds 16 fragments of 1 KB ([32-channel block][hi | lo], layout.h), contiguous: one LDS stage =
+// 16 KB of G + 16 KB of X (+ the k-block's 16 normalisers).  A ring of kFragStages stages is filled by LDS-DMA -
+// `buffer_load_dwordx4 ... lds` moves a fragment from HBM to LDS in one instruction, lane l's 16 bytes to byte 16 l of the
 // destination, which is exactly where the lane that contracts reads its operand slot (conflict-free by construction) - so the
-// loads need no registers and nothing is transposed; X is consumed as it lands, a wave's own G operands (two blocks) are split
-// into f16 hi / lo with the batch's max |dz| as scale (16 three-instruction splits per k-block against 24 MFMAs); up to
-// kFragStages - 1 stages (96 KB per CU) are in flight while one is contracted.  Eight waves: wave w
+// loads need no registers and nothing is transposed.  X is consumed as it lands; G's fragments hold NORMALISED gradients
+// (kActScale * dz / s_p: the chain's own f16 halves, 22 bits whatever the point's gradient scale), so a wave brings its own
+// two G blocks to the product's scale first: hi + lo, times s_p and the power of two that puts the batch's max |dz| at 2^13,
+// split again - ~50 VALU instructions per block and k-block against 24 MFMAs.  Up to kFragStages - 1 stages (96 KB per CU) are
+// in flight while one is contracted.  Eight waves: wave w
 // requests fragments 4 (w & 3) .. + 3 of G (w < 4) or X (w >= 4) of every stage and contracts rows 64 (w & 3) .. + 63 x columns
 // 128 (w >> 2) .. + 127 (2 x 4 accumulator blocks; 12 operand reads and 24 MFMAs per k-block).
 // Synchronisation per stage: every wave waits for ITS OWN requests of the stage (counted vmcnt: the younger stages stay in
@@ -301,12 +314,14 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
 #endif
 constexpr int kFragStages = INERF_WGRAD_FRAG_STAGES;
 constexpr int kFragStageBytes = 2 * kFragKbBytes;               // G | X of one k-block
+constexpr int kFragScaleBytes = 8 * 256;                        // per stage: every wave's own copy of the k-block's normalisers (64 lanes x 4 bytes)
 static_assert(kFragStages >= 3 && kFragStages <= 5, "ring depth");
 
 struct WgradFragParams {
-    const void* G;           // fragment slot of dZ: fp32 in operand order
+    const void* G;           // fragment slot of dZ: f16 hi / lo of kActScale * dz / s_p
+    const float* g_scale;    // the points' normalisers s_p: 64 * n_tiles (+ 64 readable) floats
     const void* X;           // fragment slot of activations: f16 hi / lo of kActScale * h
-    const float* ranges;     // device: {gmax, ...}: upper bound of |G|
+    const float* ranges;     // device: {gmax, ...}: upper bound of |dz|
     float* partial;          // workgroup g writes its 256 x 256 tile at partial + g * partial_stride
     float* bias_partial;     // optional: ... its column sums of G
     int64_t partial_stride;  // floats
@@ -324,8 +339,11 @@ __global__ __launch_bounds__(512, 1) void k_mlp_wgrad_frag(const WgradFragParams
                                                                            (int)((unsigned)p.n_kb * (unsigned)kFragKbBytes), 0x00020000);
     const int my_bytes = (dma_g ? 0 : kFragKbBytes) + (wave & 3) * 4 * kFragBytes;      // this wave's four fragments inside a stage
     const int src_bytes = (wave & 3) * 4 * kFragBytes;                                   // ... inside its matrix's k-block
-    // one stage: four requests; lane l's 16 bytes of fragment j land at stage + my_bytes + 1024 j + 16 l (the instruction
-    // offset advances the source and the destination alike)
+    const __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.g_scale), 0, (p.n_kb * 16 + 64) * 4, 0x00020000);
+    char* const scale_lds = ldsw + kFragStages * kFragStageBytes + wave * 256;          // + buf * kFragScaleBytes
+    // one stage: four fragment requests - lane l's 16 bytes of fragment j land at stage + my_bytes + 1024 j + 16 l (the
+    // instruction offset advances the source and the destination alike) - and one for the k-block's normalisers (lane l's float
+    // = point 16 kb + l; 16 of the 64 are used): every wave fetches its OWN copy, so that nothing but its own counter orders them
     auto request = [&](int kb, int buf) {
         __attribute__((address_space(3))) char* dst = (__attribute__((address_space(3))) char*)(ldsw) + buf * kFragStageBytes + my_bytes;
         const int soff = (int)((unsigned)kb * (unsigned)kFragKbBytes) + src_bytes;
@@ -333,6 +351,7 @@ __global__ __launch_bounds__(512, 1) void k_mlp_wgrad_frag(const WgradFragParams
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, lane * 16, soff, 1 * kFragBytes, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, lane * 16, soff, 2 * kFragBytes, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, lane * 16, soff, 3 * kFragBytes, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (__attribute__((address_space(3))) char*)(scale_lds) + buf * kFragScaleBytes, 4, lane * 4, kb * 64, 0, 0);
     };
     const int rb0 = 2 * (wave & 3), cb0 = 4 * (wave >> 2);
     f32x16 acc[2][4];
@@ -345,27 +364,31 @@ __global__ __launch_bounds__(512, 1) void k_mlp_wgrad_frag(const WgradFragParams
     float bias_sum[2] = {0.0f, 0.0f};          // waves 0..3: this lane's channel of row block rb, its k-half's points (units of 1 / sg)
     auto pow2_for = [](float m) { int e; if (!(m > 0.0f) || !(m < 3.0e38f)) return 1.0f; frexpf(m, &e); return ldexpf(1.0f, 14 - e); };
     const float sg = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pow2_for(p.ranges[0]))));
+    const float sgc = sg * (1.0f / kActScale);
     auto contract = [&](int buf) {
         const char* gset = ldsw + buf * kFragStageBytes + lane * 16;
         const char* xset = gset + kFragKbBytes;
         auto frag = [&](const char* set, int block, int plane) { return *reinterpret_cast<const f16x8*>(set + (block * 2 + plane) * kFragBytes); };
         f16x8 gh[2], gl[2], xh[2], xl[2];
-        f32x4 graw[2][2];
+        f16x8 g16[2][2];
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            graw[rb][0] = *reinterpret_cast<const f32x4*>(gset + ((rb0 + rb) * 2 + 0) * kFragBytes);
-            graw[rb][1] = *reinterpret_cast<const f32x4*>(gset + ((rb0 + rb) * 2 + 1) * kFragBytes);
-        }
+        for (int rb = 0; rb < 2; ++rb) { g16[rb][0] = frag(gset, rb0 + rb, 0); g16[rb][1] = frag(gset, rb0 + rb, 1); }
+        // the normalisers of this lane's eight points: 16 kb + 4 (lane >> 5) + 0..3 and + 8..11 (layout.h frag_point)
+        const float* sc = reinterpret_cast<const float*>(scale_lds + buf * kFragScaleBytes) + 4 * lh;
+        const f32x4 s03 = *reinterpret_cast<const f32x4*>(sc), s47 = *reinterpret_cast<const f32x4*>(sc + 8);
         xh[0] = frag(xset, cb0, 0); xl[0] = frag(xset, cb0, 1);
+        float spc[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { spc[i] = s03[i] * sgc; spc[4 + i] = s47[i] * sgc; }
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
             float v[8];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { v[i] = graw[rb][0][i]; v[4 + i] = graw[rb][1][i]; }
-            split8(v, sg, gh[rb], gl[rb]);
+            for (int i = 0; i < 8; ++i) v[i] = ((float)g16[rb][0][i] + (float)g16[rb][1][i]) * spc[i];
+            split8(v, 1.0f, gh[rb], gl[rb]);
             if (wave < 4 && p.bias_partial) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) bias_sum[rb] += v[i] * sg;
+                for (int i = 0; i < 8; ++i) bias_sum[rb] += v[i];
             }
         }
 #pragma unroll
@@ -391,11 +414,11 @@ __global__ __launch_bounds__(512, 1) void k_mlp_wgrad_frag(const WgradFragParams
         if (j < n_mine) request(b + j * g, j);
     int buf = 0;
     for (int i = 0; i < n_mine; ++i) {
-        // requests of stages i + 1 .. may stay in flight: four per stage, at most kFragStages - 2 stages, fewer at the end
+        // requests of stages i + 1 .. may stay in flight: five per stage, at most kFragStages - 2 stages, fewer at the end
         const int ahead = n_mine - 1 - i;
-        if (ahead >= 3 && kFragStages >= 5) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (ahead >= 2 && kFragStages >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (ahead >= 3 && kFragStages >= 5) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+        else if (ahead >= 2 && kFragStages >= 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -483,42 +506,43 @@ extern "C" int inerf_mlp_weight_gradient(const float* G, int ldg, const float* X
     if ((ldg & 3) || (ldx & 3) || (((uintptr_t)G | (uintptr_t)X) & 15)) return INERF_E_INVALID;      // 16-byte row pieces
     if (partial_stride < (int64_t)M * N) return INERF_E_INVALID;
     WgradParams p;
-    p.G = G; p.X = X; p.ranges = ranges; p.partial = partial; p.bias_partial = bias_partial; p.partial_stride = partial_stride;
+    p.G = G; p.g_scale = nullptr; p.X = X; p.ranges = ranges; p.partial = partial; p.bias_partial = bias_partial; p.partial_stride = partial_stride;
     p.ldg = ldg; p.ldx = ldx; p.n_points = (int)n_points; p.M = M; p.N = N;
     p.n_tiles = (int)((n_points + kTilePoints - 1) / kTilePoints);
     return launch_rows(p, false, stream);
 }
 
-// G: a (fp32) FRAGMENT slot of the gradient buffer (256 channels); X: rows.  ranges: device {gmax, xmax} as above.
-extern "C" int inerf_mlp_weight_gradient_gfrag(const void* G_frag, const float* X, int ldx, int64_t n_points, int N,
+// G: a FRAGMENT slot of the gradient buffer (256 channels) and the points' normalisers (slot 0 of that buffer); X: rows.
+extern "C" int inerf_mlp_weight_gradient_gfrag(const void* G_frag, const float* g_scale, const float* X, int ldx, int64_t n_points, int N,
                                                const float* ranges, float* partial, float* bias_partial, int64_t partial_stride,
                                                void* stream) {
     using namespace inerf;
-    if (!G_frag || !X || !ranges || !partial || n_points <= 0 || ldx < N) return INERF_E_INVALID;
+    if (!G_frag || !g_scale || !X || !ranges || !partial || n_points <= 0 || ldx < N) return INERF_E_INVALID;
     if (n_points > kMaxTrainPoints) return INERF_E_UNSUPPORTED;
-    if ((ldx & 3) || (((uintptr_t)G_frag | (uintptr_t)X) & 15)) return INERF_E_INVALID;
+    if ((ldx & 3) || (((uintptr_t)G_frag | (uintptr_t)X | (uintptr_t)g_scale) & 15)) return INERF_E_INVALID;
     if (partial_stride < (int64_t)kWidth * N) return INERF_E_INVALID;
     WgradParams p;
-    p.G = static_cast<const float*>(G_frag); p.X = X; p.ranges = ranges; p.partial = partial; p.bias_partial = bias_partial;
+    p.G = static_cast<const float*>(G_frag); p.g_scale = g_scale; p.X = X; p.ranges = ranges; p.partial = partial; p.bias_partial = bias_partial;
     p.partial_stride = partial_stride;
     p.ldg = kWidth; p.ldx = ldx; p.n_points = (int)n_points; p.M = kWidth; p.N = N;
     p.n_tiles = (int)((n_points + kTilePoints - 1) / kTilePoints);
     return launch_rows(p, true, stream);
 }
 
-// Both operands FRAGMENT slots (256 x 256): G of the gradient buffer (fp32), X of the activation buffer (split), on the same
-// n_points.  ranges: device {gmax, ...}: an upper bound of |G| (the dz_max of inerf_mlp_backward_inputs).
-extern "C" int inerf_mlp_weight_gradient_frag(const void* G_frag, const void* X_frag, const float* ranges, int64_t n_points,
-                                              float* partial, float* bias_partial, int64_t partial_stride, void* stream) {
+// Both operands FRAGMENT slots (256 x 256): G of the gradient buffer with the points' normalisers, X of the activation buffer,
+// on the same n_points.  ranges: device {gmax, ...}: an upper bound of |dz| (the dz_max of inerf_mlp_backward_inputs).
+extern "C" int inerf_mlp_weight_gradient_frag(const void* G_frag, const float* g_scale, const void* X_frag, const float* ranges,
+                                              int64_t n_points, float* partial, float* bias_partial, int64_t partial_stride, void* stream) {
     using namespace inerf;
-    if (!G_frag || !X_frag || !ranges || !partial || n_points <= 0) return INERF_E_INVALID;
+    if (!G_frag || !g_scale || !X_frag || !ranges || !partial || n_points <= 0) return INERF_E_INVALID;
     if (n_points > kMaxTrainPoints) return INERF_E_UNSUPPORTED;
-    if ((((uintptr_t)G_frag | (uintptr_t)X_frag) & 15) || partial_stride < (int64_t)kWidth * kWidth) return INERF_E_INVALID;
+    if ((((uintptr_t)G_frag | (uintptr_t)X_frag) & 15) || ((uintptr_t)g_scale & 3) || partial_stride < (int64_t)kWidth * kWidth) return INERF_E_INVALID;
     WgradFragParams p;
-    p.G = G_frag; p.X = X_frag; p.ranges = ranges; p.partial = partial; p.bias_partial = bias_partial; p.partial_stride = partial_stride;
+    p.G = G_frag; p.g_scale = g_scale; p.X = X_frag; p.ranges = ranges; p.partial = partial; p.bias_partial = bias_partial;
+    p.partial_stride = partial_stride;
     p.n_kb = (int)((n_points + kTilePoints - 1) / kTilePoints) * 4;
     const int grid = inerf_wgrad_grid(n_points);
-    constexpr int lds = kFragStages * kFragStageBytes;
+    constexpr int lds = kFragStages * (kFragStageBytes + kFragScaleBytes);
     static PerDeviceOnce attr_set;
     if (attr_set.first()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_wgrad_frag), hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -363,8 +363,9 @@ extern "C" int inerf_mlp_backward(const inerf_net_desc* net, const float* packed
         float* tile = partial + j.src;
         float* bias = j.bias_src >= 0 ? partial + j.bias_src : nullptr;
         const bool g_frag = !l.sem && save_is_frag(l.g_slot, true), x_frag = save_is_frag(l.x_slot, false);
-        if (g_frag && x_frag) rc = inerf_mlp_weight_gradient_frag(G, X, sc + 4, n_points, tile, bias, t.total, stream);
-        else if (g_frag)      rc = inerf_mlp_weight_gradient_gfrag(G, X, save_width(*net, l.x_slot), n_points, j.n, sc + 4, tile, bias, t.total, stream);
+        const float* g_scale = dz + save_offset(*net, SAVE_ENC, n_points);        // the points' normalisers, written by the chain
+        if (g_frag && x_frag) rc = inerf_mlp_weight_gradient_frag(G, g_scale, X, sc + 4, n_points, tile, bias, t.total, stream);
+        else if (g_frag)      rc = inerf_mlp_weight_gradient_gfrag(G, g_scale, X, save_width(*net, l.x_slot), n_points, j.n, sc + 4, tile, bias, t.total, stream);
         else if (x_frag)      rc = INERF_E_UNSUPPORTED;       // (no product of the table reads row gradients against fragment activations)
         else rc = inerf_mlp_weight_gradient(G, ldg, X, save_width(*net, l.x_slot), n_points, j.m, j.n, sc + (l.sem ? 8 : 4), tile, bias, t.total, stream);
         if (rc) return rc;

@@ -499,22 +499,24 @@ def frag_encode(rows, scale=ACT_SCALE):
     return both.permute(1, 2, 3, 7, 0, 5, 8, 4, 6).contiguous().view(-1)     # [tile, pb, q, cb, plane, h, c, i_hi, i_lo]
 
 
-def grad_frag_decode(frag, n_points):
-    """A 256-wide FRAGMENT slot of a GRADIENT buffer (fp32 in the same operand order: where the split format has a k-block's
-    hi | lo pieces this one has the lane's points 0..3 | 4..7) -> the fp32 [n_points, 256] matrix."""
-    tiles = frag.numel() // (64 * 256)
-    v = frag.view(tiles, 2, 2, 8, 2, 2, 32, 4)                               # [tile, pb, q, cb, j = i_hi, h, c, i_lo]
-    return v.permute(0, 1, 2, 4, 5, 7, 3, 6).reshape(tiles * 64, 256)[:n_points]       # -> [tile, pb, q, i_hi, h, i_lo, cb, c]
-
-
 def grad_frag_encode(rows):
-    """fp32 [n_points, 256] -> the gradient-buffer FRAGMENT slot of ``grad_frag_decode`` (padding points zero)."""
+    """fp32 [n_points, 256] gradients -> (FRAGMENT slot, normalisers) as the input-gradient chain writes them into a gradient
+    buffer: every point p is normalised by s_p = the power of two above its largest |value| (the chain uses its largest HEAD
+    gradient; any power of two keeps the encoding exact) and stored as the split f16 halves of 8 * value / s_p;
+    normalisers: float32[64 * ceil(n / 64) + 64] (1 for padding points; 64 readable floats behind the end)."""
     n = rows.shape[0]
     tiles = (n + 63) // 64
-    v = torch.zeros(tiles * 64, 256, dtype=torch.float32, device=rows.device)
-    v[:n] = rows.float()
-    v = v.view(tiles, 2, 2, 2, 2, 4, 8, 32)                                  # [tile, pb, q, i_hi, h, i_lo, cb, c]
-    return v.permute(0, 1, 2, 6, 3, 4, 7, 5).contiguous().view(-1)           # [tile, pb, q, cb, i_hi, h, c, i_lo]
+    m = rows.float().abs().amax(1)
+    _, e = torch.frexp(m)
+    s = torch.where(m > 0, torch.ldexp(torch.ones_like(m), e), torch.ones_like(m))
+    scales = torch.ones(tiles * 64 + 64, dtype=torch.float32, device=rows.device)
+    scales[:n] = s
+    return frag_encode(rows.float() / s[:, None], ACT_SCALE), scales
+
+
+def grad_frag_decode(frag, scales, n_points):
+    """The inverse: (FRAGMENT slot of a gradient buffer, the points' normalisers) -> fp32 [n_points, 256]."""
+    return frag_decode(frag, n_points, ACT_SCALE) * scales[:n_points, None]
 
 
 def save_slot_views(desc, buf, n_points, gradient=False):
@@ -523,12 +525,14 @@ def save_slot_views(desc, buf, n_points, gradient=False):
     views = []
     lib = _capi.lib()
     off, width = C.c_int64(), C.c_int()
+    padded = (n_points + 63) // 64 * 64
     for slot in range(SAVE_SLOTS):
         _capi.check(lib.inerf_mlp_save_slot(desc, slot, n_points, C.byref(off), C.byref(width)), "inerf_mlp_save_slot")
         if lib.inerf_mlp_save_slot_is_fragment(slot, 1 if gradient else 0) == 1:
-            padded = (n_points + 63) // 64 * 64
             frag = buf[off.value: off.value + padded * width.value]
-            views.append(grad_frag_decode(frag, n_points) if gradient else frag_decode(frag, n_points))
+            views.append(grad_frag_decode(frag, views[SAVE_ENC], n_points) if gradient else frag_decode(frag, n_points))
+        elif gradient and slot == SAVE_ENC:         # the points' normalisers (include/inerf.h), not an [n, 64] matrix
+            views.append(buf[off.value: off.value + padded])
         else:
             views.append(buf[off.value: off.value + n_points * width.value].view(n_points, width.value))
     return views
@@ -700,11 +704,11 @@ def weight_gradient(g, x, m, n, ranges=None, want_bias=False):
     return (b.result(k), b.bias(k)) if want_bias else b.result(k)
 
 
-def weight_gradient_frag(g_frag, x_frag, ranges, n_points, want_bias=False, x_rows=None, n=256):
-    """G^T X with G a FRAGMENT slot of a gradient buffer (256 channels, fp32 in operand order) through the HIP split-K kernels:
-    against ``x_frag``, a FRAGMENT slot of activations (split f16; the LDS-DMA kernel, 256 x 256), or, with ``x_rows``
-    ([n_points, >= n] fp32 rows), against row-format activations.  ``ranges``: float32[2] device tensor, upper bounds of |G|
-    and |X|."""
+def weight_gradient_frag(g_frag, g_scale, x_frag, ranges, n_points, want_bias=False, x_rows=None, n=256):
+    """G^T X with G a FRAGMENT slot of a gradient buffer (256 channels; ``g_scale``: the points' normalisers, see
+    ``grad_frag_encode``) through the HIP split-K kernels: against ``x_frag``, a FRAGMENT slot of activations (the LDS-DMA
+    kernel, 256 x 256), or, with ``x_rows`` ([n_points, >= n] fp32 rows), against row-format activations.  ``ranges``:
+    float32[2] device tensor, upper bounds of the true |G| and of |X|."""
     lib = _capi.lib()
     grid = lib.inerf_wgrad_grid(n_points)
     total = 256 * n + (256 if want_bias else 0)
@@ -713,9 +717,10 @@ def weight_gradient_frag(g_frag, x_frag, ranges, n_points, want_bias=False, x_ro
     bias = C.c_void_p(base + 4 * 256 * n) if want_bias else None
     with torch.cuda.device(ranges.device):
         if x_rows is None:
-            rc = lib.inerf_mlp_weight_gradient_frag(_ptr(g_frag), _ptr(x_frag), _ptr(ranges), n_points, C.c_void_p(base), bias, total, _stream(ranges))
+            rc = lib.inerf_mlp_weight_gradient_frag(_ptr(g_frag), _ptr(g_scale), _ptr(x_frag), _ptr(ranges), n_points, C.c_void_p(base), bias,
+                                                    total, _stream(ranges))
         else:
-            rc = lib.inerf_mlp_weight_gradient_gfrag(_ptr(g_frag), C.c_void_p(x_rows.data_ptr()), x_rows.stride(0), n_points, n,
+            rc = lib.inerf_mlp_weight_gradient_gfrag(_ptr(g_frag), _ptr(g_scale), C.c_void_p(x_rows.data_ptr()), x_rows.stride(0), n_points, n,
                                                      _ptr(ranges), C.c_void_p(base), bias, total, _stream(ranges))
     _capi.check(rc, "inerf_mlp_weight_gradient_frag")
     sums = buf.sum(0)

@@ -61,7 +61,7 @@ def frag_slot(buf, slot):
 
 
 ranges = torch.cat([dz_max, act_max])
-t_one, _ = timed(lambda: kernels.weight_gradient_frag(frag_slot(dz, kernels.SAVE_H0 + 3), frag_slot(save, kernels.SAVE_H0 + 2), ranges, p, want_bias=True))
+t_one, _ = timed(lambda: kernels.weight_gradient_frag(frag_slot(dz, kernels.SAVE_H0 + 3), frag_slot(dz, kernels.SAVE_ENC), frag_slot(save, kernels.SAVE_H0 + 2), ranges, p, want_bias=True))
 gb = save.numel() * 4 / 1e9
 saved = (8 * 256 + 256 + 256 + 256 + 128 + 96) * 4 * p / 1e9          # what the training forward writes (h0..h7 fragments, h7 rows, as1h, feat, vh, enc + dir)
 print(f"{n} rays x {s} samples = {p} points; activation buffer {gb:.2f} GB")

@@ -431,8 +431,8 @@ def test_weight_gradient_kernel_vs_fp64(p, m, n):
 @pytest.mark.gpu
 @pytest.mark.parametrize("p", [1, 15, 17, 63, 65, 1000, 5000, 70001, 131072])
 def test_weight_gradient_from_fragment_slots(p):
-    """The LDS-DMA kernel of the nine 256 x 256 products (both operands FRAGMENT slots, include/inerf.h: fp32 gradients in
-    operand order x split-f16 activations) and the mixed form (G fragments x row-format X, 64 columns) against fp64 products of
+    """The LDS-DMA kernel of the nine 256 x 256 products (both operands FRAGMENT slots, include/inerf.h: per-point normalised
+    gradients with their normalisers x activations) and the mixed form (G fragments x row-format X, 64 columns) against fp64 products of
     what the fragments encode - down to a single sample point (k-blocks and tiles that are mostly padding), ragged counts,
     more k-blocks than the ring is deep and than the grid is wide; gradients spanning four decades.  The row-format kernel
     on the same matrices agrees."""
@@ -441,21 +441,20 @@ def test_weight_gradient_from_fragment_slots(p):
     g = torch.Generator().manual_seed(100 + p)
     G = (torch.randn(p, 256, generator=g) * torch.logspace(0, -4, p)[:, None] * 2.0 ** -7 * 0.9).to(dev)
     X = torch.relu(torch.randn(p, 256, generator=g) * 3).to(dev)
-    gf = kernels.grad_frag_encode(G)
+    gf, gs = kernels.grad_frag_encode(G)
     xf = kernels.frag_encode(X)
-    assert torch.equal(kernels.grad_frag_decode(gf, p), G)
-    Gq, Xq = G.double(), kernels.frag_decode(xf, p).double()
-    assert float((Xq - X.double()).norm()) <= 1e-6 * float(X.double().norm())
+    Gq, Xq = kernels.grad_frag_decode(gf, gs, p).double(), kernels.frag_decode(xf, p).double()
+    assert float((Gq - G.double()).norm()) <= 1e-6 * float(G.double().norm()) and float((Xq - X.double()).norm()) <= 1e-6 * float(X.double().norm())
     want_w, want_b = Gq.t() @ Xq, Gq.sum(0)
     ranges = torch.stack([G.abs().max() * 1.7, X.abs().max()]).float()          # upper bounds, as the training kernels deliver them
-    w, b = kernels.weight_gradient_frag(gf, xf, ranges, p, want_bias=True)
+    w, b = kernels.weight_gradient_frag(gf, gs, xf, ranges, p, want_bias=True)
     assert float((w.double() - want_w).norm()) <= 2e-6 * float(want_w.norm())
     assert float((b.double() - want_b).norm()) <= 2e-6 * float(want_b.norm()) + 1e-12
-    w0 = kernels.weight_gradient_frag(gf, xf, ranges, p)                                        # without the bias sums
+    w0 = kernels.weight_gradient_frag(gf, gs, xf, ranges, p)                                    # without the bias sums
     assert torch.equal(w0, w)
     # G fragments x 64 columns of row-format X (pts_linears.0 / .5 against the encoding)
     xr = X[:, 64:128]
-    w64, b64 = kernels.weight_gradient_frag(gf, None, ranges, p, want_bias=True, x_rows=xr, n=64)
+    w64, b64 = kernels.weight_gradient_frag(gf, gs, None, ranges, p, want_bias=True, x_rows=xr, n=64)
     want64 = Gq.t() @ xr.double()
     assert float((w64.double() - want64).norm()) <= 2e-6 * float(want64.norm())
     assert float((b64.double() - want_b).norm()) <= 2e-6 * float(want_b.norm()) + 1e-12

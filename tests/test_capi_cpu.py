@@ -109,8 +109,8 @@ def test_argument_validation(capi):
     assert [lib.inerf_mlp_save_slot_is_fragment(s, 0) for s in range(16)] == [0, 0] + [1] * 8 + [0] * 6
     assert [lib.inerf_mlp_save_slot_is_fragment(s, 1) for s in range(16)] == [0, 0] + [1] * 10 + [0] * 4
     assert lib.inerf_mlp_save_slot_is_fragment(16, 0) == capi.E_INVALID
-    assert lib.inerf_mlp_weight_gradient_frag(None, None, None, 1000, None, None, 65536, None) == capi.E_INVALID
-    assert lib.inerf_mlp_weight_gradient_gfrag(None, None, 64, 1000, 64, None, None, None, 16384, None) == capi.E_INVALID
+    assert lib.inerf_mlp_weight_gradient_frag(None, None, None, None, 1000, None, None, 65536, None) == capi.E_INVALID
+    assert lib.inerf_mlp_weight_gradient_gfrag(None, None, None, 64, 1000, 64, None, None, None, 16384, None) == capi.E_INVALID
     assert lib.inerf_wgrad_grid(0) == 0 and lib.inerf_mlp_backward_grid(64 * 7) == 7
     assert lib.inerf_mlp_head_partial_floats() == 1672
 

@@ -264,7 +264,7 @@ def test_ssr_trainer_with_another_netwidth_runs_staged():
     H, W = 240, 320
     fx = W / 2.0 / np.tan(np.deg2rad(45.0))
     rays = ssr.create_rays(1, torch.eye(4)[None], H, W, fx, fx, (W - 1.0) / 2.0, (H - 1.0) / 2.0, 0.1, 10.0).reshape(-1, 11)
-    sub = rays[torch.arange(0, H * W, 301)].contiguous()
+    sub = rays[torch.arange(0, H * W, 61)].contiguous()
     with torch.no_grad():       # default init leaves the density near zero and of one sign: a density head that straddles zero on this camera
         z = torch.linspace(0.1, 10.0, 64)
         pts = (sub[:, None, 0:3] + sub[:, None, 3:6] * z[None, :, None]).reshape(-1, 3)
@@ -296,7 +296,7 @@ def test_ssr_trainer_with_another_netwidth_runs_staged():
                                for k in o32 if not k.startswith("raw")])
     score = np.maximum(score, cal.fine_pass_hazard(sub, sd_f, cfg, o32, o64, subset=score <= 0.2))
     well = score <= 0.2
-    assert well.sum() >= 30, int(well.sum())
+    assert well.sum() >= 20, int(well.sum())       # (a white-spectrum random network: most rays are ill-conditioned in the reference itself)
     # (the layers are library GEMMs on the GPU against the oracle's on the CPU: another summation order, same tolerance)
     for k in sorted(keys | {"z_std", "sem_logits_coarse", "sem_logits_fine"}):
         assert_maps_close(out[k].cpu().numpy()[well], o32[ren.get(k, k)].numpy()[well], 5e-4 if k.startswith("disp") else RTOL, ATOL, k)
