@@ -217,7 +217,10 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
                     float v[8];
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
-                        v[i] = ((float)gfr[ph][q][0][i] + (float)gfr[ph][q][1][i]) * (gsc[ph][q][i >> 2][i & 3] * (sg * (1.0f / kActScale)));
+                    {
+                        const float spc = gsc[ph][q][i >> 2][i & 3] * (sg * (1.0f / kActScale));          // a power of two: both products exact
+                        v[i] = __builtin_fmaf((float)gfr[ph][q][0][i], spc, (float)gfr[ph][q][1][i] * spc);
+                    }
                     split8(v, 1.0f, gh[q], gl[q]);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) bias_sum += v[i];            // (in units of 1 / sg, like the other form's)
@@ -302,8 +305,8 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
 // two G blocks to the product's scale first: hi + lo, times s_p and the power of two that puts the batch's max |dz| at 2^13,
 // split again - ~50 VALU instructions per block and k-block against 24 MFMAs.  Up to kFragStages - 1 stages (96 KB per CU) are
 // in flight while one is contracted.  Eight waves: wave w
-// requests fragments 4 (w & 3) .. + 3 of G (w < 4) or X (w >= 4) of every stage and contracts rows 64 (w & 3) .. + 63 x columns
-// 128 (w >> 2) .. + 127 (2 x 4 accumulator blocks; 12 operand reads and 24 MFMAs per k-block).
+// requests fragments 4 (w & 3) .. + 3 of G (w < 4) or X (w >= 4) of every stage and contracts rows 32 w .. + 31 x all 256 columns
+// (1 x 8 accumulator blocks: 18 operand reads and 24 MFMAs per k-block) - every G block is rescaled by exactly one wave.
 // Synchronisation per stage: every wave waits for ITS OWN requests of the stage (counted vmcnt: the younger stages stay in
 // flight), then one raw s_barrier - behind it every wave's fragments of the stage have landed, and every wave has finished
 // reading the stage before, whose buffer is the one re-filled next.  (A __syncthreads() would drain vmcnt to 0.)
@@ -353,15 +356,12 @@ __global__ __launch_bounds__(512, 1) void k_mlp_wgrad_frag(const WgradFragParams
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, lane * 16, soff, 3 * kFragBytes, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (__attribute__((address_space(3))) char*)(scale_lds) + buf * kFragScaleBytes, 4, lane * 4, kb * 64, 0, 0);
     };
-    const int rb0 = 2 * (wave & 3), cb0 = 4 * (wave >> 2);
-    f32x16 acc[2][4];
+    f32x16 acc[8];                             // rows 32 wave .. + 31, column block cb
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int cb = 0; cb < 8; ++cb)
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.0f;
-    float bias_sum[2] = {0.0f, 0.0f};          // waves 0..3: this lane's channel of row block rb, its k-half's points (units of 1 / sg)
+        for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
+    float bias_sum = 0.0f;                     // this lane's channel of the wave's row block, its k-half's points (units of 1 / sg)
     auto pow2_for = [](float m) { int e; if (!(m > 0.0f) || !(m < 3.0e38f)) return 1.0f; frexpf(m, &e); return ldexpf(1.0f, 14 - e); };
     const float sg = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pow2_for(p.ranges[0]))));
     const float sgc = sg * (1.0f / kActScale);
@@ -369,38 +369,33 @@ __global__ __launch_bounds__(512, 1) void k_mlp_wgrad_frag(const WgradFragParams
         const char* gset = ldsw + buf * kFragStageBytes + lane * 16;
         const char* xset = gset + kFragKbBytes;
         auto frag = [&](const char* set, int block, int plane) { return *reinterpret_cast<const f16x8*>(set + (block * 2 + plane) * kFragBytes); };
-        f16x8 gh[2], gl[2], xh[2], xl[2];
-        f16x8 g16[2][2];
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) { g16[rb][0] = frag(gset, rb0 + rb, 0); g16[rb][1] = frag(gset, rb0 + rb, 1); }
+        f16x8 gh, gl, xh[2], xl[2];
+        const f16x8 g16h = frag(gset, wave, 0), g16l = frag(gset, wave, 1);
         // the normalisers of this lane's eight points: 16 kb + 4 (lane >> 5) + 0..3 and + 8..11 (layout.h frag_point)
         const float* sc = reinterpret_cast<const float*>(scale_lds + buf * kFragScaleBytes) + 4 * lh;
         const f32x4 s03 = *reinterpret_cast<const f32x4*>(sc), s47 = *reinterpret_cast<const f32x4*>(sc + 8);
-        xh[0] = frag(xset, cb0, 0); xl[0] = frag(xset, cb0, 1);
-        float spc[8];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { spc[i] = s03[i] * sgc; spc[4 + i] = s47[i] * sgc; }
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
+        xh[0] = frag(xset, 0, 0); xl[0] = frag(xset, 0, 1);
+        {   // this wave's G block at the product's scale: (hi + lo) x s_p x 2^k - both products exact (powers of two), one rounding
+            // that does nothing (22 bits) - then the usual split
             float v[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = ((float)g16[rb][0][i] + (float)g16[rb][1][i]) * spc[i];
-            split8(v, 1.0f, gh[rb], gl[rb]);
-            if (wave < 4 && p.bias_partial) {
+            for (int i = 0; i < 8; ++i) {
+                const float spc = (i < 4 ? s03[i & 3] : s47[i & 3]) * sgc;
+                v[i] = __builtin_fmaf((float)g16h[i], spc, (float)g16l[i] * spc);
+            }
+            split8(v, 1.0f, gh, gl);
+            if (p.bias_partial) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) bias_sum[rb] += v[i];
+                for (int i = 0; i < 8; ++i) bias_sum += v[i];
             }
         }
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {     // X operands one read ahead of their MFMAs, fenced (unfenced, the scheduler hoists every read to the top)
-            if (cb + 1 < 4) { xh[(cb + 1) & 1] = frag(xset, cb0 + cb + 1, 0); xl[(cb + 1) & 1] = frag(xset, cb0 + cb + 1, 1); }
+        for (int cb = 0; cb < 8; ++cb) {     // X operands one read ahead of their MFMAs, fenced (unfenced, the scheduler hoists every read to the top)
+            if (cb + 1 < 8) { xh[(cb + 1) & 1] = frag(xset, cb + 1, 0); xl[(cb + 1) & 1] = frag(xset, cb + 1, 1); }
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
-                acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[rb], xh[cb & 1], acc[rb][cb], 0, 0, 0);
-                acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[rb], xl[cb & 1], acc[rb][cb], 0, 0, 0);
-                acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl[rb], xh[cb & 1], acc[rb][cb], 0, 0, 0);
-            }
+            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xh[cb & 1], acc[cb], 0, 0, 0);
+            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xl[cb & 1], acc[cb], 0, 0, 0);
+            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl, xh[cb & 1], acc[cb], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -428,24 +423,19 @@ __global__ __launch_bounds__(512, 1) void k_mlp_wgrad_frag(const WgradFragParams
     }
 
     // ---- this workgroup's partial tile and its column sums of G ----
-    if (p.bias_partial && wave < 4) {          // the two lane halves hold complementary points of the same channel
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            const float both = bias_sum[rb] + __shfl_xor(bias_sum[rb], 32);
-            if (lh == 0) p.bias_partial[(size_t)blockIdx.x * p.partial_stride + 32 * (rb0 + rb) + lp] = both / sg;
-        }
+    if (p.bias_partial) {                      // the two lane halves hold complementary points of the same channel
+        const float both = bias_sum + __shfl_xor(bias_sum, 32);
+        if (lh == 0) p.bias_partial[(size_t)blockIdx.x * p.partial_stride + 32 * wave + lp] = both / sg;
     }
     const float back = 1.0f / (sg * kActScale);
     float* out = p.partial + (size_t)blockIdx.x * p.partial_stride;
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int cb = 0; cb < 8; ++cb)
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int m = 32 * (rb0 + rb) + (j & 3) + 8 * (j >> 2) + 4 * lh;
-                out[(size_t)m * 256 + 32 * (cb0 + cb) + lp] = acc[rb][cb][j] * back;
-            }
+        for (int j = 0; j < 16; ++j) {
+            const int m = 32 * wave + (j & 3) + 8 * (j >> 2) + 4 * lh;
+            out[(size_t)m * 256 + 32 * cb + lp] = acc[cb][j] * back;
+        }
 }
 
 }  // namespace inerf
