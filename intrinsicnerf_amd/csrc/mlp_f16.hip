@@ -292,13 +292,15 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
 // LDS per workgroup: two planes (hi, lo) of X[64 points][296 halfs] = [h 256 | dir 32 | pad 8]; 592-byte rows
 // put the 16 rows of a ds_read_b128 lane group on 16 distinct bank slots.
 // ================================================================================================
-// kSplit (SSR inference with a scratch buffer): the semantic hidden layer is split over the waves by CHANNEL like the other
-// hidden layers - wave w computes channels 32w .. 32w+31 for all 64 points, so semantic_linear.0.0 is streamed once per tile
-// instead of four times (in the per-wave form below the head's weight stream, 512 KB per tile through the CU's 64 B/clk vector
-// memory path, takes 2.7x the cycles of its own MFMAs).  The price is that the logits then exist as four per-wave partial sums
-// while LDS is still full of h7: each wave parks ITS partials (32 accumulator registers per 32 classes) in a private,
-// L2-resident scratch slot - an explicit spill, placed where nothing waits for it - and fetches them back at the end of the
-// tile, when the activation planes are dead and the four partials can meet in LDS.
+// kSplit (SSR inference with a scratch buffer): the semantic hidden layer (128 channels) is split over the waves by channel
+// HALF and point HALF - wave w computes channels 64 (w & 1) .. + 63 of points 32 (w >> 1) .. + 31: the 64-channel wave tile of
+// the 256-wide layers (6 MFMAs per 2 LDS operand reads; the 32-channel x 64-point form of round 3 had 6 per 4 and ran at 34 %
+// matrix-pipe busy), semantic_linear.0.0 streamed twice per tile instead of four times (in the per-wave form below the head's
+// weight stream, 512 KB per tile through the CU's 64 B/clk vector memory path, takes 2.7x the cycles of its own MFMAs).  The
+// price is that the logits then exist as TWO partial sums per point (one per channel half) while LDS is still full of h7: each
+// wave parks ITS partials (16 accumulator registers per 32 classes) in a private, L2-resident scratch slot - an explicit
+// spill, placed where nothing waits for it - and fetches them back at the end of the tile, when the activation planes are
+// dead and the two partials of a point can meet in LDS.
 template <bool kSave, bool kSsr, bool kSplit = false>
 __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParams p) {
     static_assert(!kSplit || (kSsr && !kSave), "the channel-split semantic head is the SSR inference form");
@@ -491,11 +493,12 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
 
         // albedo + shading: hidden layer (this wave: 64 of its 256 channels) -> registers -> partial output sums
         f32x4 part_as[2], part_res[2];
+        WidePreH<2> pre2s;                           // kSplit: first fragments of the semantic hidden layer, requested under the albedo|shading head
         {
             wide_gemm_h<2, 16, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.as1, 16), xr, 0, 0, lane, am2);
             load_bias<2>(bias2, inv2, wb, (L.as1.b + 64 * wave) * 4, (L.as1.b + kWidth) * 4, lane);
             prefetch_w<2>(pre2, wb, frag256(L.feat, 16));
-            if constexpr (kSplit) prefetch_w<1>(pre1, wb, frag128(L.sem1, 16));
+            if constexpr (kSplit) prefetch_w<2, 2048, 16 * 2048>(pre2s, wb, (L.sem1.w + 2 * (wave & 1) * 16 * 2 * 256) * 4);
             f16x8 hi[4][2], lo[4][2];
             const SaveDst sv = save_dst(SAVE_AS1H, kWidth, 64 * wave);
             to_operands<2, kSave>(am2, inv2, bias2, amax2, hi, lo, &sv);
@@ -503,27 +506,30 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
         }
         const __amdgpu_buffer_rsrc_t sem_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             p.sem_scratch, 0, kSplit ? (int)((unsigned)gridDim.x * (unsigned)L.sem_rb32 * (unsigned)kSemScratchBytes) : 0, 0x00020000);
-        if constexpr (kSplit) {                    // semantic_nerf.py:150-152, hidden layer split over the waves by channel
-            f32x16 am1[1][2];
-            f32x4 bias1[1][4];
+        if constexpr (kSplit) {                    // semantic_nerf.py:150-152, hidden layer split over the waves by channel half x point half
+            const int ch = wave & 1, ph = wave >> 1;
+            f32x16 am1[2][1];
+            f32x4 bias1[2][4];
             float inv1;
-            wide_gemm_h<1, 16, 0, kRowD, kPlaneD>(pre1, wb, frag128(L.sem1, 16), xr, 0, 0, lane, am1);
-            load_bias<1>(bias1, inv1, wb, (L.sem1.b + 32 * wave) * 4, (L.sem1.b + kHalf) * 4, lane);
-            f16x8 hi[2][2], lo[2][2];
-            to_operands<1, false>(am1, inv1, bias1, amax2, hi, lo, nullptr);
+            // this wave's two 32-channel streams of the layer's 4-wave packing (16 k-blocks x 2 KiB each)
+            // (operand rows from the per-tile laundered lane index: as a loop invariant this address is one more spilled register)
+            const _Float16* xr_half = ldsd + ((lane_t & 31) + 32 * ph) * kRowD + 8 * (lane_t >> 5);
+            wide_gemm_h<2, 16, 0, kRowD, kPlaneD, true, 2048, 1, 16 * 2048>(pre2s, wb, (L.sem1.w + 2 * ch * 16 * 2 * 256) * 4, xr_half, 0, 0, lane, am1);
+            load_bias<2>(bias1, inv1, wb, (L.sem1.b + 64 * ch) * 4, (L.sem1.b + kHalf) * 4, lane);
+            f16x8 hi[4][1], lo[4][1];
+            to_operands<2, false, 1>(am1, inv1, bias1, amax2, hi, lo, nullptr);
 #pragma unroll 1
-            for (int rb = 0; rb < L.sem_rb32; ++rb) {      // this wave's partial logits of classes 32 rb .. +31 -> its scratch slot
-                f32x16 acc[2];
-                regop_gemm_full<2>(wb, (L.sem2q.w + (rb * 4 + wave) * 2 * 2 * 256) * 4, hi, lo, acc);
+            for (int rb = 0; rb < L.sem_rb32; ++rb) {      // this wave's partial logits of classes 32 rb .. +31, its 32 points -> its scratch slot
+                f32x16 acc[1];
+                // sem2q fragments of hidden channels 64 ch .. + 63 = packing waves 2 ch, 2 ch + 1 (two k-blocks each, contiguous)
+                regop_gemm_full<4, 1>(wb, (L.sem2q.w + (rb * 4 + 2 * ch) * 2 * 2 * 256) * 4, hi, lo, acc);
                 const int slot = ((int)blockIdx.x * L.sem_rb32 + rb) * kSemScratchBytes + wave * (kSemScratchBytes / 4);
 #pragma unroll
-                for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 v = {acc[pb][4 * g], acc[pb][4 * g + 1], acc[pb][4 * g + 2], acc[pb][4 * g + 3]};
-                        // (whole offset in the VGPR operand: a 16-byte buffer store with a register SGPR offset gets no hazard wait state, tests/test_isa_audit_cpu.py)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), sem_rsrc, lane * 16 + slot + (pb * 4 + g) * 1024, 0, 0);
-                    }
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = {acc[0][4 * g], acc[0][4 * g + 1], acc[0][4 * g + 2], acc[0][4 * g + 3]};
+                    // (whole offset in the VGPR operand: a 16-byte buffer store with a register SGPR offset gets no hazard wait state, tests/test_isa_audit_cpu.py)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), sem_rsrc, lane_t * 16 + slot + g * 1024, 0, 0);
+                }
             }
         } else if (kSsr && L.sem_rbs > 0) {        // semantic logits straight to raw[11 .. 11+C), every wave the whole head for its 16 points
             SaveDst sv;
@@ -548,34 +554,27 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
             to_operands<1, kSave>(am1, inv1, bias1, amax2, hi, lo, &sv);
             regop_gemm<2>(wb, (L.resr.w + wave * 2 * 2 * 256) * 4, hi, lo, part_res);
         }
-        // kSplit: the four waves' partial logits meet in dead columns too - per point 4 x 32 floats: waves 0, 1 at bytes 256..511 of
-        // the row in the hi plane, waves 2, 3 at bytes 128..383 in the lo plane (clear of the heads' exchange area, bytes 128..255 of
-        // the hi plane, and of what the next tile's encode writes before its first barriers: bytes 0..127 and 512..575).  Each wave
-        // fetches its OWN partials back from its scratch slot (sc0: past the vector L1, whose lines of an earlier tile may be stale);
-        // block 0 is requested here, so that the fetch runs under the barrier and the heads' exchange.
+        // kSplit: the partial logits meet in dead columns too - per point 2 x 32 floats (one per channel half): half 0 at bytes
+        // 256..383 of the row in the hi plane, half 1 at bytes 128..255 in the lo plane (clear of the heads' exchange area, bytes
+        // 128..255 of the hi plane, and of what the next tile's encode writes before its first barriers: bytes 0..127 and 512..575).
+        // Each wave fetches its OWN partials back from its scratch slot (sc0: past the vector L1, whose lines of an earlier tile may
+        // be stale); block 0 is requested here, so that the fetch runs under the barrier and the heads' exchange.
         constexpr int kRowF = kRowD / 2;                                      // floats per LDS row
-        auto sem_ex = [&](int w, int r) { return reinterpret_cast<float*>(ldsd) + (w < 2 ? 64 + 32 * w : kPlaneD / 2 + 32 * (w - 1)) + r * kRowF; };
-        auto sem_fetch = [&](int rb, u32x4 (&v)[2][4]) {
+        auto sem_ex = [&](int half, int r) { return reinterpret_cast<float*>(ldsd) + (half == 0 ? 64 : kPlaneD / 2 + 32) + r * kRowF; };
+        auto sem_fetch = [&](int rb, u32x4 (&v)[4]) {
             const int slot = ((int)blockIdx.x * L.sem_rb32 + rb) * kSemScratchBytes + wave * (kSemScratchBytes / 4);
 #pragma unroll
-            for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) v[pb][g] = __builtin_amdgcn_raw_buffer_load_b128(sem_rsrc, lane * 16 + slot + (pb * 4 + g) * 1024, 0, 1);
+            for (int g = 0; g < 4; ++g) v[g] = __builtin_amdgcn_raw_buffer_load_b128(sem_rsrc, lane_t * 16 + slot + g * 1024, 0, 1);
         };
-        auto sem_post = [&](const u32x4 (&v)[2][4]) {                         // accumulator register 4g + i = class 8g + 4 (lane >> 5) + i
+        auto sem_post = [&](const u32x4 (&v)[4]) {                            // accumulator register 4g + i = class 8g + 4 (lane >> 5) + i of point (lane & 31) of this wave's half
 #pragma unroll
-            for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) *reinterpret_cast<u32x4*>(sem_ex(wave, 32 * pb + (lane & 31)) + 8 * g + 4 * (lane >> 5)) = v[pb][g];
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<u32x4*>(sem_ex(wave & 1, 32 * (wave >> 1) + (lane_t & 31)) + 8 * g + 4 * (lane_t >> 5)) = v[g];
         };
         auto sem_sum = [&](int rb, float inv2) {                              // this wave's 16 points x 32 classes: lane = (point, 8 classes)
-            const int r = 16 * wave + (lane & 15), c8 = 8 * (lane >> 4);
-            f32x4 s0 = {0.0f, 0.0f, 0.0f, 0.0f}, s1 = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {                                     // fixed order: deterministic
-                s0 += *reinterpret_cast<const f32x4*>(sem_ex(w, r) + c8);
-                s1 += *reinterpret_cast<const f32x4*>(sem_ex(w, r) + c8 + 4);
-            }
+            const int r = 16 * wave + (lane_t & 15), c8 = 8 * (lane_t >> 4);
+            // fixed order: deterministic
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(sem_ex(0, r) + c8) + *reinterpret_cast<const f32x4*>(sem_ex(1, r) + c8);
+            const f32x4 s1 = *reinterpret_cast<const f32x4*>(sem_ex(0, r) + c8 + 4) + *reinterpret_cast<const f32x4*>(sem_ex(1, r) + c8 + 4);
             const int c0 = 32 * rb + c8;
             const f32x4 b0 = wb.vec4((L.sem2.b + c0) * 4, 0), b1 = wb.vec4((L.sem2.b + c0 + 4) * 4, 0);
 #pragma unroll
@@ -584,7 +583,7 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
                 if (my_valid && c0 + 4 + i < p.n_classes) __builtin_nontemporal_store(__builtin_fmaf(s1[i], inv2, b1[i]), out_row + INERF_BASE_CHANNELS + c0 + 4 + i);
             }
         };
-        u32x4 sem_v[2][4];
+        u32x4 sem_v[4];
         float sem_inv2 = 0.0f;
         if constexpr (kSplit) {
             sem_fetch(0, sem_v);

@@ -105,13 +105,17 @@ __device__ __forceinline__ void wide_prefetch_h(WidePreH<RB>& pre, const WeightB
 }
 
 // KSTRIDE: bytes between a wave's consecutive k-blocks in the packed stream (default: its RB row blocks are contiguous; a
-// wave that takes ONE of the two row blocks of the 4-wave packing passes 4096)
-template <int RB, int KB0, int KB1, int ROW = kRowH, int PLANE = kPlaneH, bool ZERO = true, int KSTRIDE = RB * 2048>
+// wave that takes ONE of the two row blocks of the 4-wave packing passes 4096).
+// PB: blocks of 32 points (2: the whole tile; 1: the 32 points `xl` points at).  RBSTRIDE: bytes between the wave's row blocks
+// (default: consecutive inside a k-block; a wave that takes two 32-channel STREAMS of a 128-channel layer's 4-wave packing
+// passes the size of one stream).
+template <int RB, int KB0, int KB1, int ROW = kRowH, int PLANE = kPlaneH, bool ZERO = true, int KSTRIDE = RB * 2048, int PB = 2, int RBSTRIDE = 2048>
 __device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const WeightBuf& wb, int frag_bytes,
                                             const _Float16* xl,      // plane_hi + (lane&31)*kRowH + 8*(lane>>5)
-                                            int col0, int col1, int lane, f32x16 (&am)[RB][2]) {
+                                            int col0, int col1, int lane, f32x16 (&am)[RB][PB]) {
     constexpr int KBT = KB0 + KB1;
     static_assert(KBT % 2 == 0 && KBT >= 4, "k-block count");
+    static_assert(PB == 2 || (PB == 1 && RB == 2), "point blocks");
     if constexpr (ZERO) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
@@ -120,24 +124,24 @@ __device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const Weigh
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int pb = 0; pb < 2; ++pb) am[rb][pb][4 * g + i] = 0.0f;
+                    for (int pb = 0; pb < PB; ++pb) am[rb][pb][4 * g + i] = 0.0f;
     }
     auto xoff = [&](int kb) { return kb < KB0 ? col0 + 16 * kb : col1 + 16 * (kb - KB0); };
     // 4 rotating weight buffers (two k-blocks ahead; three measured slower), 2 activation buffers (one ahead);
     // all indices static
-    f16x8 w[4][RB][2], x[2][2][2];
+    f16x8 w[4][RB][2], x[2][PB][2];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int part = 0; part < 2; ++part) { w[0][rb][part] = pre.w[0][rb][part]; w[1][rb][part] = pre.w[1][rb][part]; }
 #pragma unroll
-    for (int pb = 0; pb < 2; ++pb)
+    for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
         for (int part = 0; part < 2; ++part)
             x[0][pb][part] = *reinterpret_cast<const f16x8*>(xl + part * PLANE + xoff(0) + pb * 32 * ROW);
 
-// one k-block: request operands for k+2 (weights) / k+1 (activations) and run 3*RB*2 MFMAs on block k, with the
-// 2*RB global loads and 4 LDS reads interleaved BETWEEN the MFMAs (an f16 MFMA occupies the pipe for only 32
+// one k-block: request operands for k+2 (weights) / k+1 (activations) and run 3*RB*PB MFMAs on block k, with the
+// 2*RB global loads and 2*PB LDS reads interleaved BETWEEN the MFMAs (an f16 MFMA occupies the pipe for only 32
 // cycles, so a burst of 8 memory instructions ahead of them is not hidden; measured +x % vs the burst form).
 // A macro, not a lambda: the buffer indices must stay compile-time constants for the arrays to live in registers.
 #define INERF_F16_STEP(K, I)                                                                                         \
@@ -147,28 +151,40 @@ __device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const Weigh
         const int xo_ = xoff(k1_);                                                                                   \
         _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                                            \
             _Pragma("unroll") for (int part = 0; part < 2; ++part)                                                   \
-                w[((I) + 2) & 3][rb][part] = wb.frag(frag_bytes + k2_ * KSTRIDE + (rb * 2 + part) * 1024);          \
-        _Pragma("unroll") for (int pb = 0; pb < 2; ++pb)                                                             \
+                w[((I) + 2) & 3][rb][part] = wb.frag(frag_bytes + k2_ * KSTRIDE + rb * RBSTRIDE + part * 1024);      \
+        _Pragma("unroll") for (int pb = 0; pb < PB; ++pb)                                                            \
             _Pragma("unroll") for (int part = 0; part < 2; ++part)                                                   \
                 x[((I) + 1) & 1][pb][part] =                                                                         \
                     *reinterpret_cast<const f16x8*>(xl + part * PLANE + xo_ + pb * 32 * ROW);                        \
         /* hi*hi, hi*lo, lo*hi into the same accumulator; product-major: an accumulator is touched every 4th MFMA */ \
         _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                                            \
-            _Pragma("unroll") for (int pb = 0; pb < 2; ++pb)                                                         \
+            _Pragma("unroll") for (int pb = 0; pb < PB; ++pb)                                                        \
                 am[rb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[(I) & 3][rb][0], x[(I) & 1][pb][0], am[rb][pb], 0, 0, 0); \
         _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                                            \
-            _Pragma("unroll") for (int pb = 0; pb < 2; ++pb)                                                         \
+            _Pragma("unroll") for (int pb = 0; pb < PB; ++pb)                                                        \
                 am[rb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[(I) & 3][rb][0], x[(I) & 1][pb][1], am[rb][pb], 0, 0, 0); \
         _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                                            \
-            _Pragma("unroll") for (int pb = 0; pb < 2; ++pb)                                                         \
+            _Pragma("unroll") for (int pb = 0; pb < PB; ++pb)                                                        \
                 am[rb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[(I) & 3][rb][1], x[(I) & 1][pb][0], am[rb][pb], 0, 0, 0); \
-        /* issue order: MFMA, global load, MFMA, LDS read, MFMA - 2*RB times (masks: 0x8 MFMA, 0x20 VMEM read, 0x100 DS read) */ \
-        _Pragma("unroll") for (int q = 0; q < 2 * RB; ++q) {                                                        \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                       \
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                       \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                       \
-            __builtin_amdgcn_sched_group_barrier(0x100, 4 / (2 * RB), 0);                                            \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                       \
+        /* issue order (masks: 0x8 MFMA, 0x20 VMEM read, 0x100 DS read).  PB = 2: MFMA, global load, MFMA, LDS read(s), MFMA - 2*RB  \
+           times; PB = 1 (RB = 2: 6 MFMAs, 4 global loads, 2 LDS reads): MFMA, global load, MFMA, global load, MFMA, LDS read - twice */ \
+        if constexpr (PB == 2) {                                                                                     \
+            _Pragma("unroll") for (int q = 0; q < 2 * RB; ++q) {                                                    \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                   \
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                   \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                   \
+                __builtin_amdgcn_sched_group_barrier(0x100, 4 / (2 * RB), 0);                                        \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                   \
+            }                                                                                                        \
+        } else {                                                                                                     \
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                         \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                   \
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                   \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                   \
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                   \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                   \
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                   \
+            }                                                                                                        \
         }                                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
     }
@@ -396,14 +412,14 @@ __device__ __forceinline__ f32x4 skinny_gemm_h(const WeightBuf& wb, int frag_byt
 __device__ __forceinline__ float sigmoid_ref_h(float x) { return __fdiv_rn(1.0f, 1.0f + expf(-x)); }
 
 
-template <int RB, int KSTRIDE = RB * 2048>
+template <int RB, int KSTRIDE = RB * 2048, int RBSTRIDE = 2048>
 __device__ __forceinline__ void prefetch_w(WidePreH<RB>& pre, const WeightBuf& wb, int frag_bytes) {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-            for (int part = 0; part < 2; ++part) pre.w[kb][rb][part] = wb.frag(frag_bytes + kb * KSTRIDE + (rb * 2 + part) * 1024);
+            for (int part = 0; part < 2; ++part) pre.w[kb][rb][part] = wb.frag(frag_bytes + kb * KSTRIDE + rb * RBSTRIDE + part * 1024);
 }
 
 template <int RB>

@@ -13,13 +13,13 @@ constexpr int kColExD = 64;                       // exchange area: floats [wave
 
 // accumulators of this wave's 32*RB channels x 64 points -> (bias, ReLU, hi/lo split) -> B operands, one per
 // 16-channel k-block q (accumulator registers 8*(q&1) .. +7 of row block q>>1) and point block
-template <int RB, bool SAVE = false>
-__device__ __forceinline__ void to_operands(const f32x16 (&am)[RB][2], float inv, const f32x4 (&bias)[RB][4], f16x2& amax2,
-                                            f16x8 (&hi)[2 * RB][2], f16x8 (&lo)[2 * RB][2], const SaveDst* sv = nullptr) {
+template <int RB, bool SAVE = false, int PB = 2>
+__device__ __forceinline__ void to_operands(const f32x16 (&am)[RB][PB], float inv, const f32x4 (&bias)[RB][4], f16x2& amax2,
+                                            f16x8 (&hi)[2 * RB][PB], f16x8 (&lo)[2 * RB][PB], const SaveDst* sv = nullptr) {
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int pb = 0; pb < 2; ++pb) {
+        for (int pb = 0; pb < PB; ++pb) {
 #pragma unroll
             for (int q2 = 0; q2 < 2; ++q2) {
                 f16x8 fh, fl;
@@ -84,18 +84,18 @@ __device__ __forceinline__ void regop_gemm(const WeightBuf& wb, int frag_bytes, 
 }
 
 // all 32 rows of a register-operand product (the semantic logits of one 32-class block, summed over this wave's Q k-blocks)
-template <int Q>
-__device__ __forceinline__ void regop_gemm_full(const WeightBuf& wb, int frag_bytes, const f16x8 (&hi)[Q][2], const f16x8 (&lo)[Q][2],
-                                                f32x16 (&acc)[2]) {
+template <int Q, int PB = 2>
+__device__ __forceinline__ void regop_gemm_full(const WeightBuf& wb, int frag_bytes, const f16x8 (&hi)[Q][PB], const f16x8 (&lo)[Q][PB],
+                                                f32x16 (&acc)[PB]) {
 #pragma unroll
-    for (int pb = 0; pb < 2; ++pb)
+    for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[pb][r] = 0.0f;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         const f16x8 wh = wb.frag(frag_bytes + (2 * q) * 1024), wl = wb.frag(frag_bytes + (2 * q + 1) * 1024);
 #pragma unroll
-        for (int pb = 0; pb < 2; ++pb) {
+        for (int pb = 0; pb < PB; ++pb) {
             acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hi[q][pb], acc[pb], 0, 0, 0);
             acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, lo[q][pb], acc[pb], 0, 0, 0);
             acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, hi[q][pb], acc[pb], 0, 0, 0);
@@ -103,7 +103,8 @@ __device__ __forceinline__ void regop_gemm_full(const WeightBuf& wb, int frag_by
     }
 }
 
-constexpr int kSemScratchBytes = 4 * 2 * 16 * 64 * 4;      // per workgroup and 32-class block: [wave][point block][16 registers][64 lanes] floats = 32 KiB
+constexpr int kSemScratchBytes = 4 * 2 * 16 * 64 * 4;      // per workgroup and 32-class block: 32 KiB, 8 KiB per wave (the channel-split head parks
+                                                           // [16 registers][64 lanes] floats = 4 KiB there: its partial logits of 32 classes x 32 points)
 
 // semantic head of the two-workgroup kernel (SSR): there is no room in LDS for the 128-channel hidden layer and no
 // registers to hold partial logits across the feature / view layers, so every wave does the whole head for ITS 16
