@@ -30,7 +30,7 @@ extern "C" {
 #define INERF_VERSION_MINOR 2
 /* Bumped whenever a struct layout, an argument list or the packed-weight format of this header changes; bindings
  * compare it with inerf_abi_version() of the library they loaded (a stale .so then fails loudly, not silently). */
-#define INERF_ABI_VERSION 40001
+#define INERF_ABI_VERSION 40002
 
 /* error codes */
 #define INERF_OK              0
@@ -146,17 +146,17 @@ int inerf_encode_mlp_ws(const inerf_net_desc* net, const float* packed_weights, 
  * WHOLE 64-point tiles (64 * ceil(n_points / 64) points; inerf_mlp_save_slot() gives offset, width and format):
  *   slot 0 enc 64 | 1 dir 32 | 2..9 h0..h7 256 | 10 albedo|shading hidden 256 | 11 feature 256 |
  *   12 views hidden 128 | 13 semantic hidden 128 (SSR with classes, else width 0) |
- *   14 (dz only) head pre-activation gradients 8: albedo 3, shading 1, residual 3, sigma 1 | 15 (save only) h7 again.
+ *   14 (dz only) head pre-activation gradients 8: albedo 3, shading 1, residual 3, sigma 1 | 15 unused (width 0).
  * Two slot formats:
- *   ROWS      a row-major fp32 [n_points, width] matrix.  save: 0, 1, 10, 11, 12, 13, 15; dz: 12, 13, 14.
- *   FRAGMENTS the operands of the nine 256 x 256 weight-gradient products dW = dZ^T X exactly as the matrix core consumes
+ *   ROWS      a row-major fp32 [n_points, width] matrix.  save: 0, 1, 10, 12, 13; dz: 12, 13, 14.
+ *   FRAGMENTS the operands of the 256-wide weight-gradient products dW = dZ^T X exactly as the matrix core consumes
  *             them: every value v is stored as f16 hi = f16(v') (towards zero) and f16 lo = f16(v' - hi) in 1 KB fragments
  *             [32 channels x 16 points]; with kb = 16-point block of the tile (0..3), cb = 32-channel block:
  *               byte offset = (((tile * 4 + kb) * 8 + cb) * 2 + (0: hi, 1: lo)) * 1024 + lane * 16 + 2 * i      (i = 0..7)
  *               channel = 32 cb + (lane & 31),  point = 64 tile + 32 (kb >> 1) + (i & 3) + 8 ((i >> 2) + 2 (kb & 1)) + 4 (lane >> 5)
  *             (lane = channel, 8 k-values = 8 points: one 16-byte operand slot of v_mfma_f32_32x32x16_f16; the point order
  *             inside a block is the accumulator's register order).
- *             save, slots 2..9: v' = 8 v (the forward kernel's own operand halves).
+ *             save, slots 2..9 and 11: v' = 8 v (the forward kernel's own operand halves).
  *             dz, slots 2..11: v' = 8 v / s_p, s_p = the point's NORMALISER (the power of two above its largest head
  *             gradient; the chain works on normalised gradients, so these halves keep 22 bits whatever a point's gradient
  *             scale) - the normalisers are the first 64 * ceil(n_points / 64) floats of slot 0 of dz, and the weight-gradient
@@ -216,6 +216,10 @@ int inerf_mlp_weight_gradient(const float* G, int ldg, const float* X, int ldx, 
 /* The same with G a FRAGMENT slot of the gradient buffer (M = 256) - g_scale: the points' normalisers, slot 0 of that buffer,
  * see above - and X row-format: N in {64} (the encoding columns of pts_linears.0 / .5).  ranges as above (of the TRUE |dz|). */
 int inerf_mlp_weight_gradient_gfrag(const void* G_frag, const float* g_scale, const float* X, int ldx, int64_t n_points, int N,
+                                    const float* ranges, float* partial, float* bias_partial, int64_t partial_stride, void* stream);
+/* G row-format (M = 128), X a FRAGMENT slot of the activation buffer (N = 256): views_linears.0's feature columns and the
+ * semantic hidden layer.  ranges[0]: an upper bound of |G|. */
+int inerf_mlp_weight_gradient_xfrag(const float* G, int ldg, const void* X_frag, int64_t n_points, int M,
                                     const float* ranges, float* partial, float* bias_partial, int64_t partial_stride, void* stream);
 /* ... and with BOTH operands FRAGMENT slots (256 x 256: G of the gradient buffer, X of the activation buffer, same points):
  * a ring of LDS stages filled by LDS-DMA - bound by HBM bandwidth.  ranges[0]: an upper bound of the true |dz|. */

@@ -160,7 +160,8 @@ inline NetLayout make_layout(const inerf_net_desc& net) {
 //     (a power of two): 22 bits whatever the point's scale, straight from the chain's LDS planes - and the normalisers travel
 //     beside them (SAVE_ENC of the gradient buffer: one float per point); the consumer multiplies them back in when it brings
 //     its own operands to the batch's max |dz| (~50 VALU instructions per fragment pair, beside 24 MFMAs per k-block).
-//   activation buffer: ENC, DIR, AS1H, FEAT, VH, SEMH, H7R rows; H0..H7 fragments (H7 in both formats: the chain reads its rows);
+//   activation buffer: ENC, DIR, AS1H, VH, SEMH rows; H0..H7, FEAT fragments (the chain reads h7 - ReLU mask and operand of the
+//                      alpha_linear weight gradient - from its fragments: the matrix core transposes them back); H7R unused;
 //   gradient buffer:   VH, SEMH, DPRE rows; H0..H7, AS1H, FEAT fragments; ENC: the normalisers (8 floats per point of DPRE: albedo 3, shading 1,
 //                      residual 3, sigma 1); ENC, DIR, H7R unused.
 enum SaveSlot {
@@ -173,21 +174,21 @@ enum SaveSlot {
     SAVE_VH,           // 128 views_linears.0 output, post-ReLU
     SAVE_SEMH,         // 128 semantic hidden, post-ReLU (SSR with classes only; width 0 otherwise)
     SAVE_DPRE,         // 8   (gradient buffer only)
-    SAVE_H7R,          // 256 h7 once more, as rows (activation buffer only)
+    SAVE_H7R,          // 0   (unused: early in round 4, h7 once more as rows)
     SAVE_SLOTS
 };
 
 constexpr int kFragBytes = 1024;                       // one operand fragment: 64 lanes x 8 halfs
 constexpr int kFragKbBytes = 8 * 2 * kFragBytes;       // one 16-point k-block of a 256-wide slot: [cb 8][hi | lo]
 constexpr int kFragTileBytes = 4 * kFragKbBytes;       // = 64 points x 256 channels x 4 bytes
-inline int frag_point(int q, int h, int i) { return (i & 3) + 8 * ((i >> 2) + 2 * q) + 4 * h; }
+constexpr int frag_point(int q, int h, int i) { return (i & 3) + 8 * ((i >> 2) + 2 * q) + 4 * h; }
 inline int64_t padded_points(int64_t n_points) { return (n_points + kTilePoints - 1) / kTilePoints * kTilePoints; }
 
 inline int save_width(const inerf_net_desc& net, int slot) {
     if (slot == SAVE_ENC) return kEncCols;
     if (slot == SAVE_DIR) return kDirCols;
     if (slot >= SAVE_H0 && slot <= SAVE_H7) return kWidth;
-    if (slot == SAVE_AS1H || slot == SAVE_FEAT || slot == SAVE_H7R) return kWidth;
+    if (slot == SAVE_AS1H || slot == SAVE_FEAT) return kWidth;
     if (slot == SAVE_VH) return kHalf;
     if (slot == SAVE_SEMH) return (net.variant == INERF_VARIANT_SSR && net.n_classes > 0) ? kHalf : 0;
     if (slot == SAVE_DPRE) return 8;
@@ -196,8 +197,8 @@ inline int save_width(const inerf_net_desc& net, int slot) {
 
 // format of a slot: 1 = fragments, 0 = rows (gradient: the buffer of pre-activation gradients, else the activation buffer)
 inline int save_is_frag(int slot, bool gradient) {
-    if (slot >= SAVE_H0 && slot <= SAVE_H7) return 1;
-    return (gradient && (slot == SAVE_AS1H || slot == SAVE_FEAT)) ? 1 : 0;
+    if ((slot >= SAVE_H0 && slot <= SAVE_H7) || slot == SAVE_FEAT) return 1;
+    return (gradient && slot == SAVE_AS1H) ? 1 : 0;
 }
 
 inline int64_t save_offset(const inerf_net_desc& net, int slot, int64_t n_points) {     // in floats

@@ -15,7 +15,8 @@
 //     gradient (exact; columns of a GEMM scale independently) and scaled back when dZ is written;
 //   * the ReLU masks of the trunk (h0..h6) are the bit words the training forward left behind the activation slots
 //     (layout.h relu_bits_offset: one 8-byte load per lane and layer instead of 64 floats); the stages that need the
-//     activations' VALUES anyway (h7 for the alpha_linear weight gradient, the three head hidden layers) read those;
+//     activations' VALUES anyway (h7 for the alpha_linear weight gradient - from its fragments, transposed back by the matrix
+//     core -, the three head hidden layers) read those;
 //   * the heads with 1-4 outputs (sigma, albedo/shading outputs, residual) are outer products: VALU, not MFMA;
 //   * the three matrices that feed d h7 (feature_linear^T, as1^T, sem1^T) share a weight scale and one accumulator.
 #include <cstdlib>
@@ -140,6 +141,7 @@ __device__ __forceinline__ void bwd_store(const f32x16 (&am)[RB][2], float inv,
                 // invalid points carry zeros: no need to exclude them from the running maximum
                 gmax = fmaxf(gmax, fmaxf(fmaxf(fabsf(t[0]), fabsf(t[1])), fmaxf(fabsf(t[2]), fabsf(t[3]))) * back);
             }
+#ifndef INERF_ABL_NO_FRAG
             // transpose (see DzDst): D'[point][channel] = sum_k A[point][k] Sel[k][channel], two k-blocks of 16 channels, hi and lo each
             const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
             f32x16 trh = zero, trl = zero;
@@ -160,10 +162,15 @@ __device__ __forceinline__ void bwd_store(const f32x16 (&am)[RB][2], float inv,
                     oh[i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(trh[8 * q + 2 * i], trh[8 * q + 2 * i + 1]));
                     ol[i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(trl[8 * q + 2 * i], trl[8 * q + 2 * i + 1]));
                 }
+#ifdef INERF_ABL_NO_FRAG_STORE
+                asm volatile("" :: "v"(oh), "v"(ol));
+#else
                 // (whole offset in the VGPR operand: a 16-byte buffer store with a register SGPR offset gets no hazard wait state, tests/test_isa_audit_cpu.py)
                 __builtin_amdgcn_raw_buffer_store_b128(oh, dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, rb, 0)), 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(ol, dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, rb, 1)), 0, 0);
+#endif
             }
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -471,17 +478,23 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
         }
 
         // ---------------- d h7 = W_feat^T d feature + W_as1^T dZ_as1 (+ W_sem1^T dZ_semh) + w_alpha d sigma ----------------
-        f32x4 h7v[RB][2][4];                 // h7 of this lane's values: ReLU mask AND operand of the alpha_linear weight gradient
+        // h7 of this lane's values - ReLU mask AND operand of the alpha_linear weight gradient - comes from the forward's FRAGMENTS
+        // (lane = channel, 8 points per 16-byte operand slot): requested here, ahead of the two GEMMs, and transposed back into
+        // the accumulator layout (lane = point, registers = channels) by the matrix core just before the epilogue that needs it.
+        f16x8 h7f[RB][2][2][2];              // [row block][point half][k-block of the half][hi | lo]
         {
-            const __amdgpu_buffer_rsrc_t r = slot_rsrc(p.save, SAVE_H7R, kWidth);     // (the row copy; SAVE_H7 itself holds fragments)
-            const int voff = ((lane & 31) * kWidth + WCH * wave + 4 * (lane >> 5)) * 4;
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.save) + p.off[SAVE_H7], 0,
+                                                                                (int)((unsigned)p.n_tiles * (unsigned)kFragTileBytes), 0x00020000);
+            const unsigned voff = (unsigned)tile * (unsigned)kFragTileBytes + (unsigned)(WCH / 32 * wave) * (2u * kFragBytes) + (unsigned)lane * 16u;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                 for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        h7v[rb][pb][g] = load4(r, voff + ((tile * kPts + 32 * pb) * kWidth + 32 * rb + 8 * g) * 4);
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int plane = 0; plane < 2; ++plane)
+                            h7f[rb][pb][q][plane] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r, (int)(voff + frag_off(2 * pb + q, rb, plane)), 0, 0));
         }
         wide_gemm_h<RB, 16, 0, kRowH, kPlaneH, true, KS>(preA, wb, frag(L.feat_t, 16), xr, kColB, 0, lane, am);
         if (sem) prefetch_w<RB, KS>(preA, wb, frag(L.sem1_t, 8));
@@ -530,6 +543,33 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
                 for (int g = 0; g < 4; ++g)
                     aw[rb][g] = wb.vec4((L.alpha_w + WCH * wave + 32 * rb + 8 * g) * 4, 16 * (lane >> 5)) * kActScale;
             const float e0 = ptf(lane & 31)[7], e1 = ptf((lane & 31) + 32)[7];
+            // D[channel][point] = sum_k A[channel][k] Sel[k][point]: a fragment is the A operand as it is (row = channel, k-slot
+            // 8 h + i = point frag_point(q, h, i) of the half), the selector of k-block q picks that point's column; hi + lo, both
+            // k-blocks into one accumulator = h7 (x 1/kActScale, in the selector) in the layout of `am`
+            f32x4 h7v[RB][2][4];
+            {
+                int ln = lane;
+                asm volatile("" : "+v"(ln));              // (the selectors are rebuilt per tile, not kept in 16 registers)
+                f16x8 selq[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        selq[q][i] = frag_point(q, ln >> 5, i) == (ln & 31) ? (_Float16)(1.0f / kActScale) : (_Float16)0.0f;
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int pb = 0; pb < 2; ++pb) {
+                        f32x16 hv = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            hv = __builtin_amdgcn_mfma_f32_32x32x16_f16(h7f[rb][pb][q][0], selq[q], hv, 0, 0, 0);
+                            hv = __builtin_amdgcn_mfma_f32_32x32x16_f16(h7f[rb][pb][q][1], selq[q], hv, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) h7v[rb][pb][g] = f32x4{hv[4 * g], hv[4 * g + 1], hv[4 * g + 2], hv[4 * g + 3]};
+                    }
+            }
             STAMP();
             __syncthreads();                 // every wave is done reading A and B
             STAMP();

@@ -149,16 +149,17 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
         // ReLU masks of h0..h6 for the input-gradient chain (layout.h relu_bits_offset): one descriptor for the area
         const __amdgpu_buffer_rsrc_t bits_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             p.save + (kSave ? p.bits_off : 0), 0, kSave ? (int)((unsigned)p.n_tiles * (unsigned)kReluBitTileBytes) : 0, 0x00020000);
-        // training forward (layout.h SaveSlot): h0..h7 leave as operand fragments of the weight-gradient products (planes_to_frag,
-        // after the layer's barrier), h0..h6 also as ReLU mask bits; h7 (as H7R), the albedo|shading hidden layer and the feature
-        // layer as fp32 rows from the epilogue's registers
+        // training forward (layout.h SaveSlot): h0..h7 and the feature layer leave as operand fragments of the weight-gradient
+        // products (planes_to_frag, after the layer's barrier), h0..h6 also as ReLU mask bits; the albedo|shading hidden layer as
+        // fp32 rows from the epilogue's registers
         const Selector fsel = plane_selector(lane);
         auto step256 = [&](const GemmSlot& s, auto kb0c, auto kb1c, int c0, int c1, int dcol, bool relu, auto slot_c,
                            auto&& prefetch_next) {
             constexpr int KB0 = decltype(kb0c)::value, KB1 = decltype(kb1c)::value;
             constexpr int slot = decltype(slot_c)::value;
             constexpr bool kTrunk = slot >= SAVE_H0 && slot <= SAVE_H7;
-            constexpr bool kRows = kSave && slot >= SAVE_H7;             // H7 (-> H7R), AS1H, FEAT
+            constexpr bool kFrag = kTrunk || slot == SAVE_FEAT;
+            constexpr bool kRows = kSave && slot == SAVE_AS1H;
             constexpr bool kBits = kSave && kTrunk && slot < SAVE_H7;
             f32x16 am[2][2];
             f32x4 bias[2][4];
@@ -169,11 +170,11 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
             const float inv = pre2.inv;
             wide_gemm_h<2, KB0, KB1>(pre2, wb, frag256(s, KB0 + KB1), xr, c0, c1, lane, am);
             prefetch_next();
-            const SaveDst sv = save_dst(slot == SAVE_H7 ? SAVE_H7R : slot, kWidth, 64 * wave);
+            const SaveDst sv = save_dst(slot, kWidth, 64 * wave);
             const BitsDst bd = {bits_rsrc, kBits ? (((tile * kReluBitLayers + (slot - SAVE_H0)) * 4 + wave) * 64 + lane) * 8 : 0};
             wide_store_h<2, kRowH, kPlaneH, kRows, kBits>(am, inv, bias, xd + dcol + 64 * wave, relu, amax2, nullptr, 0, 0, 0, &sv, &bd);
             __syncthreads();
-            if constexpr (kSave && kTrunk) {
+            if constexpr (kSave && kFrag) {
                 FragDst d;
                 d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save + p.save_off[slot], 0, (int)((unsigned)p.n_tiles * (unsigned)kFragTileBytes), 0x00020000);
                 d.voff = (unsigned)tile * (unsigned)kFragTileBytes + (unsigned)(2 * wave) * (2u * kFragBytes) + (unsigned)lane * 16u;
@@ -426,7 +427,8 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
         const __amdgpu_buffer_rsrc_t bits_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             p.save + (kSave ? p.bits_off : 0), 0, kSave ? (int)((unsigned)p.n_tiles * (unsigned)kReluBitTileBytes) : 0, 0x00020000);
         // training forward: where a 256-wide layer goes besides the planes (layout.h SaveSlot) - `rows_slot`: fp32 rows from the
-        // epilogue's registers (16-byte pieces; only what the chain's VALU stages and the narrow products read: FEAT, H7R);
+        // epilogue's registers (16-byte pieces: 2.3 x the cost per byte of the fragments' whole-line stores - no 256-wide layer
+        // leaves that way any more);
         // `frag_slot`: operand fragments of the weight-gradient products, transposed out of the finished planes by the matrix
         // core (planes_to_frag: whole 1 KB stores); the ReLU masks of h0..h6 as bits.
         auto frag_dst = [&](int slot) {
@@ -436,15 +438,13 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
             d.voff = (unsigned)tile * (unsigned)kFragTileBytes + (unsigned)(2 * wave) * (2u * kFragBytes) + (unsigned)lane_t * 16u;
             return d;
         };
-        auto store256 = [&](const GemmSlot& s, bool relu, auto rows_tag, int rows_slot, int frag_slot, auto&& prefetch_next, auto bits_tag) {
+        auto store256 = [&](const GemmSlot& s, bool relu, int frag_slot, auto&& prefetch_next, auto bits_tag) {
             load_bias<2>(bias2, inv2, wb, (s.b + 64 * wave) * 4, (s.b + kWidth) * 4, lane);
             prefetch_next();
-            constexpr bool kRows = kSave && decltype(rows_tag)::value;
-            const SaveDst sv = save_dst(kRows ? rows_slot : SAVE_H0, kWidth, 64 * wave);
             constexpr bool kBits = kSave && decltype(bits_tag)::value;
             const BitsDst bd = {bits_rsrc, kBits ? (((tile * kReluBitLayers + (frag_slot - SAVE_H0)) * 4 + wave) * 64 + lane_t) * 8 : 0};
             __syncthreads();                       // every wave has read the layer's input
-            wide_store_h<2, kRowD, kPlaneD, kRows, kBits>(am2, inv2, bias2, xd, relu, amax2, nullptr, 0, 0, 0, &sv, &bd);
+            wide_store_h<2, kRowD, kPlaneD, false, kBits>(am2, inv2, bias2, xd, relu, amax2, nullptr, 0, 0, 0, nullptr, &bd);
             __syncthreads();
             if constexpr (kSave)                   // this wave's 64 channels of all 64 points (the layer is complete behind the barrier)
                 if (frag_slot >= 0) {
@@ -453,8 +453,8 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
                     planes_to_frag<2, kRowD, kPlaneD>(xr + 64 * wave, plane_selector(lane_o), frag_dst(frag_slot));
                 }
         };
-        constexpr std::true_type kWithBits{}, kRowsToo{};
-        constexpr std::false_type kNoBits{}, kNoRows{};
+        constexpr std::true_type kWithBits{};
+        constexpr std::false_type kNoBits{};
         auto pf256 = [&](const GemmSlot& s, int kbt) { return [&, kbt]() { prefetch_w<2>(pre2, wb, frag256(s, kbt)); }; };
         auto pf256_at = [&](const GemmSlot& s, int kbt, int kb_first) {
             return [&, kbt, kb_first]() { prefetch_w<2>(pre2, wb, frag256(s, kbt) + kb_first * 2 * 2 * 1024); };
@@ -463,12 +463,12 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
 
         // ---------------- trunk ----------------
         wide_gemm_h<2, 4, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.trunk[0], 4), xr, 0, 0, lane, am2);
-        store256(L.trunk[0], true, kNoRows, -1, SAVE_H0, pf256(L.trunk[1], 16), kWithBits);
+        store256(L.trunk[0], true, SAVE_H0, pf256(L.trunk[1], 16), kWithBits);
 #pragma unroll 1
         for (int layer = 1; layer < kSkipInput; ++layer) {
             wide_gemm_h<2, 16, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.trunk[layer], 16), xr, 0, 0, lane, am2);
-            if (layer + 1 < kSkipInput) store256(L.trunk[layer], true, kNoRows, -1, SAVE_H0 + layer, pf256(L.trunk[layer + 1], 16), kWithBits);
-            else                        store256(L.trunk[layer], true, kNoRows, -1, SAVE_H0 + layer, pf256_at(L.trunk[kSkipInput], 20, 4), kWithBits);
+            if (layer + 1 < kSkipInput) store256(L.trunk[layer], true, SAVE_H0 + layer, pf256(L.trunk[layer + 1], 16), kWithBits);
+            else                        store256(L.trunk[layer], true, SAVE_H0 + layer, pf256_at(L.trunk[kSkipInput], 20, 4), kWithBits);
         }
         {   // pts_linears[5] over cat([pts, h]): h-part (k-blocks 4..19 of the stream), then the encoding again
             const GemmSlot& s = L.trunk[kSkipInput];
@@ -478,12 +478,12 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
             encode(false);
             __syncthreads();
             wide_gemm_h<2, 4, 0, kRowD, kPlaneD, false>(pre2, wb, frag256(s, 20), xr, 0, 0, lane, am2);
-            store256(s, true, kNoRows, -1, SAVE_H0 + kSkipInput, pf256(L.trunk[6], 16), kWithBits);
+            store256(s, true, SAVE_H0 + kSkipInput, pf256(L.trunk[6], 16), kWithBits);
         }
         wide_gemm_h<2, 16, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.trunk[6], 16), xr, 0, 0, lane, am2);
-        store256(L.trunk[6], true, kNoRows, -1, SAVE_H0 + 6, pf256(L.trunk[7], 16), kWithBits);
+        store256(L.trunk[6], true, SAVE_H0 + 6, pf256(L.trunk[7], 16), kWithBits);
         wide_gemm_h<2, 16, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.trunk[7], 16), xr, 0, 0, lane, am2);
-        store256(L.trunk[7], true, kRowsToo, SAVE_H7R, SAVE_H7, pf256(L.as1, 16), kNoBits);
+        store256(L.trunk[7], true, SAVE_H7, pf256(L.as1, 16), kNoBits);
 
         // ---------------- heads ----------------
         const int my_pt = tile * kPts + 16 * wave + (lane_t & 15);
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
         }
         // feature (no activation) in place of h7, then the view-dependent layer over [feature | dir] -> registers
         wide_gemm_h<2, 16, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.feat, 16), xr, 0, 0, lane, am2);
-        store256(L.feat, false, kRowsToo, SAVE_FEAT, -1, pf128(L.views, 18), kNoBits);
+        store256(L.feat, false, SAVE_FEAT, pf128(L.views, 18), kNoBits);
         {
             f32x16 am1[1][2];
             f32x4 bias1[1][4];

@@ -243,7 +243,9 @@ struct EncSave {
     int voff;                         // bytes of the point's row, or kDropOffset
     static constexpr int kDropOffset = 0x7FFF0000;
     __device__ __forceinline__ void put(int col, float v) const {
+#ifndef INERF_ABL_NO_ROWS
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, voff + 4 * col, 0, 0);
+#endif
     }
 };
 
@@ -275,6 +277,9 @@ __device__ __forceinline__ unsigned frag_off(int kb, int cb, int plane) { return
 template <int NB, int ROW, int PLANE>
 __device__ __forceinline__ void planes_to_frag(const _Float16* xa /* plane_hi + (lane & 31) * ROW + 8 * (lane >> 5) + first column */,
                                                const Selector& sel, const FragDst& dst) {
+#ifdef INERF_ABL_NO_FRAG        // (timing ablation of a development build, scripts/build_variant.sh: results are wrong)
+    return;
+#endif
     const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) {
@@ -308,9 +313,13 @@ __device__ __forceinline__ void planes_to_frag(const _Float16* xa /* plane_hi + 
                     oh[i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(th[pb][8 * q + 2 * i], th[pb][8 * q + 2 * i + 1]));
                     ol[i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(tl[pb][8 * q + 2 * i], tl[pb][8 * q + 2 * i + 1]));
                 }
+#ifdef INERF_ABL_NO_FRAG_STORE  // (timing ablation: the transposition without its stores; the asm keeps the values alive)
+                asm volatile("" :: "v"(oh), "v"(ol));
+#else
                 // (whole offset in the VGPR operand: a 16-byte buffer store with a register SGPR offset gets no hazard wait state, tests/test_isa_audit_cpu.py)
                 __builtin_amdgcn_raw_buffer_store_b128(oh, dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, cb, 0)), 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(ol, dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, cb, 1)), 0, 0);
+#endif
             }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -355,11 +364,13 @@ __device__ __forceinline__ void wide_store_h(const f32x16 (&am)[RB][2], float in
                     if (gout && (pb == 0 ? valid0 : valid1))
                         gout[(size_t)pb * 32 * gstride + 32 * rb + 8 * g + i] = t[i] * (1.0f / kActScale);
                 }
+#ifndef INERF_ABL_NO_ROWS
                 if constexpr (SAVE) {
                     const f32x4 v = f32x4{t[0], t[1], t[2], t[3]} * (1.0f / kActScale);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), sv->rsrc,
                                                            sv->voff + (pb * 32 * sv->stride + 32 * rb + 8 * g) * 4, 0, 0);
                 }
+#endif
                 f16x2 h01, h23, l01, l23;
                 split_pair(t[0], t[1], h01, l01);
                 split_pair(t[2], t[3], h23, l23);

@@ -36,6 +36,7 @@ __device__ __forceinline__ void to_operands(const f32x16 (&am)[RB][PB], float in
                     fh[i] = h2[0]; fh[i + 1] = h2[1];
                     fl[i] = l2[0]; fl[i + 1] = l2[1];
                 }
+#ifndef INERF_ABL_NO_ROWS
                 if constexpr (SAVE) {          // registers 8*q2 .. +7 are channels 32*rb + 8*(2*q2) + 4h .. +3 and + 8*(2*q2 + 1) + 4h .. +3
 #pragma unroll
                     for (int gg = 0; gg < 2; ++gg) {
@@ -44,6 +45,7 @@ __device__ __forceinline__ void to_operands(const f32x16 (&am)[RB][PB], float in
                                                                sv->voff + (pb * 32 * sv->stride + 32 * rb + 8 * (2 * q2 + gg)) * 4, 0, 0);
                     }
                 }
+#endif
                 const f16x2 m = __builtin_elementwise_max(__builtin_elementwise_max(f16x2{fh[0], fh[1]}, f16x2{fh[2], fh[3]}),
                                                           __builtin_elementwise_max(f16x2{fh[4], fh[5]}, f16x2{fh[6], fh[7]}));
                 amax2 = __builtin_elementwise_max(amax2, m);

@@ -90,9 +90,12 @@ __device__ __forceinline__ float transpose_block(f16x8 g0, f16x8 g1, f16x8 id0, 
 // GFRAG: G is a fragment slot of the gradient buffer (this wave's 32 channels = channel block `wave`): its operands are loaded
 // in operand order - two 16-byte requests per lane and k-block, plus the eight points' normalisers - and brought to this
 // product's scale (hi + lo, times s_p, split again).
-template <int NW, int CB, bool GFRAG = false>
+// XFRAG: X is a fragment slot of the activation buffer (256 channels at the forward's fixed scale): a tile's 64 fragments ARE the
+// LDS image the contraction reads - moved there by LDS-DMA a tile ahead (wave w: k-block w), nothing to convert.
+template <int NW, int CB, bool GFRAG = false, bool XFRAG = false>
 __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
     static_assert(!GFRAG || NW == 8, "fragment slots are 256 channels wide");
+    static_assert(!XFRAG || (NW == 4 && CB == 8 && !GFRAG), "fragment X: 256 channels, one k-block per wave");
     extern __shared__ __attribute__((aligned(16))) char ldsw[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
     // powers of two that bring the operands' bounds into [2^13, 2^14) (f16 hi/lo split range)
     auto pow2_for = [](float m) { int e; if (!(m > 0.0f) || !(m < 3.0e38f)) return 1.0f; frexpf(m, &e); return ldexpf(1.0f, 14 - e); };
     auto uniform = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
-    const float sg = uniform(pow2_for(p.ranges[0])), sx = uniform(pow2_for(p.ranges[1]));       // wave-uniform: scalar registers
+    const float sg = uniform(pow2_for(p.ranges[0])), sx = XFRAG ? kActScale : uniform(pow2_for(p.ranges[1]));       // wave-uniform: scalar registers
 
     // identity operands of the transposer: B[k][n] = (n == k) resp. (n == k + 16); lane n holds k = 8 * lh + i
     f16x8 id0, id1;
@@ -121,16 +124,18 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
     // LDS: X operands of two tiles (double buffer): [buf][cb][ph][q][plane] fragments
     constexpr int kBufBytes = CB * 8 * kWgFragBytes;
     auto xfrag = [&](int buf, int cb, int ph, int q, int plane) {
-        return ldsw + buf * kBufBytes + ((((cb * 2 + ph) * 2 + q) * 2 + plane) * kWgFragBytes) + lane * 16;
+        if constexpr (XFRAG) return ldsw + buf * kBufBytes + frag_off(2 * ph + q, cb, plane) + lane * 16;       // the slot's own order
+        else return ldsw + buf * kBufBytes + ((((cb * 2 + ph) * 2 + q) * 2 + plane) * kWgFragBytes) + lane * 16;
     };
-    constexpr int XS = (CB + NW - 1) / NW;        // column blocks of X this wave converts (cb = wave + NW * i)
+    constexpr int XS = XFRAG ? 1 : (CB + NW - 1) / NW;        // column blocks of X this wave converts (cb = wave + NW * i)
 
     // The next tile's rows - this wave's share of X and its own 32 channels of G - are requested before the contraction and
     // converted after it: a tile's loads have a whole contraction (~4 000 cycles) to arrive.  (Until round 3 G was requested
     // at the top of its own tile and waited for - ~3 000 exposed cycles of a tile's 20 000.)  One barrier per tile.
     const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G), 0,
         GFRAG ? (int)((unsigned)p.n_tiles * (unsigned)kFragTileBytes) : (int)((unsigned)p.n_points * (unsigned)p.ldg * 4u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, (int)((unsigned)p.n_points * (unsigned)p.ldx * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0,
+        XFRAG ? (int)((unsigned)p.n_tiles * (unsigned)kFragTileBytes) : (int)((unsigned)p.n_points * (unsigned)p.ldx * 4u), 0x00020000);
     const unsigned g_voff0 = (unsigned)(lp * p.ldg + 32 * wave + 8 * lh) * 4u, x_voff0 = (unsigned)(lp * p.ldx + 8 * lh) * 4u;
     float xraw[XS][2][2][8], graw[GFRAG ? 1 : 2][2][8];
     f16x8 gfr[GFRAG ? 2 : 1][2][2];           // GFRAG: [point half][k-block][hi | lo]
@@ -138,7 +143,24 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
     const __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GFRAG ? p.g_scale : p.G), 0,
                                                                              GFRAG ? p.n_tiles * kTilePoints * 4 : 0, 0x00020000);
     auto opaque = [](unsigned v) { asm volatile("" : "+v"(v)); return v; };      // keeps `voff + constant` an immediate, not a hoisted register
+    // XFRAG: k-block `wave` of a tile (16 fragments, 16 KB) straight into LDS[buf]: lane l's 16 bytes of fragment j land at
+    // 1024 j + 16 l of the destination (the instruction offset advances source and destination alike); tiles beyond the end
+    // lie outside the descriptor and write zeros
+    auto dma_x = [&](int tile, int buf) {
+        if constexpr (XFRAG) {
+#pragma unroll
+            for (int grp = 0; grp < 4; ++grp) {
+                __attribute__((address_space(3))) char* dst = (__attribute__((address_space(3))) char*)(ldsw) + buf * kBufBytes + wave * kFragKbBytes + grp * 4 * kFragBytes;
+                const int soff = (int)((unsigned)tile * (unsigned)kFragTileBytes) + wave * kFragKbBytes + grp * 4 * kFragBytes;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, dst, 16, lane * 16, soff, 0 * kFragBytes, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, dst, 16, lane * 16, soff, 1 * kFragBytes, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, dst, 16, lane * 16, soff, 2 * kFragBytes, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, dst, 16, lane * 16, soff, 3 * kFragBytes, 0);
+            }
+        }
+    };
     auto load_x = [&](int tile, int ph) {
+        if constexpr (XFRAG) return;
 #pragma unroll
             for (int i = 0; i < XS; ++i) {
                 const int cb = wave + NW * i;
@@ -176,12 +198,12 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
 #define WG_STAMP(k) do { } while (0)
 #endif
     int buf = 0;
-    load_x(blockIdx.x, 0); load_x(blockIdx.x, 1); load_g(blockIdx.x, 0);
+    load_x(blockIdx.x, 0); load_x(blockIdx.x, 1); dma_x(blockIdx.x, 0); load_g(blockIdx.x, 0);
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         WG_STAMP(0);
         // ---- X: every wave transposes its share of the column blocks and parks the operands in LDS[buf] ----
 #pragma unroll
-        for (int i = 0; i < XS; ++i) {
+        for (int i = 0; i < (XFRAG ? 0 : XS); ++i) {
             const int cb = wave + NW * i;
             if (CB % NW == 0 || cb < CB) {
 #pragma unroll
@@ -237,7 +259,9 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
             WG_STAMP(ph == 0 ? 2 : 5);
             if (ph == 0) {
                 load_x(tile + gridDim.x, 0);
+                if constexpr (XFRAG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's k-block of the tile has landed
                 __syncthreads();               // LDS[buf] complete; LDS[buf ^ 1] (last read before the previous barrier) is free
+                if constexpr (XFRAG) { asm volatile("" ::: "memory"); dma_x(tile + gridDim.x, buf ^ 1); }     // a whole contraction ahead
                 WG_STAMP(3);
             } else {
                 load_x(tile + gridDim.x, 1);
@@ -455,18 +479,20 @@ extern "C" int inerf_wgrad_grid(int64_t n_points) {
 namespace inerf {
 namespace {
 
-int launch_rows(WgradParams& p, bool gfrag, void* stream) {
+int launch_rows(WgradParams& p, bool gfrag, void* stream, bool xfrag = false) {
     const int grid = inerf_wgrad_grid(p.n_points);
     const int M = p.M, cb = p.N / 32;
     if ((M != 128 && M != 256) || p.N % 32 || cb < 1 || cb > 8) return INERF_E_UNSUPPORTED;
     // rows are addressed through 32-bit buffer descriptors, the prefetch reaches one grid stride of tiles beyond the end
-    const int64_t ld = gfrag ? p.ldx : (p.ldg > p.ldx ? p.ldg : p.ldx);
+    const int64_t ld = gfrag ? p.ldx : xfrag ? p.ldg : (p.ldg > p.ldx ? p.ldg : p.ldx);
     if (((int64_t)p.n_points + (int64_t)kTilePoints * (grid + 1)) * ld * 4 >= (int64_t)1 << 32) return INERF_E_UNSUPPORTED;
     const int lds = 2 * cb * 8 * kWgFragBytes;          // double-buffered X operands
     void (*kern)(const WgradParams) = nullptr;
     int variant = -1;
     if (gfrag) {
         if (M == 256 && cb == 2) { kern = k_mlp_wgrad<8, 2, true>; variant = 8; }
+    } else if (xfrag) {
+        if (M == 128 && cb == 8) { kern = k_mlp_wgrad<4, 8, false, true>; variant = 9; }
     } else {
 #define INERF_WG_CASE(V, NWV, CBV) if (M == 32 * NWV && cb == CBV) { kern = k_mlp_wgrad<NWV, CBV>; variant = V; }
         INERF_WG_CASE(0, 8, 8) INERF_WG_CASE(1, 8, 2) INERF_WG_CASE(2, 4, 8) INERF_WG_CASE(3, 4, 1) INERF_WG_CASE(4, 8, 1) INERF_WG_CASE(5, 4, 2)
@@ -474,8 +500,8 @@ int launch_rows(WgradParams& p, bool gfrag, void* stream) {
 #undef INERF_WG_CASE
     }
     if (!kern) return INERF_E_UNSUPPORTED;
-    static PerDeviceOnce attr_set[9];
-    if (lds > 64 * 1024 && attr_set[variant].first()) {          // only <8, 8> and <4, 8>
+    static PerDeviceOnce attr_set[10];
+    if (lds > 64 * 1024 && attr_set[variant].first()) {          // only <8, 8> and the two <4, 8>
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return record(e);
         attr_set[variant].mark();
@@ -517,6 +543,23 @@ extern "C" int inerf_mlp_weight_gradient_gfrag(const void* G_frag, const float* 
     p.ldg = kWidth; p.ldx = ldx; p.n_points = (int)n_points; p.M = kWidth; p.N = N;
     p.n_tiles = (int)((n_points + kTilePoints - 1) / kTilePoints);
     return launch_rows(p, true, stream);
+}
+
+// G: rows (128 channels); X: a FRAGMENT slot of the activation buffer (256 channels).  ranges: device {gmax, ...}.
+extern "C" int inerf_mlp_weight_gradient_xfrag(const float* G, int ldg, const void* X_frag, int64_t n_points, int M,
+                                               const float* ranges, float* partial, float* bias_partial, int64_t partial_stride,
+                                               void* stream) {
+    using namespace inerf;
+    if (!G || !X_frag || !ranges || !partial || n_points <= 0 || ldg < M) return INERF_E_INVALID;
+    if (n_points > kMaxTrainPoints) return INERF_E_UNSUPPORTED;
+    if ((ldg & 3) || (((uintptr_t)G | (uintptr_t)X_frag) & 15)) return INERF_E_INVALID;
+    if (partial_stride < (int64_t)M * kWidth) return INERF_E_INVALID;
+    WgradParams p;
+    p.G = G; p.g_scale = nullptr; p.X = static_cast<const float*>(X_frag); p.ranges = ranges; p.partial = partial; p.bias_partial = bias_partial;
+    p.partial_stride = partial_stride;
+    p.ldg = ldg; p.ldx = kWidth; p.n_points = (int)n_points; p.M = M; p.N = kWidth;
+    p.n_tiles = (int)((n_points + kTilePoints - 1) / kTilePoints);
+    return launch_rows(p, false, stream, true);
 }
 
 // Both operands FRAGMENT slots (256 x 256): G of the gradient buffer with the points' normalisers, X of the activation buffer,

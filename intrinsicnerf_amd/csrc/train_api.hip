@@ -129,12 +129,12 @@ Table build_table(const inerf_net_desc& net, int sem_rows) {
         bpiece(k, 0, 0, kHalf, "albedo_linear1"); bpiece(k, 1, kHalf, kWidth, sh1); }
     {   const int k = add(SAVE_FEAT, SAVE_H7, kWidth, kWidth);
         wpiece(k, 0, kWidth, "feature_linear", 0, kWidth); bpiece(k, 0, 0, kWidth, "feature_linear"); }
-    {   const int k = add(SAVE_VH, SAVE_FEAT, kHalf, kWidth);                     // views_linears.0 over cat([feature, views]), helpers:308
+    {   const int k = add(SAVE_VH, SAVE_FEAT, kHalf, kWidth);                     // views_linears.0 over cat([feature, views]), helpers:308 (rows x fragments)
         wpiece(k, 0, kHalf, "views_linears.0", 0, kWidth); bpiece(k, 0, 0, kHalf, "views_linears.0"); }
     {   const int k = add(SAVE_VH, SAVE_DIR, kHalf, kDirCols);
         wpiece(k, 0, kHalf, "views_linears.0", kWidth, dv); }
     if (sem) {
-        {   const int k = add(SAVE_SEMH, SAVE_H7R, kHalf, kWidth);                // (rows x rows: h7's row copy)
+        {   const int k = add(SAVE_SEMH, SAVE_H7, kHalf, kWidth);                 // (rows x fragments)
             wpiece(k, 0, kHalf, "semantic_linear.0.0", 0, kWidth); bpiece(k, 0, 0, kHalf, "semantic_linear.0.0"); }
         {   const int k = add(-1, SAVE_SEMH, sem_rows, kHalf);                   // semantic_linear.1: G = padded d_logits
             tb.launch[k].sem = 1;
@@ -366,7 +366,7 @@ extern "C" int inerf_mlp_backward(const inerf_net_desc* net, const float* packed
         const float* g_scale = dz + save_offset(*net, SAVE_ENC, n_points);        // the points' normalisers, written by the chain
         if (g_frag && x_frag) rc = inerf_mlp_weight_gradient_frag(G, g_scale, X, sc + 4, n_points, tile, bias, t.total, stream);
         else if (g_frag)      rc = inerf_mlp_weight_gradient_gfrag(G, g_scale, X, save_width(*net, l.x_slot), n_points, j.n, sc + 4, tile, bias, t.total, stream);
-        else if (x_frag)      rc = INERF_E_UNSUPPORTED;       // (no product of the table reads row gradients against fragment activations)
+        else if (x_frag)      rc = inerf_mlp_weight_gradient_xfrag(G, ldg, X, n_points, j.m, sc + 4, tile, bias, t.total, stream);
         else rc = inerf_mlp_weight_gradient(G, ldg, X, save_width(*net, l.x_slot), n_points, j.m, j.n, sc + (l.sem ? 8 : 4), tile, bias, t.total, stream);
         if (rc) return rc;
     }

@@ -728,6 +728,26 @@ def weight_gradient_frag(g_frag, g_scale, x_frag, ranges, n_points, want_bias=Fa
     return (w, sums[256 * n:]) if want_bias else w
 
 
+def weight_gradient_xfrag(g_rows, x_frag, ranges, n_points, want_bias=False):
+    """G^T X with G row-format ([n_points, >= 128] fp32: a 128-channel gradient slot) and X a FRAGMENT slot of activations
+    (256 channels): the products of views_linears.0's feature columns and of the semantic hidden layer.  ``ranges[0]``: an
+    upper bound of |G|."""
+    lib = _capi.lib()
+    grid = lib.inerf_wgrad_grid(n_points)
+    m = 128
+    total = m * 256 + (m if want_bias else 0)
+    buf = _new(ranges, grid, total)
+    base = buf.data_ptr()
+    bias = C.c_void_p(base + 4 * m * 256) if want_bias else None
+    with torch.cuda.device(ranges.device):
+        rc = lib.inerf_mlp_weight_gradient_xfrag(C.c_void_p(g_rows.data_ptr()), g_rows.stride(0), _ptr(x_frag), n_points, m, _ptr(ranges),
+                                                 C.c_void_p(base), bias, total, _stream(ranges))
+    _capi.check(rc, "inerf_mlp_weight_gradient_xfrag")
+    sums = buf.sum(0)
+    w = sums[:m * 256].view(m, 256)
+    return (w, sums[m * 256:]) if want_bias else w
+
+
 def _colsum(g, nc):
     return g.sum(0) if nc == 1 else g.view(nc, g.shape[0] // nc, g.shape[1]).sum(1).sum(0)
 

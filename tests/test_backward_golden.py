@@ -432,7 +432,7 @@ def test_weight_gradient_kernel_vs_fp64(p, m, n):
 @pytest.mark.parametrize("p", [1, 15, 17, 63, 65, 1000, 5000, 70001, 131072])
 def test_weight_gradient_from_fragment_slots(p):
     """The LDS-DMA kernel of the nine 256 x 256 products (both operands FRAGMENT slots, include/inerf.h: per-point normalised
-    gradients with their normalisers x activations) and the mixed form (G fragments x row-format X, 64 columns) against fp64 products of
+    gradients with their normalisers x activations) and the mixed forms (G fragments x row-format X, 64 columns; row-format G, 128 channels, x X fragments) against fp64 products of
     what the fragments encode - down to a single sample point (k-blocks and tiles that are mostly padding), ragged counts,
     more k-blocks than the ring is deep and than the grid is wide; gradients spanning four decades.  The row-format kernel
     on the same matrices agrees."""
@@ -458,6 +458,12 @@ def test_weight_gradient_from_fragment_slots(p):
     want64 = Gq.t() @ xr.double()
     assert float((w64.double() - want64).norm()) <= 2e-6 * float(want64.norm())
     assert float((b64.double() - want_b).norm()) <= 2e-6 * float(want_b.norm()) + 1e-12
+    # row-format G (128 channels) x X fragments (views_linears.0 against the feature layer, the semantic hidden layer against h7)
+    gr = G[:, 128:256].contiguous()
+    wx, bx = kernels.weight_gradient_xfrag(gr, xf, ranges, p, want_bias=True)
+    wantx = gr.double().t() @ Xq
+    assert float((wx.double() - wantx).norm()) <= 2e-6 * float(wantx.norm())
+    assert float((bx.double() - gr.double().sum(0)).norm()) <= 2e-6 * float(gr.double().sum(0).norm()) + 1e-12
     # the row-format kernel (lane = point form) on the same 256 x 256 product
     wr, br = kernels.weight_gradient(G, X, 256, 256, want_bias=True)
     assert float((wr.double() - G.double().t() @ X.double()).norm()) <= 2e-6 * float(want_w.norm())

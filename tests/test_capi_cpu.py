@@ -95,21 +95,22 @@ def test_argument_validation(capi):
         assert rc == capi.OK
     bits = 7 * 4 * 64 * 2                          # ReLU-mask words per 64-point tile (h0..h6, 4 waves, 64 lanes, 2 words)
     sc = 64                                        # per-evaluation scalars behind the mask area
-    per_point = 64 + 32 + 8 * 256 + 256 + 256 + 128 + 8 + 256          # ... + h7's row copy (slot 15)
+    per_point = 64 + 32 + 8 * 256 + 256 + 256 + 128 + 8                # (slot 15: width 0)
     assert lib.inerf_mlp_save_floats(good, 64) == 64 * per_point + bits + sc
     assert lib.inerf_mlp_save_floats(ssr28, 64) == 64 * (per_point + 128) + bits + sc
     assert lib.inerf_mlp_save_floats(good, 65) == 128 * per_point + 2 * bits + sc          # whole tiles: slots AND masks
     off, width = C.c_int64(), C.c_int()
     assert lib.inerf_mlp_save_slot(ssr28, 13, 100, C.byref(off), C.byref(width)) == capi.OK and width.value == 128
     assert lib.inerf_mlp_save_slot(good, 13, 100, C.byref(off), C.byref(width)) == capi.OK and width.value == 0
-    assert lib.inerf_mlp_save_slot(good, 15, 100, C.byref(off), C.byref(width)) == capi.OK and width.value == 256
-    assert off.value == 128 * (per_point - 256)                                          # slots are sized for whole tiles
+    assert lib.inerf_mlp_save_slot(good, 15, 100, C.byref(off), C.byref(width)) == capi.OK and width.value == 0
+    assert off.value == 128 * per_point                                          # slots are sized for whole tiles
     assert lib.inerf_mlp_save_slot(good, 16, 100, C.byref(off), C.byref(width)) == capi.E_INVALID
-    # formats: h0..h7 are fragment slots in both buffers, the albedo|shading hidden layer and the feature layer only as gradients
-    assert [lib.inerf_mlp_save_slot_is_fragment(s, 0) for s in range(16)] == [0, 0] + [1] * 8 + [0] * 6
+    # formats: h0..h7 and the feature layer are fragment slots in both buffers, the albedo|shading hidden layer only as gradients
+    assert [lib.inerf_mlp_save_slot_is_fragment(s, 0) for s in range(16)] == [0, 0] + [1] * 8 + [0, 1] + [0] * 4
     assert [lib.inerf_mlp_save_slot_is_fragment(s, 1) for s in range(16)] == [0, 0] + [1] * 10 + [0] * 4
     assert lib.inerf_mlp_save_slot_is_fragment(16, 0) == capi.E_INVALID
     assert lib.inerf_mlp_weight_gradient_frag(None, None, None, None, 1000, None, None, 65536, None) == capi.E_INVALID
+    assert lib.inerf_mlp_weight_gradient_xfrag(None, 128, None, 1000, 128, None, None, None, 32768, None) == capi.E_INVALID
     assert lib.inerf_mlp_weight_gradient_gfrag(None, None, None, 64, 1000, 64, None, None, None, 16384, None) == capi.E_INVALID
     assert lib.inerf_wgrad_grid(0) == 0 and lib.inerf_mlp_backward_grid(64 * 7) == 7
     assert lib.inerf_mlp_head_partial_floats() == 1672
