@@ -30,7 +30,7 @@ extern "C" {
 #define INERF_VERSION_MINOR 2
 /* Bumped whenever a struct layout, an argument list or the packed-weight format of this header changes; bindings
  * compare it with inerf_abi_version() of the library they loaded (a stale .so then fails loudly, not silently). */
-#define INERF_ABI_VERSION 40002
+#define INERF_ABI_VERSION 40003
 
 /* error codes */
 #define INERF_OK              0
@@ -222,7 +222,18 @@ int inerf_mlp_weight_gradient_gfrag(const void* G_frag, const float* g_scale, co
 int inerf_mlp_weight_gradient_xfrag(const float* G, int ldg, const void* X_frag, int64_t n_points, int M,
                                     const float* ranges, float* partial, float* bias_partial, int64_t partial_stride, void* stream);
 /* ... and with BOTH operands FRAGMENT slots (256 x 256: G of the gradient buffer, X of the activation buffer, same points):
- * a ring of LDS stages filled by LDS-DMA - bound by HBM bandwidth.  ranges[0]: an upper bound of the true |dz|. */
+ * a ring of LDS stages filled by LDS-DMA - bound by HBM bandwidth.  ranges[0]: an upper bound of the true |dz|.
+ * _batch: n_jobs (<= INERF_WGRAD_MAX_BATCH) such products over the SAME points and normalisers in one launch of
+ * inerf_wgrad_frag_grid(n_points, n_jobs) workgroups: job j is split over inerf_wgrad_frag_rows(n_points, n_jobs, j) of them
+ * (~ grid / n_jobs), K-slice s writing its tile at partial[j] + s * partial_stride (and its column sums of G at
+ * bias_partial[j] + s * partial_stride where that entry is not NULL): n_jobs times fewer partial tiles to write and to sum
+ * than n_jobs single launches.  The single form is the batch of one (inerf_wgrad_grid(n_points) slices). */
+#define INERF_WGRAD_MAX_BATCH 12
+int inerf_wgrad_frag_grid(int64_t n_points, int n_jobs);
+int inerf_wgrad_frag_rows(int64_t n_points, int n_jobs, int job);
+int inerf_mlp_weight_gradient_frag_batch(int n_jobs, const void* const* G_frag /*[host]*/, const float* g_scale, const void* const* X_frag /*[host]*/,
+                                         const float* ranges, int64_t n_points, float* const* partial /*[host]*/,
+                                         float* const* bias_partial /*[host] or NULL*/, int64_t partial_stride, void* stream);
 int inerf_mlp_weight_gradient_frag(const void* G_frag, const float* g_scale, const void* X_frag, const float* ranges, int64_t n_points,
                                    float* partial, float* bias_partial, int64_t partial_stride, void* stream);
 

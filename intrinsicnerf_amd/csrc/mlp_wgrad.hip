@@ -336,23 +336,38 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
 // reading the stage before, whose buffer is the one re-filled next.  (A __syncthreads() would drain vmcnt to 0.)
 // The column sums of G (the bias gradient) come from the operands the waves 0..3 read anyway.
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef INERF_WGRAD_MAX_BATCH
+#define INERF_WGRAD_MAX_BATCH 12
+#endif
 #ifndef INERF_WGRAD_FRAG_STAGES
 #define INERF_WGRAD_FRAG_STAGES 4
 #endif
 constexpr int kFragStages = INERF_WGRAD_FRAG_STAGES;
+#ifndef INERF_WGRAD_DMA_AUX
+#define INERF_WGRAD_DMA_AUX 2
+#endif
+constexpr int kDmaAux = INERF_WGRAD_DMA_AUX;                    // cache policy of the fragment stream: 2 = nt (every byte is read once, by one CU;
+                                                                // same-box A/B against the default policy: 1.686 vs 1.705 ms per training step)
 constexpr int kFragStageBytes = 2 * kFragKbBytes;               // G | X of one k-block
 constexpr int kFragScaleBytes = 8 * 256;                        // per stage: every wave's own copy of the k-block's normalisers (64 lanes x 4 bytes)
 static_assert(kFragStages >= 3 && kFragStages <= 5, "ring depth");
 
+// SEVERAL products over the same sample points share one launch (the nine of a network do): workgroup b works on product
+// b % n_jobs as its K-slice b / n_jobs - a product is split over ~grid / n_jobs workgroups instead of the whole grid, so the
+// chip writes (and the final sum reads) n_jobs times fewer partial tiles - 7 MB per product instead of 64 MB at nine jobs,
+// which was a tenth of the operand bytes themselves - fills its ring once instead of n_jobs times, and one launch boundary
+// replaces n_jobs.  Every workgroup still streams 32 KB stages of two contiguous matrices.
+constexpr int kMaxFragJobs = INERF_WGRAD_MAX_BATCH;
 struct WgradFragParams {
-    const void* G;           // fragment slot of dZ: f16 hi / lo of kActScale * dz / s_p
+    const void* G[kMaxFragJobs];        // fragment slot of dZ: f16 hi / lo of kActScale * dz / s_p
+    const void* X[kMaxFragJobs];        // fragment slot of activations: f16 hi / lo of kActScale * h
+    float* partial[kMaxFragJobs];       // K-slice s of the job writes its 256 x 256 tile at partial + s * partial_stride
+    float* bias_partial[kMaxFragJobs];  // optional: ... its column sums of G
     const float* g_scale;    // the points' normalisers s_p: 64 * n_tiles (+ 64 readable) floats
-    const void* X;           // fragment slot of activations: f16 hi / lo of kActScale * h
     const float* ranges;     // device: {gmax, ...}: upper bound of |dz|
-    float* partial;          // workgroup g writes its 256 x 256 tile at partial + g * partial_stride
-    float* bias_partial;     // optional: ... its column sums of G
     int64_t partial_stride;  // floats
     int n_kb;                // 16-point k-blocks: 4 per tile
+    int n_jobs;
 };
 
 __global__ __launch_bounds__(512, 1) void k_mlp_wgrad_frag(const WgradFragParams p) {
@@ -362,7 +377,9 @@ __global__ __launch_bounds__(512, 1) void k_mlp_wgrad_frag(const WgradFragParams
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lp = lane & 31, lh = lane >> 5;
     const bool dma_g = wave < 4;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(dma_g ? p.G : p.X), 0,
+    const int job = (int)blockIdx.x % p.n_jobs;
+    float* const bias_partial = p.bias_partial[job];
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(dma_g ? p.G[job] : p.X[job]), 0,
                                                                            (int)((unsigned)p.n_kb * (unsigned)kFragKbBytes), 0x00020000);
     const int my_bytes = (dma_g ? 0 : kFragKbBytes) + (wave & 3) * 4 * kFragBytes;      // this wave's four fragments inside a stage
     const int src_bytes = (wave & 3) * 4 * kFragBytes;                                   // ... inside its matrix's k-block
@@ -374,10 +391,10 @@ __global__ __launch_bounds__(512, 1) void k_mlp_wgrad_frag(const WgradFragParams
     auto request = [&](int kb, int buf) {
         __attribute__((address_space(3))) char* dst = (__attribute__((address_space(3))) char*)(ldsw) + buf * kFragStageBytes + my_bytes;
         const int soff = (int)((unsigned)kb * (unsigned)kFragKbBytes) + src_bytes;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, lane * 16, soff, 0 * kFragBytes, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, lane * 16, soff, 1 * kFragBytes, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, lane * 16, soff, 2 * kFragBytes, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, lane * 16, soff, 3 * kFragBytes, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, lane * 16, soff, 0 * kFragBytes, kDmaAux);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, lane * 16, soff, 1 * kFragBytes, kDmaAux);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, lane * 16, soff, 2 * kFragBytes, kDmaAux);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, lane * 16, soff, 3 * kFragBytes, kDmaAux);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (__attribute__((address_space(3))) char*)(scale_lds) + buf * kFragScaleBytes, 4, lane * 4, kb * 64, 0, 0);
     };
     f32x16 acc[8];                             // rows 32 wave .. + 31, column block cb
@@ -408,7 +425,7 @@ __global__ __launch_bounds__(512, 1) void k_mlp_wgrad_frag(const WgradFragParams
                 v[i] = __builtin_fmaf((float)g16h[i], spc, (float)g16l[i] * spc);
             }
             split8(v, 1.0f, gh, gl);
-            if (p.bias_partial) {
+            if (bias_partial) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) bias_sum += v[i];
             }
@@ -424,9 +441,9 @@ __global__ __launch_bounds__(512, 1) void k_mlp_wgrad_frag(const WgradFragParams
         }
     };
 
-    // this workgroup's k-blocks: blockIdx.x, + gridDim.x, ... (neighbouring workgroups stream neighbouring 32 KB: the chip
-    // walks both matrices front to back)
-    const int g = gridDim.x, b = blockIdx.x;
+    // this workgroup's k-blocks: its slice number, + the job's slice count, ... (the workgroups of a job stream neighbouring
+    // 32 KB: the chip walks every matrix front to back)
+    const int g = ((int)gridDim.x - job + p.n_jobs - 1) / p.n_jobs, b = (int)blockIdx.x / p.n_jobs;
     const int n_mine = p.n_kb > b ? (p.n_kb - b + g - 1) / g : 0;
 #pragma unroll
     for (int j = 0; j < kFragStages - 1; ++j)
@@ -447,12 +464,12 @@ __global__ __launch_bounds__(512, 1) void k_mlp_wgrad_frag(const WgradFragParams
     }
 
     // ---- this workgroup's partial tile and its column sums of G ----
-    if (p.bias_partial) {                      // the two lane halves hold complementary points of the same channel
+    if (bias_partial) {                        // the two lane halves hold complementary points of the same channel
         const float both = bias_sum + __shfl_xor(bias_sum, 32);
-        if (lh == 0) p.bias_partial[(size_t)blockIdx.x * p.partial_stride + 32 * wave + lp] = both / sg;
+        if (lh == 0) bias_partial[(size_t)b * p.partial_stride + 32 * wave + lp] = both / sg;
     }
     const float back = 1.0f / (sg * kActScale);
-    float* out = p.partial + (size_t)blockIdx.x * p.partial_stride;
+    float* out = p.partial[job] + (size_t)b * p.partial_stride;
 #pragma unroll
     for (int cb = 0; cb < 8; ++cb)
 #pragma unroll
@@ -564,17 +581,34 @@ extern "C" int inerf_mlp_weight_gradient_xfrag(const float* G, int ldg, const vo
 
 // Both operands FRAGMENT slots (256 x 256): G of the gradient buffer with the points' normalisers, X of the activation buffer,
 // on the same n_points.  ranges: device {gmax, ...}: an upper bound of |dz| (the dz_max of inerf_mlp_backward_inputs).
-extern "C" int inerf_mlp_weight_gradient_frag(const void* G_frag, const float* g_scale, const void* X_frag, const float* ranges,
-                                              int64_t n_points, float* partial, float* bias_partial, int64_t partial_stride, void* stream) {
+// n_jobs products in one launch of inerf_wgrad_frag_grid(n_points, n_jobs) workgroups: job j is split over
+// inerf_wgrad_frag_rows(n_points, n_jobs, j) K-slices, slice s writing its tile at partial[j] + s * partial_stride.
+extern "C" int inerf_wgrad_frag_grid(int64_t n_points, int n_jobs) {
+    const int g = inerf_wgrad_grid(n_points);
+    return g < n_jobs ? n_jobs : g;
+}
+
+extern "C" int inerf_wgrad_frag_rows(int64_t n_points, int n_jobs, int job) {
+    if (n_jobs < 1 || job < 0 || job >= n_jobs || n_points <= 0) return 0;
+    return (inerf_wgrad_frag_grid(n_points, n_jobs) - job + n_jobs - 1) / n_jobs;
+}
+
+extern "C" int inerf_mlp_weight_gradient_frag_batch(int n_jobs, const void* const* G_frag, const float* g_scale, const void* const* X_frag,
+                                                    const float* ranges, int64_t n_points, float* const* partial,
+                                                    float* const* bias_partial, int64_t partial_stride, void* stream) {
     using namespace inerf;
+    if (n_jobs < 1 || n_jobs > kMaxFragJobs) return INERF_E_INVALID;
     if (!G_frag || !g_scale || !X_frag || !ranges || !partial || n_points <= 0) return INERF_E_INVALID;
     if (n_points > kMaxTrainPoints) return INERF_E_UNSUPPORTED;
-    if ((((uintptr_t)G_frag | (uintptr_t)X_frag) & 15) || ((uintptr_t)g_scale & 3) || partial_stride < (int64_t)kWidth * kWidth) return INERF_E_INVALID;
-    WgradFragParams p;
-    p.G = G_frag; p.g_scale = g_scale; p.X = X_frag; p.ranges = ranges; p.partial = partial; p.bias_partial = bias_partial;
-    p.partial_stride = partial_stride;
+    if (((uintptr_t)g_scale & 3) || partial_stride < (int64_t)kWidth * kWidth) return INERF_E_INVALID;
+    WgradFragParams p{};
+    for (int j = 0; j < n_jobs; ++j) {
+        if (!G_frag[j] || !X_frag[j] || !partial[j] || (((uintptr_t)G_frag[j] | (uintptr_t)X_frag[j]) & 15)) return INERF_E_INVALID;
+        p.G[j] = G_frag[j]; p.X[j] = X_frag[j]; p.partial[j] = partial[j]; p.bias_partial[j] = bias_partial ? bias_partial[j] : nullptr;
+    }
+    p.g_scale = g_scale; p.ranges = ranges; p.partial_stride = partial_stride; p.n_jobs = n_jobs;
     p.n_kb = (int)((n_points + kTilePoints - 1) / kTilePoints) * 4;
-    const int grid = inerf_wgrad_grid(n_points);
+    const int grid = inerf_wgrad_frag_grid(n_points, n_jobs);
     constexpr int lds = kFragStages * (kFragStageBytes + kFragScaleBytes);
     static PerDeviceOnce attr_set;
     if (attr_set.first()) {
@@ -584,4 +618,10 @@ extern "C" int inerf_mlp_weight_gradient_frag(const void* G_frag, const float* g
     }
     hipLaunchKernelGGL(k_mlp_wgrad_frag, dim3(grid), dim3(512), lds, (hipStream_t)stream, p);
     return record(hipGetLastError());
+}
+
+// one product: inerf_wgrad_grid(n_points) K-slices
+extern "C" int inerf_mlp_weight_gradient_frag(const void* G_frag, const float* g_scale, const void* X_frag, const float* ranges,
+                                              int64_t n_points, float* partial, float* bias_partial, int64_t partial_stride, void* stream) {
+    return inerf_mlp_weight_gradient_frag_batch(1, &G_frag, g_scale, &X_frag, ranges, n_points, &partial, &bias_partial, partial_stride, stream);
 }

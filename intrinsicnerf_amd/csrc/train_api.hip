@@ -41,6 +41,7 @@ struct Job {
     int32_t src;           // float offset of the [m, n] tile inside a partial row
     int32_t bias_src;      // ... of its [m] column sums of G, or -1
     int32_t m, n;
+    int32_t rows;          // partial rows of this job (the batched 256 x 256 products are split over fewer workgroups than the grid)
     Piece w[2];
     BiasPiece b[2];
 };
@@ -237,16 +238,21 @@ __global__ void k_ranges(float* __restrict__ s, const float* __restrict__ act_ma
 __global__ void k_reduce_scatter(const ReduceTable t, const float* __restrict__ partial, float* __restrict__ grads) {
     const int64_t i = 4 * (blockIdx.x * (int64_t)blockDim.x + threadIdx.x);
     if (i >= t.total) return;
+    int rows = t.grid;
+    for (int k = 0; k < t.n_jobs; ++k) {
+        const Job& j = t.job[k];
+        if ((i >= j.src && i < j.src + j.m * j.n) || (j.bias_src >= 0 && i >= j.bias_src && i < j.bias_src + j.m)) rows = j.rows;
+    }
     f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
     int g = 0;
-    for (; g + 8 <= t.grid; g += 8) {
+    for (; g + 8 <= rows; g += 8) {
         f32x4 r[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) r[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(partial + (int64_t)(g + k) * t.total + i));
 #pragma unroll
         for (int k = 0; k < 8; ++k) v += r[k];           // fixed order: deterministic
     }
-    for (; g < t.grid; ++g) v += *reinterpret_cast<const f32x4*>(partial + (int64_t)g * t.total + i);
+    for (; g < rows; ++g) v += *reinterpret_cast<const f32x4*>(partial + (int64_t)g * t.total + i);
     for (int k = 0; k < t.n_jobs; ++k) {
         const Job& j = t.job[k];
         if (i >= j.src && i < j.src + j.m * j.n) {
@@ -275,18 +281,27 @@ __global__ void k_reduce_scatter(const ReduceTable t, const float* __restrict__ 
     }
 }
 
-// the 1-4-row heads' partials [grid][kHeadFloats]: 64 columns per workgroup, its four waves take every fourth row
-__global__ __launch_bounds__(256) void k_reduce_heads(const float* __restrict__ heads, int grid, HeadDst d, float* __restrict__ grads) {
-    __shared__ float part[4][64];
+// the 1-4-row heads' partials [grid][kHeadFloats]: 64 columns per workgroup, its sixteen waves take every sixteenth row
+__global__ __launch_bounds__(1024) void k_reduce_heads(const float* __restrict__ heads, int grid, HeadDst d, float* __restrict__ grads) {
+    __shared__ float part[16][64];
     const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + col;
     float v = 0.0f;
-    if (i < kHeadFloats)
-        for (int g = rg; g < grid; g += 4) v += heads[(size_t)g * kHeadFloats + i];
+    if (i < kHeadFloats) {
+        int g = rg;
+        for (; g + 48 < grid; g += 64) {           // four rows in flight per thread (64 dependent reads in a row took 29 us)
+            const float a = heads[(size_t)g * kHeadFloats + i], b = heads[(size_t)(g + 16) * kHeadFloats + i];
+            const float c = heads[(size_t)(g + 32) * kHeadFloats + i], e = heads[(size_t)(g + 48) * kHeadFloats + i];
+            v += a; v += b; v += c; v += e;         // fixed order: deterministic
+        }
+        for (; g < grid; g += 16) v += heads[(size_t)g * kHeadFloats + i];
+    }
     part[rg][col] = v;
     __syncthreads();
     if (rg != 0 || i >= kHeadFloats) return;
-    v = ((part[0][col] + part[1][col]) + part[2][col]) + part[3][col];
+    v = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += part[k][col];
     if (i < kHeadAs2) grads[d.res_w + i] = v;                                                 // residual head [3][128]
     else if (i < kHeadAlpha) {
         const int j = (i - kHeadAs2) / kWidth, c = (i - kHeadAs2) % kWidth;
@@ -354,8 +369,18 @@ extern "C" int inerf_mlp_backward(const inerf_net_desc* net, const float* packed
     const Table& tb = cache.table;
     ReduceTable t = tb.dev;
     t.grid = plan.wg_grid;
+    const float* g_scale = dz + save_offset(*net, SAVE_ENC, n_points);        // the points' normalisers, written by the chain
+    // the 256 x 256 products (both operands fragment slots): ONE launch, each product split over its share of the grid
+    const void* fg[kMaxJobs]; const void* fx[kMaxJobs]; float* ft[kMaxJobs]; float* fb[kMaxJobs];
+    int n_frag = 0;
     for (int k = 0; k < t.n_jobs; ++k) {
-        const Job& j = t.job[k];
+        const Launch& l = tb.launch[k];
+        t.job[k].rows = t.grid;
+        if (!l.sem && save_is_frag(l.g_slot, true) && save_is_frag(l.x_slot, false)) ++n_frag;
+    }
+    if (n_frag > INERF_WGRAD_MAX_BATCH) return INERF_E_UNSUPPORTED;
+    for (int k = 0, f = 0; k < t.n_jobs; ++k) {
+        Job& j = t.job[k];
         const Launch& l = tb.launch[k];
         const float* G = l.sem ? gsem : dz + save_offset(*net, l.g_slot, n_points);
         const int ldg = l.sem ? plan.sem_rows : save_width(*net, l.g_slot);
@@ -363,16 +388,25 @@ extern "C" int inerf_mlp_backward(const inerf_net_desc* net, const float* packed
         float* tile = partial + j.src;
         float* bias = j.bias_src >= 0 ? partial + j.bias_src : nullptr;
         const bool g_frag = !l.sem && save_is_frag(l.g_slot, true), x_frag = save_is_frag(l.x_slot, false);
-        const float* g_scale = dz + save_offset(*net, SAVE_ENC, n_points);        // the points' normalisers, written by the chain
-        if (g_frag && x_frag) rc = inerf_mlp_weight_gradient_frag(G, g_scale, X, sc + 4, n_points, tile, bias, t.total, stream);
-        else if (g_frag)      rc = inerf_mlp_weight_gradient_gfrag(G, g_scale, X, save_width(*net, l.x_slot), n_points, j.n, sc + 4, tile, bias, t.total, stream);
-        else if (x_frag)      rc = inerf_mlp_weight_gradient_xfrag(G, ldg, X, n_points, j.m, sc + 4, tile, bias, t.total, stream);
+        if (g_frag && x_frag) {
+            fg[f] = G; fx[f] = X; ft[f] = tile; fb[f] = bias;
+            j.rows = inerf_wgrad_frag_rows(n_points, n_frag, f);
+            if (j.rows > t.grid) return INERF_E_WORKSPACE;
+            ++f;
+            continue;
+        }
+        if (g_frag)      rc = inerf_mlp_weight_gradient_gfrag(G, g_scale, X, save_width(*net, l.x_slot), n_points, j.n, sc + 4, tile, bias, t.total, stream);
+        else if (x_frag) rc = inerf_mlp_weight_gradient_xfrag(G, ldg, X, n_points, j.m, sc + 4, tile, bias, t.total, stream);
         else rc = inerf_mlp_weight_gradient(G, ldg, X, save_width(*net, l.x_slot), n_points, j.m, j.n, sc + (l.sem ? 8 : 4), tile, bias, t.total, stream);
+        if (rc) return rc;
+    }
+    if (n_frag) {
+        rc = inerf_mlp_weight_gradient_frag_batch(n_frag, fg, g_scale, fx, sc + 4, n_points, ft, fb, t.total, stream);
         if (rc) return rc;
     }
     hipLaunchKernelGGL(k_reduce_scatter, dim3((unsigned)((t.total / 4 + 255) / 256)), dim3(256), 0, stream, t, partial, grads_out);
     const HeadDst& d = cache.heads;
-    hipLaunchKernelGGL(k_reduce_heads, dim3((kHeadFloats + 63) / 64), dim3(256), 0, stream, heads, plan.bwd_grid, d, grads_out);
+    hipLaunchKernelGGL(k_reduce_heads, dim3((kHeadFloats + 63) / 64), dim3(1024), 0, stream, heads, plan.bwd_grid, d, grads_out);
     return record(hipGetLastError());
 }
 
@@ -393,7 +427,21 @@ struct ParamPtrs {
     int32_t n;
 };
 
-__device__ __forceinline__ float param_at(const ParamPtrs& t, int src) {      // src: 1 + index into the flat concatenation, 0 = padding
+// The tensor table in LDS: the look-up below is a chain of ~6 dependent reads per element, and read from the kernel-argument
+// segment (per-lane indices: global loads) that chain was most of the three kernels' run time (33 + 13 + 5 us per blob).
+struct ParamTableLds {
+    const float* p[kMaxParamTensors];
+    int32_t first[kMaxParamTensors + 1];
+    int32_t n;
+};
+
+__device__ __forceinline__ void stage_params(const ParamPtrs& t, ParamTableLds& lds) {
+    for (int i = threadIdx.x; i < t.n; i += blockDim.x) { lds.p[i] = t.p[i]; lds.first[i] = t.first[i]; }
+    if (threadIdx.x == 0) lds.n = t.n;
+    __syncthreads();
+}
+
+__device__ __forceinline__ float param_at(const ParamTableLds& t, int src) {   // src: 1 + index into the flat concatenation, 0 = padding
     if (src <= 0) return 0.0f;
     int lo = 0, hi = t.n - 1;
     while (lo < hi) {                                                          // last tensor whose first element is <= src
@@ -410,24 +458,37 @@ __device__ __forceinline__ float group_scale(float gmax) {                    //
     return ldexpf(1.0f, 14 - e);
 }
 
-__global__ void k_repack_gmax(const ParamPtrs t, const int32_t* __restrict__ group_src, int longest, float* __restrict__ gmax) {
+// One element per thread and ONE atomic per block that saw a parameter (a group's row of the map is padded to the longest
+// group: most blocks see nothing and leave at once).  The first form walked a row with 64 blocks - twelve dependent
+// map -> table -> parameter look-ups per thread, 39 us per blob, four blobs per training step.
+__global__ __launch_bounds__(256) void k_repack_gmax(const ParamPtrs t, const int32_t* __restrict__ group_src, int longest, float* __restrict__ gmax) {
+    __shared__ float wave_max[4];
+    __shared__ ParamTableLds tl;
+    stage_params(t, tl);
     const int g = blockIdx.y;
     float m = 0.0f;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < longest; j += gridDim.x * blockDim.x)
-        m = fmaxf(m, fabsf(param_at(t, group_src[(size_t)g * longest + j])));
+        m = fmaxf(m, fabsf(param_at(tl, group_src[(size_t)g * longest + j])));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+    __syncthreads();
     // fmaxf drops a NaN parameter exactly as the host packer's std::fmax does (weight_scale, pack.cpp): same scale, and the NaN
     // itself survives as the NaN halves of that element
-    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(reinterpret_cast<unsigned int*>(gmax + g), __builtin_bit_cast(unsigned int, m));
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+        if (m > 0.0f) atomicMax(reinterpret_cast<unsigned int*>(gmax + g), __builtin_bit_cast(unsigned int, m));
+    }
 }
 
 __global__ void k_repack_halves(const ParamPtrs t, const int32_t* __restrict__ half_src, const int32_t* __restrict__ half_grp,
                                 const float* __restrict__ gmax, int64_t n_halves, _Float16* __restrict__ out) {
+    __shared__ ParamTableLds tl;
+    stage_params(t, tl);
     const int64_t h = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (h >= n_halves) return;
     const int grp = half_grp[h];
-    float vs = param_at(t, half_src[h]) * group_scale(gmax[grp >= 0 ? grp : -grp - 1]);
+    float vs = param_at(tl, half_src[h]) * group_scale(gmax[grp >= 0 ? grp : -grp - 1]);
     // keep the product and its conversion apart: fused, the compiler emits v_fma_mixlo_f16(a, b, +0), and (-0 * s) + 0 is +0 -
     // the sign of a zero weight would differ from the host packer's (found by tests/test_repack_gpu.py on an all-zero layer)
     asm volatile("" : "+v"(vs));
@@ -438,11 +499,13 @@ __global__ void k_repack_halves(const ParamPtrs t, const int32_t* __restrict__ h
 __global__ void k_repack_consts(const ParamPtrs t, const int32_t* __restrict__ c_dst, const int32_t* __restrict__ c_src,
                                 const int32_t* __restrict__ c_grp, const int32_t* __restrict__ c_code, const float* __restrict__ c_mult,
                                 const float* __restrict__ gmax, int n, float* __restrict__ out) {
+    __shared__ ParamTableLds tl;
+    stage_params(t, tl);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int code = c_code[i];
     float v;
-    if (code == 0) v = param_at(t, c_src[i]) * c_mult[i];
+    if (code == 0) v = param_at(tl, c_src[i]) * c_mult[i];
     else {
         const float inv = 1.0f / group_scale(gmax[c_grp[i]]);
         v = code == 1 ? inv : inv * 0.125f;
@@ -475,7 +538,7 @@ extern "C" int inerf_repack(const float* const* params /*[host] device pointers,
     hipStream_t stream = (hipStream_t)stream_;
     hipError_t e = hipMemsetAsync(gmax_scratch, 0, sizeof(float) * (size_t)n_groups, stream);
     if (e != hipSuccess) return record(e);
-    const int chunks = longest < 256 * 64 ? (longest + 255) / 256 : 64;
+    const int chunks = longest < 256 * 1024 ? (longest + 255) / 256 : 1024;
     hipLaunchKernelGGL(k_repack_gmax, dim3(chunks, n_groups), dim3(256), 0, stream, t, group_src, longest, gmax_scratch);
     const int64_t n_halves = 2 * packed_floats;
     hipLaunchKernelGGL(k_repack_halves, dim3((unsigned)((n_halves + 255) / 256)), dim3(256), 0, stream, t, half_src, half_grp, gmax_scratch,

@@ -728,6 +728,29 @@ def weight_gradient_frag(g_frag, g_scale, x_frag, ranges, n_points, want_bias=Fa
     return (w, sums[256 * n:]) if want_bias else w
 
 
+def weight_gradient_frag_batch(g_frags, g_scale, x_frags, ranges, n_points):
+    """Several 256 x 256 products G_j^T X_j over the same points (fragment slots, shared normalisers) in ONE launch of the LDS-DMA
+    kernel, each split over its share of the grid (include/inerf.h inerf_mlp_weight_gradient_frag_batch).  Returns [(dW_j, db_j)]."""
+    lib = _capi.lib()
+    n = len(g_frags)
+    rows = [lib.inerf_wgrad_frag_rows(n_points, n, j) for j in range(n)]
+    per = 256 * 256 + 256
+    total = n * per
+    buf = _new(ranges, max(rows), total)
+    base = buf.data_ptr()
+    arr = lambda vals: (C.c_void_p * n)(*vals)
+    with torch.cuda.device(ranges.device):
+        rc = lib.inerf_mlp_weight_gradient_frag_batch(n, arr([g.data_ptr() for g in g_frags]), _ptr(g_scale), arr([x.data_ptr() for x in x_frags]),
+                                                      _ptr(ranges), n_points, arr([base + 4 * j * per for j in range(n)]),
+                                                      arr([base + 4 * (j * per + 65536) for j in range(n)]), total, _stream(ranges))
+    _capi.check(rc, "inerf_mlp_weight_gradient_frag_batch")
+    out = []
+    for j in range(n):
+        sums = buf[:rows[j], j * per:(j + 1) * per].sum(0)
+        out.append((sums[:65536].view(256, 256), sums[65536:]))
+    return out
+
+
 def weight_gradient_xfrag(g_rows, x_frag, ranges, n_points, want_bias=False):
     """G^T X with G row-format ([n_points, >= 128] fp32: a 128-channel gradient slot) and X a FRAGMENT slot of activations
     (256 channels): the products of views_linears.0's feature columns and of the semantic hidden layer.  ``ranges[0]``: an
