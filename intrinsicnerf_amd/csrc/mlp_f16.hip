@@ -63,13 +63,6 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
     WidePreH<2> pre2;
     WidePreH<1> pre1;
     wide_prefetch_h<2>(pre2, wb, frag256(L.trunk[0], 4), bias256(L.trunk[0]), scale256(L.trunk[0]), lane);
-    auto enc_save = [&](int slot, int cols, int gp, bool ok) {          // training copy of a point's encoding row (EncSave)
-        EncSave e;
-        e.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save + (kSave ? p.save_off[slot] : 0), 0,
-                                                   kSave ? (int)((unsigned)p.n_points * (unsigned)cols * 4u) : 0, 0x00020000);
-        e.voff = ok ? gp * cols * 4 : EncSave::kDropOffset;
-        return e;
-    };
 
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         // ---------------- encode -> hi/lo planes ----------------
@@ -81,8 +74,6 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
             const float* __restrict__ r = p.rays + (size_t)ray * INERF_RAY_FLOATS;
             const float zz = __builtin_nontemporal_load(p.z + gp);     // streamed once: keep it out of the L2 the weights live in
             _Float16* row = ldsh + pt * kRowH;
-            const bool sv_ok = kSave && tile * kPts + pt < p.n_points;
-            const EncSave sv_enc = enc_save(SAVE_ENC, kEncCols, gp, sv_ok), sv_dir = enc_save(SAVE_DIR, kDirCols, gp, sv_ok);
             float x[3], v[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -98,7 +89,6 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
                     fast_sincosf(x[c] * s, &sn, &cs);
                     split_store(row + kColEnc + 3 + 6 * f + c, sn, amax);
                     split_store(row + kColEnc + 6 + 6 * f + c, cs, amax);
-                    if (kSave) { sv_enc.put(3 + 6 * f + c, sn); sv_enc.put(6 + 6 * f + c, cs); }
                 }
             }
             const int fd = kParts - 1 - part;
@@ -110,29 +100,31 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
                     fast_sincosf(v[c] * s, &sn, &cs);
                     split_store(row + kColDir + 3 + 6 * fd + c, sn, amax);
                     split_store(row + kColDir + 6 + 6 * fd + c, cs, amax);
-                    if (kSave) { sv_dir.put(3 + 6 * fd + c, sn); sv_dir.put(6 + 6 * fd + c, cs); }
                 }
             }
             if (part == 2) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) split_store(row + kColEnc + c, x[c], amax);
                 for (int c = 3 + 6 * p.l_xyz; c < kEncCols; ++c) { row[kColEnc + c] = (_Float16)0.0f; row[kPlaneH + kColEnc + c] = (_Float16)0.0f; }
-                if (kSave) {
-                    for (int c = 0; c < 3; ++c) sv_enc.put(c, x[c]);
-                    for (int c = 3 + 6 * p.l_xyz; c < kEncCols; ++c) sv_enc.put(c, 0.0f);
-                }
             }
             if (part == 3) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) split_store(row + kColDir + c, v[c], amax);
                 for (int c = 3 + 6 * p.l_dir; c < kDirCols; ++c) { row[kColDir + c] = (_Float16)0.0f; row[kPlaneH + kColDir + c] = (_Float16)0.0f; }
-                if (kSave) {
-                    for (int c = 0; c < 3; ++c) sv_dir.put(c, v[c]);
-                    for (int c = 3 + 6 * p.l_dir; c < kDirCols; ++c) sv_dir.put(c, 0.0f);
-                }
             }
         }
         __syncthreads();
+        // training forward: the encoding leaves as operand fragments of the products dW = dZ^T enc (pts_linears.0, and .5's
+        // encoding columns), straight from the planes: a 64-channel fragment slot, one channel block per wave 0 / 1
+        if constexpr (kSave)
+            if (wave < 2) {
+                FragDst d;
+                d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save + p.save_off[SAVE_ENC], 0, (int)((unsigned)p.n_tiles * (unsigned)(kFragTileBytes / 4)), 0x00020000);
+                d.voff = (unsigned)tile * (unsigned)(kFragTileBytes / 4) + (unsigned)wave * (2u * kFragBytes) + (unsigned)lane * 16u;
+                planes_to_frag<1, kRowH, kPlaneH, 2>(xr + kColEnc + 32 * wave, plane_selector(lane), d);
+            } else {
+                dir_rows<kRowH, kPlaneH>(ldsh + kColDir, p.save + p.save_off[SAVE_DIR], p.n_points, tile, wave - 2, lane);
+            }
 
         const int pt0 = tile * kPts + (lane & 31);              // this lane's points in wide results
         // training forward: fp32 copy of a layer's output, this lane's first point / first channel of its wave
@@ -329,13 +321,6 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
     WidePreH<2> pre2;
     WidePreH<1> pre1;
     prefetch_w<2>(pre2, wb, frag256(L.trunk[0], 4));
-    auto enc_save = [&](int slot, int cols, int gp, bool ok) {          // training copy of a point's encoding row (EncSave)
-        EncSave e;
-        e.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save + (kSave ? p.save_off[slot] : 0), 0,
-                                                   kSave ? (int)((unsigned)p.n_points * (unsigned)cols * 4u) : 0, 0x00020000);
-        e.voff = ok ? gp * cols * 4 : EncSave::kDropOffset;
-        return e;
-    };
 
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         // The per-tile slot / output offsets below are sums of a tile part and a lane part; derived from `lane` itself the lane
@@ -355,8 +340,6 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
             const float* __restrict__ r = p.rays + (size_t)ray * INERF_RAY_FLOATS;
             const float zz = __builtin_nontemporal_load(p.z + gp);
             _Float16* row = ldsd + pt * kRowD;
-            const bool sv_ok = kSave && with_dir && tile * kPts + pt < p.n_points;       // the skip layer's second pass re-computes only
-            const EncSave sv_enc = enc_save(SAVE_ENC, kEncCols, gp, sv_ok), sv_dir = enc_save(SAVE_DIR, kDirCols, gp, sv_ok);
             float x[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -371,17 +354,12 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
                     fast_sincosf(x[c] * s, &sn, &cs);
                     split_store<kPlaneD>(row + 3 + 6 * f + c, sn, amax);
                     split_store<kPlaneD>(row + 6 + 6 * f + c, cs, amax);
-                    if (kSave) { sv_enc.put(3 + 6 * f + c, sn); sv_enc.put(6 + 6 * f + c, cs); }
                 }
             }
             if (part == 2) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) split_store<kPlaneD>(row + c, x[c], amax);
                 for (int c = 3 + 6 * p.l_xyz; c < kEncCols; ++c) { row[c] = (_Float16)0.0f; row[kPlaneD + c] = (_Float16)0.0f; }
-                if (kSave) {
-                    for (int c = 0; c < 3; ++c) sv_enc.put(c, x[c]);
-                    for (int c = 3 + 6 * p.l_xyz; c < kEncCols; ++c) sv_enc.put(c, 0.0f);
-                }
             }
             if (with_dir) {
                 const int fd = kParts - 1 - part;
@@ -393,22 +371,33 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
                         fast_sincosf(r[8 + c] * s, &sn, &cs);
                         split_store<kPlaneD>(row + kColDirD + 3 + 6 * fd + c, sn, amax);
                         split_store<kPlaneD>(row + kColDirD + 6 + 6 * fd + c, cs, amax);
-                        if (kSave) { sv_dir.put(3 + 6 * fd + c, sn); sv_dir.put(6 + 6 * fd + c, cs); }
                     }
                 }
                 if (part == 3) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) split_store<kPlaneD>(row + kColDirD + c, r[8 + c], amax);
                     for (int c = 3 + 6 * p.l_dir; c < kDirCols; ++c) { row[kColDirD + c] = (_Float16)0.0f; row[kPlaneD + kColDirD + c] = (_Float16)0.0f; }
-                    if (kSave) {
-                        for (int c = 0; c < 3; ++c) sv_dir.put(c, r[8 + c]);
-                        for (int c = 3 + 6 * p.l_dir; c < kDirCols; ++c) sv_dir.put(c, 0.0f);
-                    }
                 }
             }
         };
         encode(true);
         __syncthreads();
+        // training forward: the encoding leaves as operand fragments of the products dW = dZ^T enc (pts_linears.0, and .5's
+        // encoding columns), straight from the planes (columns 0..63, before the first layer's output lands there): a 64-channel
+        // fragment slot, one channel block per wave 0 / 1; waves 2 / 3 write the view encoding's rows.  (Until round 4: 96
+        // four-byte stores per point at strides of 256 / 128 bytes.)
+        if constexpr (kSave) {
+            int lane_e = lane_t;
+            asm volatile("" : "+v"(lane_e));
+            if (wave < 2) {
+                FragDst d;
+                d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save + p.save_off[SAVE_ENC], 0, (int)((unsigned)p.n_tiles * (unsigned)(kFragTileBytes / 4)), 0x00020000);
+                d.voff = (unsigned)tile * (unsigned)(kFragTileBytes / 4) + (unsigned)wave * (2u * kFragBytes) + (unsigned)lane_e * 16u;
+                planes_to_frag<1, kRowD, kPlaneD, 2>(xr + 32 * wave, plane_selector(lane_e), d);
+            } else {
+                dir_rows<kRowD, kPlaneD>(ldsd + kColDirD, p.save + p.save_off[SAVE_DIR], p.n_points, tile, wave - 2, lane_e);
+            }
+        }
 
         // a 256-wide layer in place: GEMM over columns [0, 16*KBT) | barrier | store to columns [0, 256) | barrier
         f32x16 am2[2][2];

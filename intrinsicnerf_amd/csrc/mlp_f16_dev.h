@@ -234,20 +234,22 @@ struct SaveDst {
     int stride;        // floats per point
 };
 
-// Training copy of one point's encoding row (SAVE_ENC / SAVE_DIR): descriptor + 32-bit byte offset, like SaveDst.  With
-// 64-bit per-lane pointers here the two-workgroup training kernel faulted on address 0 as soon as its spill pattern
-// changed (the pointer pairs were spilled and reloaded across the encoder's divergent branches); a descriptor cannot
-// fault, and a point beyond the end gets an offset outside the slot, which the range check drops - no branch either.
-struct EncSave {
-    __amdgpu_buffer_rsrc_t rsrc;
-    int voff;                         // bytes of the point's row, or kDropOffset
-    static constexpr int kDropOffset = 0x7FFF0000;
-    __device__ __forceinline__ void put(int col, float v) const {
-#ifndef INERF_ABL_NO_ROWS
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, voff + 4 * col, 0, 0);
-#endif
+// Training copy of the view encoding (SAVE_DIR: fp32 rows of 32 floats): half a tile (32 points) per wave, read back from the
+// planes - (hi + lo) / kActScale, the 22 bits every consumer of the slot splits it into again - and stored as whole 128-byte
+// rows, eight lanes per row.  Points beyond the end are dropped by the descriptor's range check.
+template <int ROW, int PLANE>
+__device__ __forceinline__ void dir_rows(const _Float16* planes /* plane_hi + first dir column */, float* slot, int n_points, int tile, int half, int lane) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(slot, 0, (int)((unsigned)n_points * (unsigned)kDirCols * 4u), 0x00020000);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int pt = 32 * half + 8 * it + (lane >> 3), c = 4 * (lane & 7);
+        const f16x4 hi = *reinterpret_cast<const f16x4*>(planes + pt * ROW + c), lo = *reinterpret_cast<const f16x4*>(planes + pt * ROW + c + PLANE);
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = ((float)hi[i] + (float)lo[i]) * (1.0f / kActScale);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (int)(((unsigned)(tile * kTilePoints + pt) * (unsigned)kDirCols + (unsigned)c) * 4u), 0, 0);
     }
-};
+}
 
 // ------------------------------------------------------------------------------------------------
 // Fragment slots (layout.h SaveSlot): a layer's output, which sits in the hi / lo planes as X[point][channel], leaves the CU as
@@ -271,10 +273,12 @@ struct FragDst {
     __amdgpu_buffer_rsrc_t rsrc;      // the slot: n_tiles * kFragTileBytes bytes
     unsigned voff;                    // bytes: tile * kFragTileBytes + (first channel block of this wave) * 2 * kFragBytes + lane * 16
 };
-__device__ __forceinline__ unsigned frag_off(int kb, int cb, int plane) { return (unsigned)((kb * 8 + cb) * 2 + plane) * kFragBytes; }
+// (CBS: 32-channel blocks of the slot - 8 for the 256-wide slots, 2 for the encoding's)
+template <int CBS = 8>
+__device__ __forceinline__ unsigned frag_off(int kb, int cb, int plane) { return (unsigned)((kb * CBS + cb) * 2 + plane) * kFragBytes; }
 
 // NB: 32-channel blocks of this wave (consecutive, starting at the column `xa` points at).
-template <int NB, int ROW, int PLANE>
+template <int NB, int ROW, int PLANE, int CBS = 8>
 __device__ __forceinline__ void planes_to_frag(const _Float16* xa /* plane_hi + (lane & 31) * ROW + 8 * (lane >> 5) + first column */,
                                                const Selector& sel, const FragDst& dst) {
 #ifdef INERF_ABL_NO_FRAG        // (timing ablation of a development build, scripts/build_variant.sh: results are wrong)
@@ -317,8 +321,8 @@ __device__ __forceinline__ void planes_to_frag(const _Float16* xa /* plane_hi + 
                 asm volatile("" :: "v"(oh), "v"(ol));
 #else
                 // (whole offset in the VGPR operand: a 16-byte buffer store with a register SGPR offset gets no hazard wait state, tests/test_isa_audit_cpu.py)
-                __builtin_amdgcn_raw_buffer_store_b128(oh, dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, cb, 0)), 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(ol, dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, cb, 1)), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(oh, dst.rsrc, (int)(dst.voff + frag_off<CBS>(2 * pb + q, cb, 0)), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(ol, dst.rsrc, (int)(dst.voff + frag_off<CBS>(2 * pb + q, cb, 1)), 0, 0);
 #endif
             }
         __builtin_amdgcn_sched_barrier(0);

@@ -352,54 +352,63 @@ constexpr int kFragStageBytes = 2 * kFragKbBytes;               // G | X of one 
 constexpr int kFragScaleBytes = 8 * 256;                        // per stage: every wave's own copy of the k-block's normalisers (64 lanes x 4 bytes)
 static_assert(kFragStages >= 3 && kFragStages <= 5, "ring depth");
 
-// SEVERAL products over the same sample points share one launch (the nine of a network do): workgroup b works on product
-// b % n_jobs as its K-slice b / n_jobs - a product is split over ~grid / n_jobs workgroups instead of the whole grid, so the
-// chip writes (and the final sum reads) n_jobs times fewer partial tiles - 7 MB per product instead of 64 MB at nine jobs,
-// which was a tenth of the operand bytes themselves - fills its ring once instead of n_jobs times, and one launch boundary
-// replaces n_jobs.  Every workgroup still streams 32 KB stages of two contiguous matrices.
+// SEVERAL products over the same sample points share one launch (the nine 256 x 256 ones of a network and the two against the
+// 64-wide encoding do): every workgroup works on ONE product, as one of its K-slices - a product is split over its share of the
+// grid (in proportion to the bytes it streams) instead of the whole grid, so the chip writes (and the final sum reads) ~n_jobs
+// times fewer partial tiles - 7 MB per 256 x 256 product instead of 64 MB at eleven jobs, which was a tenth of the operand bytes
+// themselves - fills its ring once instead of n_jobs times, and one launch boundary replaces n_jobs.  Every workgroup still
+// streams whole stages of two contiguous matrices.  Workgroup b -> (job, slice): round-robin over the jobs that still have
+// slices left (neighbouring workgroups stream different matrices; contiguous shares measured slower in round 2).
+// X of a job is 256 channels wide (8 channel blocks: 16 KB per k-block) or 64 (the encoding: 2 blocks, 4 KB).
 constexpr int kMaxFragJobs = INERF_WGRAD_MAX_BATCH;
 struct WgradFragParams {
     const void* G[kMaxFragJobs];        // fragment slot of dZ: f16 hi / lo of kActScale * dz / s_p
     const void* X[kMaxFragJobs];        // fragment slot of activations: f16 hi / lo of kActScale * h
-    float* partial[kMaxFragJobs];       // K-slice s of the job writes its 256 x 256 tile at partial + s * partial_stride
+    float* partial[kMaxFragJobs];       // K-slice s of the job writes its 256 x N tile at partial + s * partial_stride
     float* bias_partial[kMaxFragJobs];  // optional: ... its column sums of G
     const float* g_scale;    // the points' normalisers s_p: 64 * n_tiles (+ 64 readable) floats
     const float* ranges;     // device: {gmax, ...}: upper bound of |dz|
     int64_t partial_stride;  // floats
     int n_kb;                // 16-point k-blocks: 4 per tile
     int n_jobs;
+    uint16_t slices[kMaxFragJobs];      // K-slices (= workgroups) of every job; their sum is the grid
+    uint8_t x_blocks[kMaxFragJobs];     // 8 | 2
 };
 
-__global__ __launch_bounds__(512, 1) void k_mlp_wgrad_frag(const WgradFragParams p) {
-    extern __shared__ __attribute__((aligned(16))) char ldsw[];
+// XB: 32-channel blocks of X
+template <int XB>
+__device__ __forceinline__ void wgrad_frag_body(const WgradFragParams& p, char* ldsw, const int job, const int b /* slice */, const int g /* slices */) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lp = lane & 31, lh = lane >> 5;
     const bool dma_g = wave < 4;
-    const int job = (int)blockIdx.x % p.n_jobs;
+    constexpr int kXKbBytes = XB * 2 * kFragBytes;            // X bytes per k-block
+    constexpr int kXFrags = XB / 2;                           // fragments an X wave (4..7) requests per stage: 4 | 1
     float* const bias_partial = p.bias_partial[job];
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(dma_g ? p.G[job] : p.X[job]), 0,
-                                                                           (int)((unsigned)p.n_kb * (unsigned)kFragKbBytes), 0x00020000);
-    const int my_bytes = (dma_g ? 0 : kFragKbBytes) + (wave & 3) * 4 * kFragBytes;      // this wave's four fragments inside a stage
-    const int src_bytes = (wave & 3) * 4 * kFragBytes;                                   // ... inside its matrix's k-block
+        (int)((unsigned)p.n_kb * (unsigned)(dma_g ? kFragKbBytes : kXKbBytes)), 0x00020000);
+    const int src_bytes = (wave & 3) * (dma_g ? 4 : kXFrags) * kFragBytes;               // this wave's fragments inside its matrix's k-block
+    const int my_bytes = (dma_g ? 0 : kFragKbBytes) + src_bytes;                         // ... inside a stage
     const __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.g_scale), 0, (p.n_kb * 16 + 64) * 4, 0x00020000);
     char* const scale_lds = ldsw + kFragStages * kFragStageBytes + wave * 256;          // + buf * kFragScaleBytes
-    // one stage: four fragment requests - lane l's 16 bytes of fragment j land at stage + my_bytes + 1024 j + 16 l (the
+    // one stage: this wave's fragment requests - lane l's 16 bytes of fragment j land at stage + my_bytes + 1024 j + 16 l (the
     // instruction offset advances the source and the destination alike) - and one for the k-block's normalisers (lane l's float
     // = point 16 kb + l; 16 of the 64 are used): every wave fetches its OWN copy, so that nothing but its own counter orders them
     auto request = [&](int kb, int buf) {
         __attribute__((address_space(3))) char* dst = (__attribute__((address_space(3))) char*)(ldsw) + buf * kFragStageBytes + my_bytes;
-        const int soff = (int)((unsigned)kb * (unsigned)kFragKbBytes) + src_bytes;
+        const int soff = (int)((unsigned)kb * (unsigned)(dma_g ? kFragKbBytes : kXKbBytes)) + src_bytes;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, lane * 16, soff, 0 * kFragBytes, kDmaAux);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, lane * 16, soff, 1 * kFragBytes, kDmaAux);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, lane * 16, soff, 2 * kFragBytes, kDmaAux);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, lane * 16, soff, 3 * kFragBytes, kDmaAux);
+        if (XB == 8 || dma_g) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, lane * 16, soff, 1 * kFragBytes, kDmaAux);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, lane * 16, soff, 2 * kFragBytes, kDmaAux);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, lane * 16, soff, 3 * kFragBytes, kDmaAux);
+        }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (__attribute__((address_space(3))) char*)(scale_lds) + buf * kFragScaleBytes, 4, lane * 4, kb * 64, 0, 0);
     };
-    f32x16 acc[8];                             // rows 32 wave .. + 31, column block cb
+    f32x16 acc[XB];                            // rows 32 wave .. + 31, column block cb
 #pragma unroll
-    for (int cb = 0; cb < 8; ++cb)
+    for (int cb = 0; cb < XB; ++cb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
     float bias_sum = 0.0f;                     // this lane's channel of the wave's row block, its k-half's points (units of 1 / sg)
@@ -431,8 +440,8 @@ __global__ __launch_bounds__(512, 1) void k_mlp_wgrad_frag(const WgradFragParams
             }
         }
 #pragma unroll
-        for (int cb = 0; cb < 8; ++cb) {     // X operands one read ahead of their MFMAs, fenced (unfenced, the scheduler hoists every read to the top)
-            if (cb + 1 < 8) { xh[(cb + 1) & 1] = frag(xset, cb + 1, 0); xl[(cb + 1) & 1] = frag(xset, cb + 1, 1); }
+        for (int cb = 0; cb < XB; ++cb) {    // X operands one read ahead of their MFMAs, fenced (unfenced, the scheduler hoists every read to the top)
+            if (cb + 1 < XB) { xh[(cb + 1) & 1] = frag(xset, cb + 1, 0); xl[(cb + 1) & 1] = frag(xset, cb + 1, 1); }
             __builtin_amdgcn_sched_barrier(0);
             acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xh[cb & 1], acc[cb], 0, 0, 0);
             acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xl[cb & 1], acc[cb], 0, 0, 0);
@@ -442,20 +451,27 @@ __global__ __launch_bounds__(512, 1) void k_mlp_wgrad_frag(const WgradFragParams
     };
 
     // this workgroup's k-blocks: its slice number, + the job's slice count, ... (the workgroups of a job stream neighbouring
-    // 32 KB: the chip walks every matrix front to back)
-    const int g = ((int)gridDim.x - job + p.n_jobs - 1) / p.n_jobs, b = (int)blockIdx.x / p.n_jobs;
+    // stages: the chip walks every matrix front to back)
     const int n_mine = p.n_kb > b ? (p.n_kb - b + g - 1) / g : 0;
 #pragma unroll
     for (int j = 0; j < kFragStages - 1; ++j)
         if (j < n_mine) request(b + j * g, j);
     int buf = 0;
+    const bool five = XB == 8 || dma_g;        // requests per stage of this wave: 5, or 2 (an X wave of a 64-wide product)
     for (int i = 0; i < n_mine; ++i) {
-        // requests of stages i + 1 .. may stay in flight: five per stage, at most kFragStages - 2 stages, fewer at the end
+        // requests of stages i + 1 .. may stay in flight: at most kFragStages - 2 stages, fewer at the end
         const int ahead = n_mine - 1 - i;
-        if (ahead >= 3 && kFragStages >= 5) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-        else if (ahead >= 2 && kFragStages >= 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (five) {
+            if (ahead >= 3 && kFragStages >= 5) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+            else if (ahead >= 2 && kFragStages >= 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (ahead >= 3 && kFragStages >= 5) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (ahead >= 2 && kFragStages >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (i + kFragStages - 1 < n_mine) request(b + (i + kFragStages - 1) * g, buf == 0 ? kFragStages - 1 : buf - 1);
@@ -463,7 +479,7 @@ __global__ __launch_bounds__(512, 1) void k_mlp_wgrad_frag(const WgradFragParams
         buf = buf + 1 == kFragStages ? 0 : buf + 1;
     }
 
-    // ---- this workgroup's partial tile and its column sums of G ----
+    // ---- this slice's partial tile and its column sums of G ----
     if (bias_partial) {                        // the two lane halves hold complementary points of the same channel
         const float both = bias_sum + __shfl_xor(bias_sum, 32);
         if (lh == 0) bias_partial[(size_t)b * p.partial_stride + 32 * wave + lp] = both / sg;
@@ -471,12 +487,35 @@ __global__ __launch_bounds__(512, 1) void k_mlp_wgrad_frag(const WgradFragParams
     const float back = 1.0f / (sg * kActScale);
     float* out = p.partial[job] + (size_t)b * p.partial_stride;
 #pragma unroll
-    for (int cb = 0; cb < 8; ++cb)
+    for (int cb = 0; cb < XB; ++cb)
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int m = 32 * wave + (j & 3) + 8 * (j >> 2) + 4 * lh;
-            out[(size_t)m * 256 + 32 * cb + lp] = acc[cb][j] * back;
+            out[(size_t)m * (32 * XB) + 32 * cb + lp] = acc[cb][j] * back;
         }
+}
+
+__global__ __launch_bounds__(512, 1) void k_mlp_wgrad_frag(const WgradFragParams p) {
+    extern __shared__ __attribute__((aligned(16))) char ldsw[];
+    // workgroup -> (job, slice): round r hands one slice to every job that has more than r
+    int rem = blockIdx.x, round = 0, job = 0;
+    for (;;) {
+        int live = 0;
+        for (int j = 0; j < p.n_jobs; ++j) live += p.slices[j] > round ? 1 : 0;
+        if (rem < live || live == 0) break;
+        rem -= live;
+        ++round;
+    }
+    for (int j = 0; j < p.n_jobs; ++j)
+        if (p.slices[j] > round) {
+            if (rem == 0) { job = j; break; }
+            --rem;
+        }
+    job = __builtin_amdgcn_readfirstlane(job);
+    round = __builtin_amdgcn_readfirstlane(round);
+    const int n_slices = p.slices[job];
+    if (p.x_blocks[job] == 8) wgrad_frag_body<8>(p, ldsw, job, round, n_slices);
+    else                      wgrad_frag_body<2>(p, ldsw, job, round, n_slices);
 }
 
 }  // namespace inerf
@@ -579,32 +618,72 @@ extern "C" int inerf_mlp_weight_gradient_xfrag(const float* G, int ldg, const vo
     return launch_rows(p, false, stream, true);
 }
 
-// Both operands FRAGMENT slots (256 x 256): G of the gradient buffer with the points' normalisers, X of the activation buffer,
-// on the same n_points.  ranges: device {gmax, ...}: an upper bound of |dz| (the dz_max of inerf_mlp_backward_inputs).
-// n_jobs products in one launch of inerf_wgrad_frag_grid(n_points, n_jobs) workgroups: job j is split over
-// inerf_wgrad_frag_rows(n_points, n_jobs, j) K-slices, slice s writing its tile at partial[j] + s * partial_stride.
+// Both operands FRAGMENT slots: G (256 channels) of the gradient buffer with the points' normalisers, X of the activation buffer
+// (x_cols[j] = 256, or 64 for the encoding's slot; NULL: all 256), on the same n_points.  ranges: device {gmax, ...}: an upper
+// bound of |dz| (the dz_max of inerf_mlp_backward_inputs).  n_jobs products in one launch of
+// inerf_wgrad_frag_grid(n_points, n_jobs) workgroups: job j is split over inerf_wgrad_frag_rows(n_points, n_jobs, x_cols, j)
+// K-slices, slice s writing its [256, x_cols[j]] tile at partial[j] + s * partial_stride.
 extern "C" int inerf_wgrad_frag_grid(int64_t n_points, int n_jobs) {
     const int g = inerf_wgrad_grid(n_points);
     return g < n_jobs ? n_jobs : g;
 }
 
-extern "C" int inerf_wgrad_frag_rows(int64_t n_points, int n_jobs, int job) {
-    if (n_jobs < 1 || job < 0 || job >= n_jobs || n_points <= 0) return 0;
-    return (inerf_wgrad_frag_grid(n_points, n_jobs) - job + n_jobs - 1) / n_jobs;
+namespace inerf {
+namespace {
+// the grid divided among the jobs in proportion to the bytes a k-block of each moves (G 16 KB + X 2 KB per channel block):
+// largest remainders, at least one slice each
+bool frag_slices(int64_t n_points, int n_jobs, const int* x_cols, uint16_t* slices) {
+    if (n_jobs < 1 || n_jobs > kMaxFragJobs || n_points <= 0) return false;
+    const int grid = inerf_wgrad_frag_grid(n_points, n_jobs);
+    int64_t w[kMaxFragJobs], total = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const int c = x_cols ? x_cols[j] : kWidth;
+        if (c != kWidth && c != kEncCols) return false;
+        w[j] = 16 + 2 * (c / 32);
+        total += w[j];
+    }
+    int given = 0;
+    int64_t frac[kMaxFragJobs];
+    const int spare = grid - n_jobs;                       // one slice each up front
+    for (int j = 0; j < n_jobs; ++j) {
+        const int64_t num = (int64_t)spare * w[j];
+        slices[j] = (uint16_t)(1 + num / total);
+        frac[j] = num % total;
+        given += slices[j];
+    }
+    while (given < grid) {                                 // (first job wins ties: deterministic)
+        int best = 0;
+        for (int j = 1; j < n_jobs; ++j)
+            if (frac[j] > frac[best]) best = j;
+        ++slices[best]; frac[best] = -1; ++given;
+    }
+    return true;
+}
+}  // namespace
+}  // namespace inerf
+
+extern "C" int inerf_wgrad_frag_rows(int64_t n_points, int n_jobs, const int* x_cols, int job) {
+    uint16_t slices[inerf::kMaxFragJobs];
+    if (job < 0 || job >= n_jobs || !inerf::frag_slices(n_points, n_jobs, x_cols, slices)) return 0;
+    return slices[job];
 }
 
 extern "C" int inerf_mlp_weight_gradient_frag_batch(int n_jobs, const void* const* G_frag, const float* g_scale, const void* const* X_frag,
-                                                    const float* ranges, int64_t n_points, float* const* partial,
+                                                    const int* x_cols, const float* ranges, int64_t n_points, float* const* partial,
                                                     float* const* bias_partial, int64_t partial_stride, void* stream) {
     using namespace inerf;
     if (n_jobs < 1 || n_jobs > kMaxFragJobs) return INERF_E_INVALID;
     if (!G_frag || !g_scale || !X_frag || !ranges || !partial || n_points <= 0) return INERF_E_INVALID;
     if (n_points > kMaxTrainPoints) return INERF_E_UNSUPPORTED;
-    if (((uintptr_t)g_scale & 3) || partial_stride < (int64_t)kWidth * kWidth) return INERF_E_INVALID;
+    if (((uintptr_t)g_scale & 3)) return INERF_E_INVALID;
     WgradFragParams p{};
+    if (!frag_slices(n_points, n_jobs, x_cols, p.slices)) return INERF_E_INVALID;
     for (int j = 0; j < n_jobs; ++j) {
+        const int cols = x_cols ? x_cols[j] : kWidth;
         if (!G_frag[j] || !X_frag[j] || !partial[j] || (((uintptr_t)G_frag[j] | (uintptr_t)X_frag[j]) & 15)) return INERF_E_INVALID;
+        if (partial_stride < (int64_t)kWidth * cols) return INERF_E_INVALID;
         p.G[j] = G_frag[j]; p.X[j] = X_frag[j]; p.partial[j] = partial[j]; p.bias_partial[j] = bias_partial ? bias_partial[j] : nullptr;
+        p.x_blocks[j] = (uint8_t)(cols / 32);
     }
     p.g_scale = g_scale; p.ranges = ranges; p.partial_stride = partial_stride; p.n_jobs = n_jobs;
     p.n_kb = (int)((n_points + kTilePoints - 1) / kTilePoints) * 4;
@@ -623,5 +702,5 @@ extern "C" int inerf_mlp_weight_gradient_frag_batch(int n_jobs, const void* cons
 // one product: inerf_wgrad_grid(n_points) K-slices
 extern "C" int inerf_mlp_weight_gradient_frag(const void* G_frag, const float* g_scale, const void* X_frag, const float* ranges,
                                               int64_t n_points, float* partial, float* bias_partial, int64_t partial_stride, void* stream) {
-    return inerf_mlp_weight_gradient_frag_batch(1, &G_frag, g_scale, &X_frag, ranges, n_points, &partial, &bias_partial, partial_stride, stream);
+    return inerf_mlp_weight_gradient_frag_batch(1, &G_frag, g_scale, &X_frag, nullptr, ranges, n_points, &partial, &bias_partial, partial_stride, stream);
 }

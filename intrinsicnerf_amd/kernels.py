@@ -469,25 +469,27 @@ ACT_SCALE = 8.0                 # activations travel as f16 hi/lo of 8 * value (
 SAVE_SCALARS = 64               # floats behind the slots and the mask area (reserved; include/inerf.h)
 
 
-def frag_decode(frag, n_points, scale=ACT_SCALE):
-    """A 256-wide FRAGMENT slot of an ACTIVATION buffer (include/inerf.h: f16 hi/lo operand fragments of the weight-gradient
-    products; ``frag``: its elements as a float32 or float16 tensor) -> the fp32 [n_points, 256] matrix it encodes: (hi + lo) / scale."""
+def frag_decode(frag, n_points, scale=ACT_SCALE, width=256):
+    """A FRAGMENT slot of an ACTIVATION buffer (include/inerf.h: f16 hi/lo operand fragments of the weight-gradient products;
+    ``frag``: its elements as a float32 or float16 tensor; ``width``: 256, or 64 for the encoding's slot) -> the fp32
+    [n_points, width] matrix it encodes: (hi + lo) / scale."""
     h = frag.view(torch.float16) if frag.dtype != torch.float16 else frag
-    tiles = h.numel() // (64 * 256 * 2)
+    cbs = width // 32
+    tiles = h.numel() // (64 * width * 2)
     # [tile, pb, q, cb, plane, h, c, i_hi, i_lo]: point = 32 pb + 16 q + 8 i_hi + 4 h + i_lo, channel = 32 cb + c
-    v = h.view(tiles, 2, 2, 8, 2, 2, 32, 2, 4).float()
+    v = h.view(tiles, 2, 2, cbs, 2, 2, 32, 2, 4).float()
     v = v[:, :, :, :, 0] + v[:, :, :, :, 1]                                  # hi + lo: [tile, pb, q, cb, h, c, i_hi, i_lo]
-    v = v.permute(0, 1, 2, 6, 4, 7, 3, 5).reshape(tiles * 64, 256)          # -> [tile, pb, q, i_hi, h, i_lo, cb, c]
+    v = v.permute(0, 1, 2, 6, 4, 7, 3, 5).reshape(tiles * 64, width)        # -> [tile, pb, q, i_hi, h, i_lo, cb, c]
     return v[:n_points] / scale
 
 
 def frag_encode(rows, scale=ACT_SCALE):
-    """fp32 [n_points, 256] -> the FRAGMENT slot of ``frag_decode`` (float16 tensor of 64 * ceil(n / 64) * 512 halfs): hi = f16
-    of scale * value rounded towards zero, lo = f16(scale * value - hi); padding points are zero.  What the training forward's
-    epilogue emits, restated with torch for the tests of the weight-gradient kernel."""
-    n = rows.shape[0]
+    """fp32 [n_points, W] (W = 256 or 64) -> the FRAGMENT slot of ``frag_decode`` (float16 tensor of 64 * ceil(n / 64) * 2 W
+    halfs): hi = f16 of scale * value rounded towards zero, lo = f16(scale * value - hi); padding points are zero.  What the
+    training forward's epilogue emits, restated with torch for the tests of the weight-gradient kernel."""
+    n, width = rows.shape
     tiles = (n + 63) // 64
-    v = torch.zeros(tiles * 64, 256, dtype=torch.float32, device=rows.device)
+    v = torch.zeros(tiles * 64, width, dtype=torch.float32, device=rows.device)
     v[:n] = rows.float() * scale
     hi = (v.view(torch.int32) & ~0x1FFF).view(torch.float32)                 # 13 low mantissa bits cleared: exact in f16's normal range
     hi16 = hi.clamp(-65504.0, 65504.0).half()
@@ -495,7 +497,7 @@ def frag_encode(rows, scale=ACT_SCALE):
     hi16 = torch.where(sub & (hi16.float().abs() > v.abs()), torch.nextafter(hi16.float(), torch.zeros_like(v)).half(), hi16)
     lo16 = (v - hi16.float()).half()
     both = torch.stack([hi16, lo16], 0)                                      # [plane, point, channel]
-    both = both.view(2, tiles, 2, 2, 2, 2, 4, 8, 32)                         # [plane, tile, pb, q, i_hi, h, i_lo, cb, c]
+    both = both.view(2, tiles, 2, 2, 2, 2, 4, width // 32, 32)               # [plane, tile, pb, q, i_hi, h, i_lo, cb, c]
     return both.permute(1, 2, 3, 7, 0, 5, 8, 4, 6).contiguous().view(-1)     # [tile, pb, q, cb, plane, h, c, i_hi, i_lo]
 
 
@@ -530,7 +532,7 @@ def save_slot_views(desc, buf, n_points, gradient=False):
         _capi.check(lib.inerf_mlp_save_slot(desc, slot, n_points, C.byref(off), C.byref(width)), "inerf_mlp_save_slot")
         if lib.inerf_mlp_save_slot_is_fragment(slot, 1 if gradient else 0) == 1:
             frag = buf[off.value: off.value + padded * width.value]
-            views.append(grad_frag_decode(frag, views[SAVE_ENC], n_points) if gradient else frag_decode(frag, n_points))
+            views.append(grad_frag_decode(frag, views[SAVE_ENC], n_points) if gradient else frag_decode(frag, n_points, width=width.value))
         elif gradient and slot == SAVE_ENC:         # the points' normalisers (include/inerf.h), not an [n, 64] matrix
             views.append(buf[off.value: off.value + padded])
         else:
@@ -728,12 +730,15 @@ def weight_gradient_frag(g_frag, g_scale, x_frag, ranges, n_points, want_bias=Fa
     return (w, sums[256 * n:]) if want_bias else w
 
 
-def weight_gradient_frag_batch(g_frags, g_scale, x_frags, ranges, n_points):
-    """Several 256 x 256 products G_j^T X_j over the same points (fragment slots, shared normalisers) in ONE launch of the LDS-DMA
-    kernel, each split over its share of the grid (include/inerf.h inerf_mlp_weight_gradient_frag_batch).  Returns [(dW_j, db_j)]."""
+def weight_gradient_frag_batch(g_frags, g_scale, x_frags, ranges, n_points, x_cols=None):
+    """Several products G_j^T X_j over the same points (fragment slots, shared normalisers; X_j 256 channels wide, or 64 where
+    ``x_cols[j]`` says so) in ONE launch of the LDS-DMA kernel, each split over its share of the grid (include/inerf.h
+    inerf_mlp_weight_gradient_frag_batch).  Returns [(dW_j [256, cols], db_j [256])]."""
     lib = _capi.lib()
     n = len(g_frags)
-    rows = [lib.inerf_wgrad_frag_rows(n_points, n, j) for j in range(n)]
+    cols = [256] * n if x_cols is None else [int(c) for c in x_cols]
+    ccols = (C.c_int * n)(*cols)
+    rows = [lib.inerf_wgrad_frag_rows(n_points, n, ccols, j) for j in range(n)]
     per = 256 * 256 + 256
     total = n * per
     buf = _new(ranges, max(rows), total)
@@ -741,13 +746,13 @@ def weight_gradient_frag_batch(g_frags, g_scale, x_frags, ranges, n_points):
     arr = lambda vals: (C.c_void_p * n)(*vals)
     with torch.cuda.device(ranges.device):
         rc = lib.inerf_mlp_weight_gradient_frag_batch(n, arr([g.data_ptr() for g in g_frags]), _ptr(g_scale), arr([x.data_ptr() for x in x_frags]),
-                                                      _ptr(ranges), n_points, arr([base + 4 * j * per for j in range(n)]),
+                                                      ccols, _ptr(ranges), n_points, arr([base + 4 * j * per for j in range(n)]),
                                                       arr([base + 4 * (j * per + 65536) for j in range(n)]), total, _stream(ranges))
     _capi.check(rc, "inerf_mlp_weight_gradient_frag_batch")
     out = []
     for j in range(n):
         sums = buf[:rows[j], j * per:(j + 1) * per].sum(0)
-        out.append((sums[:65536].view(256, 256), sums[65536:]))
+        out.append((sums[:256 * cols[j]].view(256, cols[j]), sums[65536:]))
     return out
 
 

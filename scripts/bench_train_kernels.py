@@ -62,12 +62,18 @@ def frag_slot(buf, slot):
 
 ranges = torch.cat([dz_max, act_max])
 t_one, _ = timed(lambda: kernels.weight_gradient_frag(frag_slot(dz, kernels.SAVE_H0 + 3), frag_slot(dz, kernels.SAVE_ENC), frag_slot(save, kernels.SAVE_H0 + 2), ranges, p, want_bias=True))
+# the nine 256 x 256 products of the network as mlp_backward launches them: one launch, each product on its share of the grid
+pairs = [(kernels.SAVE_H0 + i, kernels.SAVE_H0 + i - 1) for i in range(1, 8)] + [(kernels.SAVE_AS1H, kernels.SAVE_H0 + 7), (kernels.SAVE_FEAT, kernels.SAVE_H0 + 7)]
+t_nine, _ = timed(lambda: kernels.weight_gradient_frag_batch([frag_slot(dz, g) for g, _ in pairs], frag_slot(dz, kernels.SAVE_ENC),
+                                                              [frag_slot(save, x) for _, x in pairs], ranges, p))
 gb = save.numel() * 4 / 1e9
-saved = (8 * 256 + 256 + 256 + 256 + 128 + 96) * 4 * p / 1e9          # what the training forward writes (h0..h7 fragments, h7 rows, as1h, feat, vh, enc + dir)
+saved = (8 * 256 + 256 + 256 + 128 + 96) * 4 * p / 1e9          # what the training forward writes (h0..h7 and feat fragments, as1h, vh, enc + dir rows)
 print(f"{n} rays x {s} samples = {p} points; activation buffer {gb:.2f} GB")
 print(f"inference forward        {t_inf:7.3f} ms  {flop / t_inf / 1e9:6.1f} TFLOP/s")
 print(f"training forward (save)  {t_fwd:7.3f} ms  {flop / t_fwd / 1e9:6.1f} TFLOP/s   writes {saved / t_fwd:5.2f} TB/s")
 print(f"input-gradient chain (+ head gradients, pre-pass) {t_bwd:7.3f} ms  {0.89 * flop / t_bwd / 1e9:6.1f} TFLOP/s")
 print(f"whole backward, one C call (chain + 13 products + reduction) {t_all:7.3f} ms; weight gradients = {t_all - t_bwd:7.3f} ms  {flop / (t_all - t_bwd) / 1e9:6.1f} TFLOP/s")
 print(f"one 256 x 256 product from fragment slots (incl. the sum over {_capi.lib().inerf_wgrad_grid(p)} partial tiles) {t_one * 1e3:7.1f} us: operands {2 * p * 1024 / t_one / 1e9:5.2f} TB/s")
+print(f"the nine 256 x 256 products in one launch (incl. the sums over ~{_capi.lib().inerf_wgrad_frag_rows(p, 9, None, 0)} partial tiles each) {t_nine:7.3f} ms: "
+      f"operands {9 * 2 * p * 1024 / t_nine / 1e9:5.2f} TB/s")
 print(f"weight gradients, library GEMMs on decoded slots (reference) {t_wl:7.3f} ms")

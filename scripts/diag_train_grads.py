@@ -97,7 +97,7 @@ act_max = torch.zeros(1, device=dev)
 raw2, save2 = kernels.encode_mlp_train(dsc, pf, rays, z, act_max=act_max)
 ranges = torch.cat([dz_max, act_max])
 names = tuple(k for k, _ in packing.tensor_table(dsc))
-ours = kernels.mlp_weight_gradients(dsc, names, save2, dz, cot.view(n * s, chn).contiguous(), n * s, False, ranges, None)
+ours = kernels.mlp_weight_gradients(dsc, names, save2, dz, cot.view(n * s, chn).contiguous(), n * s, False, None)
 net.zero_grad()
 emb32 = torch.cat([embed(pts.reshape(-1, 3)), embed_d(rays[:, None, 8:11].expand(pts.shape).reshape(-1, 3))], -1)
 (net(emb32).reshape(n, s, -1) * cot).sum().backward()

@@ -6,7 +6,7 @@ for d in sys.argv[1:]:
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"]
-            for kern in ("k_encode_mlp", "k_mlp_dgrad", "k_mlp_wgrad<8, 8>"):
+            for kern in ("k_encode_mlp", "k_mlp_dgrad", "k_mlp_wgrad_frag", "k_mlp_wgrad<8, 2", "k_mlp_wgrad<4, 8", "k_mlp_wgrad<4, 1", "k_reduce_scatter"):
                 if kern in name:
                     agg[(kern if kern != "k_encode_mlp" else name.split("(")[0][-40:], r["Counter_Name"])].append(float(r["Counter_Value"]))
         print(d)

@@ -458,13 +458,17 @@ def test_weight_gradient_from_fragment_slots(p):
     want64 = Gq.t() @ xr.double()
     assert float((w64.double() - want64).norm()) <= 2e-6 * float(want64.norm())
     assert float((b64.double() - want_b).norm()) <= 2e-6 * float(want_b.norm()) + 1e-12
-    # three products in one launch, each split over a third of the grid: (G, X), (G, X'), (G', X) with G' = -G, X' = X rolled
+    # several products in one launch, each split over its share of the grid: (G, X), (G, X'), (G', X) with G' = -G, X' = X rolled
     gf2, gs2 = kernels.grad_frag_encode(-G)
     assert torch.equal(gs2, gs)                                   # (one set of normalisers per gradient buffer)
     x2 = torch.roll(X, 1, dims=1).contiguous()
     xf2 = kernels.frag_encode(x2)
-    res = kernels.weight_gradient_frag_batch([gf, gf, gf2], gs, [xf, xf2, xf], ranges, p)
-    for (wj, bj), ww, wb in zip(res, (want_w, Gq.t() @ kernels.frag_decode(xf2, p).double(), -want_w), (want_b, want_b, -want_b)):
+    # ... and one against a 64-channel fragment slot (the encoding's format), which gets a smaller share of the grid
+    x64 = torch.sin(torch.arange(p * 64, dtype=torch.float32).view(p, 64) * 0.37).to(dev)
+    xf64 = kernels.frag_encode(x64)
+    want64f = Gq.t() @ kernels.frag_decode(xf64, p, width=64).double()
+    res = kernels.weight_gradient_frag_batch([gf, gf, gf2, gf], gs, [xf, xf2, xf, xf64], ranges, p, x_cols=[256, 256, 256, 64])
+    for (wj, bj), ww, wb in zip(res, (want_w, Gq.t() @ kernels.frag_decode(xf2, p).double(), -want_w, want64f), (want_b, want_b, -want_b, want_b)):
         assert float((wj.double() - ww).norm()) <= 2e-6 * float(ww.norm())
         assert float((bj.double() - wb).norm()) <= 2e-6 * float(wb.norm()) + 1e-12
     # row-format G (128 channels) x X fragments (views_linears.0 against the feature layer, the semantic hidden layer against h7)
