@@ -443,14 +443,18 @@ __device__ __forceinline__ void stage_params(const ParamPtrs& t, ParamTableLds& 
     __syncthreads();
 }
 
-__device__ __forceinline__ float param_at(const ParamTableLds& t, int src) {   // src: 1 + index into the flat concatenation, 0 = padding
-    if (src <= 0) return 0.0f;
+__device__ __forceinline__ const float* param_ptr(const ParamTableLds& t, int src) {   // src: 1 + index into the flat concatenation, 0 = padding
+    if (src <= 0) return nullptr;
     int lo = 0, hi = t.n - 1;
     while (lo < hi) {                                                          // last tensor whose first element is <= src
         const int mid = (lo + hi + 1) >> 1;
         if (t.first[mid] <= src) lo = mid; else hi = mid - 1;
     }
-    return t.p[lo][src - t.first[lo]];
+    return t.p[lo] + (src - t.first[lo]);
+}
+__device__ __forceinline__ float param_at(const ParamTableLds& t, int src) {
+    const float* at = param_ptr(t, src);
+    return at ? *at : 0.0f;
 }
 
 __device__ __forceinline__ float group_scale(float gmax) {                    // 2^k with gmax * 2^k in [2^13, 2^14); 1 for 0 / inf / nan
@@ -460,17 +464,27 @@ __device__ __forceinline__ float group_scale(float gmax) {                    //
     return ldexpf(1.0f, 14 - e);
 }
 
-// One element per thread and ONE atomic per block that saw a parameter (a group's row of the map is padded to the longest
-// group: most blocks see nothing and leave at once).  The first form walked a row with 64 blocks - twelve dependent
-// map -> table -> parameter look-ups per thread, 39 us per blob, four blobs per training step.
+// Eight elements per thread, their look-ups batched, and ONE atomic per block that saw a parameter (a group's row of the map is
+// padded to the longest group).  The first form walked a row with 64 blocks - twelve dependent map -> table -> parameter
+// look-ups per thread, 39 us per blob, four blobs per training step; one element per thread was no better (32 us): then every
+// block's atomic met the others in the one cache line that holds all maxima.
 __global__ __launch_bounds__(256) void k_repack_gmax(const ParamPtrs t, const int32_t* __restrict__ group_src, int longest, float* __restrict__ gmax) {
     __shared__ float wave_max[4];
     __shared__ ParamTableLds tl;
     stage_params(t, tl);
     const int g = blockIdx.y;
     float m = 0.0f;
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < longest; j += gridDim.x * blockDim.x)
-        m = fmaxf(m, fabsf(param_at(tl, group_src[(size_t)g * longest + j])));
+    constexpr int U = 8;                       // elements per thread and round: the map reads, then the table look-ups, then the
+    for (int j0 = blockIdx.x * blockDim.x * U + threadIdx.x; j0 < longest; j0 += gridDim.x * blockDim.x * U) {      // parameter reads, each batch in flight together
+        int src[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) src[u] = j0 + u * 256 < longest ? group_src[(size_t)g * longest + j0 + u * 256] : 0;
+        const float* at[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) at[u] = param_ptr(tl, src[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) m = fmaxf(m, at[u] ? fabsf(*at[u]) : 0.0f);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
@@ -479,7 +493,11 @@ __global__ __launch_bounds__(256) void k_repack_gmax(const ParamPtrs t, const in
     // itself survives as the NaN halves of that element
     if (threadIdx.x == 0) {
         m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
-        if (m > 0.0f) atomicMax(reinterpret_cast<unsigned int*>(gmax + g), __builtin_bit_cast(unsigned int, m));
+        // (a block whose maximum is not above what the line already holds has nothing to add; a stale read only costs a
+        // redundant atomic)
+        unsigned int* dst = reinterpret_cast<unsigned int*>(gmax + g);
+        const unsigned int bits = __builtin_bit_cast(unsigned int, m);
+        if (m > 0.0f && bits > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, bits);
     }
 }
 
@@ -540,7 +558,7 @@ extern "C" int inerf_repack(const float* const* params /*[host] device pointers,
     hipStream_t stream = (hipStream_t)stream_;
     hipError_t e = hipMemsetAsync(gmax_scratch, 0, sizeof(float) * (size_t)n_groups, stream);
     if (e != hipSuccess) return record(e);
-    const int chunks = longest < 256 * 1024 ? (longest + 255) / 256 : 1024;
+    const int chunks = longest < 2048 * 1024 ? (longest + 2047) / 2048 : 1024;             // 8 elements per thread (k_repack_gmax)
     hipLaunchKernelGGL(k_repack_gmax, dim3(chunks, n_groups), dim3(256), 0, stream, t, group_src, longest, gmax_scratch);
     const int64_t n_halves = 2 * packed_floats;
     hipLaunchKernelGGL(k_repack_halves, dim3((unsigned)((n_halves + 255) / 256)), dim3(256), 0, stream, t, half_src, half_grp, gmax_scratch,

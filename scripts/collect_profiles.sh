@@ -1,5 +1,5 @@
 #!/bin/bash
-# Collects the rocprofv3 evidence a round commits under profiles/ (run on the GPU box through gpurun; ~6 minutes):
+# Collects the rocprofv3 evidence a round commits under profiles/ (run on the GPU box through gpurun; ~20 minutes with the GPU suite):
 #   scripts/collect_profiles.sh r02
 # Writes gpurun_out/<tag>_*; copy what is to be kept into profiles/.
 tag=${1:-rXX}
@@ -8,6 +8,9 @@ OUT=$REPO/gpurun_out
 export TMPDIR=/tmp
 mkdir -p $OUT/prof
 cd $REPO
+python -c 'import __graft_entry__ as g; g.build()' || exit 1
+# 0. the GPU suite on this code
+timeout 1200 python -m pytest tests -m gpu -q -x > $OUT/${tag}_pytest_gpu.log 2>&1; tail -3 $OUT/${tag}_pytest_gpu.log
 # 1. the benchmark as the driver runs it (with the CPU oracle: parity + cpu_baseline)
 python bench.py --steps 5 --warmup 1 > $OUT/${tag}_bench.json 2> $OUT/${tag}_bench.err
 # 2. the same under rocprofv3 --kernel-trace --stats (no CPU legs: the profiler only sees the GPU)
