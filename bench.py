@@ -63,10 +63,10 @@ PEAK_F32_MFMA_TFLOPS = 157.3                 # MI355X_MICROARCH.md: dense fp32 m
 PEAK_F16_MFMA_TFLOPS = 2500.0                # MI355X_MICROARCH.md: dense f16/bf16 matrix peak
 MEASURED_F16_MFMA_ONLY_TFLOPS = 1590.0       # dense f16, random operands, 170-340 ms runs (zero operands: 2470)
 # HBM bytes per sample point of the encode+MLP kernels from the PMC passes (FETCH_SIZE + WRITE_SIZE, separate passes).
-# f16x3: profiles/r03_pmc_digest.txt, measured on the bench frame's own fine launch (640,000 rays x 192 samples):
-# 6230.5 MB per 122,880,000-point launch (algorithmic 5929.1 MB).  f32: profiles/r01_mlp_pmc_traffic.txt (kernel unchanged).
-PMC_HBM_BYTES_PER_POINT = {"f16x3": 50.7, "f32": 49.5}
-PMC_SOURCE = {"f16x3": ("profiles/r03_pmc_digest.txt", "1.05"), "f32": ("profiles/r01_mlp_pmc_traffic.txt", "1.02")}
+# f16x3: profiles/r04_pmc_digest.txt, measured on the bench frame's own fine launch (640,000 rays x 192 samples):
+# 6341.9 MB per 122,880,000-point launch (algorithmic 5929.1 MB; round 3: 6230.5).  f32: profiles/r01_mlp_pmc_traffic.txt (kernel unchanged).
+PMC_HBM_BYTES_PER_POINT = {"f16x3": 51.6, "f32": 49.5}
+PMC_SOURCE = {"f16x3": ("profiles/r04_pmc_digest.txt", "1.07"), "f32": ("profiles/r01_mlp_pmc_traffic.txt", "1.02")}
 PARITY_RAYS = 4096
 RTOL, ATOL, RTOL_DISP = 1e-4, 1e-5, 5e-4
 
@@ -745,8 +745,8 @@ def main():
                                f"{len(sel)} rays of a default-init (white-spectrum) network the end-to-end delta is dominated by its sampling term "
                                "(per_map.sampling_sigma_db: the cross term of |HIP - oracle| ~ 1e-2 on the ill-conditioned rays with the "
                                "perturbation, zero-mean, shrinking with the pixel count); 'systematic' is the part that survives on a full "
-                               "frame (profiles/r03_psnr_full_frame.txt: all 640000 rays).  The fine pass on the reference's depths and the "
-                               "trained network (profiles/r03_trained_network.txt) are the well-conditioned figures")
+                               "frame (profiles/r04_psnr_full_frame.txt, r03_psnr_full_frame.txt: all 640000 rays).  The fine pass on the reference's depths and the "
+                               "trained network (profiles/r04_trained_network.txt) are the well-conditioned figures")
 
     if rank == 0:
         print(json.dumps({

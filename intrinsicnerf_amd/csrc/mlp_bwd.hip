@@ -357,7 +357,6 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
         {
             const int c4 = (tid & 31) * 4;
             const StageRows rows(tid >> 5, kColA + c4);
-            const __amdgpu_buffer_rsrc_t dz_vh = slot_rsrc(p.dz, SAVE_VH, kHalf);
             f32x4 w4[4];
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) w4[cc] = wb.vec4((L.res_w + 4 * cc) * 4, 16 * c4);
@@ -389,9 +388,8 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
                 for (int cc = 0; cc < 4; ++cc) v[cc] = act[cc] > 0.0f ? v[cc] : 0.0f;
                 split_store4(ldsb + rows.st[i / HALF][0] + (i % HALF) * VH_STEP * kRowH, ldsb + rows.st[i / HALF][1] + (i % HALF) * VH_STEP * kRowH,
                              v, amax2);
-                {   // (a point beyond the end: act = 0 -> v = 0, and the store is dropped)
+                {   // (a point beyond the end: act = 0 -> v = 0)
                     const f32x4 o = f32x4{v[0], v[1], v[2], v[3]} * f[8];
-                    store4(dz_vh, vh_voff + (tile * kPts + VH_STEP * i) * kHalf * 4, o);
                     gmax = fmaxf(gmax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
                 }
                 if (i & 1) __builtin_amdgcn_sched_barrier(0);      // two points at a time: unfenced, the scheduler interleaves all of them and spills
@@ -403,6 +401,14 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
 
         int lane_t = lane;
         asm volatile("" : "+v"(lane_t));
+        // dZ_vh (128 channels) leaves as the fragments of a four-block slot, straight from the planes the stage above wrote
+        // (normalised halves, like every gradient slot): one channel block per wave 0..3
+        if (wave < 4) {
+            FragDst d;
+            d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dz + p.off[SAVE_VH], 0, (int)((unsigned)p.n_tiles * (unsigned)(kFragTileBytes / 2)), 0x00020000);
+            d.voff = (unsigned)tile * (unsigned)(kFragTileBytes / 2) + (unsigned)wave * (2u * kFragBytes) + (unsigned)lane_t * 16u;
+            planes_to_frag<1, kRowH, kPlaneH, 4>(xr + kColA + 32 * wave, plane_selector(lane_t), d);
+        }
         const int pt0 = tile * kPts + (lane & 31);
         const bool valid0 = pt0 < p.n_points, valid1 = pt0 + 32 < p.n_points;
         const float s0 = ptf(lane & 31)[8], s1 = ptf((lane & 31) + 32)[8];

@@ -372,24 +372,31 @@ struct WgradFragParams {
     int n_kb;                // 16-point k-blocks: 4 per tile
     int n_jobs;
     uint16_t slices[kMaxFragJobs];      // K-slices (= workgroups) of every job; their sum is the grid
-    uint8_t x_blocks[kMaxFragJobs];     // 8 | 2
+    uint8_t g_blocks[kMaxFragJobs];     // 32-channel blocks of G: 8 | 4
+    uint8_t x_blocks[kMaxFragJobs];     // ... of X: 8 | 2 | 1; supported pairs: (8, 8) (8, 2) (4, 8) (4, 1)
 };
 
-// XB: 32-channel blocks of X
-template <int XB>
+// GB / XB: 32-channel blocks of G (8 | 4) and X (8 | 2 | 1).  Roles of the eight waves:
+//   DMA        waves 0..3 request G's fragments of the stage (GB / 2 each), waves 4..7 X's (XB / 2 each; XB = 1: one each for
+//              waves 4 and 5), every wave its own copy of the k-block's normalisers;
+//   contract   GB = 8: wave w = row block w x all column blocks; GB = 4: wave w = row block (w & 3) x column half (w >> 2).
+template <int GB, int XB>
 __device__ __forceinline__ void wgrad_frag_body(const WgradFragParams& p, char* ldsw, const int job, const int b /* slice */, const int g /* slices */) {
+    static_assert((GB == 8 || GB == 4) && (XB == 8 || XB == 2 || XB == 1), "shapes");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lp = lane & 31, lh = lane >> 5;
     const bool dma_g = wave < 4;
-    constexpr int kXKbBytes = XB * 2 * kFragBytes;            // X bytes per k-block
-    constexpr int kXFrags = XB / 2;                           // fragments an X wave (4..7) requests per stage: 4 | 1
-    float* const bias_partial = p.bias_partial[job];
+    constexpr int kGKbBytes = GB * 2 * kFragBytes, kXKbBytes = XB * 2 * kFragBytes;        // bytes per k-block
+    constexpr int kXPer = XB >= 2 ? XB / 2 : 1;
+    const int n_frag = dma_g ? GB / 2 : (XB >= 2 ? XB / 2 : ((wave & 3) < 2 ? 1 : 0));    // fragments this wave requests per stage
+    const int n_req = n_frag + 1;                                                          // ... + the normalisers
+    float* const bias_partial = (GB == 8 || wave < 4) ? p.bias_partial[job] : nullptr;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(dma_g ? p.G[job] : p.X[job]), 0,
-        (int)((unsigned)p.n_kb * (unsigned)(dma_g ? kFragKbBytes : kXKbBytes)), 0x00020000);
-    const int src_bytes = (wave & 3) * (dma_g ? 4 : kXFrags) * kFragBytes;               // this wave's fragments inside its matrix's k-block
-    const int my_bytes = (dma_g ? 0 : kFragKbBytes) + src_bytes;                         // ... inside a stage
+        (int)((unsigned)p.n_kb * (unsigned)(dma_g ? kGKbBytes : kXKbBytes)), 0x00020000);
+    const int src_bytes = (wave & 3) * (dma_g ? GB / 2 : kXPer) * kFragBytes;            // this wave's fragments inside its matrix's k-block
+    const int my_bytes = (dma_g ? 0 : kFragKbBytes) + src_bytes;                         // ... inside a stage (G | X at 16 KB)
     const __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.g_scale), 0, (p.n_kb * 16 + 64) * 4, 0x00020000);
     char* const scale_lds = ldsw + kFragStages * kFragStageBytes + wave * 256;          // + buf * kFragScaleBytes
     // one stage: this wave's fragment requests - lane l's 16 bytes of fragment j land at stage + my_bytes + 1024 j + 16 l (the
@@ -397,18 +404,37 @@ __device__ __forceinline__ void wgrad_frag_body(const WgradFragParams& p, char* 
     // = point 16 kb + l; 16 of the 64 are used): every wave fetches its OWN copy, so that nothing but its own counter orders them
     auto request = [&](int kb, int buf) {
         __attribute__((address_space(3))) char* dst = (__attribute__((address_space(3))) char*)(ldsw) + buf * kFragStageBytes + my_bytes;
-        const int soff = (int)((unsigned)kb * (unsigned)(dma_g ? kFragKbBytes : kXKbBytes)) + src_bytes;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, lane * 16, soff, 0 * kFragBytes, kDmaAux);
-        if (XB == 8 || dma_g) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, lane * 16, soff, 1 * kFragBytes, kDmaAux);
+        const int soff = (int)((unsigned)kb * (unsigned)(dma_g ? kGKbBytes : kXKbBytes)) + src_bytes;
+        if (n_frag > 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, lane * 16, soff, 0 * kFragBytes, kDmaAux);
+        if (n_frag > 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, lane * 16, soff, 1 * kFragBytes, kDmaAux);
+        if (n_frag > 2) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, lane * 16, soff, 2 * kFragBytes, kDmaAux);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, lane * 16, soff, 3 * kFragBytes, kDmaAux);
         }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (__attribute__((address_space(3))) char*)(scale_lds) + buf * kFragScaleBytes, 4, lane * 4, kb * 64, 0, 0);
     };
-    f32x16 acc[XB];                            // rows 32 wave .. + 31, column block cb
+    // wait until at most `stages` of this wave's younger stages are still in flight (n_req requests each, returned in order)
+    auto wait_for = [&](int stages) {
+        switch (stages * n_req) {
+            case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+            case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+            case 9:  asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+            case 6:  asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 5:  asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 4:  asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 3:  asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 2:  asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 1:  asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+    };
+    constexpr int NC = GB == 8 ? XB : (XB >= 2 ? XB / 2 : 1);         // column blocks this wave contracts
+    const int rbk = GB == 8 ? wave : (wave & 3);                      // its row block
+    const int cb0 = GB == 8 ? 0 : (wave >> 2) * NC;                   // its first column block
+    const bool contracts = GB == 8 || XB >= 2 || wave < 4;
+    f32x16 acc[NC];
 #pragma unroll
-    for (int cb = 0; cb < XB; ++cb)
+    for (int cb = 0; cb < NC; ++cb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
     float bias_sum = 0.0f;                     // this lane's channel of the wave's row block, its k-half's points (units of 1 / sg)
@@ -417,10 +443,10 @@ __device__ __forceinline__ void wgrad_frag_body(const WgradFragParams& p, char* 
     const float sgc = sg * (1.0f / kActScale);
     auto contract = [&](int buf) {
         const char* gset = ldsw + buf * kFragStageBytes + lane * 16;
-        const char* xset = gset + kFragKbBytes;
+        const char* xset = gset + kFragKbBytes + cb0 * 2 * kFragBytes;
         auto frag = [&](const char* set, int block, int plane) { return *reinterpret_cast<const f16x8*>(set + (block * 2 + plane) * kFragBytes); };
         f16x8 gh, gl, xh[2], xl[2];
-        const f16x8 g16h = frag(gset, wave, 0), g16l = frag(gset, wave, 1);
+        const f16x8 g16h = frag(gset, rbk, 0), g16l = frag(gset, rbk, 1);
         // the normalisers of this lane's eight points: 16 kb + 4 (lane >> 5) + 0..3 and + 8..11 (layout.h frag_point)
         const float* sc = reinterpret_cast<const float*>(scale_lds + buf * kFragScaleBytes) + 4 * lh;
         const f32x4 s03 = *reinterpret_cast<const f32x4*>(sc), s47 = *reinterpret_cast<const f32x4*>(sc + 8);
@@ -440,8 +466,8 @@ __device__ __forceinline__ void wgrad_frag_body(const WgradFragParams& p, char* 
             }
         }
 #pragma unroll
-        for (int cb = 0; cb < XB; ++cb) {    // X operands one read ahead of their MFMAs, fenced (unfenced, the scheduler hoists every read to the top)
-            if (cb + 1 < XB) { xh[(cb + 1) & 1] = frag(xset, cb + 1, 0); xl[(cb + 1) & 1] = frag(xset, cb + 1, 1); }
+        for (int cb = 0; cb < NC; ++cb) {    // X operands one read ahead of their MFMAs, fenced (unfenced, the scheduler hoists every read to the top)
+            if (cb + 1 < NC) { xh[(cb + 1) & 1] = frag(xset, cb + 1, 0); xl[(cb + 1) & 1] = frag(xset, cb + 1, 1); }
             __builtin_amdgcn_sched_barrier(0);
             acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xh[cb & 1], acc[cb], 0, 0, 0);
             acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xl[cb & 1], acc[cb], 0, 0, 0);
@@ -457,41 +483,31 @@ __device__ __forceinline__ void wgrad_frag_body(const WgradFragParams& p, char* 
     for (int j = 0; j < kFragStages - 1; ++j)
         if (j < n_mine) request(b + j * g, j);
     int buf = 0;
-    const bool five = XB == 8 || dma_g;        // requests per stage of this wave: 5, or 2 (an X wave of a 64-wide product)
     for (int i = 0; i < n_mine; ++i) {
         // requests of stages i + 1 .. may stay in flight: at most kFragStages - 2 stages, fewer at the end
         const int ahead = n_mine - 1 - i;
-        if (five) {
-            if (ahead >= 3 && kFragStages >= 5) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-            else if (ahead >= 2 && kFragStages >= 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            if (ahead >= 3 && kFragStages >= 5) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if (ahead >= 2 && kFragStages >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        wait_for(ahead < kFragStages - 2 ? ahead : kFragStages - 2);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (i + kFragStages - 1 < n_mine) request(b + (i + kFragStages - 1) * g, buf == 0 ? kFragStages - 1 : buf - 1);
-        contract(buf);
+        if (contracts) contract(buf);
         buf = buf + 1 == kFragStages ? 0 : buf + 1;
     }
 
     // ---- this slice's partial tile and its column sums of G ----
     if (bias_partial) {                        // the two lane halves hold complementary points of the same channel
         const float both = bias_sum + __shfl_xor(bias_sum, 32);
-        if (lh == 0) bias_partial[(size_t)b * p.partial_stride + 32 * wave + lp] = both / sg;
+        if (lh == 0) bias_partial[(size_t)b * p.partial_stride + 32 * rbk + lp] = both / sg;
     }
+    if (!contracts) return;
     const float back = 1.0f / (sg * kActScale);
     float* out = p.partial[job] + (size_t)b * p.partial_stride;
 #pragma unroll
-    for (int cb = 0; cb < XB; ++cb)
+    for (int cb = 0; cb < NC; ++cb)
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const int m = 32 * wave + (j & 3) + 8 * (j >> 2) + 4 * lh;
-            out[(size_t)m * (32 * XB) + 32 * cb + lp] = acc[cb][j] * back;
+            const int m = 32 * rbk + (j & 3) + 8 * (j >> 2) + 4 * lh;
+            out[(size_t)m * (32 * XB) + 32 * (cb0 + cb) + lp] = acc[cb][j] * back;
         }
 }
 
@@ -514,8 +530,11 @@ __global__ __launch_bounds__(512, 1) void k_mlp_wgrad_frag(const WgradFragParams
     job = __builtin_amdgcn_readfirstlane(job);
     round = __builtin_amdgcn_readfirstlane(round);
     const int n_slices = p.slices[job];
-    if (p.x_blocks[job] == 8) wgrad_frag_body<8>(p, ldsw, job, round, n_slices);
-    else                      wgrad_frag_body<2>(p, ldsw, job, round, n_slices);
+    const int shape = p.g_blocks[job] * 16 + p.x_blocks[job];
+    if (shape == 8 * 16 + 8)      wgrad_frag_body<8, 8>(p, ldsw, job, round, n_slices);
+    else if (shape == 8 * 16 + 2) wgrad_frag_body<8, 2>(p, ldsw, job, round, n_slices);
+    else if (shape == 4 * 16 + 8) wgrad_frag_body<4, 8>(p, ldsw, job, round, n_slices);
+    else                          wgrad_frag_body<4, 1>(p, ldsw, job, round, n_slices);
 }
 
 }  // namespace inerf
@@ -618,11 +637,12 @@ extern "C" int inerf_mlp_weight_gradient_xfrag(const float* G, int ldg, const vo
     return launch_rows(p, false, stream, true);
 }
 
-// Both operands FRAGMENT slots: G (256 channels) of the gradient buffer with the points' normalisers, X of the activation buffer
-// (x_cols[j] = 256, or 64 for the encoding's slot; NULL: all 256), on the same n_points.  ranges: device {gmax, ...}: an upper
+// Both operands FRAGMENT slots: G of the gradient buffer (g_rows[j] = 256, or 128 for the views hidden layer's slot) with the
+// points' normalisers, X of the activation buffer (x_cols[j] = 256, 64 for the position encoding's slot, 32 for the view
+// encoding's; NULL: all 256; supported pairs 256 x 256, 256 x 64, 128 x 256, 128 x 32), on the same n_points.  ranges: device {gmax, ...}: an upper
 // bound of |dz| (the dz_max of inerf_mlp_backward_inputs).  n_jobs products in one launch of
-// inerf_wgrad_frag_grid(n_points, n_jobs) workgroups: job j is split over inerf_wgrad_frag_rows(n_points, n_jobs, x_cols, j)
-// K-slices, slice s writing its [256, x_cols[j]] tile at partial[j] + s * partial_stride.
+// inerf_wgrad_frag_grid(n_points, n_jobs) workgroups: job j is split over inerf_wgrad_frag_rows(n_points, n_jobs, g_rows, x_cols, j)
+// K-slices, slice s writing its [g_rows[j], x_cols[j]] tile at partial[j] + s * partial_stride.
 extern "C" int inerf_wgrad_frag_grid(int64_t n_points, int n_jobs) {
     const int g = inerf_wgrad_grid(n_points);
     return g < n_jobs ? n_jobs : g;
@@ -630,16 +650,21 @@ extern "C" int inerf_wgrad_frag_grid(int64_t n_points, int n_jobs) {
 
 namespace inerf {
 namespace {
-// the grid divided among the jobs in proportion to the bytes a k-block of each moves (G 16 KB + X 2 KB per channel block):
-// largest remainders, at least one slice each
-bool frag_slices(int64_t n_points, int n_jobs, const int* x_cols, uint16_t* slices) {
+bool frag_shape_ok(int rows, int cols) {
+    return (rows == kWidth && (cols == kWidth || cols == kEncCols)) || (rows == kHalf && (cols == kWidth || cols == kDirCols));
+}
+
+// the grid divided among the jobs in proportion to what a k-block of each costs - the KB it moves (2 per 32-channel block of G
+// and of X) plus a fixed 8 for the stage's barrier, waits and re-scaling (a 256 x 64 product's stage takes ~0.7 of a 256 x 256
+// one's, not 0.625): largest remainders, at least one slice each
+bool frag_slices(int64_t n_points, int n_jobs, const int* g_rows, const int* x_cols, uint16_t* slices) {
     if (n_jobs < 1 || n_jobs > kMaxFragJobs || n_points <= 0) return false;
     const int grid = inerf_wgrad_frag_grid(n_points, n_jobs);
     int64_t w[kMaxFragJobs], total = 0;
     for (int j = 0; j < n_jobs; ++j) {
-        const int c = x_cols ? x_cols[j] : kWidth;
-        if (c != kWidth && c != kEncCols) return false;
-        w[j] = 16 + 2 * (c / 32);
+        const int r = g_rows ? g_rows[j] : kWidth, c = x_cols ? x_cols[j] : kWidth;
+        if (!frag_shape_ok(r, c)) return false;
+        w[j] = 8 + 2 * (r / 32) + 2 * (c / 32);
         total += w[j];
     }
     int given = 0;
@@ -662,28 +687,28 @@ bool frag_slices(int64_t n_points, int n_jobs, const int* x_cols, uint16_t* slic
 }  // namespace
 }  // namespace inerf
 
-extern "C" int inerf_wgrad_frag_rows(int64_t n_points, int n_jobs, const int* x_cols, int job) {
+extern "C" int inerf_wgrad_frag_rows(int64_t n_points, int n_jobs, const int* g_rows, const int* x_cols, int job) {
     uint16_t slices[inerf::kMaxFragJobs];
-    if (job < 0 || job >= n_jobs || !inerf::frag_slices(n_points, n_jobs, x_cols, slices)) return 0;
+    if (job < 0 || job >= n_jobs || !inerf::frag_slices(n_points, n_jobs, g_rows, x_cols, slices)) return 0;
     return slices[job];
 }
 
 extern "C" int inerf_mlp_weight_gradient_frag_batch(int n_jobs, const void* const* G_frag, const float* g_scale, const void* const* X_frag,
-                                                    const int* x_cols, const float* ranges, int64_t n_points, float* const* partial,
-                                                    float* const* bias_partial, int64_t partial_stride, void* stream) {
+                                                    const int* g_rows, const int* x_cols, const float* ranges, int64_t n_points,
+                                                    float* const* partial, float* const* bias_partial, int64_t partial_stride, void* stream) {
     using namespace inerf;
     if (n_jobs < 1 || n_jobs > kMaxFragJobs) return INERF_E_INVALID;
     if (!G_frag || !g_scale || !X_frag || !ranges || !partial || n_points <= 0) return INERF_E_INVALID;
     if (n_points > kMaxTrainPoints) return INERF_E_UNSUPPORTED;
     if (((uintptr_t)g_scale & 3)) return INERF_E_INVALID;
     WgradFragParams p{};
-    if (!frag_slices(n_points, n_jobs, x_cols, p.slices)) return INERF_E_INVALID;
+    if (!frag_slices(n_points, n_jobs, g_rows, x_cols, p.slices)) return INERF_E_INVALID;
     for (int j = 0; j < n_jobs; ++j) {
-        const int cols = x_cols ? x_cols[j] : kWidth;
+        const int rows = g_rows ? g_rows[j] : kWidth, cols = x_cols ? x_cols[j] : kWidth;
         if (!G_frag[j] || !X_frag[j] || !partial[j] || (((uintptr_t)G_frag[j] | (uintptr_t)X_frag[j]) & 15)) return INERF_E_INVALID;
-        if (partial_stride < (int64_t)kWidth * cols) return INERF_E_INVALID;
+        if (partial_stride < (int64_t)rows * cols) return INERF_E_INVALID;
         p.G[j] = G_frag[j]; p.X[j] = X_frag[j]; p.partial[j] = partial[j]; p.bias_partial[j] = bias_partial ? bias_partial[j] : nullptr;
-        p.x_blocks[j] = (uint8_t)(cols / 32);
+        p.g_blocks[j] = (uint8_t)(rows / 32); p.x_blocks[j] = (uint8_t)(cols / 32);
     }
     p.g_scale = g_scale; p.ranges = ranges; p.partial_stride = partial_stride; p.n_jobs = n_jobs;
     p.n_kb = (int)((n_points + kTilePoints - 1) / kTilePoints) * 4;
@@ -702,5 +727,5 @@ extern "C" int inerf_mlp_weight_gradient_frag_batch(int n_jobs, const void* cons
 // one product: inerf_wgrad_grid(n_points) K-slices
 extern "C" int inerf_mlp_weight_gradient_frag(const void* G_frag, const float* g_scale, const void* X_frag, const float* ranges,
                                               int64_t n_points, float* partial, float* bias_partial, int64_t partial_stride, void* stream) {
-    return inerf_mlp_weight_gradient_frag_batch(1, &G_frag, g_scale, &X_frag, nullptr, ranges, n_points, &partial, &bias_partial, partial_stride, stream);
+    return inerf_mlp_weight_gradient_frag_batch(1, &G_frag, g_scale, &X_frag, nullptr, nullptr, ranges, n_points, &partial, &bias_partial, partial_stride, stream);
 }
