@@ -30,7 +30,7 @@ extern "C" {
 #define INERF_VERSION_MINOR 2
 /* Bumped whenever a struct layout, an argument list or the packed-weight format of this header changes; bindings
  * compare it with inerf_abi_version() of the library they loaded (a stale .so then fails loudly, not silently). */
-#define INERF_ABI_VERSION 40004
+#define INERF_ABI_VERSION 40005
 
 /* error codes */
 #define INERF_OK              0
@@ -148,7 +148,7 @@ int inerf_encode_mlp_ws(const inerf_net_desc* net, const float* packed_weights, 
  *   12 views hidden 128 | 13 semantic hidden 128 (SSR with classes, else width 0) |
  *   14 (dz only) head pre-activation gradients 8: albedo 3, shading 1, residual 3, sigma 1 | 15 unused (width 0).
  * Two slot formats:
- *   ROWS      a row-major fp32 [n_points, width] matrix.  save: 1, 10, 12, 13; dz: 12, 13, 14.
+ *   ROWS      a row-major fp32 [n_points, width] matrix.  save: 10, 12, 13; dz: 13, 14.
  *   FRAGMENTS the operands of the 256-wide weight-gradient products dW = dZ^T X exactly as the matrix core consumes
  *             them: every value v is stored as f16 hi = f16(v') (towards zero) and f16 lo = f16(v' - hi) in 1 KB fragments
  *             [32 channels x 16 points]; with kb = 16-point block of the tile (0..3), cb = 32-channel block:
@@ -156,9 +156,10 @@ int inerf_encode_mlp_ws(const inerf_net_desc* net, const float* packed_weights, 
  *               channel = 32 cb + (lane & 31),  point = 64 tile + 32 (kb >> 1) + (i & 3) + 8 ((i >> 2) + 2 (kb & 1)) + 4 (lane >> 5)
  *             (lane = channel, 8 k-values = 8 points: one 16-byte operand slot of v_mfma_f32_32x32x16_f16; the point order
  *             inside a block is the accumulator's register order).
- *             save, slots 2..9 and 11: v' = 8 v (the forward kernel's own operand halves); slot 0 (the encoding, 64 channels): the
- *             same with TWO channel blocks per k-block - byte offset = (((tile * 4 + kb) * 2 + cb) * 2 + plane) * 1024 + ...
- *             dz, slots 2..11: v' = 8 v / s_p, s_p = the point's NORMALISER (the power of two above its largest head
+ *             save, slots 2..9 and 11: v' = 8 v (the forward kernel's own operand halves); slots 0 and 1 (the encodings, 64 / 32
+ *             channels): the same with width / 32 = TWO / ONE channel blocks per k-block instead of eight -
+ *             byte offset = (((tile * 4 + kb) * (width / 32) + cb) * 2 + plane) * 1024 + ...
+ *             dz, slots 2..11 and 12 (the views hidden layer: 128 channels = FOUR blocks per k-block): v' = 8 v / s_p, s_p = the point's NORMALISER (the power of two above its largest head
  *             gradient; the chain works on normalised gradients, so these halves keep 22 bits whatever a point's gradient
  *             scale) - the normalisers are the first 64 * ceil(n_points / 64) floats of slot 0 of dz, and the weight-gradient
  *             kernels multiply them back in when they bring a fragment to the batch's max |dz|.
@@ -225,16 +226,18 @@ int inerf_mlp_weight_gradient_xfrag(const float* G, int ldg, const void* X_frag,
 /* ... and with BOTH operands FRAGMENT slots (256 x 256: G of the gradient buffer, X of the activation buffer, same points):
  * a ring of LDS stages filled by LDS-DMA - bound by HBM bandwidth.  ranges[0]: an upper bound of the true |dz|.
  * _batch: n_jobs (<= INERF_WGRAD_MAX_BATCH) such products over the SAME points and normalisers in one launch of
- * inerf_wgrad_frag_grid(n_points, n_jobs) workgroups; x_cols[j] = 256, or 64 when X_frag[j] is the encoding's slot (NULL: all
- * 256).  Job j is split over inerf_wgrad_frag_rows(n_points, n_jobs, x_cols, j) of them (its share of the bytes), K-slice s
- * writing its [256, x_cols[j]] tile at partial[j] + s * partial_stride (and its column sums of G at bias_partial[j] + s *
+ * inerf_wgrad_frag_grid(n_points, n_jobs) workgroups; g_rows[j] x x_cols[j] = 256 x 256, 256 x 64 (X the position encoding's
+ * slot), 128 x 256 or 128 x 32 (G the views hidden layer's slot; X the view encoding's) - NULL: all 256.  Job j is split over
+ * inerf_wgrad_frag_rows(n_points, n_jobs, g_rows, x_cols, j) of them (its share of the work), K-slice s
+ * writing its [g_rows[j], x_cols[j]] tile at partial[j] + s * partial_stride (and its column sums of G at bias_partial[j] + s *
  * partial_stride where that entry is not NULL): ~n_jobs times fewer partial tiles to write and to sum than n_jobs single
  * launches.  The single form is the batch of one 256 x 256 product (inerf_wgrad_grid(n_points) slices). */
-#define INERF_WGRAD_MAX_BATCH 12
+#define INERF_WGRAD_MAX_BATCH 16
 int inerf_wgrad_frag_grid(int64_t n_points, int n_jobs);
-int inerf_wgrad_frag_rows(int64_t n_points, int n_jobs, const int* x_cols /*[host] or NULL*/, int job);
+int inerf_wgrad_frag_rows(int64_t n_points, int n_jobs, const int* g_rows /*[host] or NULL*/, const int* x_cols /*[host] or NULL*/, int job);
 int inerf_mlp_weight_gradient_frag_batch(int n_jobs, const void* const* G_frag /*[host]*/, const float* g_scale, const void* const* X_frag /*[host]*/,
-                                         const int* x_cols /*[host] or NULL*/, const float* ranges, int64_t n_points, float* const* partial /*[host]*/,
+                                         const int* g_rows /*[host] or NULL*/, const int* x_cols /*[host] or NULL*/, const float* ranges,
+                                         int64_t n_points, float* const* partial /*[host]*/,
                                          float* const* bias_partial /*[host] or NULL*/, int64_t partial_stride, void* stream);
 int inerf_mlp_weight_gradient_frag(const void* G_frag, const float* g_scale, const void* X_frag, const float* ranges, int64_t n_points,
                                    float* partial, float* bias_partial, int64_t partial_stride, void* stream);

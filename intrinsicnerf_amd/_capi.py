@@ -10,7 +10,7 @@ import os
 from . import _build
 from ._build import LIB_PATH
 
-ABI_VERSION = 40004          # INERF_ABI_VERSION of include/inerf.h these ctypes declarations mirror
+ABI_VERSION = 40005          # INERF_ABI_VERSION of include/inerf.h these ctypes declarations mirror
 
 OK, E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_HIP = 0, -1, -2, -3, -4
 VARIANT_OBJECT, VARIANT_SSR = 0, 1
@@ -75,8 +75,9 @@ SYMBOLS = {
     "inerf_mlp_weight_gradient_gfrag": (_I, [_P, _P, _P, _I, _L, _I, _P, _P, _P, _L, _P]),
     "inerf_mlp_weight_gradient_xfrag": (_I, [_P, _I, _P, _L, _I, _P, _P, _P, _L, _P]),
     "inerf_wgrad_frag_grid": (_I, [_L, _I]),
-    "inerf_wgrad_frag_rows": (_I, [_L, _I, C.POINTER(C.c_int), _I]),
-    "inerf_mlp_weight_gradient_frag_batch": (_I, [_I, C.POINTER(_P), _P, C.POINTER(_P), C.POINTER(C.c_int), _P, _L, C.POINTER(_P), C.POINTER(_P), _L, _P]),
+    "inerf_wgrad_frag_rows": (_I, [_L, _I, C.POINTER(C.c_int), C.POINTER(C.c_int), _I]),
+    "inerf_mlp_weight_gradient_frag_batch": (_I, [_I, C.POINTER(_P), _P, C.POINTER(_P), C.POINTER(C.c_int), C.POINTER(C.c_int), _P, _L, C.POINTER(_P),
+                                                  C.POINTER(_P), _L, _P]),
     "inerf_mlp_weight_gradient_frag": (_I, [_P, _P, _P, _P, _L, _P, _P, _L, _P]),
     "inerf_mlp_save_slot_is_fragment": (_I, [_I, _I]),
     "inerf_param_floats": (_L, [C.POINTER(NetDesc)]),

@@ -115,15 +115,18 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
         }
         __syncthreads();
         // training forward: the encoding leaves as operand fragments of the products dW = dZ^T enc (pts_linears.0, and .5's
-        // encoding columns), straight from the planes: a 64-channel fragment slot, one channel block per wave 0 / 1
+        // encoding columns), straight from the planes: a 64-channel fragment slot, one channel block per wave 0 / 1 (wave 2: the view encoding)
         if constexpr (kSave)
             if (wave < 2) {
                 FragDst d;
                 d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save + p.save_off[SAVE_ENC], 0, (int)((unsigned)p.n_tiles * (unsigned)(kFragTileBytes / 4)), 0x00020000);
                 d.voff = (unsigned)tile * (unsigned)(kFragTileBytes / 4) + (unsigned)wave * (2u * kFragBytes) + (unsigned)lane * 16u;
                 planes_to_frag<1, kRowH, kPlaneH, 2>(xr + kColEnc + 32 * wave, plane_selector(lane), d);
-            } else {
-                dir_rows<kRowH, kPlaneH>(ldsh + kColDir, p.save + p.save_off[SAVE_DIR], p.n_points, tile, wave - 2, lane);
+            } else if (wave == 2) {                 // the view encoding: a 32-channel fragment slot (one block per k-block)
+                FragDst d;
+                d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save + p.save_off[SAVE_DIR], 0, (int)((unsigned)p.n_tiles * (unsigned)(kFragTileBytes / 8)), 0x00020000);
+                d.voff = (unsigned)tile * (unsigned)(kFragTileBytes / 8) + (unsigned)lane * 16u;
+                planes_to_frag<1, kRowH, kPlaneH, 1>(xr + kColDir, plane_selector(lane), d);
             }
 
         const int pt0 = tile * kPts + (lane & 31);              // this lane's points in wide results
@@ -384,8 +387,8 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
         __syncthreads();
         // training forward: the encoding leaves as operand fragments of the products dW = dZ^T enc (pts_linears.0, and .5's
         // encoding columns), straight from the planes (columns 0..63, before the first layer's output lands there): a 64-channel
-        // fragment slot, one channel block per wave 0 / 1; waves 2 / 3 write the view encoding's rows.  (Until round 4: 96
-        // four-byte stores per point at strides of 256 / 128 bytes.)
+        // fragment slot, one channel block per wave 0 / 1; wave 2: the view encoding (32 channels, one block).  (Until round 4:
+        // 96 four-byte stores per point at strides of 256 / 128 bytes.)
         if constexpr (kSave) {
             int lane_e = lane_t;
             asm volatile("" : "+v"(lane_e));
@@ -394,8 +397,11 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
                 d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save + p.save_off[SAVE_ENC], 0, (int)((unsigned)p.n_tiles * (unsigned)(kFragTileBytes / 4)), 0x00020000);
                 d.voff = (unsigned)tile * (unsigned)(kFragTileBytes / 4) + (unsigned)wave * (2u * kFragBytes) + (unsigned)lane_e * 16u;
                 planes_to_frag<1, kRowD, kPlaneD, 2>(xr + 32 * wave, plane_selector(lane_e), d);
-            } else {
-                dir_rows<kRowD, kPlaneD>(ldsd + kColDirD, p.save + p.save_off[SAVE_DIR], p.n_points, tile, wave - 2, lane_e);
+            } else if (wave == 2) {                 // the view encoding: a 32-channel fragment slot (one block per k-block)
+                FragDst d;
+                d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save + p.save_off[SAVE_DIR], 0, (int)((unsigned)p.n_tiles * (unsigned)(kFragTileBytes / 8)), 0x00020000);
+                d.voff = (unsigned)tile * (unsigned)(kFragTileBytes / 8) + (unsigned)lane_e * 16u;
+                planes_to_frag<1, kRowD, kPlaneD, 1>(xr + kColDirD, plane_selector(lane_e), d);
             }
         }
 

@@ -234,23 +234,6 @@ struct SaveDst {
     int stride;        // floats per point
 };
 
-// Training copy of the view encoding (SAVE_DIR: fp32 rows of 32 floats): half a tile (32 points) per wave, read back from the
-// planes - (hi + lo) / kActScale, the 22 bits every consumer of the slot splits it into again - and stored as whole 128-byte
-// rows, eight lanes per row.  Points beyond the end are dropped by the descriptor's range check.
-template <int ROW, int PLANE>
-__device__ __forceinline__ void dir_rows(const _Float16* planes /* plane_hi + first dir column */, float* slot, int n_points, int tile, int half, int lane) {
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(slot, 0, (int)((unsigned)n_points * (unsigned)kDirCols * 4u), 0x00020000);
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int pt = 32 * half + 8 * it + (lane >> 3), c = 4 * (lane & 7);
-        const f16x4 hi = *reinterpret_cast<const f16x4*>(planes + pt * ROW + c), lo = *reinterpret_cast<const f16x4*>(planes + pt * ROW + c + PLANE);
-        f32x4 v;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = ((float)hi[i] + (float)lo[i]) * (1.0f / kActScale);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (int)(((unsigned)(tile * kTilePoints + pt) * (unsigned)kDirCols + (unsigned)c) * 4u), 0, 0);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Fragment slots (layout.h SaveSlot): a layer's output, which sits in the hi / lo planes as X[point][channel], leaves the CU as
 // operand fragments of the weight-gradient products (lane = channel, 8 k-values = 8 sample points).  The transposition is done

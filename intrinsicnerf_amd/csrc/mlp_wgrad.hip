@@ -21,6 +21,7 @@
 //     8 consecutive channels: a natural 32-byte read of a point's row) with an identity matrix returns that block in
 //     accumulator layout - lane = channel, registers = points - which, converted back to f16 (exact: the inputs were f16), IS
 //     an operand of the next MFMA.  The resulting k order is layout.h's frag_point order, the fragment slots' own.
+#include <cstdio>
 #include <cstdlib>
 
 #include "mlp_f16_dev.h"
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
 // The column sums of G (the bias gradient) come from the operands the waves 0..3 read anyway.
 // ---------------------------------------------------------------------------------------------------------------------
 #ifndef INERF_WGRAD_MAX_BATCH
-#define INERF_WGRAD_MAX_BATCH 12
+#define INERF_WGRAD_MAX_BATCH 16
 #endif
 #ifndef INERF_WGRAD_FRAG_STAGES
 #define INERF_WGRAD_FRAG_STAGES 4
@@ -665,6 +666,12 @@ bool frag_slices(int64_t n_points, int n_jobs, const int* g_rows, const int* x_c
         const int r = g_rows ? g_rows[j] : kWidth, c = x_cols ? x_cols[j] : kWidth;
         if (!frag_shape_ok(r, c)) return false;
         w[j] = 8 + 2 * (r / 32) + 2 * (c / 32);
+#ifdef INERF_WGRAD_TUNE_SHARES          // development build: weights of the four shapes from $INERF_WGRAD_WEIGHTS = "w88,w82,w48,w41"
+        if (const char* e = getenv("INERF_WGRAD_WEIGHTS")) {
+            int w88, w82, w48, w41;
+            if (sscanf(e, "%d,%d,%d,%d", &w88, &w82, &w48, &w41) == 4) w[j] = r == kWidth ? (c == kWidth ? w88 : w82) : (c == kWidth ? w48 : w41);
+        }
+#endif
         total += w[j];
     }
     int given = 0;

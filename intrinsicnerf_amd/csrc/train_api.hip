@@ -370,15 +370,15 @@ extern "C" int inerf_mlp_backward(const inerf_net_desc* net, const float* packed
     ReduceTable t = tb.dev;
     t.grid = plan.wg_grid;
     const float* g_scale = dz + save_offset(*net, SAVE_ENC, n_points);        // the points' normalisers, written by the chain
-    // the products whose operands are both fragment slots (the nine 256 x 256 ones, the two against the encoding): ONE launch, each
-    // product split over its share of the grid
+    // the products whose operands are both fragment slots (the nine 256 x 256 ones, the two against the position encoding, the views
+    // hidden layer's two): ONE launch, each product split over its share of the grid
     const void* fg[kMaxJobs]; const void* fx[kMaxJobs]; float* ft[kMaxJobs]; float* fb[kMaxJobs];
-    int fcols[kMaxJobs];
+    int frows[kMaxJobs], fcols[kMaxJobs];
     int n_frag = 0;
     for (int k = 0; k < t.n_jobs; ++k) {
         const Launch& l = tb.launch[k];
         t.job[k].rows = t.grid;
-        if (!l.sem && save_is_frag(l.g_slot, true) && save_is_frag(l.x_slot, false)) fcols[n_frag++] = t.job[k].n;
+        if (!l.sem && save_is_frag(l.g_slot, true) && save_is_frag(l.x_slot, false)) { frows[n_frag] = t.job[k].m; fcols[n_frag++] = t.job[k].n; }
     }
     if (n_frag > INERF_WGRAD_MAX_BATCH) return INERF_E_UNSUPPORTED;
     for (int k = 0, f = 0; k < t.n_jobs; ++k) {
@@ -392,7 +392,7 @@ extern "C" int inerf_mlp_backward(const inerf_net_desc* net, const float* packed
         const bool g_frag = !l.sem && save_is_frag(l.g_slot, true), x_frag = save_is_frag(l.x_slot, false);
         if (g_frag && x_frag) {
             fg[f] = G; fx[f] = X; ft[f] = tile; fb[f] = bias;
-            j.rows = inerf_wgrad_frag_rows(n_points, n_frag, fcols, f);
+            j.rows = inerf_wgrad_frag_rows(n_points, n_frag, frows, fcols, f);
             if (j.rows > t.grid) return INERF_E_WORKSPACE;
             ++f;
             continue;
@@ -403,7 +403,7 @@ extern "C" int inerf_mlp_backward(const inerf_net_desc* net, const float* packed
         if (rc) return rc;
     }
     if (n_frag) {
-        rc = inerf_mlp_weight_gradient_frag_batch(n_frag, fg, g_scale, fx, fcols, sc + 4, n_points, ft, fb, t.total, stream);
+        rc = inerf_mlp_weight_gradient_frag_batch(n_frag, fg, g_scale, fx, frows, fcols, sc + 4, n_points, ft, fb, t.total, stream);
         if (rc) return rc;
     }
     hipLaunchKernelGGL(k_reduce_scatter, dim3((unsigned)((t.total / 4 + 255) / 256)), dim3(256), 0, stream, t, partial, grads_out);

@@ -502,7 +502,7 @@ def frag_encode(rows, scale=ACT_SCALE):
 
 
 def grad_frag_encode(rows):
-    """fp32 [n_points, 256] gradients -> (FRAGMENT slot, normalisers) as the input-gradient chain writes them into a gradient
+    """fp32 [n_points, W] gradients (W = 256, or 128) -> (FRAGMENT slot, normalisers) as the input-gradient chain writes them into a gradient
     buffer: every point p is normalised by s_p = the power of two above its largest |value| (the chain uses its largest HEAD
     gradient; any power of two keeps the encoding exact) and stored as the split f16 halves of 8 * value / s_p;
     normalisers: float32[64 * ceil(n / 64) + 64] (1 for padding points; 64 readable floats behind the end)."""
@@ -516,9 +516,9 @@ def grad_frag_encode(rows):
     return frag_encode(rows.float() / s[:, None], ACT_SCALE), scales
 
 
-def grad_frag_decode(frag, scales, n_points):
-    """The inverse: (FRAGMENT slot of a gradient buffer, the points' normalisers) -> fp32 [n_points, 256]."""
-    return frag_decode(frag, n_points, ACT_SCALE) * scales[:n_points, None]
+def grad_frag_decode(frag, scales, n_points, width=256):
+    """The inverse: (FRAGMENT slot of a gradient buffer, the points' normalisers) -> fp32 [n_points, width]."""
+    return frag_decode(frag, n_points, ACT_SCALE, width) * scales[:n_points, None]
 
 
 def save_slot_views(desc, buf, n_points, gradient=False):
@@ -532,7 +532,7 @@ def save_slot_views(desc, buf, n_points, gradient=False):
         _capi.check(lib.inerf_mlp_save_slot(desc, slot, n_points, C.byref(off), C.byref(width)), "inerf_mlp_save_slot")
         if lib.inerf_mlp_save_slot_is_fragment(slot, 1 if gradient else 0) == 1:
             frag = buf[off.value: off.value + padded * width.value]
-            views.append(grad_frag_decode(frag, views[SAVE_ENC], n_points) if gradient else frag_decode(frag, n_points, width=width.value))
+            views.append(grad_frag_decode(frag, views[SAVE_ENC], n_points, width.value) if gradient else frag_decode(frag, n_points, width=width.value))
         elif gradient and slot == SAVE_ENC:         # the points' normalisers (include/inerf.h), not an [n, 64] matrix
             views.append(buf[off.value: off.value + padded])
         else:
@@ -730,15 +730,16 @@ def weight_gradient_frag(g_frag, g_scale, x_frag, ranges, n_points, want_bias=Fa
     return (w, sums[256 * n:]) if want_bias else w
 
 
-def weight_gradient_frag_batch(g_frags, g_scale, x_frags, ranges, n_points, x_cols=None):
-    """Several products G_j^T X_j over the same points (fragment slots, shared normalisers; X_j 256 channels wide, or 64 where
-    ``x_cols[j]`` says so) in ONE launch of the LDS-DMA kernel, each split over its share of the grid (include/inerf.h
-    inerf_mlp_weight_gradient_frag_batch).  Returns [(dW_j [256, cols], db_j [256])]."""
+def weight_gradient_frag_batch(g_frags, g_scale, x_frags, ranges, n_points, x_cols=None, g_rows=None):
+    """Several products G_j^T X_j over the same points (fragment slots, shared normalisers; shapes ``g_rows[j]`` x ``x_cols[j]`` =
+    256 x 256 (default), 256 x 64, 128 x 256, 128 x 32) in ONE launch of the LDS-DMA kernel, each split over its share of the
+    grid (include/inerf.h inerf_mlp_weight_gradient_frag_batch).  Returns [(dW_j [rows, cols], db_j [rows])]."""
     lib = _capi.lib()
     n = len(g_frags)
     cols = [256] * n if x_cols is None else [int(c) for c in x_cols]
-    ccols = (C.c_int * n)(*cols)
-    rows = [lib.inerf_wgrad_frag_rows(n_points, n, ccols, j) for j in range(n)]
+    grows = [256] * n if g_rows is None else [int(r) for r in g_rows]
+    ccols, crows = (C.c_int * n)(*cols), (C.c_int * n)(*grows)
+    rows = [lib.inerf_wgrad_frag_rows(n_points, n, crows, ccols, j) for j in range(n)]
     per = 256 * 256 + 256
     total = n * per
     buf = _new(ranges, max(rows), total)
@@ -746,13 +747,13 @@ def weight_gradient_frag_batch(g_frags, g_scale, x_frags, ranges, n_points, x_co
     arr = lambda vals: (C.c_void_p * n)(*vals)
     with torch.cuda.device(ranges.device):
         rc = lib.inerf_mlp_weight_gradient_frag_batch(n, arr([g.data_ptr() for g in g_frags]), _ptr(g_scale), arr([x.data_ptr() for x in x_frags]),
-                                                      ccols, _ptr(ranges), n_points, arr([base + 4 * j * per for j in range(n)]),
+                                                      crows, ccols, _ptr(ranges), n_points, arr([base + 4 * j * per for j in range(n)]),
                                                       arr([base + 4 * (j * per + 65536) for j in range(n)]), total, _stream(ranges))
     _capi.check(rc, "inerf_mlp_weight_gradient_frag_batch")
     out = []
     for j in range(n):
         sums = buf[:rows[j], j * per:(j + 1) * per].sum(0)
-        out.append((sums[:256 * cols[j]].view(256, cols[j]), sums[65536:]))
+        out.append((sums[:grows[j] * cols[j]].view(grows[j], cols[j]), sums[65536:65536 + grows[j]]))
     return out
 
 

@@ -74,6 +74,6 @@ print(f"training forward (save)  {t_fwd:7.3f} ms  {flop / t_fwd / 1e9:6.1f} TFLO
 print(f"input-gradient chain (+ head gradients, pre-pass) {t_bwd:7.3f} ms  {0.89 * flop / t_bwd / 1e9:6.1f} TFLOP/s")
 print(f"whole backward, one C call (chain + 13 products + reduction) {t_all:7.3f} ms; weight gradients = {t_all - t_bwd:7.3f} ms  {flop / (t_all - t_bwd) / 1e9:6.1f} TFLOP/s")
 print(f"one 256 x 256 product from fragment slots (incl. the sum over {_capi.lib().inerf_wgrad_grid(p)} partial tiles) {t_one * 1e3:7.1f} us: operands {2 * p * 1024 / t_one / 1e9:5.2f} TB/s")
-print(f"the nine 256 x 256 products in one launch (incl. the sums over ~{_capi.lib().inerf_wgrad_frag_rows(p, 9, None, 0)} partial tiles each) {t_nine:7.3f} ms: "
+print(f"the nine 256 x 256 products in one launch (incl. the sums over ~{_capi.lib().inerf_wgrad_frag_rows(p, 9, None, None, 0)} partial tiles each) {t_nine:7.3f} ms: "
       f"operands {9 * 2 * p * 1024 / t_nine / 1e9:5.2f} TB/s")
 print(f"weight gradients, library GEMMs on decoded slots (reference) {t_wl:7.3f} ms")

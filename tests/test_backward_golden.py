@@ -467,8 +467,16 @@ def test_weight_gradient_from_fragment_slots(p):
     x64 = torch.sin(torch.arange(p * 64, dtype=torch.float32).view(p, 64) * 0.37).to(dev)
     xf64 = kernels.frag_encode(x64)
     want64f = Gq.t() @ kernels.frag_decode(xf64, p, width=64).double()
-    res = kernels.weight_gradient_frag_batch([gf, gf, gf2, gf], gs, [xf, xf2, xf, xf64], ranges, p, x_cols=[256, 256, 256, 64])
-    for (wj, bj), ww, wb in zip(res, (want_w, Gq.t() @ kernels.frag_decode(xf2, p).double(), -want_w, want64f), (want_b, want_b, -want_b, want_b)):
+    # ... and with a 128-channel G slot (the views hidden layer's format) against 256 and 32 channels (the view encoding's)
+    g128 = (G[:, 64:192] * 0.5).contiguous()
+    gf128 = kernels.frag_encode(g128 / gs[:p, None])             # (one set of normalisers per gradient buffer: the 256-wide slot's)
+    Gq128 = kernels.grad_frag_decode(gf128, gs, p, 128).double()
+    x32 = torch.cos(torch.arange(p * 32, dtype=torch.float32).view(p, 32) * 0.73).to(dev)
+    xf32 = kernels.frag_encode(x32)
+    res = kernels.weight_gradient_frag_batch([gf, gf, gf2, gf, gf128, gf128], gs, [xf, xf2, xf, xf64, xf, xf32], ranges, p,
+                                             x_cols=[256, 256, 256, 64, 256, 32], g_rows=[256, 256, 256, 256, 128, 128])
+    wants = (want_w, Gq.t() @ kernels.frag_decode(xf2, p).double(), -want_w, want64f, Gq128.t() @ Xq, Gq128.t() @ kernels.frag_decode(xf32, p, width=32).double())
+    for (wj, bj), ww, wb in zip(res, wants, (want_b, want_b, -want_b, want_b, Gq128.sum(0), Gq128.sum(0))):
         assert float((wj.double() - ww).norm()) <= 2e-6 * float(ww.norm())
         assert float((bj.double() - wb).norm()) <= 2e-6 * float(wb.norm()) + 1e-12
     # row-format G (128 channels) x X fragments (views_linears.0 against the feature layer, the semantic hidden layer against h7)

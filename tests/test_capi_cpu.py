@@ -106,15 +106,18 @@ def test_argument_validation(capi):
     assert off.value == 128 * per_point                                          # slots are sized for whole tiles
     assert lib.inerf_mlp_save_slot(good, 16, 100, C.byref(off), C.byref(width)) == capi.E_INVALID
     # formats: h0..h7 and the feature layer are fragment slots in both buffers, the albedo|shading hidden layer only as gradients, the
-    # encoding (64 channels) only as activations; job shares of a batched launch add up to its grid
-    assert [lib.inerf_mlp_save_slot_is_fragment(s, 0) for s in range(16)] == [1, 0] + [1] * 8 + [0, 1] + [0] * 4
-    assert [lib.inerf_mlp_save_slot_is_fragment(s, 1) for s in range(16)] == [0, 0] + [1] * 10 + [0] * 4
+    # encodings (64 / 32 channels) only as activations, the views hidden layer (128) only as gradients; job shares of a batched
+    # launch add up to its grid
+    assert [lib.inerf_mlp_save_slot_is_fragment(s, 0) for s in range(16)] == [1, 1] + [1] * 8 + [0, 1] + [0] * 4
+    assert [lib.inerf_mlp_save_slot_is_fragment(s, 1) for s in range(16)] == [0, 0] + [1] * 11 + [0] * 3
     assert lib.inerf_mlp_save_slot_is_fragment(16, 0) == capi.E_INVALID
     assert lib.inerf_mlp_weight_gradient_frag(None, None, None, None, 1000, None, None, 65536, None) == capi.E_INVALID
-    cols = (C.c_int * 11)(*([256] * 9 + [64] * 2))
-    shares = [lib.inerf_wgrad_frag_rows(393216, 11, cols, j) for j in range(11)]
-    assert sum(shares) == lib.inerf_wgrad_frag_grid(393216, 11) and min(shares[:9]) > max(shares[9:]) >= 1
-    assert [lib.inerf_wgrad_frag_rows(64, 11, cols, j) for j in range(11)] == [1] * 11 and lib.inerf_wgrad_frag_grid(64, 11) == 11
+    cols = (C.c_int * 13)(*([256] * 9 + [64] * 2 + [256, 32]))
+    rws = (C.c_int * 13)(*([256] * 11 + [128, 128]))
+    shares = [lib.inerf_wgrad_frag_rows(393216, 13, rws, cols, j) for j in range(13)]
+    assert sum(shares) == lib.inerf_wgrad_frag_grid(393216, 13) and min(shares[:9]) > max(shares[9:]) and shares[11] > shares[9] > shares[12] >= 1
+    assert [lib.inerf_wgrad_frag_rows(64, 13, rws, cols, j) for j in range(13)] == [1] * 13 and lib.inerf_wgrad_frag_grid(64, 13) == 13
+    assert lib.inerf_wgrad_frag_rows(393216, 1, (C.c_int * 1)(128), (C.c_int * 1)(64), 0) == 0          # not a supported pair
     assert lib.inerf_mlp_weight_gradient_xfrag(None, 128, None, 1000, 128, None, None, None, 32768, None) == capi.E_INVALID
     assert lib.inerf_mlp_weight_gradient_gfrag(None, None, None, 64, 1000, 64, None, None, None, 16384, None) == capi.E_INVALID
     assert lib.inerf_wgrad_grid(0) == 0 and lib.inerf_mlp_backward_grid(64 * 7) == 7
