@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
         __syncthreads();
         // training forward: the encoding leaves as operand fragments of the products dW = dZ^T enc (pts_linears.0, and .5's
         // encoding columns), straight from the planes: a 64-channel fragment slot, one channel block per wave 0 / 1 (wave 2: the view encoding)
-        if constexpr (kSave)
+        if constexpr (kSave) {
             if (wave < 2) {
                 FragDst d;
                 d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save + p.save_off[SAVE_ENC], 0, (int)((unsigned)p.n_tiles * (unsigned)(kFragTileBytes / 4)), 0x00020000);
@@ -128,6 +128,7 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
                 d.voff = (unsigned)tile * (unsigned)(kFragTileBytes / 8) + (unsigned)lane * 16u;
                 planes_to_frag<1, kRowH, kPlaneH, 1>(xr + kColDir, plane_selector(lane), d);
             }
+        }
 
         const int pt0 = tile * kPts + (lane & 31);              // this lane's points in wide results
         // training forward: fp32 copy of a layer's output, this lane's first point / first channel of its wave
