@@ -148,7 +148,7 @@ int inerf_encode_mlp_ws(const inerf_net_desc* net, const float* packed_weights, 
  *   12 views hidden 128 | 13 semantic hidden 128 (SSR with classes, else width 0) |
  *   14 (dz only) head pre-activation gradients 8: albedo 3, shading 1, residual 3, sigma 1 | 15 unused (width 0).
  * Two slot formats:
- *   ROWS      a row-major fp32 [n_points, width] matrix.  save: 10, 12, 13; dz: 13, 14.
+ *   ROWS      a row-major fp32 [n_points, width] matrix.  save: 10, 12, 13; dz: 14.
  *   FRAGMENTS the operands of the 256-wide weight-gradient products dW = dZ^T X exactly as the matrix core consumes
  *             them: every value v is stored as f16 hi = f16(v') (towards zero) and f16 lo = f16(v' - hi) in 1 KB fragments
  *             [32 channels x 16 points]; with kb = 16-point block of the tile (0..3), cb = 32-channel block:
@@ -159,7 +159,7 @@ int inerf_encode_mlp_ws(const inerf_net_desc* net, const float* packed_weights, 
  *             save, slots 2..9 and 11: v' = 8 v (the forward kernel's own operand halves); slots 0 and 1 (the encodings, 64 / 32
  *             channels): the same with width / 32 = TWO / ONE channel blocks per k-block instead of eight -
  *             byte offset = (((tile * 4 + kb) * (width / 32) + cb) * 2 + plane) * 1024 + ...
- *             dz, slots 2..11 and 12 (the views hidden layer: 128 channels = FOUR blocks per k-block): v' = 8 v / s_p, s_p = the point's NORMALISER (the power of two above its largest head
+ *             dz, slots 2..11 and 12, 13 (the views / semantic hidden layers: 128 channels = FOUR blocks per k-block): v' = 8 v / s_p, s_p = the point's NORMALISER (the power of two above its largest head
  *             gradient; the chain works on normalised gradients, so these halves keep 22 bits whatever a point's gradient
  *             scale) - the normalisers are the first 64 * ceil(n_points / 64) floats of slot 0 of dz, and the weight-gradient
  *             kernels multiply them back in when they bring a fragment to the batch's max |dz|.
@@ -227,7 +227,7 @@ int inerf_mlp_weight_gradient_xfrag(const float* G, int ldg, const void* X_frag,
  * a ring of LDS stages filled by LDS-DMA - bound by HBM bandwidth.  ranges[0]: an upper bound of the true |dz|.
  * _batch: n_jobs (<= INERF_WGRAD_MAX_BATCH) such products over the SAME points and normalisers in one launch of
  * inerf_wgrad_frag_grid(n_points, n_jobs) workgroups; g_rows[j] x x_cols[j] = 256 x 256, 256 x 64 (X the position encoding's
- * slot), 128 x 256 or 128 x 32 (G the views hidden layer's slot; X the view encoding's) - NULL: all 256.  Job j is split over
+ * slot), 128 x 256 or 128 x 32 (G the views / semantic hidden layer's slot; X the view encoding's) - NULL: all 256.  Job j is split over
  * inerf_wgrad_frag_rows(n_points, n_jobs, g_rows, x_cols, j) of them (its share of the work), K-slice s
  * writing its [g_rows[j], x_cols[j]] tile at partial[j] + s * partial_stride (and its column sums of G at bias_partial[j] + s *
  * partial_stride where that entry is not NULL): ~n_jobs times fewer partial tiles to write and to sum than n_jobs single

@@ -164,8 +164,8 @@ inline NetLayout make_layout(const inerf_net_desc& net) {
 //                      with two / one channel blocks per k-block instead of eight, straight from the encoder's planes);
 //                      the chain reads h7 - ReLU mask and operand of the alpha_linear weight gradient - from its fragments: the
 //                      matrix core transposes them back; H7R unused;
-//   gradient buffer:   SEMH, DPRE rows (DPRE: 8 floats per point: albedo 3, shading 1, residual 3, sigma 1); H0..H7, AS1H, FEAT
-//                      fragments, VH fragments of a 128-channel slot (four channel blocks per k-block); ENC: the normalisers;
+//   gradient buffer:   DPRE rows (8 floats per point: albedo 3, shading 1, residual 3, sigma 1); H0..H7, AS1H, FEAT fragments,
+//                      VH and SEMH fragments of 128-channel slots (four channel blocks per k-block); ENC: the normalisers;
 //                      DIR, H7R unused.
 enum SaveSlot {
     SAVE_ENC = 0,      // 64  encoded position (63 + zero pad)
@@ -202,7 +202,7 @@ inline int save_width(const inerf_net_desc& net, int slot) {
 inline int save_is_frag(int slot, bool gradient) {
     if ((slot >= SAVE_H0 && slot <= SAVE_H7) || slot == SAVE_FEAT) return 1;
     if (slot == SAVE_ENC || slot == SAVE_DIR) return gradient ? 0 : 1;      // activation buffer: NARROW fragment slots (64 / 32 channels = 2 / 1 blocks per k-block)
-    return (gradient && (slot == SAVE_AS1H || slot == SAVE_VH)) ? 1 : 0;   // (VH: 128 channels = 4 blocks)
+    return (gradient && (slot == SAVE_AS1H || slot == SAVE_VH || slot == SAVE_SEMH)) ? 1 : 0;   // (VH, SEMH: 128 channels = 4 blocks)
 }
 
 inline int64_t save_offset(const inerf_net_desc& net, int slot, int64_t n_points) {     // in floats

@@ -532,11 +532,16 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
                 split_store4(ldsb + pt * kRowH + kColA + c4, ldsb + pt * kRowH + kColA + c4 + kPlaneH, v, amax2);
                 if (valid) {
                     const f32x4 o = f32x4{v[0], v[1], v[2], v[3]} * f[8];
-                    *reinterpret_cast<f32x4*>(p.dz + p.off[SAVE_SEMH] + (size_t)gp * kHalf + c4) = o;
                     gmax = fmaxf(gmax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
                 }
             }
             __syncthreads();
+            if (wave < 4) {                  // dZ of the semantic hidden layer: fragments of a 128-channel slot, like dZ_vh
+                FragDst d;
+                d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dz + p.off[SAVE_SEMH], 0, (int)((unsigned)p.n_tiles * (unsigned)(kFragTileBytes / 2)), 0x00020000);
+                d.voff = (unsigned)tile * (unsigned)(kFragTileBytes / 2) + (unsigned)wave * (2u * kFragBytes) + (unsigned)lane_t * 16u;
+                planes_to_frag<1, kRowH, kPlaneH, 4>(xr + kColA + 32 * wave, plane_selector(lane_t), d);
+            }
             wide_gemm_h<RB, 8, 0, kRowH, kPlaneH, false, KS>(preA, wb, frag(L.sem1_t, 8), xr, kColA, 0, lane, am);
             prefetch_w<RB, KS>(preA, wb, frag(L.trunk_t[7], 16));
         }

@@ -530,7 +530,9 @@ def save_slot_views(desc, buf, n_points, gradient=False):
     padded = (n_points + 63) // 64 * 64
     for slot in range(SAVE_SLOTS):
         _capi.check(lib.inerf_mlp_save_slot(desc, slot, n_points, C.byref(off), C.byref(width)), "inerf_mlp_save_slot")
-        if lib.inerf_mlp_save_slot_is_fragment(slot, 1 if gradient else 0) == 1:
+        if width.value == 0:                        # (a slot this network does not have)
+            views.append(buf[0:0].view(n_points, 0))
+        elif lib.inerf_mlp_save_slot_is_fragment(slot, 1 if gradient else 0) == 1:
             frag = buf[off.value: off.value + padded * width.value]
             views.append(grad_frag_decode(frag, views[SAVE_ENC], n_points, width.value) if gradient else frag_decode(frag, n_points, width=width.value))
         elif gradient and slot == SAVE_ENC:         # the points' normalisers (include/inerf.h), not an [n, 64] matrix

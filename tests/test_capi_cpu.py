@@ -109,7 +109,7 @@ def test_argument_validation(capi):
     # encodings (64 / 32 channels) only as activations, the views hidden layer (128) only as gradients; job shares of a batched
     # launch add up to its grid
     assert [lib.inerf_mlp_save_slot_is_fragment(s, 0) for s in range(16)] == [1, 1] + [1] * 8 + [0, 1] + [0] * 4
-    assert [lib.inerf_mlp_save_slot_is_fragment(s, 1) for s in range(16)] == [0, 0] + [1] * 11 + [0] * 3
+    assert [lib.inerf_mlp_save_slot_is_fragment(s, 1) for s in range(16)] == [0, 0] + [1] * 12 + [0] * 2
     assert lib.inerf_mlp_save_slot_is_fragment(16, 0) == capi.E_INVALID
     assert lib.inerf_mlp_weight_gradient_frag(None, None, None, None, 1000, None, None, 65536, None) == capi.E_INVALID
     cols = (C.c_int * 13)(*([256] * 9 + [64] * 2 + [256, 32]))
