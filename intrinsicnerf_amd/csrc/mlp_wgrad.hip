@@ -10,13 +10,14 @@
 //
 // The operands of that MFMA must hold, per lane, 8 consecutive k (= points) of one channel, while the network
 // kernels work point-major.  Two kernels:
-//   * k_mlp_wgrad_frag - the nine 256 x 256 products of a network (90 % of the operand bytes): both operands arrive as
-//     FRAGMENT slots, i.e. split into f16 hi / lo and in operand order (the producers transpose with the matrix core and
+//   * k_mlp_wgrad_frag - every product whose operands are both FRAGMENT slots (all thirteen of the object-level network, in ONE
+//     launch: nine 256 x 256, two 256 x 64, 128 x 256, 128 x 32): both operands arrive i.e. split into f16 hi / lo and in operand order (the producers transpose with the matrix core and
 //     store whole 1 KB fragments) - the activations at the forward's fixed scale, the gradients NORMALISED per point, with
 //     the points' normalisers beside them (their common scale is only known now).  The kernel is a ring of LDS stages filled
 //     by LDS-DMA (buffer_load ... lds: no row registers, no transposition), a re-scaling of the wave's own G operands to the
 //     batch's max |dz|, and 24 MFMAs per wave and 16-point k-block; bound by HBM.
-//   * k_mlp_wgrad - every other shape (operands 32..128 wide, or 128 rows): row-format X (and G, unless it is a fragment
+//   * k_mlp_wgrad - products with a row-format operand (the SSR semantic output layer's; the public single-product entry
+//     points): row-format X (and G, unless it is a fragment
 //     slot) transposed inside the kernel by the matrix core: an MFMA of a [32 points x 16 channels] fragment (lane = point,
 //     8 consecutive channels: a natural 32-byte read of a point's row) with an identity matrix returns that block in
 //     accumulator layout - lane = channel, registers = points - which, converted back to f16 (exact: the inputs were f16), IS
@@ -319,9 +320,10 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 256 x 256 products (nine of a network's thirteen, 90 % of the weight-gradient bytes): both operands are FRAGMENT slots.
+// Products of two FRAGMENT slots (described for the 256 x 256 shape; the narrower ones - wgrad_frag_body<GB, XB> - move fewer
+// fragments per stage).
 //
-// Per 16-point k-block a slot holds 16 fragments of 1 KB ([32-channel block][hi | lo], layout.h), contiguous: one LDS stage =
+// Per 16-point k-block a 256-channel slot holds 16 fragments of 1 KB ([32-channel block][hi | lo], layout.h), contiguous: one LDS stage =
 // 16 KB of G + 16 KB of X (+ the k-block's 16 normalisers).  A ring of kFragStages stages is filled by LDS-DMA -
 // `buffer_load_dwordx4 ... lds` moves a fragment from HBM to LDS in one instruction, lane l's 16 bytes to byte 16 l of the
 // destination, which is exactly where the lane that contracts reads its operand slot (conflict-free by construction) - so the
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_wgrad(const WgradParams p) {
 // (1 x 8 accumulator blocks: 18 operand reads and 24 MFMAs per k-block) - every G block is rescaled by exactly one wave.
 // Synchronisation per stage: every wave waits for ITS OWN requests of the stage (counted vmcnt: the younger stages stay in
 // flight), then one raw s_barrier - behind it every wave's fragments of the stage have landed, and every wave has finished
-// reading the stage before, whose buffer is the one re-filled next.  (A __syncthreads() would drain vmcnt to 0.)
+// reading the stage before, whose buffer is the one re-filled next.
 // The column sums of G (the bias gradient) come from the operands the waves 0..3 read anyway.
 // ---------------------------------------------------------------------------------------------------------------------
 #ifndef INERF_WGRAD_MAX_BATCH
@@ -353,9 +355,9 @@ constexpr int kFragStageBytes = 2 * kFragKbBytes;               // G | X of one 
 constexpr int kFragScaleBytes = 8 * 256;                        // per stage: every wave's own copy of the k-block's normalisers (64 lanes x 4 bytes)
 static_assert(kFragStages >= 3 && kFragStages <= 5, "ring depth");
 
-// SEVERAL products over the same sample points share one launch (the nine 256 x 256 ones of a network and the two against the
-// 64-wide encoding do): every workgroup works on ONE product, as one of its K-slices - a product is split over its share of the
-// grid (in proportion to the bytes it streams) instead of the whole grid, so the chip writes (and the final sum reads) ~n_jobs
+// SEVERAL products over the same sample points share one launch (all of a network's whose operands are fragment slots): every
+// workgroup works on ONE product, as one of its K-slices - a product is split over its share of the grid (in proportion to
+// what a stage of it costs) instead of the whole grid, so the chip writes (and the final sum reads) ~n_jobs
 // times fewer partial tiles - 7 MB per 256 x 256 product instead of 64 MB at eleven jobs, which was a tenth of the operand bytes
 // themselves - fills its ring once instead of n_jobs times, and one launch boundary replaces n_jobs.  Every workgroup still
 // streams whole stages of two contiguous matrices.  Workgroup b -> (job, slice): round-robin over the jobs that still have
