@@ -661,6 +661,11 @@ def test_one_call_backward_equals_library_products_of_its_own_buffers(variant, c
     raw = kernels.mlp_train(desc, net, rays, z, endpoint)
     (raw * cot).sum().backward()
     got = {k: p.grad.clone() for k, p in net.named_parameters()}
+    # the whole backward is deterministic: fixed K-slices, partial tiles summed in a fixed order, no atomics on the data path
+    net.zero_grad()
+    (kernels.mlp_train(desc, net, rays, z, endpoint) * cot).sum().backward()
+    for k, p in net.named_parameters():
+        assert torch.equal(p.grad, got[k]), f"{k}: a second identical step gave other gradients"
     # the same step taken apart
     d16 = _capi.NetDesc(desc.variant, desc.n_classes, desc.l_xyz, desc.l_dir, desc.xyz_div, _capi.PREC_F16X3)
     named = dict(net.named_parameters())
