@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4, run o: chain epilogue with packed maxima for the batch's max |dz|, L2-warming DMA of h7's fragments (variant nopf: without)
+# round 4, run o: chain stage variants against the previous commit
 export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out
@@ -10,7 +10,7 @@ timeout 900 python -m pytest tests/test_backward_golden.py tests/test_train_mask
 tail -3 $OUT/r04o_tests.txt
 rm -f $OUT/r04_ab_prof.txt
 for rep in 1 2 3; do
-  for tree in new nopf prev; do
+  for tree in new prev; do
     dir=$REPO; [ $tree = prev ] && dir=$REPO/_ab_prev
     unset INERF_LIB_OVERRIDE; [ $tree = nopf ] && export INERF_LIB_OVERRIDE=$REPO/intrinsicnerf_amd/libinerf_nopf.so
     rm -rf $OUT/prof/ab
