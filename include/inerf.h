@@ -30,7 +30,7 @@ extern "C" {
 #define INERF_VERSION_MINOR 2
 /* Bumped whenever a struct layout, an argument list or the packed-weight format of this header changes; bindings
  * compare it with inerf_abi_version() of the library they loaded (a stale .so then fails loudly, not silently). */
-#define INERF_ABI_VERSION 40005
+#define INERF_ABI_VERSION 40006
 
 /* error codes */
 #define INERF_OK              0
@@ -148,7 +148,7 @@ int inerf_encode_mlp_ws(const inerf_net_desc* net, const float* packed_weights, 
  *   12 views hidden 128 | 13 semantic hidden 128 (SSR with classes, else width 0) |
  *   14 (dz only) head pre-activation gradients 8: albedo 3, shading 1, residual 3, sigma 1 | 15 unused (width 0).
  * Two slot formats:
- *   ROWS      a row-major fp32 [n_points, width] matrix.  save: 10, 12, 13; dz: 14.
+ *   ROWS      a row-major fp32 [n_points, width] matrix.  save: 13; dz: 14.
  *   FRAGMENTS the operands of the 256-wide weight-gradient products dW = dZ^T X exactly as the matrix core consumes
  *             them: every value v is stored as f16 hi = f16(v') (towards zero) and f16 lo = f16(v' - hi) in 1 KB fragments
  *             [32 channels x 16 points]; with kb = 16-point block of the tile (0..3), cb = 32-channel block:
@@ -156,8 +156,8 @@ int inerf_encode_mlp_ws(const inerf_net_desc* net, const float* packed_weights, 
  *               channel = 32 cb + (lane & 31),  point = 64 tile + 32 (kb >> 1) + (i & 3) + 8 ((i >> 2) + 2 (kb & 1)) + 4 (lane >> 5)
  *             (lane = channel, 8 k-values = 8 points: one 16-byte operand slot of v_mfma_f32_32x32x16_f16; the point order
  *             inside a block is the accumulator's register order).
- *             save, slots 2..9 and 11: v' = 8 v (the forward kernel's own operand halves); slots 0 and 1 (the encodings, 64 / 32
- *             channels): the same with width / 32 = TWO / ONE channel blocks per k-block instead of eight -
+ *             save, slots 2..11: v' = 8 v (the forward kernel's own operand halves); slots 12 (views hidden, 128 channels), 0 and 1
+ *             (the encodings, 64 / 32 channels): the same with width / 32 = FOUR / TWO / ONE channel blocks per k-block instead of eight -
  *             byte offset = (((tile * 4 + kb) * (width / 32) + cb) * 2 + plane) * 1024 + ...
  *             dz, slots 2..11 and 12, 13 (the views / semantic hidden layers: 128 channels = FOUR blocks per k-block): v' = 8 v / s_p, s_p = the point's NORMALISER (the power of two above its largest head
  *             gradient; the chain works on normalised gradients, so these halves keep 22 bits whatever a point's gradient

@@ -10,7 +10,7 @@ import os
 from . import _build
 from ._build import LIB_PATH
 
-ABI_VERSION = 40005          # INERF_ABI_VERSION of include/inerf.h these ctypes declarations mirror
+ABI_VERSION = 40006          # INERF_ABI_VERSION of include/inerf.h these ctypes declarations mirror
 
 OK, E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_HIP = 0, -1, -2, -3, -4
 VARIANT_OBJECT, VARIANT_SSR = 0, 1

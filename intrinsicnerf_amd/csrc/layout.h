@@ -160,8 +160,8 @@ inline NetLayout make_layout(const inerf_net_desc& net) {
 //     (a power of two): 22 bits whatever the point's scale, straight from the chain's LDS planes - and the normalisers travel
 //     beside them (SAVE_ENC of the gradient buffer: one float per point); the consumer multiplies them back in when it brings
 //     its own operands to the batch's max |dz| (~50 VALU instructions per fragment pair, beside 24 MFMAs per k-block).
-//   activation buffer: AS1H, VH, SEMH rows; H0..H7, FEAT fragments; ENC / DIR fragments of a 64- / 32-channel slot (the same format
-//                      with two / one channel blocks per k-block instead of eight, straight from the encoder's planes);
+//   activation buffer: SEMH rows; H0..H7, FEAT, AS1H fragments, VH fragments of a 128-channel slot; ENC / DIR fragments of a 64- /
+//                      32-channel slot (the same format with four / two / one channel blocks per k-block instead of eight);
 //                      the chain reads h7 - ReLU mask and operand of the alpha_linear weight gradient - from its fragments: the
 //                      matrix core transposes them back; H7R unused;
 //   gradient buffer:   DPRE rows (8 floats per point: albedo 3, shading 1, residual 3, sigma 1); H0..H7, AS1H, FEAT fragments,
@@ -200,9 +200,9 @@ inline int save_width(const inerf_net_desc& net, int slot) {
 
 // format of a slot: 1 = fragments, 0 = rows (gradient: the buffer of pre-activation gradients, else the activation buffer)
 inline int save_is_frag(int slot, bool gradient) {
-    if ((slot >= SAVE_H0 && slot <= SAVE_H7) || slot == SAVE_FEAT) return 1;
+    if ((slot >= SAVE_H0 && slot <= SAVE_H7) || slot == SAVE_FEAT || slot == SAVE_AS1H || slot == SAVE_VH) return 1;   // (VH: 128 channels = 4 blocks)
     if (slot == SAVE_ENC || slot == SAVE_DIR) return gradient ? 0 : 1;      // activation buffer: NARROW fragment slots (64 / 32 channels = 2 / 1 blocks per k-block)
-    return (gradient && (slot == SAVE_AS1H || slot == SAVE_VH || slot == SAVE_SEMH)) ? 1 : 0;   // (VH, SEMH: 128 channels = 4 blocks)
+    return (gradient && slot == SAVE_SEMH) ? 1 : 0;                         // (the semantic hidden layer's activations stay rows: a scalar-loop stage reads them)
 }
 
 inline int64_t save_offset(const inerf_net_desc& net, int slot, int64_t n_points) {     // in floats

@@ -74,21 +74,8 @@ struct DzDst {
     __amdgpu_buffer_rsrc_t rsrc;      // the layer's dZ slot: n_tiles * kFragTileBytes (whole tiles: padding points carry zeros)
     unsigned voff;                    // bytes: tile * kFragTileBytes + (first channel block of this wave) * 2 * kFragBytes + lane * 16
 };
-// B operand of bwd_store's transposing MFMAs (see DzDst): lane (j = lane & 31, kg = lane >> 5) holds Sel[8 kg + m][j], m = 0..7,
-// per k-block - in the k order of the ACCUMULATOR registers (planes_to_frag's operands come from LDS in channel order).  Rebuilt
-// by every epilogue from a laundered lane index: as a loop invariant it would occupy eight registers for the whole kernel,
-// which sits at its 256.
-__device__ __forceinline__ Selector accumulator_selector(int lane) {
-    asm volatile("" : "+v"(lane));
-    Selector sel;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int m = 0; m < 8; ++m)
-            sel.k[kb][m] = (16 * kb + 8 * (m >> 2) + 4 * (lane >> 5) + (m & 3)) == (lane & 31) ? (_Float16)1.0f : (_Float16)0.0f;
-    return sel;
-}
-
+// (the B operand of the transposing MFMAs: mlp_f16_dev.h accumulator_selector - the k order of the ACCUMULATOR registers;
+// planes_to_frag's operands come from LDS in channel order)
 template <int RB, bool BITS = false, typename AlphaAcc = NoAlpha>
 __device__ __forceinline__ void bwd_store(const f32x16 (&am)[RB][2], float inv,
                                           const f32x4 (*acts)[2][4] /* [RB][2][4] saved activations of this lane's values (requested
@@ -189,25 +176,6 @@ __device__ __forceinline__ void split_store4(_Float16* hi_ptr, _Float16* lo_ptr,
     *reinterpret_cast<f16x4*>(lo_ptr) = lo4;
 }
 
-// The VALU stages walk 8 / 16 / 8 rows of the planes per thread.  Written as `ldsb + pt * kRowH + ...` the unrolled loops need one
-// address register per (row, plane) - offsets beyond the 16-bit DS immediate - which the compiler computes once, hoists out
-// of the tile loop (40 registers) and spills; their reloads then queue behind the stage's prefetched global loads.  Instead:
-// four bases per stage, opaque to the optimiser and made inside the tile loop: [rows 0..31 | rows 32..63] x [hi | lo plane],
-// every access = base + an immediate below 64 KB.
-__device__ __forceinline__ int opaque_off(int v) { asm volatile("" : "+v"(v)); return v; }
-struct StageRows {
-    int st[2][2];      // element offsets of this thread's first row of each half, at its destination columns, [half][plane]
-    int f[2];          // ... of the per-point scratch floats (column 0 of the hi plane), [half]
-    __device__ __forceinline__ StageRows(int row0, int col) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            st[h][0] = opaque_off((row0 + 32 * h) * kRowH + col);
-            st[h][1] = opaque_off((row0 + 32 * h) * kRowH + col + kPlaneH);
-            f[h] = opaque_off((row0 + 32 * h) * kRowH);
-        }
-    }
-};
-
 // Pre-activation gradients of one point's output heads (albedo 3, shading 1, residual 3, sigma 1) from d loss / d raw and raw,
 // and the point's normaliser: the power of two above its largest head gradient (1 for a point without gradient).
 __device__ __forceinline__ float head_gradients(const BwdParams& p, int gp, bool sem, float (&dp)[8]) {
@@ -270,38 +238,23 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
 
     WidePreH<RB> preA, preB;
     prefetch_w<RB, KS>(preA, wb, frag(L.views_t, 8));
-    // Rows of the activation / gradient slots are reached through buffer descriptors (wave-uniform, in SGPRs) + ONE 32-bit
-    // per-thread offset per stage + a wave-uniform tile offset: with 64-bit per-thread pointers every stage kept four address
-    // registers alive across the tile loop (spilled in the eight-wave form).  The range check also replaces the `valid` tests:
-    // rows beyond n_points read as zeros and are not written.
-    auto slot_rsrc = [&](const float* base, int slot, int width) {
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base) + p.off[slot], 0, (int)((unsigned)p.n_points * (unsigned)width * 4u), 0x00020000);
-    };
-    // The whole offset goes into the VGPR operand and the SGPR offset stays the constant 0.  (1) A 16-byte buffer store whose
-    // SGPR offset is a REGISTER is followed by no wait state before its data registers may be overwritten - the compiler's
-    // hazard table says none is needed in that form - and on this chip the store then sometimes sends what the NEXT
-    // instruction wrote: the last row of these stages came out as the running |max| it feeds one instruction later, in 4 % of
-    // the launches of the eight-wave form (bit-exact repeat test; 400 launches of each form to pin it).  With the constant
-    // 0 the compiler inserts the s_nop.  (2) The range check then sees the complete offset.
-    auto load4 = [](__amdgpu_buffer_rsrc_t r, int off) {
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
-    };
-    auto store4 = [](__amdgpu_buffer_rsrc_t r, int off, f32x4 v) {
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
-    };
-    const int vh_voff = ((tid >> 5) * kHalf + (tid & 31) * 4) * 4;        // 128-wide stages: this thread's first row / channels, bytes
-    const int as_voff = ((tid >> 6) * kWidth + (tid & 63) * 4) * 4;       // 256-wide stage
+    // (Fragment and row stores carry their WHOLE offset in the VGPR operand, the SGPR offset stays the constant 0: a 16-byte buffer
+    // store whose SGPR offset is a REGISTER gets no wait state before its data registers may be overwritten - the compiler's
+    // hazard table says none is needed in that form - and on this chip the store then sometimes sends what the NEXT instruction
+    // wrote: found in round 2 in 4 % of the launches of the row-wise stages this kernel had then; tests/test_isa_audit_cpu.py.)
     const __amdgpu_buffer_rsrc_t bits_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.save) + p.bits_off, 0, (int)((unsigned)p.n_tiles * (unsigned)kReluBitTileBytes), 0x00020000);
 
     // head weight gradients, accumulated over this workgroup's tiles (see kHead*)
     const bool heads = p.head_partial != nullptr;
     float hb[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};     // threads 0..63: sums of the head gradients
-    f32x4 hres[3], has2[4], halpha[RB][4];                                 // [row][4 channels]; alpha: [rb][g]
+    // residual head / albedo|shading outputs: ONE channel per lane (the VALU stages work on the layers' fragments: lane = channel)
+    float hres[3], has2[4];
+    f32x4 halpha[RB][4];                                                   // alpha: [rb][g], four channels each
 #pragma unroll
-    for (int j = 0; j < 3; ++j) hres[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int j = 0; j < 3; ++j) hres[j] = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) has2[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int j = 0; j < 4; ++j) has2[j] = 0.0f;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -318,15 +271,24 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
     stagger_start(p.stagger);
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         STAMP();
-        // The saved activations the three VALU stages need are requested a stage ahead (with one wave per SIMD a load issued
-        // inside the stage that uses it is 2 000 exposed cycles per loop iteration: the two stages took 60 k of a tile's 235 k).
-        constexpr int VH_STEP = NT / 32, VH_IT = kPts / VH_STEP;        // rows per pass of the 128-wide stages, passes
-        constexpr int AS_STEP = NT / 64, AS_IT = kPts / AS_STEP;        // ... of the 256-wide stage
-        f32x4 act_vh[VH_IT];
+        // The saved activations the two fragment-native VALU stages need are requested a stage ahead (a load issued inside the
+        // stage that uses it is thousands of exposed cycles).  Both layers were kept as FRAGMENTS (lane = channel, 8 points per
+        // 16-byte slot): the views hidden layer (128 channels: wave w takes channel block w & 3, k-blocks 2 (w >> 2) and + 1), the
+        // albedo | shading hidden layer (256: channel block w, all four k-blocks).
+        static_assert(NW == 8, "the fragment-native stages are written for eight waves");
+        int lane_s = lane;
+        asm volatile("" : "+v"(lane_s));
+        const int vh_cb = wave & 3, vh_kb0 = 2 * (wave >> 2);
+        f16x8 act_vh[2][2];                  // [k-block][hi | lo]
         {
-            const __amdgpu_buffer_rsrc_t r = slot_rsrc(p.save, SAVE_VH, kHalf);
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.save) + p.off[SAVE_VH], 0,
+                                                                                (int)((unsigned)p.n_tiles * (unsigned)(kFragTileBytes / 2)), 0x00020000);
+            const unsigned voff = (unsigned)tile * (unsigned)(kFragTileBytes / 2) + (unsigned)lane_s * 16u;
 #pragma unroll
-            for (int i = 0; i < VH_IT; ++i) act_vh[i] = load4(r, vh_voff + (tile * kPts + VH_STEP * i) * kHalf * 4);
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int plane = 0; plane < 2; ++plane)
+                    act_vh[k][plane] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r, (int)(voff + frag_off<4>(vh_kb0 + k, vh_cb, plane)), 0, 0));
         }
         // ---------------- heads: pre-activation gradients of the output heads, per-point scale ----------------
         if (tid < kPts) {
@@ -354,45 +316,57 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
         STAMP();
 
         // ---------------- dZ of the view-dependent layer: relu'(vh) * (W_res^T d_res [+ d endpoint feature]) -> A ----------------
+        // lane = channel 32 (w & 3) + (lane & 31); per k-block the lane's eight points (layout.h frag_point).  The result IS the
+        // layer's dZ fragment (stored as it is: no transposition) and goes into the planes for the views^T GEMM.
         {
-            const int c4 = (tid & 31) * 4;
-            const StageRows rows(tid >> 5, kColA + c4);
-            f32x4 w4[4];
+            const int cch = 32 * vh_cb + (lane_s & 31), lh = lane_s >> 5;
+            const f32x4 w4 = wb.vec4(L.res_w * 4, 16 * cch);                    // (W_res[0][c], W_res[1][c], W_res[2][c], 0)
+            const __amdgpu_buffer_rsrc_t dz_vh = __builtin_amdgcn_make_buffer_rsrc(p.dz + p.off[SAVE_VH], 0,
+                                                                                   (int)((unsigned)p.n_tiles * (unsigned)(kFragTileBytes / 2)), 0x00020000);
+            _Float16* const col = ldsb + kColA + cch;
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) w4[cc] = wb.vec4((L.res_w + 4 * cc) * 4, 16 * c4);
+            for (int k = 0; k < 2; ++k) {
+                const int kb = vh_kb0 + k;
+                f16x8 oh, ol;
 #pragma unroll
-            for (int i = 0; i < VH_IT; ++i) {
-                constexpr int HALF = VH_IT / 2;
-                const int pt = (tid >> 5) + VH_STEP * i;
-                const int gp = tile * kPts + pt;
-                const bool valid = gp < p.n_points;
-                const float* f = reinterpret_cast<const float*>(ldsb + rows.f[i / HALF] + (i % HALF) * VH_STEP * kRowH);
-                const float d0 = f[4], d1 = f[5], d2 = f[6];
-                float v[4];
+                for (int i = 0; i < 8; i += 2) {
+                    float t[2];
 #pragma unroll
-                for (int cc = 0; cc < 4; ++cc) v[cc] = w4[cc][0] * d0 + w4[cc][1] * d1 + w4[cc][2] * d2;
-                const f32x4 act = act_vh[i];
-                if (valid) {
-                    if (kSsr && p.endpoint) {       // raw[..., -128:] is this layer's output itself (semantic_nerf.py:163-164)
-                        const float* ge = p.d_raw + (size_t)gp * ch + ch - INERF_ENDPOINT_DIM + c4;
+                    for (int e = 0; e < 2; ++e) {
+                        const int pt = 32 * (kb >> 1) + frag_point(kb & 1, lh, i + e);
+                        const float* f = ptf(pt);
+                        const f32x4 d = *reinterpret_cast<const f32x4*>(f + 4);          // normalised d_res (3), d_sigma
+                        const float sp = f[8];
+                        const float act = ((float)act_vh[k][0][i + e] + (float)act_vh[k][1][i + e]) * (1.0f / kActScale);
+                        float v = w4[0] * d[0] + w4[1] * d[1] + w4[2] * d[2];
+                        if (kSsr && p.endpoint) {       // raw[..., -128:] is this layer's output itself (semantic_nerf.py:163-164)
+                            const int gp = tile * kPts + pt;
+                            if (gp < p.n_points) v = __builtin_fmaf(p.d_raw[(size_t)gp * ch + ch - INERF_ENDPOINT_DIM + cch], f[9], v);
+                        }
+                        if (heads) {                   // d W_res[j][c] += (true d_res_pre[j] of the point) * vh[c]
+                            hres[0] += act * (d[0] * sp);
+                            hres[1] += act * (d[1] * sp);
+                            hres[2] += act * (d[2] * sp);
+                        }
+                        v = act > 0.0f ? v : 0.0f;         // (a point beyond the end: its head gradients are zero -> v = 0)
+                        gmax = fmaxf(gmax, fabsf(v) * sp);
+                        t[e] = v * kActScale;
+                    }
+                    f16x2 h2, l2;
+                    split_pair(t[0], t[1], h2, l2);
+                    amax2 = __builtin_elementwise_max(amax2, __builtin_bit_cast(f16x2, __builtin_bit_cast(unsigned, h2) & 0x7FFF7FFFu));
 #pragma unroll
-                        for (int cc = 0; cc < 4; ++cc) v[cc] = __builtin_fmaf(ge[cc], f[9], v[cc]);
+                    for (int e = 0; e < 2; ++e) {
+                        const int pt = 32 * (kb >> 1) + frag_point(kb & 1, lh, i + e);
+                        col[pt * kRowH] = h2[e];
+                        col[pt * kRowH + kPlaneH] = l2[e];
+                        oh[i + e] = h2[e]; ol[i + e] = l2[e];
                     }
                 }
-                if (heads) {                   // d W_res[j][c] += (true d_res_pre[j] of the point) * vh[c]
-                    hres[0] += act * (d0 * f[8]);
-                    hres[1] += act * (d1 * f[8]);
-                    hres[2] += act * (d2 * f[8]);
-                }
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) v[cc] = act[cc] > 0.0f ? v[cc] : 0.0f;
-                split_store4(ldsb + rows.st[i / HALF][0] + (i % HALF) * VH_STEP * kRowH, ldsb + rows.st[i / HALF][1] + (i % HALF) * VH_STEP * kRowH,
-                             v, amax2);
-                {   // (a point beyond the end: act = 0 -> v = 0)
-                    const f32x4 o = f32x4{v[0], v[1], v[2], v[3]} * f[8];
-                    gmax = fmaxf(gmax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
-                }
-                if (i & 1) __builtin_amdgcn_sched_barrier(0);      // two points at a time: unfenced, the scheduler interleaves all of them and spills
+                const int voff = (int)((unsigned)tile * (unsigned)(kFragTileBytes / 2) + (unsigned)lane_s * 16u + frag_off<4>(kb, vh_cb, 0));
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, oh), dz_vh, voff, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ol), dz_vh, voff + kFragBytes, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         STAMP();
@@ -401,14 +375,6 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
 
         int lane_t = lane;
         asm volatile("" : "+v"(lane_t));
-        // dZ_vh (128 channels) leaves as the fragments of a four-block slot, straight from the planes the stage above wrote
-        // (normalised halves, like every gradient slot): one channel block per wave 0..3
-        if (wave < 4) {
-            FragDst d;
-            d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dz + p.off[SAVE_VH], 0, (int)((unsigned)p.n_tiles * (unsigned)(kFragTileBytes / 2)), 0x00020000);
-            d.voff = (unsigned)tile * (unsigned)(kFragTileBytes / 2) + (unsigned)wave * (2u * kFragBytes) + (unsigned)lane_t * 16u;
-            planes_to_frag<1, kRowH, kPlaneH, 4>(xr + kColA + 32 * wave, plane_selector(lane_t), d);
-        }
         const int pt0 = tile * kPts + (lane & 31);
         const bool valid0 = pt0 < p.n_points, valid1 = pt0 + 32 < p.n_points;
         const float s0 = ptf(lane & 31)[8], s1 = ptf((lane & 31) + 32)[8];
@@ -419,15 +385,20 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
             return d;
         };
         f32x16 am[RB][2];
-        f32x4 act_as1[AS_IT];
+        f16x8 act_as1[4][2];                 // [k-block][hi | lo] of channel block `wave`
 
         // ---------------- d feature = W_views^T[:256] dZ_vh -> B (feature_linear has no activation: this is its dZ) ----------------
         wide_gemm_h<RB, 8, 0, kRowH, kPlaneH, true, KS>(preA, wb, frag(L.views_t, 8), xr, kColA, 0, lane, am);
         {   // the next stage's activations: in flight during this layer's epilogue (requested before the GEMM they sat in front
             // of its weight stream - returns are in order - and cost it 9 k cycles)
-            const __amdgpu_buffer_rsrc_t r = slot_rsrc(p.save, SAVE_AS1H, kWidth);
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.save) + p.off[SAVE_AS1H], 0,
+                                                                                (int)((unsigned)p.n_tiles * (unsigned)kFragTileBytes), 0x00020000);
+            const unsigned voff = (unsigned)tile * (unsigned)kFragTileBytes + (unsigned)lane_s * 16u;
 #pragma unroll
-            for (int i = 0; i < AS_IT; ++i) act_as1[i] = load4(r, as_voff + (tile * kPts + AS_STEP * i) * kWidth * 4);
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int plane = 0; plane < 2; ++plane)
+                    act_as1[kb][plane] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r, (int)(voff + frag_off(kb, wave, plane)), 0, 0));
         }
         {
             const float inv = wb.scalar(L.views_t.b * 4);
@@ -442,46 +413,57 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
         STAMP();
 
         // ---------------- dZ of the albedo | shading hidden layer: relu'(as1h) * (W_as2^T [d_albedo, d_shading]) -> A ----------------
+        // lane = channel 32 wave + (lane & 31), four k-blocks: like the views stage - the result is the layer's dZ fragment
         {
-            const int c4 = (tid & 63) * 4;
-            const StageRows rows(tid >> 6, kColA + c4);
-            f32x4 w4[4];
+            const int cch = 32 * wave + (lane_s & 31), lh = lane_s >> 5;
+            const f32x4 w4 = wb.vec4(L.as2_w * 4, 16 * cch);                    // albedo_linear2[0..2][c] | shading output [c - 128]
+            const __amdgpu_buffer_rsrc_t dz_as = __builtin_amdgcn_make_buffer_rsrc(p.dz + p.off[SAVE_AS1H], 0,
+                                                                                   (int)((unsigned)p.n_tiles * (unsigned)kFragTileBytes), 0x00020000);
+            _Float16* const col = ldsb + kColA + cch;
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) w4[cc] = wb.vec4((L.as2_w + 4 * cc) * 4, 16 * c4);
+            for (int kb = 0; kb < 4; ++kb) {
+                f16x8 oh, ol;
 #pragma unroll
-            for (int i = 0; i < AS_IT; ++i) {
-                constexpr int HALF = AS_IT / 2;
-                const float* f = reinterpret_cast<const float*>(ldsb + rows.f[i / HALF] + (i % HALF) * AS_STEP * kRowH);
-                const float d0 = f[0], d1 = f[1], d2 = f[2], d3 = f[3];
-                float v[4];
+                for (int i = 0; i < 8; i += 2) {
+                    float t[2];
 #pragma unroll
-                for (int cc = 0; cc < 4; ++cc) v[cc] = w4[cc][0] * d0 + w4[cc][1] * d1 + w4[cc][2] * d2 + w4[cc][3] * d3;
-                const f32x4 act = act_as1[i];
-                if (heads) {
-                    has2[0] += act * (d0 * f[8]);
-                    has2[1] += act * (d1 * f[8]);
-                    has2[2] += act * (d2 * f[8]);
-                    has2[3] += act * (d3 * f[8]);
+                    for (int e = 0; e < 2; ++e) {
+                        const int pt = 32 * (kb >> 1) + frag_point(kb & 1, lh, i + e);
+                        const float* f = ptf(pt);
+                        const f32x4 d = *reinterpret_cast<const f32x4*>(f);              // normalised d_albedo (3), d_shading
+                        const float sp = f[8];
+                        const float act = ((float)act_as1[kb][0][i + e] + (float)act_as1[kb][1][i + e]) * (1.0f / kActScale);
+                        float v = w4[0] * d[0] + w4[1] * d[1] + w4[2] * d[2] + w4[3] * d[3];
+                        if (heads) {
+                            has2[0] += act * (d[0] * sp);
+                            has2[1] += act * (d[1] * sp);
+                            has2[2] += act * (d[2] * sp);
+                            has2[3] += act * (d[3] * sp);
+                        }
+                        v = act > 0.0f ? v : 0.0f;
+                        gmax = fmaxf(gmax, fabsf(v) * sp);
+                        t[e] = v * kActScale;
+                    }
+                    f16x2 h2, l2;
+                    split_pair(t[0], t[1], h2, l2);
+                    amax2 = __builtin_elementwise_max(amax2, __builtin_bit_cast(f16x2, __builtin_bit_cast(unsigned, h2) & 0x7FFF7FFFu));
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int pt = 32 * (kb >> 1) + frag_point(kb & 1, lh, i + e);
+                        col[pt * kRowH] = h2[e];
+                        col[pt * kRowH + kPlaneH] = l2[e];
+                        oh[i + e] = h2[e]; ol[i + e] = l2[e];
+                    }
                 }
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) v[cc] = act[cc] > 0.0f ? v[cc] : 0.0f;
-                split_store4(ldsb + rows.st[i / HALF][0] + (i % HALF) * AS_STEP * kRowH, ldsb + rows.st[i / HALF][1] + (i % HALF) * AS_STEP * kRowH,
-                             v, amax2);
-                gmax = fmaxf(gmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) * f[8]);
-                if (i & 1) __builtin_amdgcn_sched_barrier(0);
+                const int voff = (int)((unsigned)tile * (unsigned)kFragTileBytes + (unsigned)lane_s * 16u + frag_off(kb, wave, 0));
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, oh), dz_as, voff, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ol), dz_as, voff + kFragBytes, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         STAMP();
         __syncthreads();
         STAMP();
-        {   // this layer's dZ leaves as fragments too (G of the albedo_linear1 | shading hidden weight gradient): the stage above
-            // works row-wise (lane = four channels of one point), so the transposition is a pass of the matrix core over the
-            // finished planes - this wave's WCH channels of all 64 points
-            FragDst d;
-            d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dz + p.off[SAVE_AS1H], 0, (int)((unsigned)p.n_tiles * (unsigned)kFragTileBytes), 0x00020000);
-            d.voff = (unsigned)tile * (unsigned)kFragTileBytes + (unsigned)(WCH / 32 * wave) * (2u * kFragBytes) + (unsigned)lane * 16u;
-            planes_to_frag<RB, kRowH, kPlaneH>(xr + kColA + WCH * wave, plane_selector(lane_t), d);
-        }
 
         // ---------------- d h7 = W_feat^T d feature + W_as1^T dZ_as1 (+ W_sem1^T dZ_semh) + w_alpha d sigma ----------------
         // h7 of this lane's values - ReLU mask AND operand of the alpha_linear weight gradient - comes from the forward's FRAGMENTS
@@ -508,6 +490,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
         wide_gemm_h<RB, 16, 0, kRowH, kPlaneH, false, KS>(preB, wb, frag(L.as1_t, 16), xr, kColA, 0, lane, am);
         if (sem) {
             __syncthreads();                 // A and B are free
+            constexpr int VH_STEP = NT / 32, VH_IT = kPts / VH_STEP;        // rows per pass of this row-wise stage, passes
             const int c4 = (tid & 31) * 4;
 #pragma unroll 1
             for (int i = 0; i < VH_IT; ++i) {
@@ -615,17 +598,18 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
     if (heads) {                          // reduce over the threads / lanes that shared a channel group, through LDS
         __syncthreads();
         constexpr int AST = 16 * RB + 1;                        // padded stride of a lane's alpha accumulators
-        float* red = reinterpret_cast<float*>(ldsb);            // [NT threads][28]: hres 12 | has2 16
-        float* mine = red + tid * 28;
+        // residual head: lane = channel 32 (w & 3) + (lane & 31), partial over (lane >> 5, w >> 2); albedo|shading outputs: lane =
+        // channel 32 w + (lane & 31), partial over lane >> 5.  The lane halves meet by a shuffle, the two wave groups through LDS.
+        float* red = reinterpret_cast<float*>(ldsb);            // [2][3][128]: hres of the wave groups; behind it the alpha / bias areas
+        float hres2[3], has22[4];
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+        for (int j = 0; j < 3; ++j) hres2[j] = hres[j] + __shfl_xor(hres[j], 32);
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) mine[4 * j + cc] = hres[j][cc];
+        for (int j = 0; j < 4; ++j) has22[j] = has2[j] + __shfl_xor(has2[j], 32);
+        if (lane < 32)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) mine[12 + 4 * j + cc] = has2[j][cc];
-        float* alpha_red = red + NT * 28;                       // [NW waves][64 lanes][AST]: halpha
+            for (int j = 0; j < 3; ++j) red[((wave >> 2) * 3 + j) * kHalf + 32 * (wave & 3) + lane] = hres2[j];
+        float* alpha_red = red + 2 * 3 * kHalf;                 // [NW waves][64 lanes][AST]: halpha
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -638,20 +622,10 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
             for (int k = 0; k < 8; ++k) bias_red[tid * 8 + k] = hb[k];
         __syncthreads();
         float* out = p.head_partial + (size_t)blockIdx.x * kHeadFloats;
-        // residual: channel c = 4 * (tid & 31) + cc was accumulated by the NT / 32 threads (tid & 31) + 32 * k
-        for (int e = tid; e < 3 * kHalf; e += NT) {
-            const int j = e / kHalf, c = e % kHalf;
-            float v = 0.0f;
-            for (int k = 0; k < NT / 32; ++k) v += red[((c >> 2) + 32 * k) * 28 + 4 * j + (c & 3)];
-            out[kHeadRes + e] = v;
-        }
-        // albedo|shading outputs: channel c = 4 * (tid & 63) + cc, NT / 64 threads (tid & 63) + 64 * k
-        for (int e = tid; e < 4 * kWidth; e += NT) {
-            const int j = e / kWidth, c = e % kWidth;
-            float v = 0.0f;
-            for (int k = 0; k < NT / 64; ++k) v += red[((c >> 2) + 64 * k) * 28 + 12 + 4 * j + (c & 3)];
-            out[kHeadAs2 + e] = v;
-        }
+        if (tid < 3 * kHalf) out[kHeadRes + tid] = red[tid] + red[3 * kHalf + tid];                  // [j][c]
+        if (lane < 32)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[kHeadAs2 + j * kWidth + 32 * wave + lane] = has22[j];
         // alpha: channel c of wave w = c / WCH: register slot (rb, g, i) with c % WCH = 32 rb + 8 g + 4 h + i; sum over the 32 lanes of half h
         if (tid < kWidth) {
             const int c = tid, w = c / WCH, cl = c % WCH, rb = cl >> 5, g = (cl >> 3) & 3, hh = (cl >> 2) & 1, i = cl & 3;

@@ -154,8 +154,8 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
             constexpr int KB0 = decltype(kb0c)::value, KB1 = decltype(kb1c)::value;
             constexpr int slot = decltype(slot_c)::value;
             constexpr bool kTrunk = slot >= SAVE_H0 && slot <= SAVE_H7;
-            constexpr bool kFrag = kTrunk || slot == SAVE_FEAT;
-            constexpr bool kRows = kSave && slot == SAVE_AS1H;
+            constexpr bool kFrag = kTrunk || slot == SAVE_FEAT || slot == SAVE_AS1H;
+            constexpr bool kRows = false;
             constexpr bool kBits = kSave && kTrunk && slot < SAVE_H7;
             f32x16 am[2][2];
             f32x4 bias[2][4];
@@ -177,9 +177,11 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
                 planes_to_frag<2, kRowH, kPlaneH>(xr + dcol + 64 * wave, fsel, d);
             }
         };
-        auto step128 = [&](const GemmSlot& s, auto kb0c, auto kb1c, int c0, int c1, int dcol, bool relu, float* gout, int slot,
+        auto step128 = [&](const GemmSlot& s, auto kb0c, auto kb1c, int c0, int c1, int dcol, bool relu, float* gout, auto slot_c,
                            auto&& prefetch_next) {
             constexpr int KB0 = decltype(kb0c)::value, KB1 = decltype(kb1c)::value;
+            constexpr int slot = decltype(slot_c)::value;
+            constexpr bool kFrag128 = kSave && slot == SAVE_VH;           // views hidden layer: a four-block fragment slot; semantic hidden: rows
             f32x16 am[1][2];
             f32x4 bias[1][4];
 #pragma unroll
@@ -188,9 +190,15 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
             wide_gemm_h<1, KB0, KB1>(pre1, wb, frag128(s, KB0 + KB1), xr, c0, c1, lane, am);
             prefetch_next();
             const SaveDst sv = save_dst(slot, kHalf, 32 * wave);
-            wide_store_h<1, kRowH, kPlaneH, kSave>(am, inv, bias, xd + dcol + 32 * wave, relu, amax2, gout, p.channels, pt0 < p.n_points,
-                                                  pt0 + 32 < p.n_points, &sv);
+            wide_store_h<1, kRowH, kPlaneH, kSave && !kFrag128>(am, inv, bias, xd + dcol + 32 * wave, relu, amax2, gout, p.channels, pt0 < p.n_points,
+                                                               pt0 + 32 < p.n_points, &sv);
             __syncthreads();
+            if constexpr (kFrag128) {
+                FragDst d;
+                d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save + p.save_off[slot], 0, (int)((unsigned)p.n_tiles * (unsigned)(kFragTileBytes / 2)), 0x00020000);
+                d.voff = (unsigned)tile * (unsigned)(kFragTileBytes / 2) + (unsigned)wave * (2u * kFragBytes) + (unsigned)lane * 16u;
+                planes_to_frag<1, kRowH, kPlaneH, 4>(xr + dcol + 32 * wave, fsel, d);
+            }
         };
         auto pf256 = [&](const GemmSlot& s, int kbt) {
             return [&, kbt]() { wide_prefetch_h<2>(pre2, wb, frag256(s, kbt), bias256(s), scale256(s), lane); };
@@ -223,7 +231,7 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
         const f32x4 sig4 = skinny_gemm_h<8>(wb, L.alpha.w * 4, L.alpha.b * 4, (L.alpha.b + 16) * 4, xs + kColB, lane);
 
         if (sem) {
-            step128(L.sem1, K16, K0, kColB, 0, kColA, true, nullptr, SAVE_SEMH, pf256(L.as1, 16));
+            step128(L.sem1, K16, K0, kColB, 0, kColA, true, nullptr, integral_constant<int, SAVE_SEMH>{}, pf256(L.as1, 16));
             for (int rb = 0; rb < L.sem_rbs; ++rb) {
                 const f32x4 lg = skinny_gemm_h<4>(wb, (L.sem2.w + rb * 4 * 2 * 256) * 4, (L.sem2.b + 16 * rb) * 4,
                                                    (L.sem2.b + 16 * L.sem_rbs) * 4, xs + kColA, lane);
@@ -244,7 +252,7 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
         float* ep = nullptr;
         if (kSsr && p.endpoint)
             ep = p.raw + (size_t)pt0 * p.channels + INERF_BASE_CHANNELS + p.n_classes + 32 * wave + 4 * (lane >> 5);
-        step128(L.views, K16, K2, kColA, kColDir, kColB, true, ep, SAVE_VH, pf256(L.trunk[0], 4));
+        step128(L.views, K16, K2, kColA, kColDir, kColB, true, ep, integral_constant<int, SAVE_VH>{}, pf256(L.trunk[0], 4));
         const f32x4 res4 = skinny_gemm_h<4>(wb, L.res.w * 4, L.res.b * 4, (L.res.b + 16) * 4, xs + kColB, lane);
 
         if (lane < 16 && my_valid) {
@@ -411,20 +419,12 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
         f32x4 bias2[2][4];
         float inv2;
         const int pt0 = tile * kPts + (lane_t & 31);
-        auto save_dst = [&](int slot, int width, int chan0) {
-            SaveDst d;
-            d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save + (kSave ? p.save_off[slot] : 0), 0,
-                                                       kSave ? (int)((unsigned)p.n_points * (unsigned)width * 4u) : 0, 0x00020000);
-            d.voff = (int)(((unsigned)pt0 * (unsigned)width + (unsigned)(chan0 + 4 * (lane_t >> 5))) * 4u);
-            d.stride = width;
-            return d;
-        };
         // ReLU masks of h0..h6 for the input-gradient chain (layout.h relu_bits_offset)
         const __amdgpu_buffer_rsrc_t bits_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             p.save + (kSave ? p.bits_off : 0), 0, kSave ? (int)((unsigned)p.n_tiles * (unsigned)kReluBitTileBytes) : 0, 0x00020000);
-        // training forward: where a 256-wide layer goes besides the planes (layout.h SaveSlot) - `rows_slot`: fp32 rows from the
-        // epilogue's registers (16-byte pieces: 2.3 x the cost per byte of the fragments' whole-line stores - no 256-wide layer
-        // leaves that way any more);
+        // training forward: where a 256-wide layer goes besides the planes (layout.h SaveSlot) - fp32 rows from the epilogue's
+        // registers cost 2.3 x as much per byte as the fragments' whole-line stores (16-byte pieces): no layer leaves that way any
+        // more except the SSR semantic hidden layer;
         // `frag_slot`: operand fragments of the weight-gradient products, transposed out of the finished planes by the matrix
         // core (planes_to_frag: whole 1 KB stores); the ReLU masks of h0..h6 as bits.
         auto frag_dst = [&](int slot) {
@@ -496,8 +496,12 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
             prefetch_w<2>(pre2, wb, frag256(L.feat, 16));
             if constexpr (kSplit) prefetch_w<2, 2048, 16 * 2048>(pre2s, wb, (L.sem1.w + 2 * (wave & 1) * 16 * 2 * 256) * 4);
             f16x8 hi[4][2], lo[4][2];
-            const SaveDst sv = save_dst(SAVE_AS1H, kWidth, 64 * wave);
-            to_operands<2, kSave>(am2, inv2, bias2, amax2, hi, lo, &sv);
+            to_operands<2>(am2, inv2, bias2, amax2, hi, lo);
+            if constexpr (kSave) {                // the hidden layer as operand fragments, transposed out of the registers (it never touches LDS)
+                int lane_o = lane_t;
+                asm volatile("" : "+v"(lane_o));
+                operands_to_frag<2>(hi, lo, accumulator_selector(lane_o), frag_dst(SAVE_AS1H));
+            }
             regop_gemm<4>(wb, (L.as2r.w + wave * 4 * 2 * 256) * 4, hi, lo, part_as);
         }
         const __amdgpu_buffer_rsrc_t sem_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -546,8 +550,15 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
             load_bias<1>(bias1, inv1, wb, (L.views.b + 32 * wave) * 4, (L.views.b + kHalf) * 4, lane);
             prefetch_w<2>(pre2, wb, frag256(L.trunk[0], 4));
             f16x8 hi[2][2], lo[2][2];
-            const SaveDst sv = save_dst(SAVE_VH, kHalf, 32 * wave);
-            to_operands<1, kSave>(am1, inv1, bias1, amax2, hi, lo, &sv);
+            to_operands<1>(am1, inv1, bias1, amax2, hi, lo);
+            if constexpr (kSave) {                // 128 channels: a four-block fragment slot, this wave's block
+                int lane_o = lane_t;
+                asm volatile("" : "+v"(lane_o));
+                FragDst d;
+                d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save + p.save_off[SAVE_VH], 0, (int)((unsigned)p.n_tiles * (unsigned)(kFragTileBytes / 2)), 0x00020000);
+                d.voff = (unsigned)tile * (unsigned)(kFragTileBytes / 2) + (unsigned)wave * (2u * kFragBytes) + (unsigned)lane_o * 16u;
+                operands_to_frag<1, 4>(hi, lo, accumulator_selector(lane_o), d);
+            }
             regop_gemm<2>(wb, (L.resr.w + wave * 2 * 2 * 256) * 4, hi, lo, part_res);
         }
         // kSplit: the partial logits meet in dead columns too - per point 2 x 32 floats (one per channel half): half 0 at bytes

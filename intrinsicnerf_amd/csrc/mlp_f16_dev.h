@@ -312,6 +312,49 @@ __device__ __forceinline__ void planes_to_frag(const _Float16* xa /* plane_hi + 
     }
 }
 
+// The same from REGISTER operands in the accumulator's k order (mlp_f16_heads.h to_operands: the hidden layers of the output
+// heads never touch LDS): hi / lo [2 cb + q2][pb] hold, per lane (point lane & 31 of point block pb, half h = lane >> 5),
+// channels 32 cb + 16 q2 + 8 (i >> 2) + 4 h + (i & 3) - the selector below picks that order apart.
+__device__ __forceinline__ Selector accumulator_selector(int lane) {
+    asm volatile("" : "+v"(lane));             // (rebuilt where it is used: as a loop invariant it would occupy eight registers for the whole kernel)
+    Selector sel;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+            sel.k[kb][m] = (16 * kb + 8 * (m >> 2) + 4 * (lane >> 5) + (m & 3)) == (lane & 31) ? (_Float16)1.0f : (_Float16)0.0f;
+    return sel;
+}
+template <int NB, int CBS = 8>
+__device__ __forceinline__ void operands_to_frag(const f16x8 (&hi)[2 * NB][2], const f16x8 (&lo)[2 * NB][2], const Selector& sel, const FragDst& dst) {
+#ifdef INERF_ABL_NO_FRAG
+    return;
+#endif
+    const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {           // one point half at a time: 32 accumulator registers beside the live operands
+            f32x16 th = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi[2 * cb][pb], sel.k[0], zero, 0, 0, 0);
+            f32x16 tl = __builtin_amdgcn_mfma_f32_32x32x16_f16(lo[2 * cb][pb], sel.k[0], zero, 0, 0, 0);
+            th = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi[2 * cb + 1][pb], sel.k[1], th, 0, 0, 0);
+            tl = __builtin_amdgcn_mfma_f32_32x32x16_f16(lo[2 * cb + 1][pb], sel.k[1], tl, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                u32x4 oh, ol;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    oh[i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(th[8 * q + 2 * i], th[8 * q + 2 * i + 1]));
+                    ol[i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(tl[8 * q + 2 * i], tl[8 * q + 2 * i + 1]));
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(oh, dst.rsrc, (int)(dst.voff + frag_off<CBS>(2 * pb + q, cb, 0)), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(ol, dst.rsrc, (int)(dst.voff + frag_off<CBS>(2 * pb + q, cb, 1)), 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // word = (word << 1) | (v > 0) in two instructions.  v > 0 <=> its bit pattern, read as a signed integer, is > 0 (-0.0 is
 // INT_MIN); the median of (pattern, 0, 1) is that bit.  (From C the compiler builds compare + select + or.)
 __device__ __forceinline__ unsigned push_positive_bit(unsigned word, float v) {

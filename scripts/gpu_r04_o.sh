@@ -6,7 +6,7 @@ OUT=$REPO/gpurun_out
 mkdir -p $OUT/prof
 cd $REPO
 python -c 'import __graft_entry__ as g; g.build()' || exit 1
-timeout 900 python -m pytest tests/test_backward_golden.py tests/test_train_masks_gpu.py tests/test_trained_network_gpu.py -m gpu -x -q > $OUT/r04o_tests.txt 2>&1
+timeout 900 python -m pytest tests/test_backward_golden.py tests/test_train_masks_gpu.py tests/test_trained_network_gpu.py tests/test_dropin_gpu.py tests/test_graphs_gpu.py -m gpu -x -q > $OUT/r04o_tests.txt 2>&1
 tail -3 $OUT/r04o_tests.txt
 rm -f $OUT/r04_ab_prof.txt
 for rep in 1 2 3; do

@@ -105,10 +105,10 @@ def test_argument_validation(capi):
     assert lib.inerf_mlp_save_slot(good, 15, 100, C.byref(off), C.byref(width)) == capi.OK and width.value == 0
     assert off.value == 128 * per_point                                          # slots are sized for whole tiles
     assert lib.inerf_mlp_save_slot(good, 16, 100, C.byref(off), C.byref(width)) == capi.E_INVALID
-    # formats: h0..h7 and the feature layer are fragment slots in both buffers, the albedo|shading hidden layer only as gradients, the
-    # encodings (64 / 32 channels) only as activations, the views hidden layer (128) only as gradients; job shares of a batched
+    # formats: h0..h7, the feature layer, the albedo|shading and the views hidden layers are fragment slots in both buffers, the
+    # encodings (64 / 32 channels) only as activations, the semantic hidden layer (128) only as gradients; job shares of a batched
     # launch add up to its grid
-    assert [lib.inerf_mlp_save_slot_is_fragment(s, 0) for s in range(16)] == [1, 1] + [1] * 8 + [0, 1] + [0] * 4
+    assert [lib.inerf_mlp_save_slot_is_fragment(s, 0) for s in range(16)] == [1, 1] + [1] * 8 + [1, 1, 1] + [0] * 3
     assert [lib.inerf_mlp_save_slot_is_fragment(s, 1) for s in range(16)] == [0, 0] + [1] * 12 + [0] * 2
     assert lib.inerf_mlp_save_slot_is_fragment(16, 0) == capi.E_INVALID
     assert lib.inerf_mlp_weight_gradient_frag(None, None, None, None, 1000, None, None, 65536, None) == capi.E_INVALID
