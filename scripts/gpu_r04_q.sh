@@ -23,3 +23,5 @@ python bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/${tag}q_bench_nocp
 grep -v amdgpu.ids $OUT/${tag}_train_step.txt; grep -v amdgpu.ids $OUT/${tag}_train_kernels.txt
 python -c "
 import json; d = json.load(open('$OUT/${tag}q_bench_nocpu.json')); print(d['value'], d['roofline']['frac'], d['train_step']['ms_per_step'], d['train_step']['graphed_ms_per_step'])"
+python -c 'import __graft_entry__ as g; g.smoke()' > $OUT/r04z_smoke.txt 2>&1; tail -1 $OUT/r04z_smoke.txt
+timeout 1200 python -m pytest tests -m gpu -q > $OUT/r04z_pytest_gpu.log 2>&1; tail -2 $OUT/r04z_pytest_gpu.log
