@@ -52,20 +52,32 @@ def built_digest(lib_path=None):
     return data[i + len(DIGEST_MARK): i + len(DIGEST_MARK) + 64].decode("ascii", "replace") if i >= 0 else ""
 
 
+def _source_paths():
+    return [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+
+
 def sources_present():
-    """False in a deployment that ships the built library without ``csrc/`` (or without some header): nothing to compare with."""
-    return all(os.path.exists(p) for p in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS)
+    """False in a deployment that ships the built library without ``csrc/`` and the headers: nothing to compare with."""
+    return all(os.path.exists(p) for p in _source_paths())
 
 
 def _stale(lib_path=None):
     """True when ``lib_path`` (default: the in-tree library) is missing or was built from other sources / flags than the
-    tree holds now.  Content-based: kernel edits, flag edits in this file and reordered mtimes are all caught.  A tree without
-    its sources cannot judge: an existing library is then taken as it is (the binding still checks its ABI number)."""
+    tree holds now.  Content-based: kernel edits, flag edits in this file and reordered mtimes are all caught.  A binary
+    deployment (NO source or header of the library in the tree) cannot judge: an existing library is then taken as it is (the
+    binding still checks its ABI number).  A tree that holds SOME of them is broken, not a deployment: the digest cannot be
+    computed and a library of unknown origin must not be loaded in its name."""
     lib_path = lib_path or LIB_PATH
     if not os.path.exists(lib_path):
         return True
-    if not sources_present():
+    present = [os.path.exists(p) for p in _source_paths()]
+    if not any(present):
         return False
+    if not all(present):
+        missing = [os.path.relpath(p, os.path.dirname(CSRC)) for p, ok in zip(_source_paths(), present) if not ok]
+        raise RuntimeError(f"intrinsicnerf_amd: the source tree is incomplete ({', '.join(missing)} missing): cannot tell whether "
+                           f"{os.path.basename(lib_path)} was built from it.  Restore the files, or remove csrc/ and the headers entirely "
+                           "for a binary deployment")
     return built_digest(lib_path) != source_digest()
 
 

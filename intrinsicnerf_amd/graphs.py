@@ -96,6 +96,34 @@ class GraphedTrainStep:
         self._grads = [p.grad for p in self.params]
         self.fallbacks = 0
 
+    def close(self):
+        """Hand the optimizer back to eager use: every group's learning rate becomes a Python float again (its current value) and
+        ``capturable`` is switched off.  Call it before ``optimizer.state_dict()`` goes into a checkpoint that other code will read
+        (run_nerf.py:1035-1043 saves it; a ``param_group['lr']`` that is a tensor on THIS device would travel with the file), or
+        use ``optimizer_state_dict()``, which leaves the live optimizer untouched.  The graphs must not be replayed afterwards."""
+        for group, t in zip(self.opt.param_groups, self._lr):
+            group["lr"] = float(t.item())
+            group["capturable"] = False
+        for st in self.opt.state.values():                # an eager Adam keeps its step counts on the host
+            if isinstance(st.get("step"), torch.Tensor):
+                st["step"] = st["step"].detach().cpu()
+        self.graph_a = self.graph_b = None
+
+    def optimizer_state_dict(self):
+        """``optimizer.state_dict()`` as an eager optimizer would have written it: float learning rates, ``capturable`` off, the
+        per-parameter state (moments, step counts) as it is.  Loads into a fresh ``torch.optim.Adam`` on any device."""
+        sd = self.opt.state_dict()
+        groups = []
+        for g in sd["param_groups"]:
+            g = dict(g)
+            if isinstance(g.get("lr"), torch.Tensor):
+                g["lr"] = float(g["lr"].item())
+            g["capturable"] = False
+            groups.append(g)
+        state = {k: {n: (v.detach().cpu() if n == "step" and isinstance(v, torch.Tensor) else v) for n, v in st.items()}
+                 for k, st in sd["state"].items()}
+        return {"state": state, "param_groups": groups}
+
     def set_lr(self, lr, group=None):
         """Learning rate of ``group`` (index; default: every group) for the following steps.  Equivalent to the reference's
         ``param_group['lr'] = lr``, which ``__call__`` also honours."""
@@ -127,6 +155,8 @@ class GraphedTrainStep:
             if dst.shape != src.shape:
                 raise ValueError(f"input of shape {tuple(src.shape)}, the graph was captured for {tuple(dst.shape)}")
             dst.copy_(src, non_blocking=True)
+        if self.graph_a is None:
+            raise RuntimeError("this GraphedTrainStep was closed")
         self._sync_lr()
         dev = self.static[0].device
         rng = torch.cuda.get_rng_state(dev) if self.status is not None else None

@@ -63,6 +63,11 @@ def rebind_object_level(namespace, with_render_path=False):
     names = OBJECT_SYMBOLS + (OBJECT_OPTIONAL if with_render_path else ())
     for name in names:
         namespace[name] = getattr(object_level, name)
+    if with_render_path and "Cluster_Manager" in namespace:
+        # run_nerf.py:818,1071 call render_path(update_cluster=True): the mean-shift fitting stays the reference's own class
+        # (run_nerf.py:24, :218), handed to the mirror as its factory
+        import functools
+        namespace["render_path"] = functools.partial(object_level.render_path, cluster_manager_factory=namespace["Cluster_Manager"])
     return names
 
 
@@ -76,6 +81,9 @@ def rebind_ssr(with_render_path=False):
         setattr(trainer.SSRTrainer, name, getattr(ssr.SSRRenderMixin, name))
     for extra in ("return_raw", "check_numerics", "_staged"):          # what the mixin's methods read besides the trainer's attributes
         setattr(trainer.SSRTrainer, extra, getattr(ssr.SSRRenderMixin, extra))
+    if with_render_path and hasattr(trainer, "Cluster_Manager"):
+        # trainer.py:1065 renders with update_cluster = not self.no_cluster: the fitting is the reference's class (trainer.py:16, :1416-1418)
+        trainer.SSRTrainer.cluster_manager_factory = staticmethod(trainer.Cluster_Manager)
     bound["SSR.training.trainer.SSRTrainer"] = list(methods)
     for mod_name in SSR_MODULES:
         mod = sys.modules.get(mod_name)

@@ -493,7 +493,13 @@ class SSRRenderMixin:
             # the resampled depths carry no gradient (z_samples.detach(), trainer.py:762)
             z_samples, z_fine, z_std = kernels.sample_fine(z_vals, c["weights"].detach(), u, self.N_importance)
             raw = query(z_fine, self.ssr_net_fine, ep)
-            f = kernels.composite(raw, z_fine, rays_d, noise_f, self.white_bkgd, n_classes=c_sem, feat_dim=128 if ep else 0)
+            # the endpoint feature is the LAST 128 channels of raw (model_utils.py:99-103, a literal 128 there).  A foreign netwidth
+            # gives raw another width (W // 2 feature channels): the kernel's feature lanes only take the 256-wide network's layout,
+            # the reference's literal slice is evaluated as written for any other
+            native_feat = ep and raw.shape[-1] == 11 + c_sem + 128
+            f = kernels.composite(raw, z_fine, rays_d, noise_f, self.white_bkgd, n_classes=c_sem, feat_dim=128 if native_feat else 0)
+            if ep and not native_feat:
+                f["feat"] = torch.sum(f["weights"][..., None] * raw[..., -128:], -2)
             o.update({k + "_fine": v for k, v in f.items()})
             o["raw_fine"], o["z_std"] = raw, z_std
         return o

@@ -192,7 +192,9 @@ def psnr_delta_db(hip, ref32, ref64, target_psnr_db=30.0, seed=0, detail=False):
     ``detail``: also return the statistic's two parts.  With e = hip - ref32 and r = ref32 - T,
     MSE(hip) - MSE(ref32) = mean(e^2) + 2 mean(e r): the first term is SYSTEMATIC (it survives any number of pixels), the
     second is a zero-mean sum over the perturbation whose standard deviation, 2 sigma_T sqrt(mean(e^2) / n), shrinks with the
-    number of values n - on a few thousand sampled rays of an ill-conditioned network it is the larger one."""
+    number of values n - on a few thousand sampled rays of an ill-conditioned network it is the larger one.
+    ``expected_db``: the delta's expectation over the perturbation (its cross terms vanish): mean (hip - ref64)^2 - mean (ref32 -
+    ref64)^2, in dB - negative when hip is further from the fp64 evaluation than the reference arithmetic is."""
     hip, ref32, ref64 = (np.asarray(a, np.float64) for a in (hip, ref32, ref64))
     sigma_t = 10.0 ** (-target_psnr_db / 20.0)
     rng = np.random.RandomState(seed)
@@ -203,5 +205,8 @@ def psnr_delta_db(hip, ref32, ref64, target_psnr_db=30.0, seed=0, detail=False):
     mse = float(np.mean((ref32 - target) ** 2))
     e2 = float(np.mean((hip - ref32) ** 2))
     k = 10.0 / np.log(10.0)
-    return {"delta_db": delta, "systematic_db": -k * e2 / mse, "sampling_sigma_db": k * 2.0 * sigma_t * np.sqrt(e2 / hip.size) / mse,
+    # expectation of MSE(hip) - MSE(ref32) over the perturbation: the cross terms with it vanish, the distances to fp64 stay
+    expected = float(np.mean((hip - ref64) ** 2) - np.mean((ref32 - ref64) ** 2))
+    return {"delta_db": delta, "systematic_db": -k * e2 / mse, "expected_db": -k * expected / mse,
+            "sampling_sigma_db": k * 2.0 * sigma_t * np.sqrt(e2 / hip.size) / mse,
             "rms_hip_minus_reference": np.sqrt(e2), "values": int(hip.size)}

@@ -478,6 +478,18 @@ def test_abi_version_and_stale_library_guard(capi, monkeypatch, tmp_path):
     junk.write_bytes(b"\x7fELF no digest here")
     assert _build.built_digest(str(junk)) == "" and _build._stale(str(junk)) and _build._stale(str(tmp_path / "missing.so"))
 
+    # a tree that holds only SOME of the library's sources is broken, not a binary deployment: no digest can be computed for it and
+    # whatever library lies there must not be accepted in its name; with none of them an existing library is taken as is
+    real_exists = os.path.exists
+    gone = os.path.join(_build.CSRC, "mlp_bwd.hip")
+    monkeypatch.setattr(_build.os.path, "exists", lambda q: False if q == gone else real_exists(q))
+    with pytest.raises(RuntimeError, match="incomplete.*mlp_bwd.hip"):
+        _build._stale()
+    every = set(_build._source_paths())
+    monkeypatch.setattr(_build.os.path, "exists", lambda q: False if q in every else real_exists(q))
+    assert not _build.sources_present() and not _build._stale()
+    monkeypatch.undo()
+
     monkeypatch.setattr(capi, "_lib", None)
     monkeypatch.setattr(capi, "ABI_VERSION", capi.ABI_VERSION + 1)
     with pytest.raises(RuntimeError, match="ABI"):

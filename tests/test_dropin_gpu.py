@@ -309,6 +309,20 @@ def test_ssr_trainer_with_another_netwidth_runs_staged():
         else:
             err = np.abs(got - want) / (ATOL + rt * np.abs(want))
             assert np.median(err) <= 1.0 and err.max() <= 30.0, (k, float(np.median(err)), float(err.max()))
+    # endpoint feature of a foreign width (64 feature channels here): the reference takes raw[..., -128:] as written
+    # (model_utils.py:99-103), whatever those channels are - so does the staged path (it used to hand the kernel a
+    # 128-wide feature lane layout this raw does not have)
+    t.endpoint_feat = True
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with torch.no_grad():
+            oe = t.render_rays(sub[:256].to(dev))
+    # 11 + 5 + 64 = 80 channels < 128: the literal slice is the whole of raw, so the "feature" map's leading columns are the maps
+    # the same weights composite from those channels (white_bkgd off: nothing is added)
+    assert oe["raw_fine"].shape[-1] == 11 + C + 64 and oe["feat_map_fine"].shape == (256, 11 + C + 64)
+    assert torch.allclose(oe["feat_map_fine"][:, 0:3], oe["rgb_fine"], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(oe["feat_map_fine"][:, 11:11 + C], oe["sem_logits_fine"], rtol=1e-5, atol=1e-6)
+    t.endpoint_feat = False
     # a training step through the same methods
     t.training = True
     t.ssr_net_coarse.train(); t.ssr_net_fine.train()

@@ -79,6 +79,55 @@ def test_graphed_step_equals_the_eager_step(perturb, monkeypatch):
         np.testing.assert_allclose(results["eager"][0], results["graph"][0], rtol=0.2)
 
 
+def test_checkpoint_of_a_graphed_optimizer_loads_into_an_eager_one(monkeypatch, tmp_path):
+    """run_nerf.py:1035-1043 / trainer.py:1042-1047 save optimizer.state_dict() next to the networks.  The graphed step keeps every
+    group's learning rate in a device tensor; ``optimizer_state_dict()`` writes what an eager optimizer would have written (float
+    rates, host step counts), ``close()`` hands the live optimizer back the same way, and a fresh eager Adam that loads the file
+    continues with the same update an eager Adam that had done those steps itself would make."""
+    from intrinsicnerf_amd import graphs
+    monkeypatch.setenv("INERF_PRECISION", "f16x3")
+    dev = torch.device("cuda:0")
+    ol, net_c, net_f, query, rays = _setup(dev)
+    params = list(net_c.parameters()) + list(net_f.parameters())
+    opt = torch.optim.Adam(params, lr=2e-4, capturable=True)
+    r, t = rays[:12], torch.rand(12, 3, generator=torch.Generator().manual_seed(0)).to(dev)
+
+    def loss_fn(r, t):
+        ret = ol.render_rays(r, net_c, query, 64, retraw=True, perturb=0.0, N_importance=64, network_fine=net_f, white_bkgd=True)
+        return ((ret["rgb_map"] - t) ** 2).mean() + ((ret["rgb0"] - t) ** 2).mean()
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        step = graphs.GraphedTrainStep(loss_fn, (r, t), opt)
+        for _ in range(3):
+            step(r, t)
+    sd = step.optimizer_state_dict()
+    assert all(isinstance(g["lr"], float) and g["lr"] == pytest.approx(2e-4) and g["capturable"] is False for g in sd["param_groups"])
+    assert all(st["step"].device.type == "cpu" and float(st["step"]) == 3.0 for st in sd["state"].values())
+    assert isinstance(opt.param_groups[0]["lr"], torch.Tensor)            # the live optimizer is untouched: the graphs still replay
+    path = tmp_path / "ckpt.tar"
+    torch.save({"optimizer_state_dict": sd, "network_fn_state_dict": net_c.state_dict()}, path)
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    clones = [p.detach().clone().requires_grad_(True) for p in params]
+    fresh = torch.optim.Adam(clones, lr=5e-4)                              # run_nerf.py:307 + :322: created, then load_state_dict
+    fresh.load_state_dict(ck["optimizer_state_dict"])
+    assert fresh.param_groups[0]["lr"] == pytest.approx(2e-4) and isinstance(fresh.param_groups[0]["lr"], float)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        step(r, t)                                                         # step 4 through the graphs ...
+    for c, p in zip(clones, params):                                       # ... and through the reloaded eager optimizer, same gradients
+        c.grad = p.grad.detach().clone()
+    fresh.step()
+    worst = max(float((c - p).abs().max()) for c, p in zip(clones, params))
+    assert worst <= 1e-7, worst
+    step.close()
+    assert all(isinstance(g["lr"], float) and not g["capturable"] for g in opt.param_groups)
+    assert all(st["step"].device.type == "cpu" for st in opt.state.values())
+    opt.step()                                                             # eager use works again
+    with pytest.raises(RuntimeError, match="closed"):
+        step(r, t)
+
+
 def test_a_batch_outside_the_f16_range_does_not_reach_the_optimizer_through_the_graph(monkeypatch):
     from intrinsicnerf_amd import graphs
     monkeypatch.setenv("INERF_PRECISION", "f16x3")

@@ -81,6 +81,57 @@ assert t.render_rays.__func__ is ssr.SSRRenderMixin.render_rays and t.return_raw
 print("ssr launcher ok")
 '''
 
+OBJECT_RP = PRELUDE + r"""
+import numpy as np
+mod, main = launch.prepare(%(ref)r + "/object_level/run_nerf.py", with_render_path=True)
+rp = mod.render_path
+assert rp.func is ol.render_path and rp.keywords["cluster_manager_factory"] is mod.Cluster_Manager      # run_nerf.py:24's class
+assert mod.Cluster_Manager.__module__ == "cluster" and mod.to8b is ol.to8b
+# run_nerf.py:818 / :1071 call render_path(..., update_cluster=True): a stub renderer and a recording stand-in for the mean-shift fit
+seen = {}
+mod.Cluster_Manager.update_center = lambda self, labels, pixels, band_factor=0.5: seen.update(labels=labels.shape, pixels=pixels.shape, b_f=band_factor)
+mod.Cluster_Manager.dest_color = lambda self, rgb, label: rgb * 0.5
+H = W = 8
+def fake_render(H_, W_, K, chunk=0, c2w=None, **kw):
+    g = torch.Generator().manual_seed(int(c2w[0, 3]))
+    m = lambda c: torch.rand(H_, W_, c, generator=g) if c > 1 else torch.rand(H_, W_, generator=g)
+    return [m(3), m(1), m(1), m(3), m(1), m(3), {}]
+ol.render = fake_render
+poses = [torch.cat([torch.eye(4)[:, :3], torch.full((4, 1), float(i))], 1) for i in range(3)]
+rgbs, disps, cm = rp(poses, (H, W, 10.0), np.eye(3), 64, {}, update_cluster=True, b_f=0.25)
+assert isinstance(cm, mod.Cluster_Manager) and cm.class_num == 1
+assert rgbs.shape == (3, H, W, 3) and disps.shape == (3, H, W)
+assert seen == {"labels": (3 * 16, 1), "pixels": (3 * 16, 3), "b_f": 0.25}, seen
+print("object-level render_path ok")
+"""
+
+SSR_RP = PRELUDE + r"""
+import numpy as np
+torch.Tensor.cuda = lambda self, *a, **k: self
+torch.nn.Module.cuda = lambda self, *a, **k: self
+mod, main = launch.prepare(%(ref)r + "/train_SSR_main.py", with_render_path=True)
+trainer = sys.modules["SSR.training.trainer"]
+assert trainer.SSRTrainer.render_path is ssr.SSRRenderMixin.render_path
+t = trainer.SSRTrainer.__new__(trainer.SSRTrainer)
+assert t.cluster_manager_factory is trainer.Cluster_Manager                                # trainer.py:16's class, not bound as a method
+seen = {}
+trainer.Cluster_Manager.update_center = lambda self, labels, pixels, band_factor=0.5: seen.update(labels=labels.shape, pixels=pixels.shape, n=self.class_num)
+trainer.Cluster_Manager.dest_color = lambda self, rgb, label: rgb
+H, W, C = 6, 8, 5
+t.H_scaled, t.W_scaled, t.near, t.far, t.N_importance, t.enable_semantic, t.num_valid_semantic_class, t.no_semantic_tree = H, W, 0.1, 10.0, 128, True, C, False
+def fake_render_rays(rays):
+    n = rays.shape[0]
+    g = torch.Generator().manual_seed(n)
+    out = {k + "_fine": torch.rand(n, w, generator=g).squeeze(-1) for k, w in (("rgb", 3), ("disp", 1), ("depth", 1), ("albedo", 3), ("shading", 1), ("residual", 3))}
+    out["sem_logits_fine"] = torch.randn(n, C, generator=g)
+    return out
+t.render_rays = fake_render_rays
+ret = t.render_path(torch.zeros(2, H * W, 11), update_cluster=True)            # trainer.py:1065: update_cluster = not self.no_cluster
+assert len(ret) == 12 and isinstance(ret[-1], trainer.Cluster_Manager) and seen["n"] == C, seen
+assert ret[0].shape == (2, H, W, 3) and ret[4].shape == (2, H, W)
+print("ssr render_path ok")
+"""
+
 
 def _run(code):
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
@@ -111,3 +162,15 @@ def test_launcher_rejects_other_scripts(tmp_path):
     assert ns["x"] == 1 and "y" not in ns
     exec(main, ns)
     assert ns["y"] == 2
+
+
+@pytest.mark.skipif(not os.path.isdir(REF + "/object_level"), reason="reference not mounted")
+def test_launcher_render_path_hands_the_reference_cluster_manager_to_the_mirror():
+    """--inerf-render-path: the reference's loop calls render_path(update_cluster=True) (run_nerf.py:818,1071) - the mirror must
+    have the reference's Cluster_Manager as its factory."""
+    assert "object-level render_path ok" in _run(OBJECT_RP)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF + "/SSR"), reason="reference not mounted")
+def test_launcher_render_path_gives_the_ssr_trainer_its_cluster_manager_factory():
+    assert "ssr render_path ok" in _run(SSR_RP)
