@@ -165,7 +165,7 @@ int inerf_encode_mlp_ws(const inerf_net_desc* net, const float* packed_weights, 
  *             kernels multiply them back in when they bring a fragment to the batch's max |dz|.
  *             Padding points of the last tile hold a copy of the last point (save) / zeros (dz).  Same 4 bytes per element as
  *             fp32; the producers write whole fragments and inerf_mlp_weight_gradient_frag moves them HBM -> LDS by DMA.
- * Behind the slots `save` carries the ReLU masks of h0..h6 as bits (14 336 bytes per 64-point tile, written by
+ * Behind the slots `save` carries the ReLU masks of h0..h7 as bits (16 384 bytes per 64-point tile, written by
  * inerf_encode_mlp_train and read by inerf_mlp_backward_inputs in place of the activations; layout private to the
  * two kernels) and 64 scalars: always pass a buffer that inerf_encode_mlp_train itself filled, of inerf_mlp_save_floats() floats.
  * The gradient w.r.t. the semantic logits is d_raw[..., 11:11+C] itself (no activation).

@@ -211,15 +211,15 @@ inline int64_t save_offset(const inerf_net_desc& net, int slot, int64_t n_points
     return w * padded_points(n_points);
 }
 
-// Behind the slots of the ACTIVATION buffer: the ReLU masks of the trunk outputs h0..h6, one bit per activation, which the
-// input-gradient chain reads instead of the activations themselves (1 KB instead of 7 KB per sample point).  The chain's
+// Behind the slots of the ACTIVATION buffer: the ReLU masks of the trunk outputs h0..h7, one bit per activation, which the
+// input-gradient chain reads instead of the activations themselves (1 KB instead of 8 KB per sample point).  The chain's
 // accumulator layout is the forward's, so a mask word is simply what one lane owns: per 64-point tile, per layer, per wave
 // (64 channels), per lane two 32-bit words - word rb = row block (32 channels), bit 31 - (16*pb + 4*g + i) = the lane's
 // register 4*g + i of point block pb (the forward shifts the bits in in that order), i.e. channel
 // 64*wave + 32*rb + 8*g + 4*(lane >> 5) + i of point 32*pb + (lane & 31).
 // Tiles are whole (the last one is padded), so every word of the area is written by the forward.
-constexpr int kReluBitLayers = 7;
-constexpr int kReluBitTileBytes = kReluBitLayers * 4 * 64 * 8;      // 14,336 B per 64-point tile
+constexpr int kReluBitLayers = 8;                                   // h0..h7 (h7's: the two-workgroup chain masks d h7 with them)
+constexpr int kReluBitTileBytes = kReluBitLayers * 4 * 64 * 8;      // 16,384 B per 64-point tile
 inline int64_t relu_bits_offset(const inerf_net_desc& net, int64_t n_points) { return save_offset(net, SAVE_SLOTS, n_points); }
 inline int64_t relu_bits_floats(int64_t n_points) { return (n_points + kTilePoints - 1) / kTilePoints * (kReluBitTileBytes / 4); }
 // Behind the mask area: 64 floats of per-evaluation scalars (reserved).

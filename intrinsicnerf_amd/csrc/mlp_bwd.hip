@@ -23,6 +23,7 @@
 #include <type_traits>
 
 #include "mlp_f16_dev.h"
+#include "mlp_f16_heads.h"
 
 namespace inerf {
 
@@ -76,7 +77,7 @@ struct DzDst {
 };
 // (the B operand of the transposing MFMAs: mlp_f16_dev.h accumulator_selector - the k order of the ACCUMULATOR registers;
 // planes_to_frag's operands come from LDS in channel order)
-template <int RB, bool BITS = false, typename AlphaAcc = NoAlpha>
+template <int RB, bool BITS = false, typename AlphaAcc = NoAlpha, int ROW = kRowH, int PLANE = kPlaneH>
 __device__ __forceinline__ void bwd_store(const f32x16 (&am)[RB][2], float inv,
                                           const f32x4 (*acts)[2][4] /* [RB][2][4] saved activations of this lane's values (requested
                                                                        before the GEMM; zero for points beyond the end), or nullptr */,
@@ -122,9 +123,9 @@ __device__ __forceinline__ void bwd_store(const f32x16 (&am)[RB][2], float inv,
                 amax2 = __builtin_elementwise_max(amax2, __builtin_elementwise_max(a01, a23));
                 hi_g[g] = f16x4{h01[0], h01[1], h23[0], h23[1]};
                 lo_g[g] = f16x4{l01[0], l01[1], l23[0], l23[1]};
-                _Float16* d = dl + pb * 32 * kRowH + 32 * rb + 8 * g;
+                _Float16* d = dl + pb * 32 * ROW + 32 * rb + 8 * g;
                 *reinterpret_cast<f16x4*>(d) = hi_g[g];
-                *reinterpret_cast<f16x4*>(d + kPlaneH) = lo_g[g];
+                *reinterpret_cast<f16x4*>(d + PLANE) = lo_g[g];
                 // invalid points carry zeros: no need to exclude them from the running maximum
                 gmax = fmaxf(gmax, fmaxf(fmaxf(fabsf(t[0]), fabsf(t[1])), fmaxf(fabsf(t[2]), fabsf(t[3]))) * back);
             }
@@ -153,8 +154,8 @@ __device__ __forceinline__ void bwd_store(const f32x16 (&am)[RB][2], float inv,
                 asm volatile("" :: "v"(oh), "v"(ol));
 #else
                 // (whole offset in the VGPR operand: a 16-byte buffer store with a register SGPR offset gets no hazard wait state, tests/test_isa_audit_cpu.py)
-                __builtin_amdgcn_raw_buffer_store_b128(oh, dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, rb, 0)), 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(ol, dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, rb, 1)), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(oh, dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, rb, 0)), 0, INERF_FRAG_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(ol, dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, rb, 1)), 0, INERF_FRAG_AUX);
 #endif
             }
 #endif
@@ -364,8 +365,8 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
                     }
                 }
                 const int voff = (int)((unsigned)tile * (unsigned)(kFragTileBytes / 2) + (unsigned)lane_s * 16u + frag_off<4>(kb, vh_cb, 0));
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, oh), dz_vh, voff, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ol), dz_vh, voff + kFragBytes, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, oh), dz_vh, voff, 0, INERF_FRAG_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ol), dz_vh, voff + kFragBytes, 0, INERF_FRAG_AUX);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -456,8 +457,8 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
                     }
                 }
                 const int voff = (int)((unsigned)tile * (unsigned)kFragTileBytes + (unsigned)lane_s * 16u + frag_off(kb, wave, 0));
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, oh), dz_as, voff, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ol), dz_as, voff + kFragBytes, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, oh), dz_as, voff, 0, INERF_FRAG_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ol), dz_as, voff + kFragBytes, 0, INERF_FRAG_AUX);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -648,6 +649,467 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_dgrad(const BwdParams p) {
     }
 }
 
+// ================================================================================================
+// Two workgroups per CU - the chain in the shape of the forward's k_encode_mlp_f16x3_dual (mlp_f16.hip).
+//
+// k_mlp_dgrad above keeps two 256-wide gradient buffers (A / B ping-pong) in LDS: 157 KB, one tile per CU, and its eight waves
+// walk GEMM -> barrier -> epilogue -> barrier together - both waves of a SIMD are always in the same phase, each activation
+// fragment is read from LDS by all eight waves (32 KB of LDS reads + 16 KB of L2 weight reads per k-block against 384 MFMA
+// cycles per SIMD).  Here a workgroup is 4 waves x 64 channels x 64 points with ONE buffer updated in place - 75,776 B of LDS,
+// <= 256 registers - so two tiles at different stages share a CU and fill each other's barriers and epilogues, and the
+// 64-channel wave tile does 12 MFMAs per 4 LDS operand reads instead of 6.  What that took:
+//   * in place: a layer's result waits in the accumulators across a barrier (every wave has read the layer's input) before
+//     it overwrites the input; two barriers per layer instead of one;
+//   * the head part re-sequenced around one buffer:  dZ_vh (128 columns) -> views^T -> d feature over the same columns ->
+//     feat^T INTO the accumulators -> dZ_as1 over the same columns -> as1^T on top (-> dZ_semh, sem1^T on top) -> d h7;
+//   * h7's ReLU mask comes from the forward's mask bits like h0..h6 (layout.h kReluBitLayers = 8) instead of from h7's
+//     fragments transposed back by the matrix core (64 + 64 registers at a 64-channel wave tile);
+//   * alpha_linear's weight gradient (d sigma^T h7) is accumulated where the other 1-4-row heads' are: in a fragment-native
+//     VALU stage, lane = channel, straight from h7's fragments (2 accumulators per lane instead of 32).
+// Same packed weights (the 4-wave packing), same slots, same head-partial layout; results differ from the eight-wave form only
+// in the summation order of the head partials and in rays whose h7 sits below the fragments' 4e-9 floor (mask bit 1, decoded 0).
+template <bool kSsr>
+__global__ __launch_bounds__(256, 2) void k_mlp_dgrad_dual(const BwdParams p) {
+    constexpr int kPts = kTilePoints;
+    constexpr int RB = 2, NT = 256, WCH = 64;
+    extern __shared__ __attribute__((aligned(16))) _Float16 ldsb[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const BwdLayout& L = p.L;
+    f16x2 amax2 = {(_Float16)0.0f, (_Float16)0.0f};
+    float gmax = 0.0f;
+
+    _Float16* const xw = ldsb + (lane & 31) * kRowD;
+    const _Float16* const xr = xw + 8 * (lane >> 5);              // wide GEMM operand reads: columns 0 ..
+    _Float16* const xd = xw + 4 * (lane >> 5) + WCH * wave;       // wide stores: this wave's 64 channels
+    // per-point scratch in the (unused) direction columns of the hi plane: [0..7] head gradients / s, [8] s, [9] 1/s
+    auto ptf = [&](int pt) { return reinterpret_cast<float*>(ldsb + pt * kRowD + kColDirD); };
+
+    WeightBuf wb;
+    wb.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wts), 0, L.total_floats * 4, 0x00020000);
+    wb.voff = lane * 16;
+    auto frag = [&](const GemmSlot& s, int kbt) { return (s.w + wave * kbt * 2 * 2 * 256) * 4; };
+    const bool sem = kSsr && L.has_sem;
+    const int ch = p.channels;
+
+    WidePreH<RB> preA;
+    const __amdgpu_buffer_rsrc_t bits_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.save) + p.bits_off, 0, (int)((unsigned)p.n_tiles * (unsigned)kReluBitTileBytes), 0x00020000);
+
+    // weight gradients of the 1-4-row heads, accumulated over this workgroup's tiles (kHead*): ONE channel per lane and block
+    const bool heads = p.head_partial != nullptr;
+    // (sums of the head gradients = the heads' bias gradients: per thread 0..63 in the direction columns of the LO plane, row = thread -
+    // eight accumulators that only one wave uses were eight registers of every wave, spilled)
+    auto hbf = [&](int t) { return reinterpret_cast<float*>(ldsb + kPlaneD + t * kRowD + kColDirD); };
+    if (tid < kPts) {
+        *reinterpret_cast<f32x4*>(hbf(tid)) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        *reinterpret_cast<f32x4*>(hbf(tid) + 4) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    float hres[3] = {0.0f, 0.0f, 0.0f};                                  // residual head: channel 32 wave + (lane & 31)
+    float has2[2][4], halpha[2];                                          // albedo|shading outputs, alpha: channel 32 (2 wave + cbi) + (lane & 31)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        halpha[c] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) has2[c][j] = 0.0f;
+    }
+
+#ifdef INERF_DGRAD_STAMPS   // development build (scripts/build_variant.sh): dz_max points at 2 + 64 x uint64; cycle stamps of
+    // workgroup 0 / thread 0 at the phase boundaries of its SECOND tile (steady state)
+    unsigned long long* const dbg = (p.dz_max && blockIdx.x == 0 && tid == 0) ? reinterpret_cast<unsigned long long*>(p.dz_max) + 1 : nullptr;
+    int dbg_n = 0;
+#define STAMP() do { if (dbg && tile == (int)gridDim.x && dbg_n < 62) { dbg[1 + dbg_n] = __builtin_readcyclecounter(); ++dbg_n; dbg[0] = dbg_n; } } while (0)
+#else
+#define STAMP() do { } while (0)
+#endif
+#ifndef INERF_DUAL_NO_STAGGER
+    stagger_start(p.stagger);
+#endif
+    for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+        STAMP();
+        int lane_s = lane;
+        asm volatile("" : "+v"(lane_s));
+        const int lh = lane_s >> 5;
+        // the views hidden layer's activations (fragments of a 128-channel slot: this wave's channel block, four k-blocks), requested a stage ahead
+        f16x8 act_vh[4][2];                  // [k-block][hi | lo]
+        {
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.save) + p.off[SAVE_VH], 0,
+                                                                                (int)((unsigned)p.n_tiles * (unsigned)(kFragTileBytes / 2)), 0x00020000);
+            const unsigned voff = (unsigned)tile * (unsigned)(kFragTileBytes / 2) + (unsigned)lane_s * 16u;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int plane = 0; plane < 2; ++plane)
+                    act_vh[kb][plane] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r, (int)(voff + frag_off<4>(kb, wave, plane)), 0, 0));
+        }
+        // ... and the albedo | shading hidden layer's and h7's (this wave's two channel blocks, four k-blocks each): operands of the
+        // 1-4-row heads' weight gradients, and the ReLU mask of dZ_as1.  All of it is in flight while wave 0 computes the head
+        // gradients below; consumed right behind that barrier, when no accumulator is live yet.  (Fetched where dZ_as1 is computed -
+        // between two GEMMs whose accumulators occupy the registers, one k-block at a time - the stage waited for memory four times
+        // per tile: 87 k of the tile's 315 k cycles, profiles/r05_dgrad_dual_timeline.txt.)
+        f16x8 act_as1[2][4][2], act_h7[2][4][2];            // [channel block][k-block][hi | lo]
+        {
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.save) + p.off[SAVE_AS1H], 0,
+                                                                                (int)((unsigned)p.n_tiles * (unsigned)kFragTileBytes), 0x00020000);
+            const __amdgpu_buffer_rsrc_t r7 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.save) + p.off[SAVE_H7], 0,
+                                                                                 (int)((unsigned)p.n_tiles * (unsigned)kFragTileBytes), 0x00020000);
+            const unsigned voff = (unsigned)tile * (unsigned)kFragTileBytes + (unsigned)lane_s * 16u;
+#pragma unroll
+            for (int cbi = 0; cbi < 2; ++cbi)
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int plane = 0; plane < 2; ++plane) {
+                        const int o = (int)(voff + frag_off(kb, 2 * wave + cbi, plane));
+                        act_as1[cbi][kb][plane] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r, o, 0, 0));
+                        // (assigned on both paths: a register array that is only conditionally written is loop-carried state to the
+                        // compiler - 64 registers kept alive, and spilled, across the whole tile)
+                        if (heads) act_h7[cbi][kb][plane] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r7, o, 0, 0));
+                        else act_h7[cbi][kb][plane] = f16x8{(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+                    }
+        }
+        // ---------------- heads: pre-activation gradients of the output heads, per-point scale ----------------
+        if (tid < kPts) {
+            const int gp = tile * kPts + tid;
+            float dp[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            float s = 1.0f;
+            if (gp < p.n_points) {
+                s = head_gradients(p, gp, sem, dp);
+                float* __restrict__ o = p.dz + p.off[SAVE_DPRE] + (size_t)gp * 8;
+                *reinterpret_cast<f32x4*>(o) = f32x4{dp[0], dp[1], dp[2], dp[3]};
+                *reinterpret_cast<f32x4*>(o + 4) = f32x4{dp[4], dp[5], dp[6], dp[7]};
+                float* h = hbf(tid);          // (this thread's own words: no barrier needed)
+                *reinterpret_cast<f32x4*>(h) += f32x4{dp[0], dp[1], dp[2], dp[3]};
+                *reinterpret_cast<f32x4*>(h + 4) += f32x4{dp[4], dp[5], dp[6], dp[7]};
+            }
+            float* f = ptf(tid);
+            const float is = 1.0f / s;
+            *reinterpret_cast<f32x4*>(f) = f32x4{dp[0] * is, dp[1] * is, dp[2] * is, dp[3] * is};
+            *reinterpret_cast<f32x4*>(f + 4) = f32x4{dp[4] * is, dp[5] * is, dp[6] * is, dp[7] * is};
+            f[8] = s;
+            f[9] = is;
+            p.dz[p.off[SAVE_ENC] + gp] = s;        // the point's normaliser, beside the fragments (padding points: 1, with all-zero fragments)
+        }
+        STAMP();
+        __syncthreads();
+        STAMP();
+
+        // ---------------- weight gradients of the albedo | shading outputs and of alpha_linear; ReLU mask of the hidden layer ----------------
+        // lane = channel 32 (2 wave + cbi) + (lane & 31), the lane's eight points per k-block: d W_as2[j][c] += d_pre[j] as1h[c],
+        // d w_alpha[c] += d sigma h7[c] (true gradients: normalised value x the point's scale).  What dZ_as1 needs of the hidden
+        // layer later is only its sign: bit 8 kb + i of mask_as1[cbi].
+        unsigned mask_as1[2] = {0u, 0u};
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const int ptb = 32 * (kb >> 1) + 16 * (kb & 1) + 4 * lh;         // frag_point(q, h, i) = (i & 3) + 8 (i >> 2) + 16 q + 4 h
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                f32x4 d = {0.0f, 0.0f, 0.0f, 0.0f};
+                float sp = 0.0f, ds = 0.0f;
+                if (heads) {                        // the point's scratch, once for both channel blocks
+                    const float* f = ptf(ptb + (i & 3) + 8 * (i >> 2));
+                    d = *reinterpret_cast<const f32x4*>(f);                                  // normalised d_albedo (3), d_shading
+                    sp = f[8] * (1.0f / kActScale);
+                    ds = f[7] * sp;                                                          // true d sigma / kActScale
+                    d *= sp;
+                }
+#pragma unroll
+                for (int cbi = 0; cbi < 2; ++cbi) {
+                    const float a8 = (float)act_as1[cbi][kb][0][i] + (float)act_as1[cbi][kb][1][i];          // kActScale * activation
+                    mask_as1[cbi] |= (a8 > 0.0f ? 1u : 0u) << (8 * kb + i);
+                    if (heads) {
+                        has2[cbi][0] += a8 * d[0];
+                        has2[cbi][1] += a8 * d[1];
+                        has2[cbi][2] += a8 * d[2];
+                        has2[cbi][3] += a8 * d[3];
+                        const float a7 = (float)act_h7[cbi][kb][0][i] + (float)act_h7[cbi][kb][1][i];
+                        halpha[cbi] += a7 * ds;       // d alpha_linear.weight[c] += (true d sigma of the point) * h7[c]
+                    }
+                }
+            }
+            // (pinned: left free, the compiler postpones the comparisons to where the mask is used - behind two GEMMs - and keeps the 64 values instead)
+            asm volatile("" : "+v"(mask_as1[0]), "+v"(mask_as1[1]));
+            __builtin_amdgcn_sched_barrier(0);      // (one k-block at a time: left free, the scheduler reads every point's scratch first - 190 registers)
+        }
+
+        // ---------------- dZ of the view-dependent layer: relu'(vh) * (W_res^T d_res [+ d endpoint feature]) -> columns 0..127 ----------------
+        // lane = channel 32 wave + (lane & 31); per k-block the lane's eight points (layout.h frag_point).  The result IS the
+        // layer's dZ fragment (stored as it is) and goes into the planes for the views^T GEMM.
+        {
+            const int cch = 32 * wave + (lane_s & 31);
+            const f32x4 w4 = wb.vec4(L.res_w * 4, 16 * cch);                    // (W_res[0][c], W_res[1][c], W_res[2][c], 0)
+            const __amdgpu_buffer_rsrc_t dz_vh = __builtin_amdgcn_make_buffer_rsrc(p.dz + p.off[SAVE_VH], 0,
+                                                                                   (int)((unsigned)p.n_tiles * (unsigned)(kFragTileBytes / 2)), 0x00020000);
+            _Float16* const col = ldsb + cch;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                f16x8 oh, ol;
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) {
+                    float t[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int pt = 32 * (kb >> 1) + frag_point(kb & 1, lh, i + e);
+                        const float* f = ptf(pt);
+                        const f32x4 d = *reinterpret_cast<const f32x4*>(f + 4);          // normalised d_res (3), d_sigma
+                        const float sp = f[8];
+                        const float act = ((float)act_vh[kb][0][i + e] + (float)act_vh[kb][1][i + e]) * (1.0f / kActScale);
+                        float v = w4[0] * d[0] + w4[1] * d[1] + w4[2] * d[2];
+                        if (kSsr && p.endpoint) {       // raw[..., -128:] is this layer's output itself (semantic_nerf.py:163-164)
+                            const int gp = tile * kPts + pt;
+                            if (gp < p.n_points) v = __builtin_fmaf(p.d_raw[(size_t)gp * ch + ch - INERF_ENDPOINT_DIM + cch], f[9], v);
+                        }
+                        if (heads) {                   // d W_res[j][c] += (true d_res_pre[j] of the point) * vh[c]
+                            hres[0] += act * (d[0] * sp);
+                            hres[1] += act * (d[1] * sp);
+                            hres[2] += act * (d[2] * sp);
+                        }
+                        v = act > 0.0f ? v : 0.0f;         // (a point beyond the end: its head gradients are zero -> v = 0)
+                        gmax = fmaxf(gmax, fabsf(v) * sp);
+                        t[e] = v * kActScale;
+                    }
+                    f16x2 h2, l2;
+                    split_pair(t[0], t[1], h2, l2);
+                    amax2 = __builtin_elementwise_max(amax2, __builtin_bit_cast(f16x2, __builtin_bit_cast(unsigned, h2) & 0x7FFF7FFFu));
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int pt = 32 * (kb >> 1) + frag_point(kb & 1, lh, i + e);
+                        col[pt * kRowD] = h2[e];
+                        col[pt * kRowD + kPlaneD] = l2[e];
+                        oh[i + e] = h2[e]; ol[i + e] = l2[e];
+                    }
+                }
+                const int voff = (int)((unsigned)tile * (unsigned)(kFragTileBytes / 2) + (unsigned)lane_s * 16u + frag_off<4>(kb, wave, 0));
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, oh), dz_vh, voff, 0, INERF_FRAG_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ol), dz_vh, voff + kFragBytes, 0, INERF_FRAG_AUX);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        prefetch_w<RB>(preA, wb, frag(L.views_t, 8));
+        STAMP();
+        __syncthreads();
+        STAMP();
+
+        int lane_t = lane;
+        asm volatile("" : "+v"(lane_t));
+        const int pt0 = tile * kPts + (lane_t & 31);
+        const bool valid0 = pt0 < p.n_points, valid1 = pt0 + 32 < p.n_points;
+        const float s0 = ptf(lane_t & 31)[8], s1 = ptf((lane_t & 31) + 32)[8];
+        auto dz_dst = [&](int slot) {                 // 256-wide slots: this wave's two channel blocks
+            DzDst d;
+            d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dz + p.off[slot], 0, (int)((unsigned)p.n_tiles * (unsigned)kFragTileBytes), 0x00020000);
+            d.voff = (unsigned)tile * (unsigned)kFragTileBytes + (unsigned)(2 * wave) * (2u * kFragBytes) + (unsigned)lane_t * 16u;
+            return d;
+        };
+        auto mask_words = [&](int layer) {            // this lane's two mask words of trunk layer `layer` (layout.h relu_bits_offset)
+            const int mbase = (((tile * kReluBitLayers + layer) * 4 + wave) * 64) * 8;
+            return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(bits_rsrc, lane_t * 8, mbase, 0));
+        };
+        f32x16 am[RB][2];
+        NoAlpha none;
+
+        // ---------------- d feature = W_views^T[:256] dZ_vh, in place (feature_linear has no activation: this is its dZ) ----------------
+        {
+            const float inv = wb.scalar(L.views_t.b * 4);        // (requested ahead of the GEMM: behind it, its L2 round trip is exposed)
+            wide_gemm_h<RB, 8, 0, kRowD, kPlaneD, true>(preA, wb, frag(L.views_t, 8), xr, 0, 0, lane, am);
+            prefetch_w<RB>(preA, wb, frag(L.feat_t, 16));
+            STAMP();
+            __syncthreads();                 // dZ_vh has been read by every wave
+            STAMP();
+            bwd_store<RB, false, NoAlpha, kRowD, kPlaneD>(am, inv, nullptr, nullptr, 0.0f, 0.0f, xd, amax2, dz_dst(SAVE_FEAT), lane_t, s0, s1,
+                                                          valid0, valid1, gmax, u32x2{0u, 0u}, none);
+        }
+        STAMP();
+        __syncthreads();
+        STAMP();
+
+        // ---------------- d h7 = W_feat^T d feature + W_as1^T dZ_as1 (+ W_sem1^T dZ_semh) + w_alpha d sigma ----------------
+        wide_gemm_h<RB, 16, 0, kRowD, kPlaneD, true>(preA, wb, frag(L.feat_t, 16), xr, 0, 0, lane, am);
+        STAMP();
+        __syncthreads();                     // d feature has been read by every wave; its product waits in the accumulators
+        STAMP();
+
+        // dZ of the albedo | shading hidden layer: relu'(as1h) * (W_as2^T [d_albedo, d_shading]) over the same columns; lane = channel
+        // 32 (2 wave + cbi) + (lane & 31), four k-blocks - the result is the layer's dZ fragment.  No memory operand: the head
+        // gradients from the scratch columns, the ReLU mask from mask_as1.
+        {
+            const __amdgpu_buffer_rsrc_t dz_as = __builtin_amdgcn_make_buffer_rsrc(p.dz + p.off[SAVE_AS1H], 0,
+                                                                                   (int)((unsigned)p.n_tiles * (unsigned)kFragTileBytes), 0x00020000);
+            const unsigned voff = (unsigned)tile * (unsigned)kFragTileBytes + (unsigned)lane_s * 16u;
+#pragma unroll
+            for (int cbi = 0; cbi < 2; ++cbi) {
+                const f32x4 w4 = wb.vec4(L.as2_w * 4, 16 * (32 * (2 * wave + cbi) + (lane_s & 31)));      // albedo_linear2[0..2][c] | shading output [c - 128]
+                _Float16* const col = ldsb + 32 * (2 * wave + cbi) + (lane_s & 31);
+#pragma unroll 1
+                for (int kb = 0; kb < 4; ++kb) {
+                    const int ptb = 32 * (kb >> 1) + 16 * (kb & 1) + 4 * lh;
+                    const int bits8 = (int)(mask_as1[cbi] >> (8 * kb));
+                    f16x8 oh, ol;
+#pragma unroll
+                    for (int i = 0; i < 8; i += 2) {
+                        float t[2];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const float* f = ptf(ptb + ((i + e) & 3) + 8 * ((i + e) >> 2));
+                            const f32x4 d = *reinterpret_cast<const f32x4*>(f);              // normalised d_albedo (3), d_shading
+                            float v = w4[0] * d[0] + w4[1] * d[1] + w4[2] * d[2] + w4[3] * d[3];
+                            v = __builtin_bit_cast(float, __builtin_bit_cast(int, v) & __builtin_amdgcn_sbfe(bits8, i + e, 1));      // relu'
+                            gmax = fmaxf(gmax, fabsf(v) * f[8]);
+                            t[e] = v * kActScale;
+                        }
+                        f16x2 h2, l2;
+                        split_pair(t[0], t[1], h2, l2);
+                        amax2 = __builtin_elementwise_max(amax2, __builtin_bit_cast(f16x2, __builtin_bit_cast(unsigned, h2) & 0x7FFF7FFFu));
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int pt = ptb + ((i + e) & 3) + 8 * ((i + e) >> 2);
+                            col[pt * kRowD] = h2[e];
+                            col[pt * kRowD + kPlaneD] = l2[e];
+                            oh[i + e] = h2[e]; ol[i + e] = l2[e];
+                        }
+                    }
+                    const int so = (int)(voff + frag_off(kb, 2 * wave + cbi, 0));
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, oh), dz_as, so, 0, INERF_FRAG_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ol), dz_as, so + kFragBytes, 0, INERF_FRAG_AUX);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        prefetch_w<RB>(preA, wb, frag(L.as1_t, 16));          // (after the stage, not before: its 32 registers next to the live accumulators spilled)
+        STAMP();
+        __syncthreads();
+        STAMP();
+        wide_gemm_h<RB, 16, 0, kRowD, kPlaneD, false>(preA, wb, frag(L.as1_t, 16), xr, 0, 0, lane, am);
+        if (sem) {
+            prefetch_w<RB>(preA, wb, frag(L.sem1_t, 8));
+            __syncthreads();                 // dZ_as1 has been read by every wave
+            constexpr int VH_STEP = NT / 32, VH_IT = kPts / VH_STEP;        // rows per pass of this row-wise stage, passes
+            const int c4 = (tid & 31) * 4;
+#pragma unroll 1
+            for (int i = 0; i < VH_IT; ++i) {
+                const int pt = (tid >> 5) + VH_STEP * i;
+                const int gp = tile * kPts + pt;
+                const bool valid = gp < p.n_points;
+                const float* f = ptf(pt);
+                float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                f32x4 act = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (valid) {
+                    const float* gl = p.d_raw + (size_t)gp * ch + INERF_BASE_CHANNELS;       // logits: no activation
+                    for (int j = 0; j < p.n_classes; ++j) {
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(p.wts + L.sem2_w + (size_t)j * kHalf + c4);
+                        const float gj = gl[j] * f[9];
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc) v[cc] = __builtin_fmaf(w[cc], gj, v[cc]);
+                    }
+                    act = *reinterpret_cast<const f32x4*>(p.save + p.off[SAVE_SEMH] + (size_t)gp * kHalf + c4);
+                }
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) v[cc] = act[cc] > 0.0f ? v[cc] : 0.0f;
+                split_store4(ldsb + pt * kRowD + c4, ldsb + pt * kRowD + c4 + kPlaneD, v, amax2);
+                if (valid) {
+                    const f32x4 o = f32x4{v[0], v[1], v[2], v[3]} * f[8];
+                    gmax = fmaxf(gmax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+                }
+            }
+            STAMP();
+        __syncthreads();
+        STAMP();
+            {                                // dZ of the semantic hidden layer: fragments of a 128-channel slot, one channel block per wave
+                FragDst d;
+                d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dz + p.off[SAVE_SEMH], 0, (int)((unsigned)p.n_tiles * (unsigned)(kFragTileBytes / 2)), 0x00020000);
+                d.voff = (unsigned)tile * (unsigned)(kFragTileBytes / 2) + (unsigned)wave * (2u * kFragBytes) + (unsigned)lane_t * 16u;
+                planes_to_frag<1, kRowD, kPlaneD, 4>(xr + 32 * wave, plane_selector(lane_t), d);
+            }
+            wide_gemm_h<RB, 8, 0, kRowD, kPlaneD, false>(preA, wb, frag(L.sem1_t, 8), xr, 0, 0, lane, am);
+        }
+        {
+            const float inv = wb.scalar(L.feat_t.b * 4);            // common scale of feat_t / as1_t / sem1_t
+            prefetch_w<RB>(preA, wb, frag(L.trunk_t[7], 16));
+            const float e0 = ptf(lane_t & 31)[7], e1 = ptf((lane_t & 31) + 32)[7];
+            const u32x2 mbits = mask_words(kDepth - 1);
+            STAMP();
+            __syncthreads();                 // every wave is done reading the buffer
+            STAMP();
+            // one 32-channel row block at a time: alpha_linear's weights of the block (16 registers) instead of the wave's (32) beside
+            // the accumulators, the next layer's first fragments and the epilogue's own transposition
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                f32x4 aw[1][4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    aw[0][g] = wb.vec4((L.alpha_w + WCH * wave + 32 * rb + 8 * g) * 4, 16 * (lane_t >> 5)) * kActScale;
+                DzDst d = dz_dst(SAVE_H7);
+                d.voff += (unsigned)rb * (2u * kFragBytes);
+                bwd_store<1, true, NoAlpha, kRowD, kPlaneD>(*reinterpret_cast<const f32x16 (*)[1][2]>(&am[rb]), inv, nullptr, aw, e0, e1, xd + 32 * rb, amax2,
+                                                            d, lane_t, s0, s1, valid0, valid1, gmax, u32x2{mbits[rb], 0u}, none);
+            }
+        }
+        STAMP();
+        __syncthreads();
+        STAMP();
+
+        // ---------------- trunk, layers 7..1: dZ_{l-1} = relu'(h_{l-1}) * W_l^T dZ_l, in place ----------------
+#pragma unroll 1
+        for (int l = kDepth - 1; l >= 1; --l) {
+            const u32x2 mbits = mask_words(l - 1);
+            const float inv = wb.scalar(L.trunk_t[l].b * 4);
+            wide_gemm_h<RB, 16, 0, kRowD, kPlaneD, true>(preA, wb, frag(L.trunk_t[l], 16), xr, 0, 0, lane, am);
+            if (l > 1) prefetch_w<RB>(preA, wb, frag(L.trunk_t[l - 1], 16));      // (the next tile's first GEMM: requested behind that tile's VALU stages, whose operands need the registers)
+            STAMP();
+            __syncthreads();                 // dZ_l has been read by every wave
+            STAMP();
+            bwd_store<RB, true, NoAlpha, kRowD, kPlaneD>(am, inv, nullptr, nullptr, 0.0f, 0.0f, xd, amax2, dz_dst(SAVE_H0 + l - 1), lane_t, s0, s1,
+                                                         valid0, valid1, gmax, mbits, none);
+            STAMP();
+        __syncthreads();
+        STAMP();
+        }
+    }
+    if (heads) {                          // lane halves meet by a shuffle (same channel, the other four points of every k-block)
+        float hres2[3], has22[2][4], halpha2[2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) hres2[j] = hres[j] + __shfl_xor(hres[j], 32);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            halpha2[c] = halpha[c] + __shfl_xor(halpha[c], 32);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) has22[c][j] = has2[c][j] + __shfl_xor(has2[c][j], 32);
+        }
+        __syncthreads();
+        float* out = p.head_partial + (size_t)blockIdx.x * kHeadFloats;
+        if (lane < 32) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) out[kHeadRes + j * kHalf + 32 * wave + lane] = hres2[j];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) out[kHeadAs2 + j * kWidth + 32 * (2 * wave + c) + lane] = has22[c][j];
+                out[kHeadAlpha + 32 * (2 * wave + c) + lane] = halpha2[c];
+            }
+        }
+        if (tid < 8) {
+            float v = 0.0f;
+            for (int k = 0; k < kPts; ++k) v += hbf(k)[tid];
+            out[kHeadBias + tid] = v;
+        }
+    }
+    const float amax_all = fmaxf((float)amax2[0], (float)amax2[1]);
+    if (p.status && __any(!(amax_all <= kF16Safe)) && lane == 0) atomicOr(p.status, INERF_STATUS_F16_RANGE);
+    if (p.dz_max) {                       // non-negative floats order like their bit patterns
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o));
+        if (lane == 0 && gmax == gmax) atomicMax(reinterpret_cast<unsigned int*>(p.dz_max), __builtin_bit_cast(unsigned int, gmax));
+    }
+}
+
+// Which form runs: two workgroups per CU (default) or the eight-wave single-tile kernel (INERF_DGRAD_KERNEL=single: A/B runs and the
+// kernel's own tests).  One decision for the launch AND for the size of the head-partial buffer.
+static bool dgrad_dual() {
+    const char* form = getenv("INERF_DGRAD_KERNEL");
+    return !(form && form[0] == 's');
+}
+
 }  // namespace inerf
 
 // floats per workgroup of the head-gradient partials, and the number of workgroups inerf_mlp_backward_inputs launches
@@ -656,7 +1118,8 @@ extern "C" int inerf_mlp_backward_grid(int64_t n_points) {
     using namespace inerf;
     if (n_points <= 0) return 0;
     const int64_t tiles = (n_points + kTilePoints - 1) / kTilePoints;
-    return (int)(tiles < device_cus() ? tiles : device_cus());
+    const int64_t max_grid = (dgrad_dual() ? 2 : 1) * device_cus();
+    return (int)(tiles < max_grid ? tiles : max_grid);
 }
 
 extern "C" int inerf_mlp_backward_inputs(const inerf_net_desc* net, const float* packed_bwd, const float* raw, const float* d_raw,
@@ -679,16 +1142,20 @@ extern "C" int inerf_mlp_backward_inputs(const inerf_net_desc* net, const float*
     p.endpoint = (ssr && (flags & INERF_FLAG_ENDPOINT)) ? 1 : 0;
     p.n_classes = ssr ? net->n_classes : 0;
     p.channels = INERF_BASE_CHANNELS + p.n_classes + (p.endpoint ? INERF_ENDPOINT_DIM : 0);
-    const int grid = p.n_tiles < device_cus() ? p.n_tiles : device_cus();
+    const bool dual = dgrad_dual();
+    const int max_grid = (dual ? 2 : 1) * device_cus();
+    const int grid = p.n_tiles < max_grid ? p.n_tiles : max_grid;
     p.stagger = stagger_units(p.n_tiles, grid);
-    // eight waves per workgroup (two per SIMD, 32 channels each)
-    void (*kern)(const BwdParams) = ssr ? k_mlp_dgrad<true, 8> : k_mlp_dgrad<false, 8>;
-    static PerDeviceOnce attr_set[2];
-    if (attr_set[(int)ssr].first()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesH);
+    // two workgroups of four waves per CU (64 channels per wave), or eight waves per workgroup (two per SIMD, 32 channels each)
+    void (*kern)(const BwdParams) = dual ? (ssr ? k_mlp_dgrad_dual<true> : k_mlp_dgrad_dual<false>) : (ssr ? k_mlp_dgrad<true, 8> : k_mlp_dgrad<false, 8>);
+    const int lds = dual ? kLdsBytesD : kLdsBytesH;
+    static PerDeviceOnce attr_set[4];
+    const int variant = 2 * (int)dual + (int)ssr;
+    if (attr_set[variant].first()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return record(e);
-        attr_set[(int)ssr].mark();
+        attr_set[variant].mark();
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), kLdsBytesH, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(dual ? 256 : 512), lds, (hipStream_t)stream, p);
     return record(hipGetLastError());
 }

@@ -142,11 +142,11 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
             d.stride = width;
             return d;
         };
-        // ReLU masks of h0..h6 for the input-gradient chain (layout.h relu_bits_offset): one descriptor for the area
+        // ReLU masks of h0..h7 for the input-gradient chain (layout.h relu_bits_offset): one descriptor for the area
         const __amdgpu_buffer_rsrc_t bits_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             p.save + (kSave ? p.bits_off : 0), 0, kSave ? (int)((unsigned)p.n_tiles * (unsigned)kReluBitTileBytes) : 0, 0x00020000);
         // training forward (layout.h SaveSlot): h0..h7 and the feature layer leave as operand fragments of the weight-gradient
-        // products (planes_to_frag, after the layer's barrier), h0..h6 also as ReLU mask bits; the albedo|shading hidden layer as
+        // products (planes_to_frag, after the layer's barrier), h0..h7 also as ReLU mask bits; the albedo|shading hidden layer as
         // fp32 rows from the epilogue's registers
         const Selector fsel = plane_selector(lane);
         auto step256 = [&](const GemmSlot& s, auto kb0c, auto kb1c, int c0, int c1, int dcol, bool relu, auto slot_c,
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
             constexpr bool kTrunk = slot >= SAVE_H0 && slot <= SAVE_H7;
             constexpr bool kFrag = kTrunk || slot == SAVE_FEAT || slot == SAVE_AS1H;
             constexpr bool kRows = false;
-            constexpr bool kBits = kSave && kTrunk && slot < SAVE_H7;
+            constexpr bool kBits = kSave && kTrunk;
             f32x16 am[2][2];
             f32x4 bias[2][4];
 #pragma unroll
@@ -419,14 +419,14 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
         f32x4 bias2[2][4];
         float inv2;
         const int pt0 = tile * kPts + (lane_t & 31);
-        // ReLU masks of h0..h6 for the input-gradient chain (layout.h relu_bits_offset)
+        // ReLU masks of h0..h7 for the input-gradient chain (layout.h relu_bits_offset)
         const __amdgpu_buffer_rsrc_t bits_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             p.save + (kSave ? p.bits_off : 0), 0, kSave ? (int)((unsigned)p.n_tiles * (unsigned)kReluBitTileBytes) : 0, 0x00020000);
         // training forward: where a 256-wide layer goes besides the planes (layout.h SaveSlot) - fp32 rows from the epilogue's
         // registers cost 2.3 x as much per byte as the fragments' whole-line stores (16-byte pieces): no layer leaves that way any
         // more except the SSR semantic hidden layer;
         // `frag_slot`: operand fragments of the weight-gradient products, transposed out of the finished planes by the matrix
-        // core (planes_to_frag: whole 1 KB stores); the ReLU masks of h0..h6 as bits.
+        // core (planes_to_frag: whole 1 KB stores); the ReLU masks of h0..h7 as bits.
         auto frag_dst = [&](int slot) {
             FragDst d;
             d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save + (kSave ? p.save_off[slot] : 0), 0,
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
         wide_gemm_h<2, 16, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.trunk[6], 16), xr, 0, 0, lane, am2);
         store256(L.trunk[6], true, SAVE_H0 + 6, pf256(L.trunk[7], 16), kWithBits);
         wide_gemm_h<2, 16, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.trunk[7], 16), xr, 0, 0, lane, am2);
-        store256(L.trunk[7], true, SAVE_H7, pf256(L.as1, 16), kNoBits);
+        store256(L.trunk[7], true, SAVE_H7, pf256(L.as1, 16), kWithBits);
 
         // ---------------- heads ----------------
         const int my_pt = tile * kPts + 16 * wave + (lane_t & 15);

@@ -35,6 +35,14 @@ struct WeightBuf {
     }
 };
 
+// Cache policy of the fragment stores (the training kernels' 1 KB operand fragments: 4-5 GB per launch, written once, read once by
+// another kernel): bit 0 sc0, bit 1 nt, bit 4 sc1.  Non-temporal: same-box A/B on the fine batch (profiles/r05_frag_store_policy.txt)
+// training forward 1.79-1.85 -> 1.76-1.78 ms, chain 1.89-1.97 -> 1.86-1.93; sc1 (write-through) is slower, sc0 neutral.  (Without
+// the stores at all: 1.48 / 1.61 ms - what the stores cost is not their bandwidth, 2.4 TB/s, but that every later load of the wave
+// - the next GEMM's weight stream - is counted behind them in vmcnt.)
+#ifndef INERF_FRAG_AUX
+#define INERF_FRAG_AUX 2
+#endif
 constexpr int kRowH = kColB + kWidth + 8;      // 616 halfs per row
 constexpr int kPlaneH = kTilePoints * kRowH;   // halfs per plane
 constexpr int kLdsBytesH = 2 * kPlaneH * 2;    // 157,696
@@ -304,8 +312,8 @@ __device__ __forceinline__ void planes_to_frag(const _Float16* xa /* plane_hi + 
                 asm volatile("" :: "v"(oh), "v"(ol));
 #else
                 // (whole offset in the VGPR operand: a 16-byte buffer store with a register SGPR offset gets no hazard wait state, tests/test_isa_audit_cpu.py)
-                __builtin_amdgcn_raw_buffer_store_b128(oh, dst.rsrc, (int)(dst.voff + frag_off<CBS>(2 * pb + q, cb, 0)), 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(ol, dst.rsrc, (int)(dst.voff + frag_off<CBS>(2 * pb + q, cb, 1)), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(oh, dst.rsrc, (int)(dst.voff + frag_off<CBS>(2 * pb + q, cb, 0)), 0, INERF_FRAG_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(ol, dst.rsrc, (int)(dst.voff + frag_off<CBS>(2 * pb + q, cb, 1)), 0, INERF_FRAG_AUX);
 #endif
             }
         __builtin_amdgcn_sched_barrier(0);
@@ -347,8 +355,8 @@ __device__ __forceinline__ void operands_to_frag(const f16x8 (&hi)[2 * NB][2], c
                     oh[i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(th[8 * q + 2 * i], th[8 * q + 2 * i + 1]));
                     ol[i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(tl[8 * q + 2 * i], tl[8 * q + 2 * i + 1]));
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(oh, dst.rsrc, (int)(dst.voff + frag_off<CBS>(2 * pb + q, cb, 0)), 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(ol, dst.rsrc, (int)(dst.voff + frag_off<CBS>(2 * pb + q, cb, 1)), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(oh, dst.rsrc, (int)(dst.voff + frag_off<CBS>(2 * pb + q, cb, 0)), 0, INERF_FRAG_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(ol, dst.rsrc, (int)(dst.voff + frag_off<CBS>(2 * pb + q, cb, 1)), 0, INERF_FRAG_AUX);
             }
         }
         __builtin_amdgcn_sched_barrier(0);

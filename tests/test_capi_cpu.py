@@ -93,7 +93,7 @@ def test_argument_validation(capi):
                lib.inerf_mlp_backward_inputs(good, None, None, None, None, 0, 0, None, None, None, None, None),
                lib.inerf_cluster_lookup(None, None, 0, None, None, None, None, None, None, 1, 0, None, None, None)):
         assert rc == capi.OK
-    bits = 7 * 4 * 64 * 2                          # ReLU-mask words per 64-point tile (h0..h6, 4 waves, 64 lanes, 2 words)
+    bits = 8 * 4 * 64 * 2                          # ReLU-mask words per 64-point tile (h0..h7, 4 waves, 64 lanes, 2 words)
     sc = 64                                        # per-evaluation scalars behind the mask area
     per_point = 64 + 32 + 8 * 256 + 256 + 256 + 128 + 8                # (slot 15: width 0)
     assert lib.inerf_mlp_save_floats(good, 64) == 64 * per_point + bits + sc

@@ -33,7 +33,9 @@ def _rays(n, s, dev, seed=0):
                                                            ("ssr", 28, False, 64, 5),
                                                            ("ssr", 5, True, 21, 7),           # one-workgroup training forward
                                                            ("object", 0, False, 700, 37)])    # more tiles than workgroups
-def test_mask_words_equal_saved_activations_and_gate_the_chain(variant, classes, endpoint, n, s):
+@pytest.mark.parametrize("form", ["dual", "single"])
+def test_mask_words_equal_saved_activations_and_gate_the_chain(variant, classes, endpoint, n, s, form, monkeypatch):
+    monkeypatch.setenv("INERF_DGRAD_KERNEL", form)     # two workgroups per CU (default) | the eight-wave single-tile chain
     dev = torch.device("cuda:0")
     ssr = variant == "ssr"
     desc = _capi.net_desc(_capi.VARIANT_SSR if ssr else _capi.VARIANT_OBJECT, classes, 10, 4, 10.0 if ssr else 1.0, _capi.PREC_F16X3)
@@ -45,12 +47,12 @@ def test_mask_words_equal_saved_activations_and_gate_the_chain(variant, classes,
     X = kernels.save_slot_views(desc, save, p)
     tiles = (p + 63) // 64
     sc = kernels.SAVE_SCALARS                          # (the mask area sits between the slots and the buffer's scalars)
-    words = save[-(tiles * 3584 + sc):-sc].view(torch.int32).view(tiles, 7, 4, 64, 2).cpu().numpy().astype(np.uint32)
+    words = save[-(tiles * 4096 + sc):-sc].view(torch.int32).view(tiles, 8, 4, 64, 2).cpu().numpy().astype(np.uint32)
     t, w, l, rb, pb_, g, i = np.meshgrid(np.arange(tiles), np.arange(4), np.arange(64), np.arange(2), np.arange(2), np.arange(4), np.arange(4), indexing="ij")
     chan = 64 * w + 32 * rb + 8 * g + 4 * (l >> 5) + i
     point = 64 * t + 32 * pb_ + (l & 31)
     ok = point < p
-    for layer in range(7):
+    for layer in range(8):
         h = X[kernels.SAVE_H0 + layer].cpu().numpy()
         bit = (words[t, layer, w, l, rb] >> (31 - (16 * pb_ + 4 * g + i))) & 1
         hv = h[np.minimum(point, p - 1), chan]
@@ -66,13 +68,13 @@ def test_mask_words_equal_saved_activations_and_gate_the_chain(variant, classes,
     G = kernels.save_slot_views(desc, dz, p, gradient=True)
     for layer in range(8):
         gz = G[kernels.SAVE_H0 + layer]
-        if layer < 7:       # closed = the forward's mask bit (a decoded h of 0 may be an activation below the fragments' 4e-9 floor)
+        if layer < 7 or form == "dual":       # closed = the forward's mask bit (a decoded h of 0 may be an activation below the fragments' 4e-9 floor)
             closed = np.ones((p, 256), dtype=bool)
             bit = (words[t, layer, w, l, rb] >> (31 - (16 * pb_ + 4 * g + i))) & 1
             closed[np.minimum(point, p - 1)[ok], chan[ok]] = bit[ok] == 0
             closed = torch.from_numpy(closed).to(dev)
         else:
-            closed = X[kernels.SAVE_H0 + 7] <= 0           # layer 7 has no mask bits: the chain reads h7's fragments themselves
+            closed = X[kernels.SAVE_H0 + 7] <= 0           # the eight-wave chain masks d h7 with h7's fragments themselves
         assert not ((gz != 0) & closed).any(), f"dZ of layer {layer} leaks through a closed ReLU"
         assert torch.isfinite(gz).all() and float(gz.abs().max()) > 0
 
@@ -102,3 +104,41 @@ def test_chain_repeats_bit_for_bit_over_many_launches():
             continue
         for slot, (a, b) in enumerate(zip(cur, ref)):
             assert torch.equal(a, b), f"launch {it}: part {slot} differs at {int((a != b).sum())} elements"
+
+
+@pytest.mark.parametrize("variant,classes,endpoint,n,s", [("object", 0, False, 700, 37), ("ssr", 28, False, 300, 23), ("ssr", 5, True, 64, 9)])
+def test_two_workgroup_chain_equals_the_eight_wave_chain(variant, classes, endpoint, n, s, monkeypatch):
+    """k_mlp_dgrad_dual (4 waves x 64 channels, in place, two tiles per CU) against k_mlp_dgrad (8 waves, A/B buffers): the same
+    GEMMs in the same k order and the same epilogue arithmetic, so every dZ slot is the same BYTES - except where h7 sits below the
+    fragments' 4e-9 floor (the dual form masks d h7 with the forward's bit, the eight-wave form with the decoded value) - and the
+    1-4-row heads' sums agree to summation order."""
+    dev = torch.device("cuda:0")
+    ssr = variant == "ssr"
+    desc = _capi.net_desc(_capi.VARIANT_SSR if ssr else _capi.VARIANT_OBJECT, classes, 10, 4, 10.0 if ssr else 1.0, _capi.PREC_F16X3)
+    sd = {k: v.to(dev) for k, v in oracle.make_state_dict(variant, classes, seed=7).items()}
+    pf, pb = packing.device_packer(desc, False, dev)(sd), packing.device_packer(desc, True, dev)(sd)
+    rays, z = _rays(n, s, dev, seed=2)
+    raw, save = kernels.encode_mlp_train(desc, pf, rays, z, endpoint=endpoint)
+    p = n * s
+    ch = raw.shape[-1]
+    d_raw = torch.randn(p, ch, device=dev)
+    out = {}
+    for form in ("single", "dual"):
+        monkeypatch.setenv("INERF_DGRAD_KERNEL", form)
+        dz_max = torch.zeros(1, device=dev)
+        dz, heads = kernels.mlp_backward_inputs(desc, pb, raw.view(p, ch), d_raw, save, endpoint=endpoint, dz_max=dz_max, want_heads=True)
+        torch.cuda.synchronize()
+        # the slots the chain writes (the buffer's unused slots - DIR, most of ENC - are whatever the allocator left there)
+        first, last = _slot_range(desc, p, kernels.SAVE_H0, kernels.SAVE_SEMH if ssr else kernels.SAVE_VH)
+        dpre = _slot_range(desc, p, kernels.SAVE_DPRE, kernels.SAVE_DPRE)
+        norm = _slot_range(desc, p, kernels.SAVE_ENC, kernels.SAVE_ENC)[0]
+        words = torch.cat([dz[first:last], dz[dpre[0]:dpre[0] + 8 * p], dz[norm:norm + (p + 63) // 64 * 64]]).view(torch.int32).clone()
+        out[form] = (words, heads.sum(0).clone(), float(dz_max), heads.shape[0])
+    assert out["dual"][3] in (out["single"][3], 2 * out["single"][3], (p + 63) // 64)
+    a, b = out["single"][0], out["dual"][0]
+    differ = int((a != b).sum())
+    assert differ <= 64, f"{differ} of {a.numel()} gradient words differ between the two chains"
+    assert out["single"][2] == pytest.approx(out["dual"][2], rel=1e-6)
+    hs, hd = out["single"][1], out["dual"][1]
+    scale = float(hs.abs().max())
+    assert float((hs - hd).abs().max()) <= 2e-5 * scale, float((hs - hd).abs().max()) / scale
