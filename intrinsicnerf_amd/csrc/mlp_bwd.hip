@@ -77,7 +77,9 @@ struct DzDst {
 };
 // (the B operand of the transposing MFMAs: mlp_f16_dev.h accumulator_selector - the k order of the ACCUMULATOR registers;
 // planes_to_frag's operands come from LDS in channel order)
-template <int RB, bool BITS = false, typename AlphaAcc = NoAlpha, int ROW = kRowH, int PLANE = kPlaneH>
+// FRAG = false: planes only - the caller writes the fragments out later, from the planes (planes_to_frag_late: behind the GEMM that
+// consumes the layer, so that the stores do not sit in front of that GEMM's weight stream).
+template <int RB, bool BITS = false, typename AlphaAcc = NoAlpha, int ROW = kRowH, int PLANE = kPlaneH, bool FRAG = true>
 __device__ __forceinline__ void bwd_store(const f32x16 (&am)[RB][2], float inv,
                                           const f32x4 (*acts)[2][4] /* [RB][2][4] saved activations of this lane's values (requested
                                                                        before the GEMM; zero for points beyond the end), or nullptr */,
@@ -130,6 +132,7 @@ __device__ __forceinline__ void bwd_store(const f32x16 (&am)[RB][2], float inv,
                 gmax = fmaxf(gmax, fmaxf(fmaxf(fabsf(t[0]), fabsf(t[1])), fmaxf(fabsf(t[2]), fabsf(t[3]))) * back);
             }
 #ifndef INERF_ABL_NO_FRAG
+            if constexpr (FRAG) {
             // transpose (see DzDst): D'[point][channel] = sum_k A[point][k] Sel[k][channel], two k-blocks of 16 channels, hi and lo each
             const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
             f32x16 trh = zero, trl = zero;
@@ -157,6 +160,7 @@ __device__ __forceinline__ void bwd_store(const f32x16 (&am)[RB][2], float inv,
                 __builtin_amdgcn_raw_buffer_store_b128(oh, dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, rb, 0)), 0, INERF_FRAG_AUX);
                 __builtin_amdgcn_raw_buffer_store_b128(ol, dst.rsrc, (int)(dst.voff + frag_off(2 * pb + q, rb, 1)), 0, INERF_FRAG_AUX);
 #endif
+            }
             }
 #endif
             __builtin_amdgcn_sched_barrier(0);
@@ -673,9 +677,8 @@ __global__ __launch_bounds__(256, 2) void k_mlp_dgrad_dual(const BwdParams p) {
     constexpr int kPts = kTilePoints;
     constexpr int RB = 2, NT = 256, WCH = 64;
     extern __shared__ __attribute__((aligned(16))) _Float16 ldsb[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // (no `tid` kept: wave 0's lanes ARE threads 0..63, a wave-uniform test)
     const BwdLayout& L = p.L;
     f16x2 amax2 = {(_Float16)0.0f, (_Float16)0.0f};
     float gmax = 0.0f;
@@ -702,9 +705,9 @@ __global__ __launch_bounds__(256, 2) void k_mlp_dgrad_dual(const BwdParams p) {
     // (sums of the head gradients = the heads' bias gradients: per thread 0..63 in the direction columns of the LO plane, row = thread -
     // eight accumulators that only one wave uses were eight registers of every wave, spilled)
     auto hbf = [&](int t) { return reinterpret_cast<float*>(ldsb + kPlaneD + t * kRowD + kColDirD); };
-    if (tid < kPts) {
-        *reinterpret_cast<f32x4*>(hbf(tid)) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        *reinterpret_cast<f32x4*>(hbf(tid) + 4) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (wave == 0) {
+        *reinterpret_cast<f32x4*>(hbf(lane)) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        *reinterpret_cast<f32x4*>(hbf(lane) + 4) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
     float hres[3] = {0.0f, 0.0f, 0.0f};                                  // residual head: channel 32 wave + (lane & 31)
     float has2[2][4], halpha[2];                                          // albedo|shading outputs, alpha: channel 32 (2 wave + cbi) + (lane & 31)
@@ -717,7 +720,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_dgrad_dual(const BwdParams p) {
 
 #ifdef INERF_DGRAD_STAMPS   // development build (scripts/build_variant.sh): dz_max points at 2 + 64 x uint64; cycle stamps of
     // workgroup 0 / thread 0 at the phase boundaries of its SECOND tile (steady state)
-    unsigned long long* const dbg = (p.dz_max && blockIdx.x == 0 && tid == 0) ? reinterpret_cast<unsigned long long*>(p.dz_max) + 1 : nullptr;
+    unsigned long long* const dbg = (p.dz_max && blockIdx.x == 0 && threadIdx.x == 0) ? reinterpret_cast<unsigned long long*>(p.dz_max) + 1 : nullptr;
     int dbg_n = 0;
 #define STAMP() do { if (dbg && tile == (int)gridDim.x && dbg_n < 62) { dbg[1 + dbg_n] = __builtin_readcyclecounter(); ++dbg_n; dbg[0] = dbg_n; } } while (0)
 #else
@@ -770,8 +773,8 @@ __global__ __launch_bounds__(256, 2) void k_mlp_dgrad_dual(const BwdParams p) {
                     }
         }
         // ---------------- heads: pre-activation gradients of the output heads, per-point scale ----------------
-        if (tid < kPts) {
-            const int gp = tile * kPts + tid;
+        if (wave == 0) {
+            const int gp = tile * kPts + lane_s;
             float dp[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
             float s = 1.0f;
             if (gp < p.n_points) {
@@ -779,11 +782,11 @@ __global__ __launch_bounds__(256, 2) void k_mlp_dgrad_dual(const BwdParams p) {
                 float* __restrict__ o = p.dz + p.off[SAVE_DPRE] + (size_t)gp * 8;
                 *reinterpret_cast<f32x4*>(o) = f32x4{dp[0], dp[1], dp[2], dp[3]};
                 *reinterpret_cast<f32x4*>(o + 4) = f32x4{dp[4], dp[5], dp[6], dp[7]};
-                float* h = hbf(tid);          // (this thread's own words: no barrier needed)
+                float* h = hbf(lane_s);       // (this thread's own words: no barrier needed)
                 *reinterpret_cast<f32x4*>(h) += f32x4{dp[0], dp[1], dp[2], dp[3]};
                 *reinterpret_cast<f32x4*>(h + 4) += f32x4{dp[4], dp[5], dp[6], dp[7]};
             }
-            float* f = ptf(tid);
+            float* f = ptf(lane_s);
             const float is = 1.0f / s;
             *reinterpret_cast<f32x4*>(f) = f32x4{dp[0] * is, dp[1] * is, dp[2] * is, dp[3] * is};
             *reinterpret_cast<f32x4*>(f + 4) = f32x4{dp[4] * is, dp[5] * is, dp[6] * is, dp[7] * is};
@@ -834,17 +837,13 @@ __global__ __launch_bounds__(256, 2) void k_mlp_dgrad_dual(const BwdParams p) {
         }
 
         // ---------------- dZ of the view-dependent layer: relu'(vh) * (W_res^T d_res [+ d endpoint feature]) -> columns 0..127 ----------------
-        // lane = channel 32 wave + (lane & 31); per k-block the lane's eight points (layout.h frag_point).  The result IS the
-        // layer's dZ fragment (stored as it is) and goes into the planes for the views^T GEMM.
+        // lane = channel 32 wave + (lane & 31); per k-block the lane's eight points (layout.h frag_point) -> the planes for the views^T GEMM.
         {
             const int cch = 32 * wave + (lane_s & 31);
             const f32x4 w4 = wb.vec4(L.res_w * 4, 16 * cch);                    // (W_res[0][c], W_res[1][c], W_res[2][c], 0)
-            const __amdgpu_buffer_rsrc_t dz_vh = __builtin_amdgcn_make_buffer_rsrc(p.dz + p.off[SAVE_VH], 0,
-                                                                                   (int)((unsigned)p.n_tiles * (unsigned)(kFragTileBytes / 2)), 0x00020000);
             _Float16* const col = ldsb + cch;
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {
-                f16x8 oh, ol;
 #pragma unroll
                 for (int i = 0; i < 8; i += 2) {
                     float t[2];
@@ -877,12 +876,8 @@ __global__ __launch_bounds__(256, 2) void k_mlp_dgrad_dual(const BwdParams p) {
                         const int pt = 32 * (kb >> 1) + frag_point(kb & 1, lh, i + e);
                         col[pt * kRowD] = h2[e];
                         col[pt * kRowD + kPlaneD] = l2[e];
-                        oh[i + e] = h2[e]; ol[i + e] = l2[e];
                     }
                 }
-                const int voff = (int)((unsigned)tile * (unsigned)(kFragTileBytes / 2) + (unsigned)lane_s * 16u + frag_off<4>(kb, wave, 0));
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, oh), dz_vh, voff, 0, INERF_FRAG_AUX);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ol), dz_vh, voff + kFragBytes, 0, INERF_FRAG_AUX);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -896,29 +891,44 @@ __global__ __launch_bounds__(256, 2) void k_mlp_dgrad_dual(const BwdParams p) {
         const int pt0 = tile * kPts + (lane_t & 31);
         const bool valid0 = pt0 < p.n_points, valid1 = pt0 + 32 < p.n_points;
         const float s0 = ptf(lane_t & 31)[8], s1 = ptf((lane_t & 31) + 32)[8];
-        auto dz_dst = [&](int slot) {                 // 256-wide slots: this wave's two channel blocks
-            DzDst d;
-            d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dz + p.off[slot], 0, (int)((unsigned)p.n_tiles * (unsigned)kFragTileBytes), 0x00020000);
-            d.voff = (unsigned)tile * (unsigned)kFragTileBytes + (unsigned)(2 * wave) * (2u * kFragBytes) + (unsigned)lane_t * 16u;
-            return d;
-        };
         auto mask_words = [&](int layer) {            // this lane's two mask words of trunk layer `layer` (layout.h relu_bits_offset)
             const int mbase = (((tile * kReluBitLayers + layer) * 4 + wave) * 64) * 8;
             return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(bits_rsrc, lane_t * 8, mbase, 0));
         };
         f32x16 am[RB][2];
         NoAlpha none;
+        // Every dZ slot leaves the CU from the PLANES, right behind the loop of the GEMM that consumes it (its input stays intact until
+        // that GEMM's closing barrier): the stores then have the whole following epilogue to complete.  Issued in front of a GEMM
+        // - as the epilogue's last act, or by the VALU stages - they stand before that GEMM's weight loads in the wave's vmcnt order,
+        // and its first k-blocks wait for them (mlp_f16_dev.h planes_to_frag_late).
+        auto flush256 = [&](int slot) {                // this wave's 64 channels of a 256-wide slot
+            int lane_o = lane_t;
+            asm volatile("" : "+v"(lane_o));
+            FragDst d;
+            d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dz + p.off[slot], 0, (int)((unsigned)p.n_tiles * (unsigned)kFragTileBytes), 0x00020000);
+            d.voff = (unsigned)tile * (unsigned)kFragTileBytes + (unsigned)(2 * wave) * (2u * kFragBytes) + (unsigned)lane_o * 16u;
+            planes_to_frag_late<2, kRowD, kPlaneD>(xr + 64 * wave, plane_selector(lane_o), d);
+        };
+        auto flush128 = [&](int slot) {                // this wave's 32 channels of a 128-wide slot (columns 0..127)
+            int lane_o = lane_t;
+            asm volatile("" : "+v"(lane_o));
+            FragDst d;
+            d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dz + p.off[slot], 0, (int)((unsigned)p.n_tiles * (unsigned)(kFragTileBytes / 2)), 0x00020000);
+            d.voff = (unsigned)tile * (unsigned)(kFragTileBytes / 2) + (unsigned)wave * (2u * kFragBytes) + (unsigned)lane_o * 16u;
+            planes_to_frag_late<1, kRowD, kPlaneD, 4>(xr + 32 * wave, plane_selector(lane_o), d);
+        };
 
         // ---------------- d feature = W_views^T[:256] dZ_vh, in place (feature_linear has no activation: this is its dZ) ----------------
         {
             const float inv = wb.scalar(L.views_t.b * 4);        // (requested ahead of the GEMM: behind it, its L2 round trip is exposed)
             wide_gemm_h<RB, 8, 0, kRowD, kPlaneD, true>(preA, wb, frag(L.views_t, 8), xr, 0, 0, lane, am);
             prefetch_w<RB>(preA, wb, frag(L.feat_t, 16));
+            flush128(SAVE_VH);
             STAMP();
             __syncthreads();                 // dZ_vh has been read by every wave
             STAMP();
-            bwd_store<RB, false, NoAlpha, kRowD, kPlaneD>(am, inv, nullptr, nullptr, 0.0f, 0.0f, xd, amax2, dz_dst(SAVE_FEAT), lane_t, s0, s1,
-                                                          valid0, valid1, gmax, u32x2{0u, 0u}, none);
+            bwd_store<RB, false, NoAlpha, kRowD, kPlaneD, false>(am, inv, nullptr, nullptr, 0.0f, 0.0f, xd, amax2, DzDst{}, lane_t, s0, s1,
+                                                                 valid0, valid1, gmax, u32x2{0u, 0u}, none);
         }
         STAMP();
         __syncthreads();
@@ -926,17 +936,15 @@ __global__ __launch_bounds__(256, 2) void k_mlp_dgrad_dual(const BwdParams p) {
 
         // ---------------- d h7 = W_feat^T d feature + W_as1^T dZ_as1 (+ W_sem1^T dZ_semh) + w_alpha d sigma ----------------
         wide_gemm_h<RB, 16, 0, kRowD, kPlaneD, true>(preA, wb, frag(L.feat_t, 16), xr, 0, 0, lane, am);
+        flush256(SAVE_FEAT);
         STAMP();
         __syncthreads();                     // d feature has been read by every wave; its product waits in the accumulators
         STAMP();
 
         // dZ of the albedo | shading hidden layer: relu'(as1h) * (W_as2^T [d_albedo, d_shading]) over the same columns; lane = channel
-        // 32 (2 wave + cbi) + (lane & 31), four k-blocks - the result is the layer's dZ fragment.  No memory operand: the head
-        // gradients from the scratch columns, the ReLU mask from mask_as1.
+        // 32 (2 wave + cbi) + (lane & 31), four k-blocks.  No memory operand: the head gradients from the scratch columns, the ReLU
+        // mask from mask_as1.
         {
-            const __amdgpu_buffer_rsrc_t dz_as = __builtin_amdgcn_make_buffer_rsrc(p.dz + p.off[SAVE_AS1H], 0,
-                                                                                   (int)((unsigned)p.n_tiles * (unsigned)kFragTileBytes), 0x00020000);
-            const unsigned voff = (unsigned)tile * (unsigned)kFragTileBytes + (unsigned)lane_s * 16u;
 #pragma unroll
             for (int cbi = 0; cbi < 2; ++cbi) {
                 const f32x4 w4 = wb.vec4(L.as2_w * 4, 16 * (32 * (2 * wave + cbi) + (lane_s & 31)));      // albedo_linear2[0..2][c] | shading output [c - 128]
@@ -945,7 +953,6 @@ __global__ __launch_bounds__(256, 2) void k_mlp_dgrad_dual(const BwdParams p) {
                 for (int kb = 0; kb < 4; ++kb) {
                     const int ptb = 32 * (kb >> 1) + 16 * (kb & 1) + 4 * lh;
                     const int bits8 = (int)(mask_as1[cbi] >> (8 * kb));
-                    f16x8 oh, ol;
 #pragma unroll
                     for (int i = 0; i < 8; i += 2) {
                         float t[2];
@@ -966,12 +973,8 @@ __global__ __launch_bounds__(256, 2) void k_mlp_dgrad_dual(const BwdParams p) {
                             const int pt = ptb + ((i + e) & 3) + 8 * ((i + e) >> 2);
                             col[pt * kRowD] = h2[e];
                             col[pt * kRowD + kPlaneD] = l2[e];
-                            oh[i + e] = h2[e]; ol[i + e] = l2[e];
                         }
                     }
-                    const int so = (int)(voff + frag_off(kb, 2 * wave + cbi, 0));
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, oh), dz_as, so, 0, INERF_FRAG_AUX);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ol), dz_as, so + kFragBytes, 0, INERF_FRAG_AUX);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -981,14 +984,16 @@ __global__ __launch_bounds__(256, 2) void k_mlp_dgrad_dual(const BwdParams p) {
         __syncthreads();
         STAMP();
         wide_gemm_h<RB, 16, 0, kRowD, kPlaneD, false>(preA, wb, frag(L.as1_t, 16), xr, 0, 0, lane, am);
+        if (sem) prefetch_w<RB>(preA, wb, frag(L.sem1_t, 8));
+        else     prefetch_w<RB>(preA, wb, frag(L.trunk_t[7], 16));
+        flush256(SAVE_AS1H);
         if (sem) {
-            prefetch_w<RB>(preA, wb, frag(L.sem1_t, 8));
             __syncthreads();                 // dZ_as1 has been read by every wave
             constexpr int VH_STEP = NT / 32, VH_IT = kPts / VH_STEP;        // rows per pass of this row-wise stage, passes
-            const int c4 = (tid & 31) * 4;
+            const int c4 = (lane_t & 31) * 4;
 #pragma unroll 1
             for (int i = 0; i < VH_IT; ++i) {
-                const int pt = (tid >> 5) + VH_STEP * i;
+                const int pt = 2 * wave + (lane_t >> 5) + VH_STEP * i;
                 const int gp = tile * kPts + pt;
                 const bool valid = gp < p.n_points;
                 const float* f = ptf(pt);
@@ -1015,17 +1020,12 @@ __global__ __launch_bounds__(256, 2) void k_mlp_dgrad_dual(const BwdParams p) {
             STAMP();
         __syncthreads();
         STAMP();
-            {                                // dZ of the semantic hidden layer: fragments of a 128-channel slot, one channel block per wave
-                FragDst d;
-                d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.dz + p.off[SAVE_SEMH], 0, (int)((unsigned)p.n_tiles * (unsigned)(kFragTileBytes / 2)), 0x00020000);
-                d.voff = (unsigned)tile * (unsigned)(kFragTileBytes / 2) + (unsigned)wave * (2u * kFragBytes) + (unsigned)lane_t * 16u;
-                planes_to_frag<1, kRowD, kPlaneD, 4>(xr + 32 * wave, plane_selector(lane_t), d);
-            }
             wide_gemm_h<RB, 8, 0, kRowD, kPlaneD, false>(preA, wb, frag(L.sem1_t, 8), xr, 0, 0, lane, am);
+            prefetch_w<RB>(preA, wb, frag(L.trunk_t[7], 16));
+            flush128(SAVE_SEMH);             // dZ of the semantic hidden layer: fragments of a 128-channel slot, one channel block per wave
         }
         {
             const float inv = wb.scalar(L.feat_t.b * 4);            // common scale of feat_t / as1_t / sem1_t
-            prefetch_w<RB>(preA, wb, frag(L.trunk_t[7], 16));
             const float e0 = ptf(lane_t & 31)[7], e1 = ptf((lane_t & 31) + 32)[7];
             const u32x2 mbits = mask_words(kDepth - 1);
             STAMP();
@@ -1039,10 +1039,8 @@ __global__ __launch_bounds__(256, 2) void k_mlp_dgrad_dual(const BwdParams p) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     aw[0][g] = wb.vec4((L.alpha_w + WCH * wave + 32 * rb + 8 * g) * 4, 16 * (lane_t >> 5)) * kActScale;
-                DzDst d = dz_dst(SAVE_H7);
-                d.voff += (unsigned)rb * (2u * kFragBytes);
-                bwd_store<1, true, NoAlpha, kRowD, kPlaneD>(*reinterpret_cast<const f32x16 (*)[1][2]>(&am[rb]), inv, nullptr, aw, e0, e1, xd + 32 * rb, amax2,
-                                                            d, lane_t, s0, s1, valid0, valid1, gmax, u32x2{mbits[rb], 0u}, none);
+                bwd_store<1, true, NoAlpha, kRowD, kPlaneD, false>(*reinterpret_cast<const f32x16 (*)[1][2]>(&am[rb]), inv, nullptr, aw, e0, e1, xd + 32 * rb,
+                                                                   amax2, DzDst{}, lane_t, s0, s1, valid0, valid1, gmax, u32x2{mbits[rb], 0u}, none);
             }
         }
         STAMP();
@@ -1056,15 +1054,17 @@ __global__ __launch_bounds__(256, 2) void k_mlp_dgrad_dual(const BwdParams p) {
             const float inv = wb.scalar(L.trunk_t[l].b * 4);
             wide_gemm_h<RB, 16, 0, kRowD, kPlaneD, true>(preA, wb, frag(L.trunk_t[l], 16), xr, 0, 0, lane, am);
             if (l > 1) prefetch_w<RB>(preA, wb, frag(L.trunk_t[l - 1], 16));      // (the next tile's first GEMM: requested behind that tile's VALU stages, whose operands need the registers)
+            flush256(SAVE_H0 + l);           // dZ_l, which this GEMM has just read
             STAMP();
             __syncthreads();                 // dZ_l has been read by every wave
             STAMP();
-            bwd_store<RB, true, NoAlpha, kRowD, kPlaneD>(am, inv, nullptr, nullptr, 0.0f, 0.0f, xd, amax2, dz_dst(SAVE_H0 + l - 1), lane_t, s0, s1,
-                                                         valid0, valid1, gmax, mbits, none);
+            bwd_store<RB, true, NoAlpha, kRowD, kPlaneD, false>(am, inv, nullptr, nullptr, 0.0f, 0.0f, xd, amax2, DzDst{}, lane_t, s0, s1,
+                                                                valid0, valid1, gmax, mbits, none);
             STAMP();
-        __syncthreads();
-        STAMP();
+            __syncthreads();
+            STAMP();
         }
+        flush256(SAVE_H0);                   // dZ_0 has no consumer in this kernel: before the next tile's stages overwrite the planes (behind their first barrier)
     }
     if (heads) {                          // lane halves meet by a shuffle (same channel, the other four points of every k-block)
         float hres2[3], has22[2][4], halpha2[2];
@@ -1088,10 +1088,10 @@ __global__ __launch_bounds__(256, 2) void k_mlp_dgrad_dual(const BwdParams p) {
                 out[kHeadAlpha + 32 * (2 * wave + c) + lane] = halpha2[c];
             }
         }
-        if (tid < 8) {
+        if (wave == 0 && lane < 8) {
             float v = 0.0f;
-            for (int k = 0; k < kPts; ++k) v += hbf(k)[tid];
-            out[kHeadBias + tid] = v;
+            for (int k = 0; k < kPts; ++k) v += hbf(k)[lane];
+            out[kHeadBias + lane] = v;
         }
     }
     const float amax_all = fmaxf((float)amax2[0], (float)amax2[1]);

@@ -320,6 +320,49 @@ __device__ __forceinline__ void planes_to_frag(const _Float16* xa /* plane_hi + 
     }
 }
 
+// One point half at a time (48 registers instead of 96), for the places where a layer's accumulators are still live: the two-workgroup
+// chain writes every dZ slot out of the planes right behind the loop of the GEMM that consumes it (its input is intact until that
+// GEMM's closing barrier).  (Tried for the ordering - a wave's later loads are counted behind its earlier stores in vmcnt, so stores
+// issued in front of a GEMM could stall its first k-blocks: no measurable difference, forward or chain, profiles/r05_frag_store_order.txt;
+// what the fragment stores cost - forward 1.79 -> 1.48 ms without them - is their share of the CU's vector-memory path, which the
+// weight stream from L2 already loads to ~2/3.  Kept in the chain: one way out for all slots, no transposition in the epilogues.)
+template <int NB, int ROW, int PLANE, int CBS = 8>
+__device__ __forceinline__ void planes_to_frag_late(const _Float16* xa /* plane_hi + (lane & 31) * ROW + 8 * (lane >> 5) + first column */,
+                                                    const Selector& sel, const FragDst& dst) {
+#ifdef INERF_ABL_NO_FRAG
+    return;
+#endif
+    const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            const _Float16* src = xa + pb * 32 * ROW + 32 * cb;
+            const f16x8 ah0 = *reinterpret_cast<const f16x8*>(src), ah1 = *reinterpret_cast<const f16x8*>(src + 16);
+            const f16x8 al0 = *reinterpret_cast<const f16x8*>(src + PLANE), al1 = *reinterpret_cast<const f16x8*>(src + PLANE + 16);
+            f32x16 th = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, sel.k[0], zero, 0, 0, 0);
+            f32x16 tl = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, sel.k[0], zero, 0, 0, 0);
+            th = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, sel.k[1], th, 0, 0, 0);
+            tl = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, sel.k[1], tl, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                u32x4 oh, ol;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    oh[i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(th[8 * q + 2 * i], th[8 * q + 2 * i + 1]));
+                    ol[i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(tl[8 * q + 2 * i], tl[8 * q + 2 * i + 1]));
+                }
+#ifdef INERF_ABL_NO_FRAG_STORE
+                asm volatile("" :: "v"(oh), "v"(ol));
+#else
+                __builtin_amdgcn_raw_buffer_store_b128(oh, dst.rsrc, (int)(dst.voff + frag_off<CBS>(2 * pb + q, cb, 0)), 0, INERF_FRAG_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(ol, dst.rsrc, (int)(dst.voff + frag_off<CBS>(2 * pb + q, cb, 1)), 0, INERF_FRAG_AUX);
+#endif
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+}
+
 // The same from REGISTER operands in the accumulator's k order (mlp_f16_heads.h to_operands: the hidden layers of the output
 // heads never touch LDS): hi / lo [2 cb + q2][pb] hold, per lane (point lane & 31 of point block pb, half h = lane >> 5),
 // channels 32 cb + 16 q2 + 8 (i >> 2) + 4 h + (i & 3) - the selector below picks that order apart.
@@ -422,6 +465,12 @@ __device__ __forceinline__ void wide_store_h(const f32x16 (&am)[RB][2], float in
                 _Float16* d = dl + pb * 32 * ROW + 32 * rb + 8 * g;
                 *reinterpret_cast<f16x4*>(d) = hi4;
                 *reinterpret_cast<f16x4*>(d + PLANE) = lo4;
+            }
+            {   // pinned per block: left free, the running maximum becomes a tree whose partial maxima stay alive (and were spilled in the
+                // training forward) until a much later fold
+                unsigned a = __builtin_bit_cast(unsigned, amax2);
+                asm volatile("" : "+v"(a));
+                amax2 = __builtin_bit_cast(f16x2, a);
             }
             // keep the scheduler from converting all 8 blocks at once (it would need >256 live VGPRs and spill)
             __builtin_amdgcn_sched_barrier(0);

@@ -109,7 +109,7 @@ def test_chain_repeats_bit_for_bit_over_many_launches():
 @pytest.mark.parametrize("variant,classes,endpoint,n,s", [("object", 0, False, 700, 37), ("ssr", 28, False, 300, 23), ("ssr", 5, True, 64, 9)])
 def test_two_workgroup_chain_equals_the_eight_wave_chain(variant, classes, endpoint, n, s, monkeypatch):
     """k_mlp_dgrad_dual (4 waves x 64 channels, in place, two tiles per CU) against k_mlp_dgrad (8 waves, A/B buffers): the same
-    GEMMs in the same k order and the same epilogue arithmetic, so every dZ slot is the same BYTES - except where h7 sits below the
+    GEMMs in the same k order and the same epilogue arithmetic, so every dZ slot holds the same f16 VALUES - except where h7 sits below the
     fragments' 4e-9 floor (the dual form masks d h7 with the forward's bit, the eight-wave form with the decoded value) - and the
     1-4-row heads' sums agree to summation order."""
     dev = torch.device("cuda:0")
@@ -135,7 +135,13 @@ def test_two_workgroup_chain_equals_the_eight_wave_chain(variant, classes, endpo
         words = torch.cat([dz[first:last], dz[dpre[0]:dpre[0] + 8 * p], dz[norm:norm + (p + 63) // 64 * 64]]).view(torch.int32).clone()
         out[form] = (words, heads.sum(0).clone(), float(dz_max), heads.shape[0])
     assert out["dual"][3] in (out["single"][3], 2 * out["single"][3], (p + 63) // 64)
-    a, b = out["single"][0], out["dual"][0]
+    # as f16 halves, -0 taken as +0: a remainder lo that underflows keeps its sign in a register (the eight-wave chain stores the two
+    # VALU stages' fragments straight from registers), not through the matrix core (0 x 1 + 0 = +0), where every slot of the
+    # two-workgroup chain passes on its way out of the planes
+    def halves(w):
+        h = w.view(torch.int16).to(torch.int32) & 0xFFFF
+        return torch.where(h == 0x8000, torch.zeros_like(h), h)
+    a, b = halves(out["single"][0]), halves(out["dual"][0])
     differ = int((a != b).sum())
     assert differ <= 64, f"{differ} of {a.numel()} gradient words differ between the two chains"
     assert out["single"][2] == pytest.approx(out["dual"][2], rel=1e-6)
