@@ -100,7 +100,11 @@ __device__ __forceinline__ void bwd_store(const f32x16 (&am)[RB][2], float inv,
             const bool valid = pb == 0 ? valid0 : valid1;
             const int bits16 = valid ? (int)(mask_bits[rb] >> (16 * (1 - pb))) : 0;     // points beyond the end carry no gradient
             const float ex = pb == 0 ? ex0 : ex1;
-            const float back = (pb == 0 ? s0 : s1) * (1.0f / kActScale);
+            // |dz| bound of the block: all sixteen values belong to ONE point, so the running maximum is taken on the packed f16 halves
+            // the range guard needs anyway and scaled back once per block (hi is t rounded toward zero: 1 + 2^-9 covers the cut) -
+            // a compare-and-scale per value was 20 of the block's ~150 VALU instructions
+            const float back = (pb == 0 ? s0 : s1) * ((1.0f + 0x1p-9f) / kActScale);
+            f16x2 bmax = {(_Float16)0.0f, (_Float16)0.0f};
             f16x4 hi_g[4], lo_g[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -122,15 +126,16 @@ __device__ __forceinline__ void bwd_store(const f32x16 (&am)[RB][2], float inv,
                 split_pair(t[2], t[3], h23, l23);
                 const f16x2 a01 = __builtin_bit_cast(f16x2, __builtin_bit_cast(unsigned, h01) & 0x7FFF7FFFu);
                 const f16x2 a23 = __builtin_bit_cast(f16x2, __builtin_bit_cast(unsigned, h23) & 0x7FFF7FFFu);
-                amax2 = __builtin_elementwise_max(amax2, __builtin_elementwise_max(a01, a23));
+                bmax = __builtin_elementwise_max(bmax, __builtin_elementwise_max(a01, a23));
                 hi_g[g] = f16x4{h01[0], h01[1], h23[0], h23[1]};
                 lo_g[g] = f16x4{l01[0], l01[1], l23[0], l23[1]};
                 _Float16* d = dl + pb * 32 * ROW + 32 * rb + 8 * g;
                 *reinterpret_cast<f16x4*>(d) = hi_g[g];
                 *reinterpret_cast<f16x4*>(d + PLANE) = lo_g[g];
-                // invalid points carry zeros: no need to exclude them from the running maximum
-                gmax = fmaxf(gmax, fmaxf(fmaxf(fabsf(t[0]), fabsf(t[1])), fmaxf(fabsf(t[2]), fabsf(t[3]))) * back);
             }
+            amax2 = __builtin_elementwise_max(amax2, bmax);
+            // invalid points carry zeros: no need to exclude them from the running maximum
+            gmax = fmaxf(gmax, fmaxf((float)bmax[0], (float)bmax[1]) * back);
 #ifndef INERF_ABL_NO_FRAG
             if constexpr (FRAG) {
             // transpose (see DzDst): D'[point][channel] = sum_k A[point][k] Sel[k][channel], two k-blocks of 16 channels, hi and lo each
@@ -201,6 +206,39 @@ __device__ __forceinline__ float head_gradients(const BwdParams& p, int gp, bool
     float m = 0.0f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) m = fmaxf(m, fabsf(dp[k]));
+    if (sem) for (int j = 0; j < p.n_classes; ++j) m = fmaxf(m, fabsf(g[INERF_BASE_CHANNELS + j]));
+    if (p.endpoint) for (int c = 0; c < INERF_ENDPOINT_DIM; ++c) m = fmaxf(m, fabsf(g[ch - INERF_ENDPOINT_DIM + c]));
+    float s = 1.0f;
+    if (m > 0.0f && m < 3.0e38f) { int e; frexpf(m, &e); s = ldexpf(1.0f, e); }
+    return s;
+}
+
+// The same in two halves, for the two-workgroup chain: the 22 values are REQUESTED before the tile's fragment operands (160 KB per
+// workgroup, which would otherwise stand in front of them in the wave's vmcnt order) and used behind them.
+struct HeadInputs { float r[11], g[11]; };
+__device__ __forceinline__ void head_inputs(const BwdParams& p, int gp, HeadInputs& in) {
+    const float* __restrict__ r = p.raw + (size_t)gp * p.channels;
+    const float* __restrict__ g = p.d_raw + (size_t)gp * p.channels;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) { in.r[k] = r[k]; in.g[k] = g[k]; }
+}
+__device__ __forceinline__ float head_gradients(const BwdParams& p, int gp, bool sem, const HeadInputs& in, float (&dp)[8]) {
+    const float sh = in.r[7];
+    float dsh = in.g[7];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float a = in.r[4 + k], rs = in.r[8 + k];
+        dp[k] = (in.g[k] * sh + in.g[4 + k]) * (a * (1.0f - a));      // rgb = albedo * shading + residual, sigmoid'
+        dsh += in.g[k] * a;
+        dp[4 + k] = (in.g[k] + in.g[8 + k]) * (rs * (1.0f - rs));
+    }
+    dp[3] = dsh * (sh * (1.0f - sh));
+    dp[7] = in.g[3];                                                   // sigma has no activation inside the network
+    float m = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m = fmaxf(m, fabsf(dp[k]));
+    const int ch = p.channels;
+    const float* __restrict__ g = p.d_raw + (size_t)gp * ch;
     if (sem) for (int j = 0; j < p.n_classes; ++j) m = fmaxf(m, fabsf(g[INERF_BASE_CHANNELS + j]));
     if (p.endpoint) for (int c = 0; c < INERF_ENDPOINT_DIM; ++c) m = fmaxf(m, fabsf(g[ch - INERF_ENDPOINT_DIM + c]));
     float s = 1.0f;
@@ -734,6 +772,14 @@ __global__ __launch_bounds__(256, 2) void k_mlp_dgrad_dual(const BwdParams p) {
         int lane_s = lane;
         asm volatile("" : "+v"(lane_s));
         const int lh = lane_s >> 5;
+        // wave 0: raw / d_raw of its 64 points, requested FIRST (head_inputs)
+        HeadInputs hin;
+        const bool s0_valid = wave == 0 && tile * kPts + lane_s < p.n_points;
+        if (s0_valid) head_inputs(p, tile * kPts + lane_s, hin);
+        else {
+#pragma unroll
+            for (int k = 0; k < 11; ++k) { hin.r[k] = 0.0f; hin.g[k] = 0.0f; }
+        }
         // the views hidden layer's activations (fragments of a 128-channel slot: this wave's channel block, four k-blocks), requested a stage ahead
         f16x8 act_vh[4][2];                  // [k-block][hi | lo]
         {
@@ -777,8 +823,8 @@ __global__ __launch_bounds__(256, 2) void k_mlp_dgrad_dual(const BwdParams p) {
             const int gp = tile * kPts + lane_s;
             float dp[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
             float s = 1.0f;
-            if (gp < p.n_points) {
-                s = head_gradients(p, gp, sem, dp);
+            if (s0_valid) {
+                s = head_gradients(p, gp, sem, hin, dp);
                 float* __restrict__ o = p.dz + p.off[SAVE_DPRE] + (size_t)gp * 8;
                 *reinterpret_cast<f32x4*>(o) = f32x4{dp[0], dp[1], dp[2], dp[3]};
                 *reinterpret_cast<f32x4*>(o + 4) = f32x4{dp[4], dp[5], dp[6], dp[7]};
