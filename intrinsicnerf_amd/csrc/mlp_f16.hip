@@ -506,6 +506,10 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
         }
         const __amdgpu_buffer_rsrc_t sem_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             p.sem_scratch, 0, kSplit ? (int)((unsigned)gridDim.x * (unsigned)L.sem_rb32 * (unsigned)kSemScratchBytes) : 0, 0x00020000);
+        // kSplit: this wave's partial logits of classes 0..31 stay in REGISTERS until the exchange at the end of the tile (round 4 parked every
+        // block in the scratch slot: the inference kernels had no 16 registers to spare before the epilogues' running maximum was pinned -
+        // 252 -> 235; further blocks of a head with more than 32 classes still go through the slot)
+        f32x16 sem_keep = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         if constexpr (kSplit) {                    // semantic_nerf.py:150-152, hidden layer split over the waves by channel half x point half
             const int ch = wave & 1, ph = wave >> 1;
             f32x16 am1[2][1];
@@ -523,6 +527,7 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
                 f32x16 acc[1];
                 // sem2q fragments of hidden channels 64 ch .. + 63 = packing waves 2 ch, 2 ch + 1 (two k-blocks each, contiguous)
                 regop_gemm_full<4, 1>(wb, (L.sem2q.w + (rb * 4 + 2 * ch) * 2 * 2 * 256) * 4, hi, lo, acc);
+                if (rb == 0) { sem_keep = acc[0]; continue; }
                 const int slot = ((int)blockIdx.x * L.sem_rb32 + rb) * kSemScratchBytes + wave * (kSemScratchBytes / 4);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -564,8 +569,8 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
         // kSplit: the partial logits meet in dead columns too - per point 2 x 32 floats (one per channel half): half 0 at bytes
         // 256..383 of the row in the hi plane, half 1 at bytes 128..255 in the lo plane (clear of the heads' exchange area, bytes
         // 128..255 of the hi plane, and of what the next tile's encode writes before its first barriers: bytes 0..127 and 512..575).
-        // Each wave fetches its OWN partials back from its scratch slot (sc0: past the vector L1, whose lines of an earlier tile may
-        // be stale); block 0 is requested here, so that the fetch runs under the barrier and the heads' exchange.
+        // Block 0 comes from the wave's registers (sem_keep); of further blocks each wave fetches its OWN partials back from its
+        // scratch slot (sc0: past the vector L1, whose lines of an earlier tile may be stale).
         constexpr int kRowF = kRowD / 2;                                      // floats per LDS row
         auto sem_ex = [&](int half, int r) { return reinterpret_cast<float*>(ldsd) + (half == 0 ? 64 : kPlaneD / 2 + 32) + r * kRowF; };
         auto sem_fetch = [&](int rb, u32x4 (&v)[4]) {
@@ -593,7 +598,9 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
         u32x4 sem_v[4];
         float sem_inv2 = 0.0f;
         if constexpr (kSplit) {
-            sem_fetch(0, sem_v);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                sem_v[g] = __builtin_bit_cast(u32x4, f32x4{sem_keep[4 * g], sem_keep[4 * g + 1], sem_keep[4 * g + 2], sem_keep[4 * g + 3]});
             sem_inv2 = wb.scalar((L.sem2.b + 16 * L.sem_rbs) * 4);
         }
         __syncthreads();                           // feature / dir columns are dead: exchange areas may be written

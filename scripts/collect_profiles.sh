@@ -40,9 +40,9 @@ bash scripts/pmc_pass.sh ${tag}_tr_m GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ
 python scripts/pmc_report.py $OUT/prof/${tag}_tr_w $OUT/prof/${tag}_tr_f $OUT/prof/${tag}_tr_m > $OUT/${tag}_train_pmc_summary.txt 2>&1
 for p in w f m; do find $OUT/prof/${tag}_tr_$p -name "*counter_collection.csv" -exec cp {} $OUT/${tag}_train_pmc_$p.csv \; ; done
 python scripts/bench_train_kernels.py > $OUT/${tag}_train_kernels.txt 2>&1
-# 7. two ranks sharing this GPU over gloo (sharding + gather logic of bench.py --gpus N, both configs; numbers mean nothing)
-INERF_BENCH_SHARE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 \
-  bench.py --gpus 2 --steps 2 --warmup 1 > $OUT/${tag}_bench_n2_shared.json 2> $OUT/${tag}_bench_n2_shared.err
+# 7. two ranks sharing this GPU over gloo (sharding + gather logic of bench.py --gpus N, both configs; numbers mean nothing): plain
+#    `python bench.py --gpus 2` - it starts its own ranks through torch.distributed.run on 127.0.0.1
+INERF_BENCH_SHARE_GPU=1 timeout 900 python bench.py --gpus 2 --steps 2 --warmup 1 --cpu-baseline-quick > $OUT/${tag}_bench_n2_shared.json 2> $OUT/${tag}_bench_n2_shared.err
 # 8. trained-network evidence
 timeout 900 python scripts/fit_synthetic.py --out $OUT/${tag}_trained_network.txt > $OUT/${tag}_fit.log 2>&1
 # 9. full-frame PSNR delta (needs gpurun_in/psnr_full_frame_oracle.npz from `scripts/psnr_full_frame.py --oracle` in the build container)
