@@ -213,8 +213,7 @@ __device__ __forceinline__ float head_gradients(const BwdParams& p, int gp, bool
     return s;
 }
 
-// The same in two halves, for the two-workgroup chain: the 22 values are REQUESTED before the tile's fragment operands (160 KB per
-// workgroup, which would otherwise stand in front of them in the wave's vmcnt order) and used behind them.
+// The same in two halves (load, compute), for the two-workgroup chain.
 struct HeadInputs { float r[11], g[11]; };
 __device__ __forceinline__ void head_inputs(const BwdParams& p, int gp, HeadInputs& in) {
     const float* __restrict__ r = p.raw + (size_t)gp * p.channels;
@@ -773,13 +772,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_dgrad_dual(const BwdParams p) {
         asm volatile("" : "+v"(lane_s));
         const int lh = lane_s >> 5;
         // wave 0: raw / d_raw of its 64 points, requested FIRST (head_inputs)
-        HeadInputs hin;
         const bool s0_valid = wave == 0 && tile * kPts + lane_s < p.n_points;
-        if (s0_valid) head_inputs(p, tile * kPts + lane_s, hin);
-        else {
-#pragma unroll
-            for (int k = 0; k < 11; ++k) { hin.r[k] = 0.0f; hin.g[k] = 0.0f; }
-        }
         // the views hidden layer's activations (fragments of a 128-channel slot: this wave's channel block, four k-blocks), requested a stage ahead
         f16x8 act_vh[4][2];                  // [k-block][hi | lo]
         {
@@ -824,6 +817,11 @@ __global__ __launch_bounds__(256, 2) void k_mlp_dgrad_dual(const BwdParams p) {
             float dp[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
             float s = 1.0f;
             if (s0_valid) {
+                // (Requested here, behind the tile's fragment operands.  Requesting them FIRST - so that they do not queue behind 160 KB
+                // in the wave's vmcnt order - was no faster and made 2 % of the launches differ: k-block 3 of every slot of a
+                // workgroup's non-first tiles, profiles/r05_chain_head_inputs_first.txt; the cause was not found, the form was dropped.)
+                HeadInputs hin;
+                head_inputs(p, gp, hin);
                 s = head_gradients(p, gp, sem, hin, dp);
                 float* __restrict__ o = p.dz + p.off[SAVE_DPRE] + (size_t)gp * 8;
                 *reinterpret_cast<f32x4*>(o) = f32x4{dp[0], dp[1], dp[2], dp[3]};
