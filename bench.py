@@ -64,10 +64,11 @@ PEAK_F32_MFMA_TFLOPS = 157.3                 # MI355X_MICROARCH.md: dense fp32 m
 PEAK_F16_MFMA_TFLOPS = 2500.0                # MI355X_MICROARCH.md: dense f16/bf16 matrix peak
 MEASURED_F16_MFMA_ONLY_TFLOPS = 1590.0       # dense f16, random operands, 170-340 ms runs (zero operands: 2470)
 # HBM bytes per sample point of the encode+MLP kernels from the PMC passes (FETCH_SIZE + WRITE_SIZE, separate passes).
-# f16x3: profiles/r04_pmc_digest.txt, measured on the bench frame's own fine launch (640,000 rays x 192 samples):
-# 6341.9 MB per 122,880,000-point launch (algorithmic 5929.1 MB; round 3: 6230.5).  f32: profiles/r01_mlp_pmc_traffic.txt (kernel unchanged).
-PMC_HBM_BYTES_PER_POINT = {"f16x3": 51.6, "f32": 49.5}
-PMC_SOURCE = {"f16x3": ("profiles/r04_pmc_digest.txt", "1.07"), "f32": ("profiles/r01_mlp_pmc_traffic.txt", "1.02")}
+# f16x3: profiles/r05_pmc_digest.txt, measured on the bench frame's own fine launch (640,000 rays x 192 samples):
+# 7125.7 MB per 122,880,000-point launch (algorithmic 5929.1 MB; rounds 3 / 4: 6230.5 / 6341.9 - the 44-byte raw rows leave as 4-byte
+# non-temporal pieces and how many of them the write path combines varies from 1.05 to 1.20 x).  f32: profiles/r01_mlp_pmc_traffic.txt.
+PMC_HBM_BYTES_PER_POINT = {"f16x3": 58.0, "f32": 49.5}
+PMC_SOURCE = {"f16x3": ("profiles/r05_pmc_digest.txt", "1.20"), "f32": ("profiles/r01_mlp_pmc_traffic.txt", "1.02")}
 PARITY_RAYS = 4096
 RTOL, ATOL, RTOL_DISP = 1e-4, 1e-5, 5e-4
 PSNR_BUDGET_DB = 1e-4                        # north_star: <= 1e-4 dB PSNR delta against the reference
@@ -268,6 +269,11 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU) and hand back rank 0's line + exit code
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+    # stdout carries ONE line: rank 0's JSON.  Everything else this process or its libraries write to file descriptor 1 (gloo announces
+    # its connections there: "[Gloo] Rank 0 is connected to 1 peer ranks ...") goes to stderr from here on.
+    json_out = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush()
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -283,8 +289,9 @@ def main():
             dist.all_reduce(seen)
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({"launch_probe": True, "n_gpus": world, "ranks_seen": int(seen.item()) if world > 1 else 1,
-                              "steps": args.steps, "warmup": args.warmup, "local_rank": local_rank}))
+            json_out.write(json.dumps({"launch_probe": True, "n_gpus": world, "ranks_seen": int(seen.item()) if world > 1 else 1,
+                                       "steps": args.steps, "warmup": args.warmup, "local_rank": local_rank}) + "\n")
+            json_out.flush()
         raise SystemExit(int(os.environ.get("INERF_BENCH_LAUNCH_PROBE_RC", "0")) if rank == world - 1 else 0)
     # one process per GPU.  INERF_BENCH_SHARE_GPU=1 (debug only) lets several ranks share device 0 over gloo, to
     # exercise the sharding + gather logic on a single-GPU box; the numbers it prints mean nothing.
@@ -846,7 +853,7 @@ def main():
                                "exceed the budget or |delta| exceeds budget + 3 sigma.  All 640000 rays: profiles/r04_psnr_full_frame.txt")
 
     if rank == 0:
-        print(json.dumps({
+        json_out.write(json.dumps({
             "metric": "rays/sec (64+128 samples/ray)", "value": rays_per_s, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
@@ -858,8 +865,8 @@ def main():
                        "rays_per_step": n_total, "parallelism": f"ray-sharded x{world}",
                        "gather": "all_gather of 12 floats/ray" if world > 1 else "none"},
             "roofline": roofline, "strict_fp32": strict, "roofline_f32_kernel": roofline_f32, "exact_f32_path": exact, "parity": parity,
-            "configs": configs, "frame_costs": frame_costs, "f16_range_fallback": fallback, "train_step": train, "cpu_baseline": cpu}))
-        sys.stdout.flush()
+            "configs": configs, "frame_costs": frame_costs, "f16_range_fallback": fallback, "train_step": train, "cpu_baseline": cpu}) + "\n")
+        json_out.flush()
     n_bad = len(problems)
     if world > 1:
         # every rank learns rank 0's verdict and all leave together, with the same exit code (round 3: a parity failure made rank 0

@@ -37,8 +37,8 @@ def _run(args, **env):
 def test_plain_invocation_with_gpus_2_starts_two_ranks_and_prints_one_line():
     out = _run(["--gpus", "2", "--steps", "1", "--warmup", "1"])
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1, out.stdout          # ONE line on stdout: what gloo and the launcher say goes to stderr
     rec = json.loads(lines[0])
     assert rec == {"launch_probe": True, "n_gpus": 2, "ranks_seen": 2, "steps": 1, "warmup": 1, "local_rank": 0}
 
