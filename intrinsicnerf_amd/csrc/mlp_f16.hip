@@ -626,6 +626,13 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
             }
             if (L.sem_rb32 > 1) __syncthreads();           // (keeps the area's last readers ahead of the next tile's fetch-and-post)
         }
+        // Object-level network, whole tile: a wave's 16 points x 11 floats are 704 CONTIGUOUS bytes of raw.  They leave as 44 sixteen-byte
+        // pieces (lanes 0..43, via 44 bytes per point in dead columns of the lo plane) instead of 11 four-byte pieces per point: every
+        // 64-byte sector is written once, by one instruction.  (As 4-byte non-temporal pieces the rows cost 1.05-1.20 x their bytes in
+        // HBM writes, depending on how far the waves that share a 128-byte line had drifted apart: profiles/r05_pmc_digest.txt.)
+        const bool whole_rows = !kSsr && p.channels == INERF_BASE_CHANNELS && tile * kPts + kPts <= p.n_points &&
+                                (reinterpret_cast<uintptr_t>(p.raw) & 15) == 0;
+        auto stage_row = [&](int r) { return reinterpret_cast<float*>(ldsd + kPlaneD + r * kRowD + 128); };      // lo plane, bytes 256..299 of row r
         if (lane_t < 16 && my_valid) {
             const float* ex = reinterpret_cast<const float*>(ldsd + (16 * wave + lane_t) * kRowD + kColExD);
             f32x4 as4 = {0.0f, 0.0f, 0.0f, 0.0f}, res4 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -644,13 +651,30 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
             const float a0 = sigmoid_ref_h(as4[0]), a1 = sigmoid_ref_h(as4[1]), a2 = sigmoid_ref_h(as4[2]);
             const float sh = sigmoid_ref_h(as4[3]);
             const float r0 = sigmoid_ref_h(res4[0]), r1 = sigmoid_ref_h(res4[1]), r2 = sigmoid_ref_h(res4[2]);
-            __builtin_nontemporal_store(__fadd_rn(__fmul_rn(a0, sh), r0), out_row + 0);          // run_nerf_helpers.py:320
-            __builtin_nontemporal_store(__fadd_rn(__fmul_rn(a1, sh), r1), out_row + 1);
-            __builtin_nontemporal_store(__fadd_rn(__fmul_rn(a2, sh), r2), out_row + 2);
-            __builtin_nontemporal_store(sig4[0], out_row + 3);
-            __builtin_nontemporal_store(a0, out_row + 4); __builtin_nontemporal_store(a1, out_row + 5); __builtin_nontemporal_store(a2, out_row + 6);
-            __builtin_nontemporal_store(sh, out_row + 7);
-            __builtin_nontemporal_store(r0, out_row + 8); __builtin_nontemporal_store(r1, out_row + 9); __builtin_nontemporal_store(r2, out_row + 10);
+            const float c0 = __fadd_rn(__fmul_rn(a0, sh), r0), c1 = __fadd_rn(__fmul_rn(a1, sh), r1), c2 = __fadd_rn(__fmul_rn(a2, sh), r2);   // run_nerf_helpers.py:320
+            if (whole_rows) {
+                float* st = stage_row(16 * wave + lane_t);
+                *reinterpret_cast<f32x4*>(st) = f32x4{c0, c1, c2, sig4[0]};
+                *reinterpret_cast<f32x4*>(st + 4) = f32x4{a0, a1, a2, sh};
+                st[8] = r0; st[9] = r1; st[10] = r2;
+            } else {
+                __builtin_nontemporal_store(c0, out_row + 0);
+                __builtin_nontemporal_store(c1, out_row + 1);
+                __builtin_nontemporal_store(c2, out_row + 2);
+                __builtin_nontemporal_store(sig4[0], out_row + 3);
+                __builtin_nontemporal_store(a0, out_row + 4); __builtin_nontemporal_store(a1, out_row + 5); __builtin_nontemporal_store(a2, out_row + 6);
+                __builtin_nontemporal_store(sh, out_row + 7);
+                __builtin_nontemporal_store(r0, out_row + 8); __builtin_nontemporal_store(r1, out_row + 9); __builtin_nontemporal_store(r2, out_row + 10);
+            }
+        }
+        if (whole_rows && lane_t < 44) {      // (LDS is in order within a wave: the sixteen lanes' rows are there)
+            f32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = 4 * lane_t + i, pt = e / INERF_BASE_CHANNELS;
+                v[i] = stage_row(16 * wave + pt)[e - INERF_BASE_CHANNELS * pt];
+            }
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p.raw + (size_t)(tile * kPts + 16 * wave) * INERF_BASE_CHANNELS) + lane_t);
         }
     }
     const float amax_all = fmaxf(amax, fmaxf((float)amax2[0], (float)amax2[1]));
