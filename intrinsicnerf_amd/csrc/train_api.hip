@@ -207,20 +207,35 @@ Plan make_plan(const inerf_net_desc& net, int64_t n_points) {
 }
 
 // scalars: [0] dz_max  [1] gsem_max  [4..5] ranges {dz_max, act_max}  [8..9] sem ranges {gsem_max, act_max}
-__global__ void k_sem_pad(const float* __restrict__ d_raw, int channels, int n_classes, int rows, int64_t n_points,
-                          float* __restrict__ g, float* __restrict__ gmax) {
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    float v = 0.0f;
-    if (i < n_points * rows) {
-        const int64_t p = i / rows;
+// (One atomic per WAVE on one address made this copy of 200 MB take 2.1 ms of the SSR step's 13: 786 000 atomics on a single cache line
+// at ~2.7 ns each - the lesson of round 4's k_repack_gmax, missed here until round 5.  Now: a grid-stride loop over float4 pieces, one
+// maximum per workgroup through LDS, and an atomic only if that maximum beats what the word already holds.)
+__global__ __launch_bounds__(256) void k_sem_pad(const float* __restrict__ d_raw, int channels, int n_classes, int rows, int64_t n_points,
+                                                 float* __restrict__ g, float* __restrict__ gmax) {
+    __shared__ float wave_max[4];
+    const int64_t n4 = n_points * rows / 4;                  // rows is a multiple of 4: a piece never straddles a point
+    float m = 0.0f;
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n4; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = 4 * q, p = i / rows;
         const int c = (int)(i - p * rows);
-        v = c < n_classes ? d_raw[p * channels + INERF_BASE_CHANNELS + c] : 0.0f;
-        g[i] = v;
+        const float* src = d_raw + p * channels + INERF_BASE_CHANNELS;
+        f32x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = c + k < n_classes ? src[c + k] : 0.0f;
+            m = fmaxf(m, fabsf(v[k]));
+        }
+        *reinterpret_cast<f32x4*>(g + i) = v;
     }
-    float m = fabsf(v);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0 && m > 0.0f && m == m) atomicMax(reinterpret_cast<unsigned int*>(gmax), __builtin_bit_cast(unsigned int, m));
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+        // non-negative floats order like their bit patterns; NaN (m != m) is left out as before
+        if (m > 0.0f && m == m && m > *reinterpret_cast<volatile float*>(gmax)) atomicMax(reinterpret_cast<unsigned int*>(gmax), __builtin_bit_cast(unsigned int, m));
+    }
 }
 
 __global__ void k_ranges(float* __restrict__ s, const float* __restrict__ act_max) {
@@ -361,9 +376,10 @@ extern "C" int inerf_mlp_backward(const inerf_net_desc* net, const float* packed
     int rc = inerf_mlp_backward_inputs(net, packed_bwd, raw, d_raw, save, n_points, flags, dz, sc + 0, heads, status, stream);
     if (rc) return rc;
     if (sem) {
-        const int64_t n = n_points * plan.sem_rows;
-        hipLaunchKernelGGL(k_sem_pad, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_raw, channels, net->n_classes, plan.sem_rows,
-                           n_points, gsem, sc + 1);
+        const int64_t n4 = n_points * plan.sem_rows / 4;
+        const int64_t blocks = (n4 + 255) / 256;
+        hipLaunchKernelGGL(k_sem_pad, dim3((unsigned)(blocks < 8 * device_cus() ? blocks : 8 * device_cus())), dim3(256), 0, stream, d_raw, channels,
+                           net->n_classes, plan.sem_rows, n_points, gsem, sc + 1);
     }
     hipLaunchKernelGGL(k_ranges, dim3(1), dim3(64), 0, stream, sc, act_max);
     const Table& tb = cache.table;
