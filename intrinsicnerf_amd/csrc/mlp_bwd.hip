@@ -1045,13 +1045,31 @@ __global__ __launch_bounds__(256, 2) void k_mlp_dgrad_dual(const BwdParams p) {
                 f32x4 act = {0.0f, 0.0f, 0.0f, 0.0f};
                 if (valid) {
                     const float* gl = p.d_raw + (size_t)gp * ch + INERF_BASE_CHANNELS;       // logits: no activation
-                    for (int j = 0; j < p.n_classes; ++j) {
-                        const f32x4 w = *reinterpret_cast<const f32x4*>(p.wts + L.sem2_w + (size_t)j * kHalf + c4);
-                        const float gj = gl[j] * f[9];
+                    const float* wt = p.wts + L.sem2_w + c4;
+                    const float is = f[9];
+                    act = *reinterpret_cast<const f32x4*>(p.save + p.off[SAVE_SEMH] + (size_t)gp * kHalf + c4);
+                    // four classes per step: their five loads (one unaligned 16-byte piece of the point's logit gradients, four weight
+                    // rows) are in flight together - one class at a time every step waited for its own two loads (0.6 ms of the SSR step)
+                    int j = 0;
+                    for (; j + 4 <= p.n_classes; j += 4) {
+                        f32x4 g4;
+                        __builtin_memcpy(&g4, gl + j, 16);
+                        f32x4 w[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) w[q] = *reinterpret_cast<const f32x4*>(wt + (size_t)(j + q) * kHalf);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float gj = g4[q] * is;
+#pragma unroll
+                            for (int cc = 0; cc < 4; ++cc) v[cc] = __builtin_fmaf(w[q][cc], gj, v[cc]);
+                        }
+                    }
+                    for (; j < p.n_classes; ++j) {
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(wt + (size_t)j * kHalf);
+                        const float gj = gl[j] * is;
 #pragma unroll
                         for (int cc = 0; cc < 4; ++cc) v[cc] = __builtin_fmaf(w[cc], gj, v[cc]);
                     }
-                    act = *reinterpret_cast<const f32x4*>(p.save + p.off[SAVE_SEMH] + (size_t)gp * kHalf + c4);
                 }
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) v[cc] = act[cc] > 0.0f ? v[cc] : 0.0f;
