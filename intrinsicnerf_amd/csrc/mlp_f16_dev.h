@@ -21,11 +21,16 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // wave-uniform SGPR offset.  With plain 64-bit global addresses the compiler materialised a VGPR address
 // pair per layer, kept ~60 of them live across the tile loop and spilled them to scratch - whose 43 MB
 // footprint then thrashed the L2 the weights are supposed to stay in.
+// cache policy of the weight-fragment stream (bit 0 sc0, bit 1 nt, bit 4 sc1): every wave streams its own 650 KB per tile from L2.
+// Round 5, same box: nt 315 vs 410 TFLOP/s (the blob no longer stays in L2), sc0 neutral in all three MLP kernels; default kept.
+#ifndef INERF_WEIGHT_AUX
+#define INERF_WEIGHT_AUX 0
+#endif
 struct WeightBuf {
     __amdgpu_buffer_rsrc_t rsrc;
     int voff;                                     // lane * 16 bytes
     __device__ __forceinline__ f16x8 frag(int byte_off) const {          // byte_off: wave-uniform
-        return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, byte_off, 0));
+        return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, byte_off, INERF_WEIGHT_AUX));
     }
     __device__ __forceinline__ f32x4 vec4(int byte_off, int lane_bytes) const {   // small per-lane offset on top
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_bytes, byte_off, 0));
