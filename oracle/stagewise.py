@@ -184,7 +184,7 @@ def psnr(x, target):
     return float(-10.0 * np.log10(np.mean((x - target) ** 2)))
 
 
-def psnr_delta_db(hip, ref32, ref64, target_psnr_db=30.0, seed=0, detail=False):
+def psnr_delta_db(hip, ref32, ref64, target_psnr_db=30.0, seed=0, detail=False, n_targets=1):
     """PSNR(hip, T) - PSNR(ref32, T) in dB for a target T = ref64 + a FIXED pseudo-random perturbation sized so that the
     reference's own PSNR is ``target_psnr_db`` (no dataset image exists here; a trained IntrinsicNeRF reaches ~30 dB on
     its targets).  north_star: |delta| <= 1e-4 dB.
@@ -207,6 +207,17 @@ def psnr_delta_db(hip, ref32, ref64, target_psnr_db=30.0, seed=0, detail=False):
     k = 10.0 / np.log(10.0)
     # expectation of MSE(hip) - MSE(ref32) over the perturbation: the cross terms with it vanish, the distances to fp64 stay
     expected = float(np.mean((hip - ref64) ** 2) - np.mean((ref32 - ref64) ** 2))
-    return {"delta_db": delta, "systematic_db": -k * e2 / mse, "expected_db": -k * expected / mse,
-            "sampling_sigma_db": k * 2.0 * sigma_t * np.sqrt(e2 / hip.size) / mse,
-            "rms_hip_minus_reference": np.sqrt(e2), "values": int(hip.size)}
+    out = {"delta_db": delta, "systematic_db": -k * e2 / mse, "expected_db": -k * expected / mse,
+           "sampling_sigma_db": k * 2.0 * sigma_t * np.sqrt(e2 / hip.size) / mse,
+           "rms_hip_minus_reference": np.sqrt(e2), "values": int(hip.size)}
+    if n_targets > 1:
+        # the same statistic against n_targets independent perturbations of the fp64 maps: the cross term averages out like 1 / sqrt(n_targets),
+        # what stays is the delta's expectation - no additional rendering, only more targets
+        ds = [delta]
+        for j in range(1, n_targets):
+            t_j = ref64 + np.random.RandomState(seed + j).randn(*ref64.shape) * sigma_t
+            ds.append(psnr(hip, t_j) - psnr(ref32, t_j))
+        out["mean_delta_db_over_targets"] = float(np.mean(ds))
+        out["mean_delta_sigma_db"] = out["sampling_sigma_db"] / np.sqrt(n_targets)
+        out["targets"] = int(n_targets)
+    return out
