@@ -9,10 +9,12 @@ import oracle  # noqa: E402
 from intrinsicnerf_amd import _capi, kernels, packing  # noqa: E402
 import ctypes as C
 ap = argparse.ArgumentParser(); ap.add_argument("--launches", type=int, default=400); ap.add_argument("--rays", type=int, default=700); ap.add_argument("--samples", type=int, default=48)
+ap.add_argument("--ssr", type=int, default=-1); ap.add_argument("--endpoint", action="store_true")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
-desc = _capi.net_desc(_capi.VARIANT_OBJECT, 0, 10, 4, 1.0, _capi.PREC_F16X3)
-sd = {k: v.to(dev) for k, v in oracle.lcg_state_dict("object", 0, seed=23, sigma_gain_log2=3, freq_decay=True).items()}
+ssr = a.ssr >= 0
+desc = _capi.net_desc(_capi.VARIANT_SSR if ssr else _capi.VARIANT_OBJECT, max(a.ssr, 0), 10, 4, 10.0 if ssr else 1.0, _capi.PREC_F16X3)
+sd = {k: v.to(dev) for k, v in oracle.lcg_state_dict("ssr" if ssr else "object", max(a.ssr, 0), seed=23, sigma_gain_log2=3, freq_decay=True).items()}
 pf, pb = packing.device_packer(desc, False, dev)(sd), packing.device_packer(desc, True, dev)(sd)
 n, s = a.rays, a.samples
 g = torch.Generator().manual_seed(5)
@@ -21,9 +23,10 @@ d = -o / o.norm(dim=-1, keepdim=True) + 0.2 * torch.randn(n, 3, generator=g)
 rays = torch.cat([o, d, 2 * torch.ones(n, 1), 6 * torch.ones(n, 1), d / d.norm(dim=-1, keepdim=True)], -1).to(dev)
 z = torch.sort(torch.rand(n, s, generator=g) * 4 + 2, -1)[0].to(dev)
 p = n * s
-cot = torch.randn(p, 11, device=dev)
-raw, save = kernels.encode_mlp_train(desc, pf, rays, z)
-names = {2 + i: f"H{i}" for i in range(8)} | {10: "AS1H", 11: "FEAT", 12: "VH", 14: "DPRE", 0: "norm"}
+raw, save = kernels.encode_mlp_train(desc, pf, rays, z, endpoint=a.endpoint)
+ch = raw.shape[-1]
+cot = torch.randn(p, ch, device=dev)
+names = {2 + i: f"H{i}" for i in range(8)} | {10: "AS1H", 11: "FEAT", 12: "VH", 14: "DPRE", 0: "norm"} | ({13: "SEMH"} if ssr and a.ssr > 0 else {})
 tiles = (p + 63) // 64
 def slot(buf, k):
     off, width = C.c_int64(), C.c_int()
@@ -32,7 +35,7 @@ def slot(buf, k):
     return buf[off.value: off.value + n_el].view(torch.int32)
 ref, bad = None, 0
 for it in range(a.launches):
-    dz, heads = kernels.mlp_backward_inputs(desc, pb, raw.view(p, 11), cot, save, want_heads=True)
+    dz, heads = kernels.mlp_backward_inputs(desc, pb, raw.view(p, ch), cot, save, endpoint=a.endpoint, want_heads=True)
     cur = {k: slot(dz, k).clone() for k in names}
     cur["heads"] = heads.view(torch.int32).clone()
     if ref is None:
