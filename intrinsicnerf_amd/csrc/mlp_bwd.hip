@@ -5,7 +5,11 @@
 // Given d loss / d raw[P, CH] and the activations the training forward kept (k_encode_mlp_f16x3<.., kSave>,
 // layout.h SaveSlot), one launch walks every tile of 64 sample points backwards through the network and writes the
 // pre-activation gradient dZ of EVERY layer (same slot layout as the activations).  The weight gradients are then
-// plain GEMMs over the sample points, dW_l = dZ_l^T X_l with K = P, left to the caller (library GEMM).
+// plain GEMMs over the sample points, dW_l = dZ_l^T X_l with K = P (mlp_wgrad.hip; train_api.hip drives both).
+//
+// Two kernels, same packed weights, same slots, same results (tests/test_train_masks_gpu.py):
+//   k_mlp_dgrad_dual   (default)  4 waves x 64 channels x 64 points, ONE buffer updated in place, two workgroups per CU - further down;
+//   k_mlp_dgrad<.., 8>            8 waves x 32 channels x 64 points, two buffers (A / B), one workgroup per CU (INERF_DGRAD_KERNEL=single).
 //
 // Same machinery as the forward kernel (mlp_f16.hip): activations - here gradients - live in LDS as f16 hi/lo planes
 // X[point][channel], each layer is D[channel][point] = sum_k W^T[channel][k] X[point][k] on v_mfma_f32_32x32x16_f16
@@ -13,10 +17,10 @@
 // Differences:
 //   * gradients have no natural scale, so every point's chain is normalised by a power of two s_p >= its largest head
 //     gradient (exact; columns of a GEMM scale independently) and scaled back when dZ is written;
-//   * the ReLU masks of the trunk (h0..h6) are the bit words the training forward left behind the activation slots
-//     (layout.h relu_bits_offset: one 8-byte load per lane and layer instead of 64 floats); the stages that need the
-//     activations' VALUES anyway (h7 for the alpha_linear weight gradient - from its fragments, transposed back by the matrix
-//     core -, the three head hidden layers) read those;
+//   * the ReLU masks of the trunk are the bit words the training forward left behind the activation slots (layout.h
+//     relu_bits_offset: one 8-byte load per lane and layer instead of 64 floats; h0..h6 in the eight-wave kernel, h0..h7 in the
+//     two-workgroup one); the stages that need the activations' VALUES anyway (h7 for the alpha_linear weight gradient, the
+//     three head hidden layers) read their fragments;
 //   * the heads with 1-4 outputs (sigma, albedo/shading outputs, residual) are outer products: VALU, not MFMA;
 //   * the three matrices that feed d h7 (feature_linear^T, as1^T, sem1^T) share a weight scale and one accumulator.
 #include <cstdlib>
