@@ -1,6 +1,6 @@
 #!/bin/bash
 # Last lease of a round: smoke(), the GPU suite, the bench line, the headline kernel's HBM traffic and the training steps on the FINAL code
-#   bash scripts/gpu_final.sh r05      (writes gpurun_out/<tag>_final_*)
+#   bash scripts/gpu_final.sh r05      (writes gpurun_out/<tag>_final_*; FINAL_SHORT=1: smoke, suite and bench only)
 tag=${1:-rXX}
 export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-$PWD}
@@ -9,6 +9,7 @@ cd $REPO
 python -c 'import __graft_entry__ as g; g.build(); g.smoke()' > $OUT/${tag}_final_smoke.txt 2>&1; tail -1 $OUT/${tag}_final_smoke.txt
 ( time timeout 1500 python -m pytest tests -m gpu -q -x ) > $OUT/${tag}_final_pytest_gpu.log 2>&1; tail -5 $OUT/${tag}_final_pytest_gpu.log
 python bench.py --steps 5 --warmup 1 > $OUT/${tag}_final_bench.json 2> $OUT/${tag}_final_bench.err; tail -c 300 $OUT/${tag}_final_bench.err
+[ -n "$FINAL_SHORT" ] && exit 0          # (smoke + suite + bench only)
 export BENCH_SIZE="--rays 640000 --iters 2" BENCH_ARGS="--precision f16x3"
 bash scripts/pmc_pass.sh ${tag}f_fetch FETCH_SIZE
 bash scripts/pmc_pass.sh ${tag}f_write WRITE_SIZE
