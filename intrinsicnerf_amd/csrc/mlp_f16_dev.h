@@ -132,7 +132,7 @@ __device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const Weigh
                                             int col0, int col1, int lane, f32x16 (&am)[RB][PB]) {
     constexpr int KBT = KB0 + KB1;
     static_assert(KBT % 2 == 0 && KBT >= 4, "k-block count");
-    static_assert(PB == 2 || (PB == 1 && RB == 2), "point blocks");
+    static_assert(PB == 2 || (PB == 1 && RB == 2) || (PB == 4 && RB == 1), "point blocks");
     if constexpr (ZERO) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
@@ -184,8 +184,22 @@ __device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const Weigh
             _Pragma("unroll") for (int pb = 0; pb < PB; ++pb)                                                        \
                 am[rb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[(I) & 3][rb][1], x[(I) & 1][pb][0], am[rb][pb], 0, 0, 0); \
         /* issue order (masks: 0x8 MFMA, 0x20 VMEM read, 0x100 DS read).  PB = 2: MFMA, global load, MFMA, LDS read(s), MFMA - 2*RB  \
-           times; PB = 1 (RB = 2: 6 MFMAs, 4 global loads, 2 LDS reads): MFMA, global load, MFMA, global load, MFMA, LDS read - twice */ \
-        if constexpr (PB == 2) {                                                                                     \
+           times; PB = 1 (RB = 2: 6 MFMAs, 4 global loads, 2 LDS reads): MFMA, global load, MFMA, global load, MFMA, LDS read - twice; \
+           PB = 4 (RB = 1, the 128-point tile: 12 MFMAs, 2 global loads, 8 LDS reads): the LDS reads (needed one step ahead) first */ \
+        if constexpr (PB == 4) {                                                                                     \
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                         \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                   \
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                   \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                   \
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                   \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                   \
+            }                                                                                                        \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                       \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                       \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                       \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                       \
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                       \
+        } else if constexpr (PB == 2) {                                                                              \
             _Pragma("unroll") for (int q = 0; q < 2 * RB; ++q) {                                                    \
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                   \
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                   \
@@ -436,19 +450,20 @@ struct BitsDst {
     int off;                          // bytes: (((tile * kReluBitLayers + layer) * 4 + wave) * 64 + lane) * 8
 };
 
-template <int RB, int ROW = kRowH, int PLANE = kPlaneH, bool SAVE = false, bool BITS = false>
-__device__ __forceinline__ void wide_store_h(const f32x16 (&am)[RB][2], float inv, const f32x4 (&bias)[RB][4],
+template <int RB, int ROW = kRowH, int PLANE = kPlaneH, bool SAVE = false, bool BITS = false, int PB = 2>
+__device__ __forceinline__ void wide_store_h(const f32x16 (&am)[RB][PB], float inv, const f32x4 (&bias)[RB][4],
                                              _Float16* dl,   // plane_hi + (lane&31)*kRowH + 4*(lane>>5) + dcol + chan0
                                              bool relu, f16x2& amax2, float* gout /* or nullptr: + chan0 + 4*(lane>>5) */,
                                              int gstride, int valid0, int valid1, const SaveDst* sv = nullptr,
                                              const BitsDst* bd = nullptr) {
-    static_assert(!BITS || RB == 2, "mask words are defined for the 64-channel wave tile");
+    static_assert(!BITS || (RB == 2 && PB == 2), "mask words are defined for the 64-channel x 64-point wave tile");
+    static_assert(PB == 2 || !SAVE, "fp32 row copies are defined for the 64-point tile");
     unsigned mask[RB];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
         mask[rb] = 0u;
 #pragma unroll
-        for (int pb = 0; pb < 2; ++pb) {
+        for (int pb = 0; pb < PB; ++pb) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float t[4];

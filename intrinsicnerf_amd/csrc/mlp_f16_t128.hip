@@ -1,0 +1,269 @@
+// mlp_f16_t128.hip - the inference form of the split-f16 encode+MLP kernel on a 128-POINT tile (round 6).
+//
+// Why: in k_encode_mlp_f16x3_dual (mlp_f16.hip) every wave pulls 4 KiB of weight fragments from L2 per 12 MFMAs - 2.65 MB per
+// 64-point tile, 43 B/clk/CU at the full matrix rate against an L2 that delivers ~56 B/clk/CU with every CU asking - and the
+// matrix pipe waits for them a third of the time (profiles/r01_mfma_mix_microbench.txt, r06_weight_stream_*.txt).  Here ONE workgroup of
+// EIGHT waves walks 128 points through the same 14 GEMMs: a wave owns 32 output channels x all 128 points of a 256-wide layer
+// (1 row block x 4 point blocks), so a weight fragment feeds four point blocks instead of two - 2 KiB per 12 MFMAs, half the
+// L2 -> CU stream - and the operand reads that double instead (8 ds_read_b128 per 12 MFMAs) go to LDS, whose 256 B/clk for
+// that instruction is a quarter used.  151,552 B of LDS, one workgroup per CU, two waves per SIMD (<= 256 registers each).
+//
+// Same arithmetic, same summation order per output element as the 64-point kernels (the packed blob is the same one: wave
+// w8 reads row block w8 & 1 of packing wave w8 >> 1):  the results are bit-identical to k_encode_mlp_f16x3_dual's.  To keep
+// that true for the two heads whose hidden layers stay in registers (albedo | shading hidden, view-dependent hidden: their
+// output sums are formed per 64- / 32-channel group, in group order), those two layers keep the 64-point kernel's wave tile -
+// channel group w8 & 3 x point half w8 >> 2 - and stream their weights twice per tile (15 % of the FLOPs).
+#include <stdlib.h>
+
+#include "mlp_f16_dev.h"
+#include "mlp_f16_heads.h"
+
+namespace inerf {
+
+constexpr int kPtsT = 128;                       // points per tile
+constexpr int kPlaneT = kPtsT * kRowD;           // halfs per plane (rows of 296 halfs = 592 B: conflict-free ds_read_b128)
+constexpr int kLdsBytesT = 2 * kPlaneT * 2;      // 151,552
+
+template <bool kSsr>
+__global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParams p) {
+    static_assert(!kSsr, "object-level network (the SSR network renders through k_encode_mlp_f16x3_dual)");
+    constexpr int kParts = 512 / kPtsT;
+    extern __shared__ __attribute__((aligned(16))) _Float16 ldst[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..7
+    const int cg = wave & 3, ph = wave >> 2;                        // heads' hidden layers: channel group x point half
+    const NetLayout& L = p.L;
+    float amax = 0.0f;
+    f16x2 amax2 = {(_Float16)0.0f, (_Float16)0.0f};
+
+    _Float16* const xw = ldst + (lane & 31) * kRowD;
+    const _Float16* const xr = xw + 8 * (lane >> 5);                       // wide GEMM operand reads (+ column)
+    _Float16* const xd = xw + 4 * (lane >> 5) + 32 * wave;                 // wide stores: this wave's 32 channels
+    const _Float16* const xs = ldst + (16 * wave + (lane & 15)) * kRowD + 8 * (lane >> 4);   // skinny operand reads: this wave's 16 points
+
+    WeightBuf wb;
+    wb.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wts), 0, L.total_floats * 4, 0x00020000);
+    wb.voff = lane * 16;
+    // this wave's 32-channel stream of a 256-wide layer: row block (wave & 1) of packing wave (wave >> 1), k-blocks 4 KiB apart
+    auto frag32 = [&](const GemmSlot& s, int kbt) { return (s.w + (wave >> 1) * kbt * 2 * 2 * 256) * 4 + (wave & 1) * 2048; };
+    auto frag256 = [&](const GemmSlot& s, int kbt) { return (s.w + cg * kbt * 2 * 2 * 256) * 4; };       // 64-channel group cg
+    auto frag128 = [&](const GemmSlot& s, int kbt) { return (s.w + cg * kbt * 1 * 2 * 256) * 4; };       // 32-channel group cg of a 128-wide layer
+
+    WidePreH<1> pre1;
+    WidePreH<2> pre2;
+    prefetch_w<1, 4096>(pre1, wb, frag32(L.trunk[0], 4));
+
+    for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+        int lane_t = lane;                        // (laundered per tile: keeps the lane parts of per-tile offsets out of the loop-invariant set)
+        asm volatile("" : "+v"(lane_t));
+        // ---------------- encode -> hi/lo planes (xyz: columns 0..63, dir: columns 256..287) ----------------
+        auto encode = [&](bool with_dir) {
+            int tid_o = tid;
+            asm volatile("" : "+v"(tid_o));
+            const int pt = tid_o % kPtsT, part = tid_o / kPtsT;
+            int gp = tile * kPtsT + pt;
+            gp = gp < p.n_points ? gp : p.n_points - 1;
+            const int ray = gp / p.n_samples;
+            const float* __restrict__ r = p.rays + (size_t)ray * INERF_RAY_FLOATS;
+            const float zz = __builtin_nontemporal_load(p.z + gp);
+            _Float16* row = ldst + pt * kRowD;
+            float x[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                x[c] = __fadd_rn(r[c], __fmul_rn(r[3 + c], zz));                                // run_nerf.py:488
+                if (kSsr && p.xyz_div != 1.0f) x[c] = __fdiv_rn(x[c], p.xyz_div);              // semantic_nerf.py:64
+            }
+            for (int f = part; f < p.l_xyz; f += kParts) {
+                const float s = (float)(1 << f);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float sn, cs;
+                    fast_sincosf(x[c] * s, &sn, &cs);
+                    split_store<kPlaneT>(row + 3 + 6 * f + c, sn, amax);
+                    split_store<kPlaneT>(row + 6 + 6 * f + c, cs, amax);
+                }
+            }
+            if (part == 2) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) split_store<kPlaneT>(row + c, x[c], amax);
+                for (int c = 3 + 6 * p.l_xyz; c < kEncCols; ++c) { row[c] = (_Float16)0.0f; row[kPlaneT + c] = (_Float16)0.0f; }
+            }
+            if (with_dir) {
+                const int fd = kParts - 1 - part;
+                if (fd < p.l_dir) {
+                    const float s = (float)(1 << fd);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        float sn, cs;
+                        fast_sincosf(r[8 + c] * s, &sn, &cs);
+                        split_store<kPlaneT>(row + kColDirD + 3 + 6 * fd + c, sn, amax);
+                        split_store<kPlaneT>(row + kColDirD + 6 + 6 * fd + c, cs, amax);
+                    }
+                }
+                if (part == 3) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) split_store<kPlaneT>(row + kColDirD + c, r[8 + c], amax);
+                    for (int c = 3 + 6 * p.l_dir; c < kDirCols; ++c) { row[kColDirD + c] = (_Float16)0.0f; row[kPlaneT + kColDirD + c] = (_Float16)0.0f; }
+                }
+            }
+        };
+        encode(true);
+        __syncthreads();
+
+        // a 256-wide layer in place: GEMM over columns [0, 16*KBT) | barrier | store to columns [0, 256) | barrier
+        f32x16 am1[1][4];
+        f32x4 bias1[1][4];
+        float inv1;
+        auto store256 = [&](const GemmSlot& s, bool relu, auto&& prefetch_next) {
+            load_bias<1>(bias1, inv1, wb, (s.b + 32 * wave) * 4, (s.b + kWidth) * 4, lane);
+            prefetch_next();
+            __syncthreads();                       // every wave has read the layer's input
+            wide_store_h<1, kRowD, kPlaneT, false, false, 4>(am1, inv1, bias1, xd, relu, amax2, nullptr, 0, 0, 0);
+            __syncthreads();
+        };
+        auto pf32 = [&](const GemmSlot& s, int kbt) { return [&, kbt]() { prefetch_w<1, 4096>(pre1, wb, frag32(s, kbt)); }; };
+        auto pf32_at = [&](const GemmSlot& s, int kbt, int kb_first) {
+            return [&, kbt, kb_first]() { prefetch_w<1, 4096>(pre1, wb, frag32(s, kbt) + kb_first * 4096); };
+        };
+        auto pf256 = [&](const GemmSlot& s, int kbt) { return [&, kbt]() { prefetch_w<2>(pre2, wb, frag256(s, kbt)); }; };
+
+        // ---------------- trunk ----------------
+        wide_gemm_h<1, 4, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(L.trunk[0], 4), xr, 0, 0, lane, am1);
+        store256(L.trunk[0], true, pf32(L.trunk[1], 16));
+#pragma unroll 1
+        for (int layer = 1; layer < kSkipInput; ++layer) {
+            wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(L.trunk[layer], 16), xr, 0, 0, lane, am1);
+            if (layer + 1 < kSkipInput) store256(L.trunk[layer], true, pf32(L.trunk[layer + 1], 16));
+            else                        store256(L.trunk[layer], true, pf32_at(L.trunk[kSkipInput], 20, 4));
+        }
+        {   // pts_linears[5] over cat([pts, h]): h-part (k-blocks 4..19 of the stream), then the encoding again
+            const GemmSlot& s = L.trunk[kSkipInput];
+            wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(s, 20) + 4 * 4096, xr, 0, 0, lane, am1);
+            prefetch_w<1, 4096>(pre1, wb, frag32(s, 20));
+            __syncthreads();
+            encode(false);
+            __syncthreads();
+            wide_gemm_h<1, 4, 0, kRowD, kPlaneT, false, 4096, 4>(pre1, wb, frag32(s, 20), xr, 0, 0, lane, am1);
+            store256(s, true, pf32(L.trunk[6], 16));
+        }
+        wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(L.trunk[6], 16), xr, 0, 0, lane, am1);
+        store256(L.trunk[6], true, pf32(L.trunk[7], 16));
+        wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(L.trunk[7], 16), xr, 0, 0, lane, am1);
+        store256(L.trunk[7], true, pf256(L.as1, 16));
+
+        // ---------------- heads ----------------
+        const int my_pt = tile * kPtsT + 16 * wave + (lane_t & 15);
+        const bool my_valid = my_pt < p.n_points;
+        float* const out_row = p.raw + (size_t)(my_valid ? my_pt : 0) * p.channels;
+        const f32x4 sig4 = skinny_gemm_h<8, kPlaneT>(wb, L.alpha.w * 4, L.alpha.b * 4, (L.alpha.b + 16) * 4, xs, lane);
+
+        // albedo + shading: hidden layer (this wave: channel group cg of point half ph) -> registers -> partial output sums
+        f32x4 part_as[2], part_res[2];
+        const _Float16* const xr_h = xr + ph * 64 * kRowD;
+        {
+            f32x16 am2[2][2];
+            f32x4 bias2[2][4];
+            float inv2;
+            wide_gemm_h<2, 16, 0, kRowD, kPlaneT>(pre2, wb, frag256(L.as1, 16), xr_h, 0, 0, lane, am2);
+            load_bias<2>(bias2, inv2, wb, (L.as1.b + 64 * cg) * 4, (L.as1.b + kWidth) * 4, lane);
+            prefetch_w<1, 4096>(pre1, wb, frag32(L.feat, 16));
+            f16x8 hi[4][2], lo[4][2];
+            to_operands<2>(am2, inv2, bias2, amax2, hi, lo);
+            regop_gemm<4>(wb, (L.as2r.w + cg * 4 * 2 * 256) * 4, hi, lo, part_as);
+        }
+        // feature (no activation) in place of h7, then the view-dependent layer over [feature | dir] -> registers
+        wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(L.feat, 16), xr, 0, 0, lane, am1);
+        {
+            WidePreH<1> prev;
+            store256(L.feat, false, [&]() { prefetch_w<1>(prev, wb, frag128(L.views, 18)); });
+            f32x16 amv[1][2];
+            f32x4 biasv[1][4];
+            float invv;
+            wide_gemm_h<1, 18, 0, kRowD, kPlaneT>(prev, wb, frag128(L.views, 18), xr_h, 0, 0, lane, amv);
+            load_bias<1>(biasv, invv, wb, (L.views.b + 32 * cg) * 4, (L.views.b + kHalf) * 4, lane);
+            prefetch_w<1, 4096>(pre1, wb, frag32(L.trunk[0], 4));
+            f16x8 hi[2][2], lo[2][2];
+            to_operands<1>(amv, invv, biasv, amax2, hi, lo);
+            regop_gemm<2>(wb, (L.resr.w + cg * 2 * 2 * 256) * 4, hi, lo, part_res);
+        }
+        __syncthreads();                           // feature / dir columns are dead: the exchange area may be written
+        if (lane_t < 32) {
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                float* ex = reinterpret_cast<float*>(ldst + (lane_t + 32 * pb + 64 * ph) * kRowD + kColExD) + 8 * cg;
+                *reinterpret_cast<f32x4*>(ex) = part_as[pb];
+                *reinterpret_cast<f32x4*>(ex + 4) = part_res[pb];
+            }
+        }
+        __syncthreads();
+        // a wave's 16 points x 11 floats are 704 CONTIGUOUS bytes of raw: they leave as 44 sixteen-byte pieces (lanes 0..43, staged in
+        // dead columns of the lo plane), every 64-byte sector written once by one instruction
+        const bool whole_rows = p.channels == INERF_BASE_CHANNELS && tile * kPtsT + kPtsT <= p.n_points &&
+                                (reinterpret_cast<uintptr_t>(p.raw) & 15) == 0;
+        auto stage_row = [&](int r) { return reinterpret_cast<float*>(ldst + kPlaneT + r * kRowD + 128); };      // lo plane, bytes 256..299 of row r
+        if (lane_t < 16 && my_valid) {
+            const float* ex = reinterpret_cast<const float*>(ldst + (16 * wave + lane_t) * kRowD + kColExD);
+            f32x4 as4 = {0.0f, 0.0f, 0.0f, 0.0f}, res4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                as4 += *reinterpret_cast<const f32x4*>(ex + 8 * w);
+                res4 += *reinterpret_cast<const f32x4*>(ex + 8 * w + 4);
+            }
+            const f32x4 b_as = wb.vec4(L.as2.b * 4, 0), b_res = wb.vec4(L.res.b * 4, 0);
+            const float inv_as = wb.scalar((L.as2.b + 16) * 4), inv_res = wb.scalar((L.res.b + 16) * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                as4[i] = __builtin_fmaf(as4[i], inv_as, b_as[i]);
+                res4[i] = __builtin_fmaf(res4[i], inv_res, b_res[i]);
+            }
+            const float a0 = sigmoid_ref_h(as4[0]), a1 = sigmoid_ref_h(as4[1]), a2 = sigmoid_ref_h(as4[2]);
+            const float sh = sigmoid_ref_h(as4[3]);
+            const float r0 = sigmoid_ref_h(res4[0]), r1 = sigmoid_ref_h(res4[1]), r2 = sigmoid_ref_h(res4[2]);
+            const float c0 = __fadd_rn(__fmul_rn(a0, sh), r0), c1 = __fadd_rn(__fmul_rn(a1, sh), r1), c2 = __fadd_rn(__fmul_rn(a2, sh), r2);   // run_nerf_helpers.py:320
+            if (whole_rows) {
+                float* st = stage_row(16 * wave + lane_t);
+                *reinterpret_cast<f32x4*>(st) = f32x4{c0, c1, c2, sig4[0]};
+                *reinterpret_cast<f32x4*>(st + 4) = f32x4{a0, a1, a2, sh};
+                st[8] = r0; st[9] = r1; st[10] = r2;
+            } else {
+                __builtin_nontemporal_store(c0, out_row + 0);
+                __builtin_nontemporal_store(c1, out_row + 1);
+                __builtin_nontemporal_store(c2, out_row + 2);
+                __builtin_nontemporal_store(sig4[0], out_row + 3);
+                __builtin_nontemporal_store(a0, out_row + 4); __builtin_nontemporal_store(a1, out_row + 5); __builtin_nontemporal_store(a2, out_row + 6);
+                __builtin_nontemporal_store(sh, out_row + 7);
+                __builtin_nontemporal_store(r0, out_row + 8); __builtin_nontemporal_store(r1, out_row + 9); __builtin_nontemporal_store(r2, out_row + 10);
+            }
+        }
+        if (whole_rows && lane_t < 44) {      // (LDS is in order within a wave: the sixteen lanes' rows are there)
+            f32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = 4 * lane_t + i, pt = e / INERF_BASE_CHANNELS;
+                v[i] = stage_row(16 * wave + pt)[e - INERF_BASE_CHANNELS * pt];
+            }
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p.raw + (size_t)(tile * kPtsT + 16 * wave) * INERF_BASE_CHANNELS) + lane_t);
+        }
+        // (the next tile's encode writes bytes 0..127 and 512..575 of the rows, both planes: clear of the exchange area (hi plane, bytes
+        // 128..255) and of the staging rows (lo plane, bytes 256..299) this tile's last readers may still be in)
+    }
+    const float amax_all = fmaxf(amax, fmaxf((float)amax2[0], (float)amax2[1]));
+    if (p.status && __any(!(amax_all <= kF16Safe)) && lane == 0) atomicOr(p.status, INERF_STATUS_F16_RANGE);
+}
+
+int launch_mlp_f16x3_t128(MlpParams& p, int64_t n_points, hipStream_t stream) {
+    p.n_tiles = (int)((n_points + kPtsT - 1) / kPtsT);
+    const int grid = p.n_tiles < device_cus() ? p.n_tiles : device_cus();
+    void (*kern)(const MlpParams) = k_encode_mlp_f16x3_t128<false>;
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesT);
+        if (e != hipSuccess) return record(e);
+        attr_set.mark();
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), kLdsBytesT, stream, p);
+    return record(hipGetLastError());
+}
+
+}  // namespace inerf

@@ -4,11 +4,13 @@
 
     python scripts/fit_synthetic.py --save-weights gpurun_out/trained.pt        (on the GPU box: 3 000 steps on the analytic scene)
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_trained.py gpurun_out/trained.pt      (build container only)
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_trained.py                           (no checkpoint: the weights
+                                                                       stored in the existing fixture, other rays / more rays)
 
 The weights come from scripts/fit_synthetic.py - both networks fitted through the product's own training path (the
 reference's step, run_nerf.py:868-1027) to an analytic 5-blob scene, held-out view at 48.6 dB - and are stored IN the fixture
-(2 x 662 152 fp32 parameters).  Everything else is make_golden_uncurated.py's recipe: every k-th ray of the held-out 64x64
-view, nothing filtered; the reference's ``render_rays`` runs on them with its ``raw2outputs`` / ``sample_pdf`` wrapped so that
+(2 x 662 152 fp32 parameters).  Everything else is make_golden_uncurated.py's recipe: ALL 4 096 rays of the held-out 64x64
+view (round 6; until then every 8th), nothing filtered, raw rows of every 16th; the reference's ``render_rays`` runs on them with its ``raw2outputs`` / ``sample_pdf`` wrapped so that
 its own stage tensors are recorded; the oracle is asserted to reproduce every output and stage tensor bit for bit; the same
 arithmetic in fp64 is stored next to it.
 """
@@ -30,7 +32,7 @@ import oracle  # noqa: E402
 from oracle import calibration as cal  # noqa: E402
 
 
-def held_out_rays(H_ref, side=64, theta=40.0, every=8):
+def held_out_rays(H_ref, side=64, theta=40.0, every=1):
     focal = 0.5 * side / np.tan(0.5 * 0.6911112070083618)
     K = np.array([[focal, 0, 0.5 * side], [0, focal, 0.5 * side], [0, 0, 1]])
     ro, rd = H_ref.get_rays(side, side, K, mg.pose_spherical(theta, -30.0, 4.0)[:3, :4])
@@ -41,9 +43,14 @@ def held_out_rays(H_ref, side=64, theta=40.0, every=8):
 
 def main(path):
     run_nerf, H_ref, _, _, _ = mg.import_reference()
-    ck = torch.load(path, map_location="cpu")
-    sd_c = {k: v.float().contiguous() for k, v in ck["coarse"].items()}
-    sd_f = {k: v.float().contiguous() for k, v in ck["fine"].items()}
+    if path and os.path.exists(path):
+        ck = torch.load(path, map_location="cpu")
+        sd_c = {k: v.float().contiguous() for k, v in ck["coarse"].items()}
+        sd_f = {k: v.float().contiguous() for k, v in ck["fine"].items()}
+    else:           # the trained weights travel inside the fixture: regenerate it (other rays, more rays) from its own copy
+        old = np.load(os.path.join(HERE, "trained_object_chair.npz"))
+        sd_c, sd_f = ({k.split("/", 1)[1]: torch.from_numpy(np.array(old[k])) for k in old.files if k.startswith(f"w_{lvl}/")} for lvl in ("coarse", "fine"))
+        print(f"weights: the {len(sd_c)} + {len(sd_f)} tensors stored in trained_object_chair.npz")
     rays = held_out_rays(H_ref)
     n = rays.shape[0]
     cfg = oracle.RenderConfig(variant="object", n_samples=64, n_importance=128, white_bkgd=True)
@@ -75,9 +82,9 @@ def main(path):
     for k in ("z_samples", "weights_coarse", "weights_fine", "z_fine"):
         fx["stage_score_" + k] = cal.scaled_errors(mine[k].numpy(), m64[k].numpy())
     fx["stage_score_fine_pass_hazard"] = mu.fine_hazard(fx, rays, sd_f, cfg, mine, m64, pairs)
-    fx.update(cap.fixture_entries(mine, torch.arange(0, n, 4)))
+    fx.update(cap.fixture_entries(mine, torch.arange(0, n, 16)))
     mg.save("trained_object_chair", **fx)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(mg.REPO, "gpurun_out", "r03c_trained.pt"))
+    main(sys.argv[1] if len(sys.argv) > 1 else None)
