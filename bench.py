@@ -105,6 +105,16 @@ def overflow_above(net, pose, y_min, gain=1.0e6):
     return big
 
 
+def mlp_kernel_name(f16, ssr=False):
+    """Name of the encode+MLP kernel a launch of the default front-ends runs (what rocprofv3's kernel trace shows)."""
+    if not f16:
+        return "k_encode_mlp<true, 2>" if ssr else "k_encode_mlp<false, 2>"
+    form = os.environ.get("INERF_F16_KERNEL", "")[:1]
+    if ssr:
+        return "k_encode_mlp_f16x3<true, false>" if form == "s" else "k_encode_mlp_f16x3_dual<false, true, true>"
+    return {"s": "k_encode_mlp_f16x3<false, false>", "d": "k_encode_mlp_f16x3_dual<false, false, false>"}.get(form, "k_encode_mlp_f16x3_t128<false>")
+
+
 def host_description():
     """CPU model string, physical cores, logical CPUs available to this process."""
     model, cores = "unknown", set()
@@ -396,6 +406,40 @@ def main():
     rays_per_s = n_total * args.steps / dt
     ms_per_step = dt / args.steps * 1e3
 
+    # ---- the same frame through the reference's own call shape: chunk = 32768 (run_nerf.py:167, :559) ----
+    # object_level.batchify_rays merges eval-mode chunks up to a workspace cap (results are bit-identical for any chunking), so a
+    # drop-in caller that never heard of this library's chunk advice gets the frame in the same few launches as `value` does.
+    ref_chunking = None
+    if not args.no_extras:
+        seqs = []
+        real_fused = kernels.render_rays_fused
+        kernels.render_rays_fused = lambda d_, pc_, pf_, r_, *a_, **k_: (seqs.append(int(r_.shape[0])), real_fused(d_, pc_, pf_, r_, *a_, **k_))[1]
+        try:
+            def step_ck():
+                maps, _ = render_band(ro_l, rd_l, chunk=32768)
+                return idist.gather_maps(maps, n_total) if world > 1 else maps
+            step_ck()
+            seqs.clear()
+            fence()
+            t1 = time.perf_counter()
+            n_ck = max(1, min(args.steps, 10))
+            for _ in range(n_ck):
+                frame_ck = step_ck()
+            fence()
+            dt_ck_all = time.perf_counter() - t1
+        finally:
+            kernels.render_rays_fused = real_fused
+        if world > 1:
+            t = torch.tensor([dt_ck_all], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_ck_all = float(t.item())
+        ref_chunking = {"value": n_total * n_ck / dt_ck_all, "unit": "rays/s", "ms_per_step": dt_ck_all / n_ck * 1e3, "steps": n_ck,
+                        "vs_value": (n_total * n_ck / dt_ck_all) / rays_per_s, "chunk": 32768,
+                        "launch_sequences_per_frame": len(seqs) // n_ck, "rays_per_launch_sequence": seqs[:len(seqs) // n_ck],
+                        "bit_identical_to_the_timed_frame": bool(all(torch.equal(torch.nan_to_num(frame_ck[k]), torch.nan_to_num(frame[k])) for k in frame)),
+                        "note": "ol.render(..., chunk=32768) exactly as run_nerf.py:167 calls it (the reference's default chunk); eval mode, no "
+                                "raw returned: batchify_rays merges the caller's chunks up to INERF_COALESCE_BYTES (default 16 GiB) of workspace"}
+
     # ---- where a frame's wall time goes besides the kernels (untimed relative to `value`) ----
     def wall_and_gpu(fn, reps):
         fence()
@@ -492,7 +536,7 @@ def main():
                 durs += events_ms(lambda: kernels.encode_mlp(desc, packed, rays_l, z))[1]
         avg_ms = sum(durs) / len(durs)
         f16 = prec == _capi.PREC_F16X3
-        out = roofline_entry(f16, "k_encode_mlp_f16x3_dual<false, false, false>" if f16 else "k_encode_mlp<false, 2>",
+        out = roofline_entry(f16, mlp_kernel_name(f16),
                              flop_per_launch / (avg_ms * 1e-3) / 1e12, avg_ms, len(durs), flop_per_launch,
                              n_local * (N_SAMPLES + (N_SAMPLES + N_IMPORTANCE)) / 2.0)
         coarse_ms = sum(durs[0::2]) / len(durs[0::2])          # the coarse-shaped launches alone = configs[1]'s kernel
@@ -539,34 +583,53 @@ def main():
         focal = K[0][0]
         big = overflow_above(net_f, chair_pose(), y_min=FAR * (0.5 * H - 29.0) / focal)
         ck = 32768
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            render_band(ro_l, rd_l, chunk=ck); fence()
-            t1 = time.perf_counter()
-            render_band(ro_l, rd_l, chunk=ck); fence()
-            dt_ck = time.perf_counter() - t1                        # the same frame in the same chunks, nothing trips
+        n_chunks = (n_local + ck - 1) // ck
+
+        def tripped_frame(coalesce):
+            """(seconds of the same chunked frame untripped, seconds tripped, render_rays calls by precision, maps)"""
+            saved = os.environ.get("INERF_COALESCE_BYTES")
+            if not coalesce:
+                os.environ["INERF_COALESCE_BYTES"] = "0"
             calls = []
             real_rr = ol.render_rays
-            ol.render_rays = lambda rb, **k: (calls.append(_capi.default_precision()), real_rr(rb, **k))[1]
             try:
+                render_band(ro_l, rd_l, chunk=ck); fence()
+                t1 = time.perf_counter()
+                render_band(ro_l, rd_l, chunk=ck); fence()
+                dt_plain = time.perf_counter() - t1                        # the same frame through the same call, nothing trips
+                ol.render_rays = lambda rb, **k: (calls.append(_capi.default_precision()), real_rr(rb, **k))[1]
                 render_band(ro_l, rd_l, chunk=ck, network_fine=big); fence()
                 calls.clear()
                 t1 = time.perf_counter()
                 fmaps, _ = render_band(ro_l, rd_l, chunk=ck, network_fine=big)
                 fence()
-                dtf = time.perf_counter() - t1
+                return dt_plain, time.perf_counter() - t1, list(calls), fmaps
             finally:
                 ol.render_rays = real_rr
-        n_chunks = (n_local + ck - 1) // ck
+                if saved is None:
+                    os.environ.pop("INERF_COALESCE_BYTES", None)
+                else:
+                    os.environ["INERF_COALESCE_BYTES"] = saved
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            dt_ck, dtf, calls, fmaps = tripped_frame(coalesce=False)
+            dt_ck_m, dtf_m, calls_m, fmaps_m = tripped_frame(coalesce=True)
         fallback = {"ms_per_step": dtf * 1e3, "vs_f16x3_frame": dtf / (dt / args.steps), "vs_same_chunking_untripped": dtf / dt_ck,
                     "chunks": n_chunks, "chunk_rays": ck, "chunks_rerun_in_f32": sum(p == _capi.PREC_F32 for p in calls),
                     "f16x3_chunk_calls": sum(p == _capi.PREC_F16X3 for p in calls),
                     "finite": bool(torch.isfinite(fmaps["rgb_map"]).all()),
-                    "note": "800x800 frame in 20 chunks of 32768 rays whose fine network leaves the f16x3 activation range "
-                            "(|activation| >= 7.5e3) on rays of chunk 0 only: one read of the 20 range words at the end of the frame, "
-                            "then chunk 0 alone again in exact fp32 (round 2 re-rendered the whole frame: 4.18x); "
+                    "merged_chunks": {"ms_per_step": dtf_m * 1e3, "vs_f16x3_frame": dtf_m / (dt / args.steps),
+                                      "vs_same_call_untripped": dtf_m / dt_ck_m,
+                                      "f16x3_calls": sum(p == _capi.PREC_F16X3 for p in calls_m), "chunks_rerun_in_f32": sum(p == _capi.PREC_F32 for p in calls_m),
+                                      "same_frame_as_per_chunk": bool(all(torch.equal(torch.nan_to_num(fmaps_m[k]), torch.nan_to_num(fmaps[k])) for k in fmaps)),
+                                      "note": "the default front-end (eval-mode chunks merged): the merged launch trips, the caller's chunks are then "
+                                              "rendered one by one to find the one that left the range, and that one again in exact fp32"},
+                    "note": "800x800 frame in 20 chunks of 32768 rays (INERF_COALESCE_BYTES=0: the caller's chunks as given) whose fine network "
+                            "leaves the f16x3 activation range (|activation| >= 7.5e3) on rays of chunk 0 only: one read of the 20 range words at "
+                            "the end of the frame, then chunk 0 alone again in exact fp32 (round 2 re-rendered the whole frame: 4.18x); "
                             "INERF_PRECISION=f32 skips the attempt"}
-        del big
+        del big, fmaps, fmaps_m
 
     def ssr_frame_leg():
         """configs[3] (N = 1) / configs[4] (N > 1): the 320x240 Replica room_0-like frame through ssr.SSRRenderer.render_rays
@@ -637,7 +700,7 @@ def main():
         kernels.encode_mlp(sdesc, spk_f, chunk, sz)
         s_ms, s_durs = events_ms(lambda: kernels.encode_mlp(sdesc, spk_f, chunk, sz), 3)
         flop_s = FLOP_PER_POINT_SSR * chunk.shape[0] * (N_SAMPLES + N_IMPORTANCE)
-        out["roofline"] = roofline_entry(f16, "k_encode_mlp_f16x3_dual<false, true, true>" if f16 else "k_encode_mlp<true, 2>",
+        out["roofline"] = roofline_entry(f16, mlp_kernel_name(f16, ssr=True),
                                          flop_s / (s_ms * 1e-3) / 1e12, s_ms, len(s_durs), flop_s, chunk.shape[0] * (N_SAMPLES + N_IMPORTANCE))
         out["roofline"]["launch"] = f"fine pass of this rank's first chunk ({chunk.shape[0]} rays x 192) on the depths the frame itself resampled"
         return out
@@ -745,6 +808,8 @@ def main():
     # ---- CPU oracle on the sampled rays of the timed frame: cpu_baseline (its fp32 run, timed) + parity (fp32 and fp64) ----
     cpu = parity = None
     problems = []
+    if rank == 0 and ref_chunking is not None and not ref_chunking["bit_identical_to_the_timed_frame"]:
+        problems.append("the frame rendered through chunk=32768 (merged chunks) differs from the timed frame")
     if rank == 0 and os.environ.get("INERF_BENCH_INJECT_FAILURE") == "1":        # (tests the N > 1 failure path: every rank must exit non-zero, promptly)
         problems.append("injected failure (INERF_BENCH_INJECT_FAILURE=1)")
     if rank == 0 and not args.no_cpu_baseline:
@@ -811,16 +876,41 @@ def main():
         else:
             p_sel, p32, p64 = sel, o32, o64
         t_fp64 = time.perf_counter() - t1
-        e2e, staged, own, e2e_small = {}, {}, {}, {}
-        for fk, ok in (("rgb_map", "rgb_fine"), ("albedo_map", "albedo_fine"), ("shading_map", "shading_fine"), ("residual_map", "residual_fine")):
+        e2e, staged, own, e2e_small, e2e_f32k = {}, {}, {}, {}, {}
+        map_pairs = (("rgb_map", "rgb_fine"), ("albedo_map", "albedo_fine"), ("shading_map", "shading_fine"), ("residual_map", "residual_fine"))
+        # the same rays through the exact-fp32 MFMA kernel (INERF_PRECISION=f32): an INDEPENDENT fp32 implementation of the same path.  On
+        # this default-init network sample_pdf amplifies last-bit differences of the coarse weights (the reference's own fp32 result is
+        # 5e-4 .. 2e-3 dB from its fp64 evaluation), so where the default arithmetic lands against the reference is judged next to where
+        # another correct fp32 implementation lands.
+        f32k = None
+        if f16:
+            with _capi.forced_precision(_capi.PREC_F32):
+                f32k, _ = render_band(ro[p_sel].contiguous(), rd[p_sel].contiguous())
+        for fk, ok in map_pairs:
             hip = frame[fk].reshape(H * W, -1)[p_sel].cpu().numpy().reshape(p32[ok].shape)
             e2e[fk] = stagewise.psnr_delta_db(hip, p32[ok].numpy(), p64[ok].numpy(), detail=True, n_targets=16)
             own[fk] = stagewise.psnr_delta_db(p32[ok].numpy(), p64[ok].numpy(), p64[ok].numpy())
+            if f32k is not None:
+                e2e_f32k[fk] = stagewise.psnr_delta_db(f32k[fk].reshape(len(p_sel), -1).cpu().numpy().reshape(p32[ok].shape), p32[ok].numpy(),
+                                                       p64[ok].numpy(), detail=True, n_targets=16)
             hip_s = frame[fk].reshape(H * W, -1)[sel].cpu().numpy().reshape(o32[ok].shape)
             e2e_small[fk] = stagewise.psnr_delta_db(hip_s, o32[ok].numpy(), o64[ok].numpy(), detail=True)
             staged[fk] = stagewise.psnr_delta_db(got[ok].reshape(o32[ok].shape), o32[ok].numpy(), o64[ok].numpy())
+
+        def psnr_gate(tag, stats, allowance=None):
+            """The budget's four tests on one map's statistics; ``allowance``: the same statistics of an independent fp32 implementation
+            (each limit becomes max(budget, |its value| + 2e-5 dB)).  Returns the verdict entry; appends to ``problems``."""
+            lim = lambda key: PSNR_BUDGET_DB if allowance is None else max(PSNR_BUDGET_DB, abs(allowance[key]) + 2e-5)
+            tests = {"systematic_db": lim("systematic_db"), "expected_db": lim("expected_db"), "mean_delta_db_over_targets": lim("mean_delta_db_over_targets")}
+            bad = [f"{k} {stats[k]:.3g} dB beyond {v:.3g}" for k, v in tests.items() if abs(stats[k]) > v]
+            if abs(stats["delta_db"]) > lim("systematic_db") + 3.0 * stats["sampling_sigma_db"]:
+                bad.append(f"delta {stats['delta_db']:.3g} dB more than 3 sampling sigmas ({stats['sampling_sigma_db']:.3g}) beyond {lim('systematic_db'):.3g}")
+            problems.extend(f"PSNR delta ({tag}): {b_}" for b_ in bad)
+            return {"verdict": "fail" if bad else "pass", "limits_db": {**tests, "delta_db": lim("systematic_db") + 3.0 * stats["sampling_sigma_db"]},
+                    "within_the_plain_budget": bool(all(abs(stats[k]) <= PSNR_BUDGET_DB for k in tests)), "failed": bad}
+
         # PSNR in the reference is computed on rgb (run_nerf_helpers.py:11-12, run_nerf.py:976-985): that map first, with the
-        # sampling sigma of the estimate next to it; the other maps per_map
+        # sampling sigma of the estimate next to it; the other intrinsic maps (run_nerf.py:512-518) per_map, every one of them GATED
         rgb = e2e["rgb_map"]
         parity["psnr_rays"] = int(len(p_sel))
         parity["psnr_delta_db_rgb"] = rgb["delta_db"]
@@ -834,18 +924,15 @@ def main():
         parity["psnr_delta_db_max_over_maps"] = max(abs(v["delta_db"]) for v in e2e.values())
         parity["psnr_delta_db_systematic_max_over_maps"] = max(abs(v["systematic_db"]) for v in e2e.values())
         parity["psnr_delta_db_per_map"] = e2e
+        parity["psnr_delta_db_per_map_exact_f32_kernel"] = e2e_f32k or None
         parity["psnr_delta_db_per_map_on_the_parity_rays"] = e2e_small
         parity["psnr_delta_db_fine_pass_on_reference_depths"] = staged
         parity["psnr_oracle_fp32_vs_fp64_db"] = own
         parity["psnr_fp64_on_device"] = {"seconds": t_fp64, "abs_difference_from_the_host_fp64_run_on_the_parity_rays": dev_vs_host}
         parity["psnr_budget_db"] = PSNR_BUDGET_DB
-        if abs(rgb["systematic_db"]) > PSNR_BUDGET_DB or abs(rgb["expected_db"]) > PSNR_BUDGET_DB:
-            problems.append(f"PSNR delta (rgb): systematic part {rgb['systematic_db']:.3g} dB / expectation {rgb['expected_db']:.3g} dB "
-                            f"beyond the {PSNR_BUDGET_DB:g} dB budget on {len(p_sel)} rays")
-        if abs(rgb["mean_delta_db_over_targets"]) > PSNR_BUDGET_DB:
-            problems.append(f"PSNR delta (rgb), mean over 16 targets: {rgb['mean_delta_db_over_targets']:.3g} dB beyond the {PSNR_BUDGET_DB:g} dB budget")
-        if abs(rgb["delta_db"]) > PSNR_BUDGET_DB + 3.0 * rgb["sampling_sigma_db"]:
-            problems.append(f"PSNR delta (rgb): {rgb['delta_db']:.3g} dB is more than 3 sampling sigmas ({rgb['sampling_sigma_db']:.3g}) beyond the budget")
+        # rgb at the plain budget (as in every round); albedo / shading / residual at the plain budget OR, where the exact-fp32 kernel
+        # itself is beyond it on this network, at that independent fp32 implementation's own distance + 2e-5 dB
+        parity["psnr_verdicts"] = {fk: psnr_gate(fk, e2e[fk], None if fk == "rgb_map" else e2e_f32k.get(fk)) for fk, _ in map_pairs}
         if dev_vs_host["median"] > 1e-10 or dev_vs_host["rays_beyond_1e-6"] > 0.05 * len(dvh):
             problems.append(f"the fp64 oracle on the device differs from the host's: {dev_vs_host}")
         parity["psnr_note"] = ("PSNR(x, T) = -10 log10 mean (x - T)^2 (run_nerf_helpers.py:11-12) over psnr_rays rays of the TIMED frame (every "
@@ -855,14 +942,76 @@ def main():
                                "systematic (-mean (HIP - oracle32)^2 / MSE, always against HIP) + a cross term with the perturbation that is "
                                "zero-mean and shrinks with the pixel count (sampling_sigma_db); 'expected' = the delta's expectation over the "
                                "perturbation, mean (HIP - fp64)^2 - mean (oracle32 - fp64)^2 in dB; 'mean_over_16_targets' = the delta averaged over 16 "
-                               "independent perturbations (sigma / 4).  The run FAILS if |systematic|, |expected| or |mean over 16 targets| "
-                               "exceed the budget or |delta| exceeds budget + 3 sigma.  All 640000 rays: profiles/r04_psnr_full_frame.txt")
+                               "independent perturbations (sigma / 4).  psnr_verdicts: EVERY map (rgb, albedo, shading, residual) fails the run if "
+                               "|systematic|, |expected| or |mean over 16 targets| exceed its limit or |delta| exceeds limit + 3 sigma; the limit is the "
+                               "1e-4 dB budget for rgb, and for the other maps max(budget, the exact-fp32 kernel's own value on the same rays + 2e-5): "
+                               "on this default-init network an independent fp32 implementation of the path is itself ~1.1e-4 dB from the reference "
+                               "on those maps (psnr_delta_db_per_map_exact_f32_kernel; sample_pdf amplifies last-bit differences of the coarse "
+                               "weights), on a trained network nothing is (parity.trained).  All 640000 rays: profiles/r04_psnr_full_frame.txt")
+
+        # ---- the same judgement on a TRAINED network (tests/golden/trained_object_chair.npz: both networks fitted for 3000 steps through
+        # the product's own training path, held-out view 48.6 dB): the full 800x800 held-out view through the product front-end ----
+        fixture = os.path.join(REPO, "tests", "golden", "trained_object_chair.npz")
+        if os.path.exists(fixture):
+            t_tr = time.perf_counter()
+            fxw = np.load(fixture)
+            tsd = [{k.split("/", 1)[1]: torch.from_numpy(np.array(fxw[k])) for k in fxw.files if k.startswith(f"w_{lvl}/")} for lvl in ("coarse", "fine")]
+            tc, tf = mk(), mk()
+            tc.load_state_dict(tsd[0]); tf.load_state_dict(tsd[1])
+            render_band(ro, rd, network_fn=tc, network_fine=tf); fence()
+            t1 = time.perf_counter()
+            tmaps, _ = render_band(ro, rd, network_fn=tc, network_fine=tf)
+            fence()
+            t_frame = time.perf_counter() - t1
+            tsel = torch.arange(0, n_total, n_total // 32768 + 1, device=dev)[:32768]
+            tvd = rd[tsel] / rd[tsel].norm(dim=-1, keepdim=True)
+            trays = torch.cat([ro[tsel], rd[tsel], NEAR * torch.ones_like(tvd[:, :1]), FAR * torch.ones_like(tvd[:, :1]), tvd], -1)
+
+            def oracle_on_device(rays_dev, dtype):
+                sdc, sdf = ({k: v.to(dtype).to(dev) for k, v in sd.items()} for sd in tsd)
+                tv = torch.linspace(0., 1., N_SAMPLES, dtype=dtype).to(dev)
+                uu = torch.linspace(0., 1., N_IMPORTANCE, dtype=dtype).to(dev)
+                parts = []
+                with torch.no_grad():
+                    for i in range(0, rays_dev.shape[0], 8192):
+                        o = oracle.render_rays(rays_dev[i:i + 8192].to(dtype), sdc, sdf, pcfg, t_vals=tv, u=uu)
+                        parts.append({k: o[k].cpu() for k in pkeys + ("acc_fine", "disp_fine")})
+                return {k: torch.cat([q[k] for q in parts]) for k in parts[0]}
+
+            t64, t32 = oracle_on_device(trays, torch.float64), oracle_on_device(trays, torch.float32)
+            # the device's fp32 evaluation of the reference arithmetic against the HOST's (== the reference's own kernels) on a subset
+            sub = torch.arange(0, trays.shape[0], 16)
+            with torch.no_grad():
+                h32 = oracle.render_rays(trays[sub.to(dev)].cpu(), tsd[0], tsd[1], pcfg)
+            tstats, tverd, frac = {}, {}, {}
+            for fk, ok in map_pairs:
+                hip = tmaps[fk].reshape(H * W, -1)[tsel].cpu().numpy().reshape(t32[ok].shape)
+                tstats[fk] = stagewise.psnr_delta_db(hip, t32[ok].numpy(), t64[ok].numpy(), detail=True, n_targets=16)
+                tverd[fk] = psnr_gate("trained network, " + fk, tstats[fk])
+                frac[fk] = float((np.abs(hip - t32[ok].numpy()) <= ATOL + RTOL * np.abs(t32[ok].numpy())).all(-1).mean()) if hip.ndim > 1 else \
+                    float((np.abs(hip - t32[ok].numpy()) <= ATOL + RTOL * np.abs(t32[ok].numpy())).mean())
+            dev_host = {ok: float((t32[ok][sub] - h32[ok]).abs().max()) for _, ok in map_pairs}
+            acc_t = tmaps["acc_map"].reshape(-1)[tsel]
+            parity["trained"] = {
+                "weights": "tests/golden/trained_object_chair.npz (scripts/fit_synthetic.py: 3000 steps through the product's training path)",
+                "frame": f"{H}x{W} held-out view ({n_total} rays) through object_level.render, one frame {t_frame * 1e3:.1f} ms = {n_total / t_frame:.0f} rays/s",
+                "rays_judged": int(len(tsel)), "acc_quantiles": [float(torch.quantile(acc_t, q)) for q in (0.0, 0.1, 0.5, 0.9, 1.0)],
+                "psnr_delta_db_per_map": tstats, "psnr_verdicts": tverd,
+                "fraction_of_rays_within_the_plain_tolerance": frac,
+                "device_fp32_oracle_vs_host_fp32_oracle_max_abs": dev_host, "host_subset_rays": int(len(sub)),
+                "seconds": time.perf_counter() - t_tr,
+                "note": "delta = PSNR(HIP, T) - PSNR(fp32 oracle, T), T = fp64 oracle + the fixed 30 dB perturbation, on every "
+                        f"{n_total // len(tsel)}th ray of the frame; both oracle runs are the reference arithmetic evaluated by torch on the "
+                        "GPU (fp64 / fp32; the host's fp32 run - the reference's own CPU kernels - on every 16th of those rays differs from "
+                        "the device's by device_fp32_oracle_vs_host_fp32_oracle_max_abs); every map gated at the plain 1e-4 dB budget"}
+            del tmaps, tc, tf
 
     if rank == 0:
         json_out.write(json.dumps({
             "metric": "rays/sec (64+128 samples/ray)", "value": rays_per_s, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
+            "value_reference_chunking": None if ref_chunking is None else ref_chunking["value"], "reference_chunking": ref_chunking,
             "dtype": "f32 (operands split into f16 hi+lo, 3 f16 MFMA products per MAC, fp32 accumulate)" if f16 else "f32",
             "data": "synthetic",
             "config": {"workload": "Blender chair 800x800 frame (640000 rays), 64 coarse + 128 importance samples, "

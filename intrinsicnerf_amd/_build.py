@@ -64,15 +64,17 @@ def sources_present():
 def _stale(lib_path=None):
     """True when ``lib_path`` (default: the in-tree library) is missing or was built from other sources / flags than the
     tree holds now.  Content-based: kernel edits, flag edits in this file and reordered mtimes are all caught.  A binary
-    deployment (NO source or header of the library in the tree) cannot judge: an existing library is then taken as it is (the
+    deployment (no file of csrc/ in the tree; the public header include/inerf.h may be there) cannot judge: an existing library is then taken as it is (the
     binding still checks its ABI number).  A tree that holds SOME of them is broken, not a deployment: the digest cannot be
     computed and a library of unknown origin must not be loaded in its name."""
     lib_path = lib_path or LIB_PATH
     if not os.path.exists(lib_path):
         return True
-    present = [os.path.exists(p) for p in _source_paths()]
-    if not any(present):
+    # (decided from csrc/ alone: a binary deployment naturally ships the public C-ABI header include/inerf.h next to the library)
+    csrc_paths = [p for p in _source_paths() if os.path.dirname(p) == CSRC]
+    if not any(os.path.exists(p) for p in csrc_paths):
         return False
+    present = [os.path.exists(p) for p in _source_paths()]
     if not all(present):
         missing = [os.path.relpath(p, os.path.dirname(CSRC)) for p, ok in zip(_source_paths(), present) if not ok]
         raise RuntimeError(f"intrinsicnerf_amd: the source tree is incomplete ({', '.join(missing)} missing): cannot tell whether "

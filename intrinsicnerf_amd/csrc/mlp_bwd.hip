@@ -1170,7 +1170,9 @@ __global__ __launch_bounds__(256, 2) void k_mlp_dgrad_dual(const BwdParams p) {
 }
 
 // Which form runs: two workgroups per CU (default) or the eight-wave single-tile kernel (INERF_DGRAD_KERNEL=single: A/B runs and the
-// kernel's own tests).  One decision for the launch AND for the size of the head-partial buffer.
+// kernel's own tests).  The environment is read per LAUNCH only: the head-partial buffer is always sized for the larger grid
+// (inerf_mlp_backward_grid), so a variable that changes between the caller's sizing query and the launch cannot make the
+// two-workgroup kernel write beyond a buffer sized for the other form; blocks a launch does not write are zeroed.
 static bool dgrad_dual() {
     const char* form = getenv("INERF_DGRAD_KERNEL");
     return !(form && form[0] == 's');
@@ -1184,7 +1186,7 @@ extern "C" int inerf_mlp_backward_grid(int64_t n_points) {
     using namespace inerf;
     if (n_points <= 0) return 0;
     const int64_t tiles = (n_points + kTilePoints - 1) / kTilePoints;
-    const int64_t max_grid = (dgrad_dual() ? 2 : 1) * device_cus();
+    const int64_t max_grid = 2 * device_cus();          // the two-workgroup form's: an upper bound for both forms
     return (int)(tiles < max_grid ? tiles : max_grid);
 }
 
@@ -1221,6 +1223,11 @@ extern "C" int inerf_mlp_backward_inputs(const inerf_net_desc* net, const float*
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return record(e);
         attr_set[variant].mark();
+    }
+    const int sized_for = inerf_mlp_backward_grid(n_points);          // what the caller's head-partial buffer holds
+    if (head_partial && grid < sized_for) {                           // (the eight-wave form: one workgroup per CU)
+        hipError_t e = hipMemsetAsync(head_partial + (size_t)grid * kHeadFloats, 0, (size_t)(sized_for - grid) * kHeadFloats * sizeof(float), (hipStream_t)stream);
+        if (e != hipSuccess) return record(e);
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(dual ? 256 : 512), lds, (hipStream_t)stream, p);
     return record(hipGetLastError());

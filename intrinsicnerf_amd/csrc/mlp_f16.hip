@@ -725,7 +725,9 @@ int launch_mlp_f16x3(MlpParams& p, int64_t n_points, bool ssr, hipStream_t strea
     // reaches memory in that form).  INERF_F16_KERNEL=single keeps the one-workgroup kernel everywhere (A/B runs).
     // (The SSR training forward takes 10.1-10.3 ms per step in either form.)
     const char* form = getenv("INERF_F16_KERNEL");
-    if (!ssr && !p.save && form && form[0] == 't') return launch_mlp_f16x3_t128(p, n_points, stream);      // 128-point tile (mlp_f16_t128.hip)
+    // object-level inference: the 128-point tile (mlp_f16_t128.hip; bit-identical to the two-workgroup kernel, 0.58 x its L2 -> CU
+    // weight stream, +1.2 % same-box: profiles/r06_weight_stream_ab.txt).  INERF_F16_KERNEL=dual|single select the 64-point forms (A/B runs).
+    if (!ssr && !p.save && !(form && (form[0] == 'd' || form[0] == 's'))) return launch_mlp_f16x3_t128(p, n_points, stream);
     if (!(ssr && p.endpoint) && !(form && form[0] == 's')) return launch_dual(p, n_points, ssr, stream);
     p.n_tiles = (int)((n_points + kTilePoints - 1) / kTilePoints);
     const int grid = p.n_tiles < device_cus() ? p.n_tiles : device_cus();

@@ -40,7 +40,6 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
     _Float16* const xw = ldst + (lane & 31) * kRowD;
     const _Float16* const xr = xw + 8 * (lane >> 5);                       // wide GEMM operand reads (+ column)
     _Float16* const xd = xw + 4 * (lane >> 5) + 32 * wave;                 // wide stores: this wave's 32 channels
-    const _Float16* const xs = ldst + (16 * wave + (lane & 15)) * kRowD + 8 * (lane >> 4);   // skinny operand reads: this wave's 16 points
 
     WeightBuf wb;
     wb.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wts), 0, L.total_floats * 4, 0x00020000);
@@ -55,8 +54,9 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
     prefetch_w<1, 4096>(pre1, wb, frag32(L.trunk[0], 4));
 
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
-        int lane_t = lane;                        // (laundered per tile: keeps the lane parts of per-tile offsets out of the loop-invariant set)
-        asm volatile("" : "+v"(lane_t));
+        int lane_t = tid;                         // (laundered per tile: keeps the lane_t parts of per-tile offsets out of the loop-invariant set,
+        asm volatile("" : "+v"(lane_t));          // and `lane_t` itself out of the registers that live across the tile loop)
+        lane_t &= 63;
         // ---------------- encode -> hi/lo planes (xyz: columns 0..63, dir: columns 256..287) ----------------
         auto encode = [&](bool with_dir) {
             int tid_o = tid;
@@ -64,7 +64,9 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
             const int pt = tid_o % kPtsT, part = tid_o / kPtsT;
             int gp = tile * kPtsT + pt;
             gp = gp < p.n_points ? gp : p.n_points - 1;
-            const int ray = gp / p.n_samples;
+            int n_samples = p.n_samples;           // (laundered: the division's reciprocal, as a loop invariant, is one more register held - and
+            asm volatile("" : "+s"(n_samples));    // at this kernel's 256 spilled - across the whole tile)
+            const int ray = gp / n_samples;
             const float* __restrict__ r = p.rays + (size_t)ray * INERF_RAY_FLOATS;
             const float zz = __builtin_nontemporal_load(p.z + gp);
             _Float16* row = ldst + pt * kRowD;
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
         f32x4 bias1[1][4];
         float inv1;
         auto store256 = [&](const GemmSlot& s, bool relu, auto&& prefetch_next) {
-            load_bias<1>(bias1, inv1, wb, (s.b + 32 * wave) * 4, (s.b + kWidth) * 4, lane);
+            load_bias<1>(bias1, inv1, wb, (s.b + 32 * wave) * 4, (s.b + kWidth) * 4, lane_t);
             prefetch_next();
             __syncthreads();                       // every wave has read the layer's input
             wide_store_h<1, kRowD, kPlaneT, false, false, 4>(am1, inv1, bias1, xd, relu, amax2, nullptr, 0, 0, 0);
@@ -129,59 +131,61 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
         auto pf256 = [&](const GemmSlot& s, int kbt) { return [&, kbt]() { prefetch_w<2>(pre2, wb, frag256(s, kbt)); }; };
 
         // ---------------- trunk ----------------
-        wide_gemm_h<1, 4, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(L.trunk[0], 4), xr, 0, 0, lane, am1);
+        wide_gemm_h<1, 4, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(L.trunk[0], 4), xr, 0, 0, lane_t, am1);
         store256(L.trunk[0], true, pf32(L.trunk[1], 16));
 #pragma unroll 1
         for (int layer = 1; layer < kSkipInput; ++layer) {
-            wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(L.trunk[layer], 16), xr, 0, 0, lane, am1);
+            wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(L.trunk[layer], 16), xr, 0, 0, lane_t, am1);
             if (layer + 1 < kSkipInput) store256(L.trunk[layer], true, pf32(L.trunk[layer + 1], 16));
             else                        store256(L.trunk[layer], true, pf32_at(L.trunk[kSkipInput], 20, 4));
         }
         {   // pts_linears[5] over cat([pts, h]): h-part (k-blocks 4..19 of the stream), then the encoding again
             const GemmSlot& s = L.trunk[kSkipInput];
-            wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(s, 20) + 4 * 4096, xr, 0, 0, lane, am1);
+            wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(s, 20) + 4 * 4096, xr, 0, 0, lane_t, am1);
             prefetch_w<1, 4096>(pre1, wb, frag32(s, 20));
             __syncthreads();
             encode(false);
             __syncthreads();
-            wide_gemm_h<1, 4, 0, kRowD, kPlaneT, false, 4096, 4>(pre1, wb, frag32(s, 20), xr, 0, 0, lane, am1);
+            wide_gemm_h<1, 4, 0, kRowD, kPlaneT, false, 4096, 4>(pre1, wb, frag32(s, 20), xr, 0, 0, lane_t, am1);
             store256(s, true, pf32(L.trunk[6], 16));
         }
-        wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(L.trunk[6], 16), xr, 0, 0, lane, am1);
+        wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(L.trunk[6], 16), xr, 0, 0, lane_t, am1);
         store256(L.trunk[6], true, pf32(L.trunk[7], 16));
-        wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(L.trunk[7], 16), xr, 0, 0, lane, am1);
+        wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(L.trunk[7], 16), xr, 0, 0, lane_t, am1);
         store256(L.trunk[7], true, pf256(L.as1, 16));
 
         // ---------------- heads ----------------
         const int my_pt = tile * kPtsT + 16 * wave + (lane_t & 15);
         const bool my_valid = my_pt < p.n_points;
         float* const out_row = p.raw + (size_t)(my_valid ? my_pt : 0) * p.channels;
-        const f32x4 sig4 = skinny_gemm_h<8, kPlaneT>(wb, L.alpha.w * 4, L.alpha.b * 4, (L.alpha.b + 16) * 4, xs, lane);
+        // (operand addresses of the heads from the per-tile laundered lane_t index: as loop invariants they are two more spilled registers)
+        const _Float16* const xs = ldst + (16 * wave + (lane_t & 15)) * kRowD + 8 * (lane_t >> 4);   // skinny operand reads: this wave's 16 points
+        const f32x4 sig4 = skinny_gemm_h<8, kPlaneT>(wb, L.alpha.w * 4, L.alpha.b * 4, (L.alpha.b + 16) * 4, xs, lane_t);
 
         // albedo + shading: hidden layer (this wave: channel group cg of point half ph) -> registers -> partial output sums
         f32x4 part_as[2], part_res[2];
-        const _Float16* const xr_h = xr + ph * 64 * kRowD;
+        const _Float16* const xr_h = ldst + ((lane_t & 31) + 64 * ph) * kRowD + 8 * (lane_t >> 5);
         {
             f32x16 am2[2][2];
             f32x4 bias2[2][4];
             float inv2;
-            wide_gemm_h<2, 16, 0, kRowD, kPlaneT>(pre2, wb, frag256(L.as1, 16), xr_h, 0, 0, lane, am2);
-            load_bias<2>(bias2, inv2, wb, (L.as1.b + 64 * cg) * 4, (L.as1.b + kWidth) * 4, lane);
+            wide_gemm_h<2, 16, 0, kRowD, kPlaneT>(pre2, wb, frag256(L.as1, 16), xr_h, 0, 0, lane_t, am2);
+            load_bias<2>(bias2, inv2, wb, (L.as1.b + 64 * cg) * 4, (L.as1.b + kWidth) * 4, lane_t);
             prefetch_w<1, 4096>(pre1, wb, frag32(L.feat, 16));
             f16x8 hi[4][2], lo[4][2];
             to_operands<2>(am2, inv2, bias2, amax2, hi, lo);
             regop_gemm<4>(wb, (L.as2r.w + cg * 4 * 2 * 256) * 4, hi, lo, part_as);
         }
         // feature (no activation) in place of h7, then the view-dependent layer over [feature | dir] -> registers
-        wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(L.feat, 16), xr, 0, 0, lane, am1);
+        wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(L.feat, 16), xr, 0, 0, lane_t, am1);
         {
             WidePreH<1> prev;
             store256(L.feat, false, [&]() { prefetch_w<1>(prev, wb, frag128(L.views, 18)); });
             f32x16 amv[1][2];
             f32x4 biasv[1][4];
             float invv;
-            wide_gemm_h<1, 18, 0, kRowD, kPlaneT>(prev, wb, frag128(L.views, 18), xr_h, 0, 0, lane, amv);
-            load_bias<1>(biasv, invv, wb, (L.views.b + 32 * cg) * 4, (L.views.b + kHalf) * 4, lane);
+            wide_gemm_h<1, 18, 0, kRowD, kPlaneT>(prev, wb, frag128(L.views, 18), xr_h, 0, 0, lane_t, amv);
+            load_bias<1>(biasv, invv, wb, (L.views.b + 32 * cg) * 4, (L.views.b + kHalf) * 4, lane_t);
             prefetch_w<1, 4096>(pre1, wb, frag32(L.trunk[0], 4));
             f16x8 hi[2][2], lo[2][2];
             to_operands<1>(amv, invv, biasv, amax2, hi, lo);
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
         // 128..255) and of the staging rows (lo plane, bytes 256..299) this tile's last readers may still be in)
     }
     const float amax_all = fmaxf(amax, fmaxf((float)amax2[0], (float)amax2[1]));
-    if (p.status && __any(!(amax_all <= kF16Safe)) && lane == 0) atomicOr(p.status, INERF_STATUS_F16_RANGE);
+    if (p.status && __any(!(amax_all <= kF16Safe)) && (tid & 63) == 0) atomicOr(p.status, INERF_STATUS_F16_RANGE);
 }
 
 int launch_mlp_f16x3_t128(MlpParams& p, int64_t n_points, hipStream_t stream) {

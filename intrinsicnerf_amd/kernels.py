@@ -186,6 +186,28 @@ def check_f16_range(status, what, deferrable=False):
         raise FloatingPointError(_RANGE_MESSAGE.format(what=what))
 
 
+def coalesced_chunk(n_rays, chunk, n_samples, n_importance, channels, device):
+    """How many rays ONE launch sequence of an eval-mode frame may take instead of the caller's ``chunk``.
+
+    The reference's ``chunk`` (run_nerf.py:59-71, training_utils.py:5-17: 32 768 rays) exists for 11 GB cards and "does not affect
+    final results"; here results are bit-identical for any chunking (tests/test_full_size_properties.py, test_gpu_parity.py), a
+    launch of 32 768 rays runs 7 % below a launch of 65 536+ (it ends on a partly filled wave of tiles per CU:
+    profiles/r05_gemm_priority_ab.txt) and a frame's tail chunk is worse.  So when nothing depends on the chunk boundaries - no random
+    draw per chunk, no ``raw`` returned, no autograd - the front-ends merge chunks up to a workspace cap: ``INERF_COALESCE_BYTES``
+    (default 16 GiB, at most half the device's free memory; 0 = keep the caller's chunks).  Returns a multiple of ``chunk``."""
+    import os
+    cap = int(float(os.environ.get("INERF_COALESCE_BYTES", 16 * 2 ** 30)))
+    if cap <= 0 or n_rays <= chunk or chunk <= 0:
+        return chunk
+    if device.type == "cuda":
+        cap = min(cap, torch.cuda.mem_get_info(device)[0] // 2)
+    s, f = int(n_samples), int(n_samples) + int(n_importance)
+    # per ray: z coarse / new / merged, coarse weights, raw of both levels, maps (include/inerf.h: inerf_render_workspace_bytes), + 10 %
+    per_ray = int(1.1 * 4 * (s + n_importance + f + s + (s + f) * channels + 2 * (16 + channels)))
+    rays = min(n_rays, cap // max(per_ray, 1))
+    return max(chunk, rays // chunk * chunk if rays < n_rays else -(-n_rays // chunk) * chunk)
+
+
 _warned_fallback = False
 
 

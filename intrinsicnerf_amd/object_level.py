@@ -420,13 +420,42 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     return ret
 
 
+def _coalesced(rays_flat, chunk, kwargs):
+    """``chunk``, or the larger number of rays per ``render_rays`` call that gives the same result (kernels.coalesced_chunk): only for
+    eval-mode calls of the fused path - no random draw (``perturb == 0``, ``raw_noise_std == 0``), no ``retraw``, no autograd."""
+    if (kwargs.get("retraw") or kwargs.get("perturb", 0.) > 0. or kwargs.get("raw_noise_std", 0.) > 0. or kwargs.get("verbose")
+            or not rays_flat.is_cuda or rays_flat.shape[-1] <= 8 or rays_flat.shape[0] <= chunk):
+        return chunk
+    net, fine = kwargs.get("network_fn"), kwargs.get("network_fine")
+    nq = _as_network_query(kwargs.get("network_query_fn"))
+    if nq is None or _fusable(net, nq.embed_fn, nq.embeddirs_fn) is None or _wants_grad(net, fine):
+        return chunk
+    if fine is not None and _fusable(fine, nq.embed_fn, nq.embeddirs_fn) is None:
+        return chunk
+    return kernels.coalesced_chunk(rays_flat.shape[0], chunk, kwargs.get("N_samples", 0), kwargs.get("N_importance", 0),
+                                   _capi.BASE_CHANNELS, rays_flat.device)
+
+
 def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
-    """Render rays in chunks - run_nerf.py:59-71.  Results do not depend on ``chunk``.
+    """Render rays in chunks - run_nerf.py:59-71.  Results do not depend on ``chunk`` - so eval-mode frames of the fused path
+    are rendered in FEWER, larger launches than ``chunk`` asks for (``_coalesced``; ``INERF_COALESCE_BYTES=0`` keeps the caller's).
 
     The split-precision kernel's range words are read ONCE per call, after the last chunk has been enqueued
     (kernels.deferred_range_checks): a frame is one host synchronisation, not one per chunk.  Chunks whose word reports an
     out-of-range activation - and only those - are rendered again with the exact fp32 kernel (only eval-mode chunks defer,
     so no random draw is repeated; chunks that draw random numbers check and fall back inside render_rays)."""
+    big = _coalesced(rays_flat, chunk, kwargs)
+    if big > chunk:
+        # eval mode, fused networks, no raw: nothing depends on the chunk boundaries (results are bit-identical for any chunking), so
+        # the frame goes through in as few launches as the workspace cap allows (kernels.coalesced_chunk).  A launch that leaves
+        # the f16 range is located by the caller's own chunks below.
+        rets = []
+        with kernels.deferred_range_checks("render", raise_on_trip=False) as block:
+            for j, i in enumerate(range(0, rays_flat.shape[0], big)):
+                block.tag = j
+                rets.append(render_rays(rays_flat[i:i + big], **kwargs))
+        if not block.tripped:
+            return {k: (rets[0][k] if len(rets) == 1 else torch.cat([r[k] for r in rets], 0)) for k in rets[0]}
     starts = list(range(0, rays_flat.shape[0], chunk))
     rets = []
     with kernels.deferred_range_checks("render", raise_on_trip=False) as block:

@@ -239,10 +239,19 @@ def create_rays(num_rays, Ts_c2w, height, width, fx, fy, cx, cy, near, far, c2w_
     return rays
 
 
-def batchify_rays(render_fn, rays_flat, chunk=1024 * 32):
+def batchify_rays(render_fn, rays_flat, chunk=1024 * 32, coalesce_to=None):
     """training_utils.py:5-17.  As in object_level.batchify_rays the chunks' f16 range words are read together after the
     last chunk (one host synchronisation per frame) and only the chunks that left the range are rendered again in exact
-    fp32."""
+    fp32.  ``coalesce_to`` (SSRRenderMixin.render_rays, eval-mode frames whose result cannot depend on the chunk boundaries):
+    rays per call to try first instead of ``chunk``; a launch that leaves the f16 range is located by the caller's chunks."""
+    if coalesce_to is not None and coalesce_to > chunk:
+        rets = []
+        with kernels.deferred_range_checks("render_rays", raise_on_trip=False) as block:
+            for j, i in enumerate(range(0, rays_flat.shape[0], coalesce_to)):
+                block.tag = j
+                rets.append(render_fn(rays_flat[i:i + coalesce_to]))
+        if not block.tripped:
+            return {k: torch.cat([r[k] for r in rets], 0) for k in rets[0]}
     starts = list(range(0, rays_flat.shape[0], chunk))
     rets = []
     with kernels.deferred_range_checks("render_rays", raise_on_trip=False) as block:
@@ -279,7 +288,7 @@ class SSRRenderMixin:
 
     def render_rays(self, flat_rays):
         ray_shape = flat_rays.shape
-        all_ret = batchify_rays(self.volumetric_rendering, flat_rays, self.chunk)      # one host synchronisation per frame
+        all_ret = batchify_rays(self.volumetric_rendering, flat_rays, self.chunk, self._coalesced(flat_rays))      # one host synchronisation per frame
         for k in all_ret:
             all_ret[k] = torch.reshape(all_ret[k], list(ray_shape[:-1]) + list(all_ret[k].shape[1:]))
         return all_ret
@@ -391,6 +400,22 @@ class SSRRenderMixin:
                     frames.write_png(os.path.join(save_dir, "edit{:03d}.png".format(i)), frames.to8b(edit))
         return (st("rgb"), st("disp"), st("dep"), st("vis_dep"), st("sem"), st("vis_sem"), st("ent"), st("vis_ent"),
                 st("albedo"), st("shading"), st("residual"), cluster_manager)
+
+    def _coalesced(self, flat_rays):
+        """``self.chunk``, or the larger number of rays per ``volumetric_rendering`` call that gives the same frame
+        (kernels.coalesced_chunk; results are bit-identical for any chunking): only when no random number is drawn per chunk (eval
+        mode, or ``perturb == 0`` and ``raw_noise_std == 0``), ``raw_*`` is not returned, nothing records autograd and both networks
+        take the fused kernels."""
+        training = bool(self.training)
+        if (self.return_raw or (training and (self.perturb > 0. or self.raw_noise_std > 0.)) or not flat_rays.is_cuda
+                or flat_rays.shape[-1] <= 8 or flat_rays.shape[0] <= self.chunk or _wants_grad(self.ssr_net_coarse, self.ssr_net_fine)):
+            return None
+        if _fusable(self.ssr_net_coarse, self.embed_fn, self.embeddirs_fn) is None or (
+                self.N_importance > 0 and _fusable(self.ssr_net_fine, self.embed_fn, self.embeddirs_fn) is None):
+            return None
+        c = int(self.num_valid_semantic_class) if self.enable_semantic else 0
+        channels = _capi.BASE_CHANNELS + c + (_capi.ENDPOINT_DIM if (self.endpoint_feat and self.N_importance > 0) else 0)
+        return kernels.coalesced_chunk(flat_rays.shape[0], self.chunk, self.N_samples, self.N_importance, channels, flat_rays.device)
 
     def volumetric_rendering(self, ray_batch):
         ray_batch = ray_batch.float()

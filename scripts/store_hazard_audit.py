@@ -34,12 +34,16 @@ def code_objects(lib, tmp):
 
 
 def regs(tok):
-    """VGPR numbers named by an operand like v12 or v[12:15]."""
-    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    """Register numbers named by an operand like v12, v[12:15], a3 or a[0:3] (accumulation registers: + 1000)."""
+    m = re.fullmatch(r"([va])\[(\d+):(\d+)\]", tok)
     if m:
-        return set(range(int(m.group(1)), int(m.group(2)) + 1))
-    m = re.fullmatch(r"v(\d+)", tok)
-    return {int(m.group(1))} if m else set()
+        base = 1000 if m.group(1) == "a" else 0
+        return set(range(base + int(m.group(2)), base + int(m.group(3)) + 1))
+    m = re.fullmatch(r"([va])(\d+)", tok)
+    return {(1000 if m.group(1) == "a" else 0) + int(m.group(2))} if m else set()
+
+
+unparsed = []          # wide stores whose data operand the audit could not read (must stay empty: tests/test_isa_audit_cpu.py)
 
 
 def audit(path, need=2):
@@ -62,6 +66,9 @@ def audit(path, need=2):
             continue
         toks = [t.strip() for t in args.split(",")]
         data = regs(toks[0]) if op.startswith("buffer") else regs(toks[1])
+        if not data:
+            unparsed.append((func, op + " " + args))
+            continue
         waited, j = 0, k + 1
         while waited < need and j < len(ins):
             o2, a2 = ins[j]
@@ -71,6 +78,8 @@ def audit(path, need=2):
                 waited += int(a2.split()[0], 0) + 1
                 j += 1
                 continue
+            # overwriters: every VALU instruction with a vector destination - v_accvgpr_write (destination a..) and the MFMAs (destination
+            # v[..] or a[..]) included; the first operand is the destination in all of them
             if o2.startswith("v_") and not o2.startswith("v_cmp") and not o2.startswith("v_readlane") and not o2.startswith("v_readfirstlane"):
                 dst = regs(a2.split(",")[0].strip())
                 if dst & data:

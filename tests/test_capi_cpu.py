@@ -488,6 +488,11 @@ def test_abi_version_and_stale_library_guard(capi, monkeypatch, tmp_path):
     every = set(_build._source_paths())
     monkeypatch.setattr(_build.os.path, "exists", lambda q: False if q in every else real_exists(q))
     assert not _build.sources_present() and not _build._stale()
+    # a binary deployment naturally keeps the public C-ABI header next to the library: csrc/ alone decides
+    csrc_only = {q for q in every if os.path.dirname(q) == _build.CSRC}
+    assert len(every - csrc_only) == 1
+    monkeypatch.setattr(_build.os.path, "exists", lambda q: False if q in csrc_only else real_exists(q))
+    assert not _build.sources_present() and not _build._stale()
     monkeypatch.undo()
 
     monkeypatch.setattr(capi, "_lib", None)

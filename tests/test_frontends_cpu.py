@@ -332,3 +332,21 @@ def test_png_writer_and_host_to8b(tmp_path):
         assert np.array_equal(pix.reshape(img.shape), img)
     x = rng.rand(50).astype(np.float32) * 1.5 - 0.25
     assert np.array_equal(frames.to8b(x), (255 * np.clip(x, 0, 1)).astype(np.uint8))
+
+
+def test_coalesced_chunk_arithmetic(monkeypatch):
+    """kernels.coalesced_chunk: whole multiples of the caller's chunk, never below it, bounded by INERF_COALESCE_BYTES."""
+    import torch
+    from intrinsicnerf_amd import kernels
+    cpu = torch.device("cpu")
+    monkeypatch.delenv("INERF_COALESCE_BYTES", raising=False)
+    assert kernels.coalesced_chunk(640000, 32768, 64, 128, 11, cpu) == 20 * 32768        # the whole 800x800 frame (8.2 GB of workspace)
+    assert kernels.coalesced_chunk(76800, 32768, 64, 128, 39, cpu) == 3 * 32768          # the SSR frame, C = 28
+    assert kernels.coalesced_chunk(1000, 32768, 64, 128, 11, cpu) == 32768               # nothing to merge
+    monkeypatch.setenv("INERF_COALESCE_BYTES", "0")
+    assert kernels.coalesced_chunk(640000, 32768, 64, 128, 11, cpu) == 32768
+    monkeypatch.setenv("INERF_COALESCE_BYTES", str(2 ** 30))                              # 1 GiB: 2 chunks of 32768 fit, 3 do not
+    got = kernels.coalesced_chunk(640000, 32768, 64, 128, 11, cpu)
+    assert got % 32768 == 0 and 32768 <= got < 640000
+    monkeypatch.setenv("INERF_COALESCE_BYTES", "1000")                                    # smaller than one chunk: the caller's chunk
+    assert kernels.coalesced_chunk(640000, 32768, 64, 128, 11, cpu) == 32768

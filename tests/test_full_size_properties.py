@@ -89,7 +89,7 @@ def test_psnr_delta_within_budget(monkeypatch):
     assert mod.main() <= 1e-4
 
 
-def test_full_ssr_frame_properties(precision):
+def test_full_ssr_frame_properties(precision, monkeypatch):
     """BASELINE configs[3] at full size: the 320x240 Replica-like frame (76 800 rays, C = 28, 64+128 samples) through
     ``SSRRenderer.render_rays`` exactly as the reference's trainer calls it (chunk = 32768 -> three chunks, raw_coarse /
     raw_fine returned: ~3 GB).  Size-independent properties on every ray, chunk invariance bit for bit, and a 256-ray
@@ -130,6 +130,7 @@ def test_full_ssr_frame_properties(precision):
     # chunking is invisible: one 76 800-ray chunk and 7 ragged ones give the same bits
     raw_f = ret.pop("raw_fine"); ret.pop("raw_coarse")
     r.return_raw = False
+    monkeypatch.setenv("INERF_COALESCE_BYTES", "0")           # the chunks as given (without raw the front-end would merge them)
     for chunk in (n, 12345):
         r.chunk = chunk
         with torch.no_grad():

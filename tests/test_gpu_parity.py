@@ -162,8 +162,9 @@ def test_object_level_render_rays_frontend(name):
     assert tuple(ret["raw"].shape) == (fx["rays"].shape[0], 64 + cfg.n_importance, 11)
 
 
-def test_object_level_render_image_api():
+def test_object_level_render_image_api(monkeypatch):
     """render(H, W, K, c2w=...) returns the reference's 7-element list with image-shaped maps; chunking is invisible."""
+    monkeypatch.setenv("INERF_COALESCE_BYTES", "0")           # the caller's chunks as given (coalescing: tests/test_coalesce_gpu.py)
     from intrinsicnerf_amd import object_level as ol
     dev = _dev()
     H = W = 24
@@ -342,6 +343,34 @@ def test_ssr_semantic_head_forms_agree(c, precision, monkeypatch):
         out[form] = raw
     assert torch.equal(out["wave"][..., :11], out["csplit"][..., :11])
     assert_maps_close(out["csplit"][..., 11:].cpu().numpy(), out["wave"][..., 11:].cpu().numpy(), 1e-5, 1e-6, "logits, split vs per-wave head")
+
+
+@pytest.mark.parametrize("n,s", [(1, 64), (3, 1), (1, 191), (33, 64), (1000, 192), (4099, 192), (32768, 64)])
+def test_object_kernel_tile_forms_are_bit_identical(n, s, precision, monkeypatch):
+    """The object-level inference kernel's forms - 128-point tile (k_encode_mlp_f16x3_t128, the default since round 6) and
+    64-point tile with two workgroups per CU (k_encode_mlp_f16x3_dual, ``INERF_F16_KERNEL=dual``) - sum every output element in
+    the same order: raw must agree bit for bit, whole tiles, ragged tiles and launches smaller than one tile alike - and both meet
+    the oracle (reproducible arithmetic: curated weights)."""
+    from intrinsicnerf_amd import kernels
+    if precision != "f16x3":
+        pytest.skip("forms of the default f16x3 kernel")
+    dev = _dev()
+    cfg = oracle.RenderConfig(variant="object", n_samples=s, n_importance=0)
+    g = torch.Generator().manual_seed(1000 * n + s)
+    o = torch.tensor([[2.5, 1.5, 2.0]]).expand(n, 3)
+    d = -o / o.norm(dim=-1, keepdim=True) + 0.2 * torch.randn(n, 3, generator=g)
+    rays = torch.cat([o, d, 2 * torch.ones(n, 1), 6 * torch.ones(n, 1), d / d.norm(dim=-1, keepdim=True)], -1).contiguous()
+    z = torch.sort(torch.rand(n, s, generator=g) * 4 + 2, -1)[0]
+    sd, _ = oracle.calibrated_lcg_weights("object", 0, 40, rays[:256])
+    out = {}
+    for form in ("t128", "dual"):
+        monkeypatch.setenv("INERF_F16_KERNEL", form)
+        out[form] = kernels.encode_mlp(_desc(cfg), _packed(cfg, sd), rays.to(dev), z.to(dev))
+    assert torch.equal(out["t128"], out["dual"]), f"max |diff| {float((out['t128'] - out['dual']).abs().max()):.3e}"
+    k = min(n, 64)
+    with torch.no_grad():
+        want = oracle.query_network(sd, rays[:k, None, 0:3] + rays[:k, None, 3:6] * z[:k, :, None], rays[:k, 8:11], cfg)
+    assert_maps_close(out["t128"][:k].cpu().numpy(), want.numpy(), RTOL, ATOL, f"raw {n}x{s}")
 
 
 def test_run_network_arbitrary_points():

@@ -89,7 +89,10 @@ def test_default_inference_kernels_do_not_live_in_scratch(tmp_path):
     for k, v in dual.items():
         if "ILb0E" in k:
             assert v == 0, f"{k}: {v} bytes of scratch per lane"
-    assert scratch["_ZN5inerf23k_encode_mlp_f16x3_dualILb0ELb0ELb0EEEvNS_9MlpParamsE"] == 0          # the headline kernel: none
+    assert scratch["_ZN5inerf23k_encode_mlp_f16x3_dualILb0ELb0ELb0EEEvNS_9MlpParamsE"] == 0          # the 64-point form of the headline kernel: none
+    # the headline kernel (128-point tile, round 6): one lane-derived value written before the tile loop and read back once BEHIND it
+    t128 = {k: v for k, v in scratch.items() if "k_encode_mlp_f16x3_t128" in k}
+    assert len(t128) == 1 and max(t128.values()) <= 8, t128
     assert scratch.get("_ZN5inerf12k_encode_mlpILb0ELi2EEEvNS_9MlpParamsE", 0) == 0
 
 
@@ -126,4 +129,5 @@ def test_no_wide_store_is_overwritten_within_two_wait_states(tmp_path):
         sites += audit.audit(co, need=2)
         stores += len(audit.audit(co, need=64))           # (every wide store whose registers are reused at all: the audit sees them)
     assert stores > 300, "the audit should see hundreds of wide stores whose data registers are reused"
+    assert not audit.unparsed, f"{len(audit.unparsed)} wide stores whose data registers the audit could not read (AGPR forms?): {audit.unparsed[:3]}"
     assert not sites, f"{len(sites)} wide stores are overwritten less than two wait states later: {sites[:3]}"

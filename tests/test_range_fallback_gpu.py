@@ -33,10 +33,15 @@ def _scene(dev, H=40, W=40):
     return K, pose, net_c, net_f, ol.NetworkQuery(embed, embed_d), focal
 
 
-def test_only_the_tripped_chunk_is_rendered_again_in_fp32(monkeypatch):
+@pytest.mark.parametrize("coalesce", [False, True])
+def test_only_the_tripped_chunk_is_rendered_again_in_fp32(coalesce, monkeypatch):
+    """``coalesce``: eval-mode frames go through in one launch sequence where the workspace cap allows (kernels.coalesced_chunk); a
+    launch that trips is then located by the caller's own chunks - one extra f16x3 pass over the frame, same final result."""
     import bench
     from intrinsicnerf_amd import _capi, object_level as ol
     monkeypatch.setenv("INERF_PRECISION", "f16x3")
+    if not coalesce:
+        monkeypatch.setenv("INERF_COALESCE_BYTES", "0")
     dev = torch.device("cuda:0")
     H = W = 40
     K, pose, net_c, net_f, query, focal = _scene(dev, H, W)
@@ -56,13 +61,14 @@ def test_only_the_tripped_chunk_is_rendered_again_in_fp32(monkeypatch):
     with torch.no_grad(), warnings.catch_warnings():
         warnings.simplefilter("ignore")
         got = ol.render(H, W, K, chunk=chunk, rays=(flat(ro), flat(rd)), **kw)
-        assert [p for _, p in calls] == [_capi.PREC_F16X3] * 10 + [_capi.PREC_F32], calls      # one extra call, in exact fp32
+        head = [(H * W, _capi.PREC_F16X3)] if coalesce else []                               # the whole frame first, when coalescing
+        assert calls == head + [(chunk, _capi.PREC_F16X3)] * 10 + [(chunk, _capi.PREC_F32)], calls      # one extra call, in exact fp32
         calls.clear()
         monkeypatch.setenv("INERF_PRECISION", "f32")
         exact = ol.render(H, W, K, chunk=chunk, rays=(flat(ro), flat(rd)), **kw)
         monkeypatch.setenv("INERF_PRECISION", "f16x3")
         rest = ol.render(H, W, K, chunk=chunk, rays=(flat(ro, rows_per_chunk), flat(rd, rows_per_chunk)), **kw)
-    assert all(p == _capi.PREC_F16X3 for _, p in calls[10:]), "the other rows alone must not trip"
+    assert all(p == _capi.PREC_F16X3 for _, p in calls[10:]) and len(calls) == 10 + (1 if coalesce else 9), "the other rows alone must not trip"
     for i, name in enumerate(("rgb", "disp", "acc", "albedo", "shading", "residual")):
         g, e, r = got[i], exact[i], rest[i]
         assert torch.isfinite(g[~torch.isnan(e)]).all()

@@ -79,8 +79,12 @@ def test_mask_words_equal_saved_activations_and_gate_the_chain(variant, classes,
         assert torch.isfinite(gz).all() and float(gz.abs().max()) > 0
 
 
-def test_chain_repeats_bit_for_bit_over_many_launches():
-    """400 launches of the chain on the same inputs: every slot identical every time.  (A 16-byte buffer store with its SGPR
+@pytest.mark.parametrize("n,s,launches", [(700, 48, 400), (2048, 192, 300)])
+def test_chain_repeats_bit_for_bit_over_many_launches(n, s, launches):
+    """Hundreds of launches of the chain on the same inputs: every slot identical every time - on 525 tiles (two per workgroup) and on
+    the training step's own fine batch, 2048 x 192 = 6144 tiles, twelve per workgroup: the most sensitive detector of the round-5
+    corruption (a development form of k_mlp_dgrad_dual whose non-first tiles got rows 48..63 of the per-point scratch wrong differed
+    in 149 of 149 launches there, in 2 % of them on the small shape).  (A 16-byte buffer store with its SGPR
     offset in a register gets no wait state before its data registers are overwritten; the last row of the two VALU stages
     came out wrong in 4 % of the launches of the eight-wave form until the offset moved into the VGPR operand.)  The fragment
     slots are compared as the bytes they are."""
@@ -88,13 +92,12 @@ def test_chain_repeats_bit_for_bit_over_many_launches():
     desc = _capi.net_desc(_capi.VARIANT_OBJECT, 0, 10, 4, 1.0, _capi.PREC_F16X3)
     sd = {k: v.to(dev) for k, v in oracle.lcg_state_dict("object", 0, seed=23, sigma_gain_log2=3, freq_decay=True).items()}
     pf, pb = packing.device_packer(desc, False, dev)(sd), packing.device_packer(desc, True, dev)(sd)
-    n, s = 700, 48                      # 525 whole tiles: two per workgroup
     rays, z = _rays(n, s, dev, seed=5)
     p = n * s
     cot = torch.randn(p, 11, device=dev)
     raw, save = kernels.encode_mlp_train(desc, pf, rays, z)
     ref = None
-    for it in range(400):                # (round 5: a form of the two-workgroup chain that differed in 2 % of its launches passed 120 more than once)
+    for it in range(launches):           # (round 5: a form of the two-workgroup chain that differed in 2 % of its launches passed 120 more than once)
         dz, heads = kernels.mlp_backward_inputs(desc, pb, raw.view(p, 11), cot, save, want_heads=True)
         views = kernels.save_slot_views(desc, dz, p, gradient=True)
         first, last = _slot_range(desc, p, kernels.SAVE_H0, kernels.SAVE_FEAT)
@@ -106,7 +109,8 @@ def test_chain_repeats_bit_for_bit_over_many_launches():
             assert torch.equal(a, b), f"launch {it}: part {slot} differs at {int((a != b).sum())} elements"
 
 
-@pytest.mark.parametrize("variant,classes,endpoint,n,s", [("object", 0, False, 700, 37), ("ssr", 28, False, 300, 23), ("ssr", 5, True, 64, 9)])
+@pytest.mark.parametrize("variant,classes,endpoint,n,s", [("object", 0, False, 700, 37), ("ssr", 28, False, 300, 23), ("ssr", 5, True, 64, 9),
+                                                          ("object", 0, False, 2048, 192)])
 def test_two_workgroup_chain_equals_the_eight_wave_chain(variant, classes, endpoint, n, s, monkeypatch):
     """k_mlp_dgrad_dual (4 waves x 64 channels, in place, two tiles per CU) against k_mlp_dgrad (8 waves, A/B buffers): the same
     GEMMs in the same k order and the same epilogue arithmetic, so every dZ slot holds the same f16 VALUES - except where h7 sits below the
@@ -143,7 +147,8 @@ def test_two_workgroup_chain_equals_the_eight_wave_chain(variant, classes, endpo
         return torch.where(h == 0x8000, torch.zeros_like(h), h)
     a, b = halves(out["single"][0]), halves(out["dual"][0])
     differ = int((a != b).sum())
-    assert differ <= 64, f"{differ} of {a.numel()} gradient words differ between the two chains"
+    # (the floor cases scale with the batch; a corrupted tile row is 4 096+ words per tile)
+    assert differ <= 64 + a.numel() // 2_000_000, f"{differ} of {a.numel()} gradient words differ between the two chains"
     assert out["single"][2] == pytest.approx(out["dual"][2], rel=1e-6)
     hs, hd = out["single"][1], out["dual"][1]
     scale = float(hs.abs().max())
