@@ -623,8 +623,8 @@ def main():
                                       "vs_same_call_untripped": dtf_m / dt_ck_m,
                                       "f16x3_calls": sum(p == _capi.PREC_F16X3 for p in calls_m), "chunks_rerun_in_f32": sum(p == _capi.PREC_F32 for p in calls_m),
                                       "same_frame_as_per_chunk": bool(all(torch.equal(torch.nan_to_num(fmaps_m[k]), torch.nan_to_num(fmaps[k])) for k in fmaps)),
-                                      "note": "the default front-end (eval-mode chunks merged): the merged launch trips, the caller's chunks are then "
-                                              "rendered one by one to find the one that left the range, and that one again in exact fp32"},
+                                      "note": "the default front-end: the eval-mode chunks merged into one launch sequence that keeps one range word "
+                                              "per caller's chunk (inerf_encode_mlp_chunked); chunk 0 alone again in exact fp32"},
                     "note": "800x800 frame in 20 chunks of 32768 rays (INERF_COALESCE_BYTES=0: the caller's chunks as given) whose fine network "
                             "leaves the f16x3 activation range (|activation| >= 7.5e3) on rays of chunk 0 only: one read of the 20 range words at "
                             "the end of the frame, then chunk 0 alone again in exact fp32 (round 2 re-rendered the whole frame: 4.18x); "
@@ -958,10 +958,11 @@ def main():
             tsd = [{k.split("/", 1)[1]: torch.from_numpy(np.array(fxw[k])) for k in fxw.files if k.startswith(f"w_{lvl}/")} for lvl in ("coarse", "fine")]
             tc, tf = mk(), mk()
             tc.load_state_dict(tsd[0]); tf.load_state_dict(tsd[1])
-            render_band(ro, rd, network_fn=tc, network_fine=tf); fence()
+            render_band(ro, rd, network_fn=tc, network_fine=tf)
+            torch.cuda.synchronize()               # (rank 0 alone is here: no collective, no fence())
             t1 = time.perf_counter()
             tmaps, _ = render_band(ro, rd, network_fn=tc, network_fine=tf)
-            fence()
+            torch.cuda.synchronize()
             t_frame = time.perf_counter() - t1
             tsel = torch.arange(0, n_total, n_total // 32768 + 1, device=dev)[:32768]
             tvd = rd[tsel] / rd[tsel].norm(dim=-1, keepdim=True)

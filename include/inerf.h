@@ -30,7 +30,7 @@ extern "C" {
 #define INERF_VERSION_MINOR 2
 /* Bumped whenever a struct layout, an argument list or the packed-weight format of this header changes; bindings
  * compare it with inerf_abi_version() of the library they loaded (a stale .so then fails loudly, not silently). */
-#define INERF_ABI_VERSION 40006
+#define INERF_ABI_VERSION 40007
 
 /* error codes */
 #define INERF_OK              0
@@ -132,6 +132,14 @@ int64_t inerf_encode_mlp_workspace_bytes(const inerf_net_desc* net, int64_t n_ra
 int inerf_encode_mlp_ws(const inerf_net_desc* net, const float* packed_weights, const float* rays, const float* z_vals,
                         int64_t n_rays, int n_samples, uint32_t flags, float* raw_out, int32_t* status, void* workspace,
                         int64_t workspace_bytes, void* stream);
+/* The same with ONE STATUS WORD PER `status_rays` RAYS: `status` then points at ceil(n_rays / status_rays) device words (caller
+ * zeroes them) and word w collects the INERF_STATUS_* bits of rays [w * status_rays, (w + 1) * status_rays).  The front-ends render
+ * an eval-mode frame as one launch whatever `chunk` the caller of batchify_rays (run_nerf.py:59-71, training_utils.py:5-17) asked
+ * for and still learn WHICH of the caller's chunks left the f16 range - only that one is rendered again in exact fp32.
+ * status_rays <= 0: one word, as inerf_encode_mlp_ws. */
+int inerf_encode_mlp_chunked(const inerf_net_desc* net, const float* packed_weights, const float* rays, const float* z_vals,
+                             int64_t n_rays, int n_samples, uint32_t flags, float* raw_out, int32_t* status, int64_t status_rays,
+                             void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Training: what autograd records for the network when the trainers call loss.backward()
@@ -359,6 +367,8 @@ typedef struct inerf_render_args {
     float* z_samples;             /* [N,n_importance]                                               */
     float* z_fine;                /* [N,n_samples+n_importance]                                     */
     int32_t* status;              /* optional device word for INERF_STATUS_* bits (caller zeroes it) */
+    int64_t  status_rays;         /* <= 0: one status word; > 0: ceil(n_rays / status_rays) words, one per that many rays
+                                     (inerf_encode_mlp_chunked)                                     */
     /* scratch */
     void*   workspace;
     int64_t workspace_bytes;

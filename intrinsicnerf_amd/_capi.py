@@ -10,7 +10,7 @@ import os
 from . import _build
 from ._build import LIB_PATH
 
-ABI_VERSION = 40006          # INERF_ABI_VERSION of include/inerf.h these ctypes declarations mirror
+ABI_VERSION = 40007          # INERF_ABI_VERSION of include/inerf.h these ctypes declarations mirror
 
 OK, E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_HIP = 0, -1, -2, -3, -4
 VARIANT_OBJECT, VARIANT_SSR = 0, 1
@@ -42,7 +42,7 @@ class RenderArgs(C.Structure):
                 ("noise_coarse", C.c_void_p), ("noise_fine", C.c_void_p),
                 ("coarse", CompositeOut), ("fine", CompositeOut), ("z_std", C.c_void_p),
                 ("raw_coarse", C.c_void_p), ("raw_fine", C.c_void_p), ("z_coarse", C.c_void_p),
-                ("z_samples", C.c_void_p), ("z_fine", C.c_void_p), ("status", C.c_void_p),
+                ("z_samples", C.c_void_p), ("z_fine", C.c_void_p), ("status", C.c_void_p), ("status_rays", C.c_int64),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
 
 
@@ -62,6 +62,7 @@ SYMBOLS = {
     "inerf_encode_mlp": (_I, [C.POINTER(NetDesc), _P, _P, _P, _L, _I, _U, _P, _P, _P]),
     "inerf_encode_mlp_workspace_bytes": (_L, [C.POINTER(NetDesc), _L, _I, _U]),
     "inerf_encode_mlp_ws": (_I, [C.POINTER(NetDesc), _P, _P, _P, _L, _I, _U, _P, _P, _P, _L, _P]),
+    "inerf_encode_mlp_chunked": (_I, [C.POINTER(NetDesc), _P, _P, _P, _L, _I, _U, _P, _P, _L, _P, _L, _P]),
     "inerf_mlp_save_floats": (_L, [C.POINTER(NetDesc), _L]),
     "inerf_mlp_save_slot": (_I, [C.POINTER(NetDesc), _I, _L, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "inerf_encode_mlp_train": (_I, [C.POINTER(NetDesc), _P, _P, _P, _L, _I, _U, _P, _P, _P, _P, _P]),

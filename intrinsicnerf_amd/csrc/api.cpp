@@ -91,7 +91,7 @@ extern "C" int inerf_render_rays(const inerf_render_args* a, void* stream) {
     if (rc) return rc;
     float* raw_c = a->raw_coarse ? a->raw_coarse : f(p.raw_c);
     // the coarse net never emits the endpoint feature (trainer.py:751-755: endpoint_feat=False)
-    rc = inerf_encode_mlp_ws(&a->net, a->packed_coarse, a->rays, z_c, n, sc, a->flags & ~INERF_FLAG_ENDPOINT, raw_c, a->status,
+    rc = inerf_encode_mlp_chunked(&a->net, a->packed_coarse, a->rays, z_c, n, sc, a->flags & ~INERF_FLAG_ENDPOINT, raw_c, a->status, a->status_rays,
                              ws + p.mlp_ws, p.mlp_ws_bytes, stream);
     if (rc) return rc;
     inerf_composite_out oc = a->coarse;
@@ -108,7 +108,7 @@ extern "C" int inerf_render_rays(const inerf_render_args* a, void* stream) {
     if (rc) return rc;
     float* raw_f = a->raw_fine ? a->raw_fine : f(p.raw_f);
     const float* w_fine = a->packed_fine ? a->packed_fine : a->packed_coarse;   // run_nerf.py:506
-    rc = inerf_encode_mlp_ws(&a->net, w_fine, a->rays, z_f, n, p.s_f, a->flags, raw_f, a->status, ws + p.mlp_ws, p.mlp_ws_bytes, stream);
+    rc = inerf_encode_mlp_chunked(&a->net, w_fine, a->rays, z_f, n, p.s_f, a->flags, raw_f, a->status, a->status_rays, ws + p.mlp_ws, p.mlp_ws_bytes, stream);
     if (rc) return rc;
     const bool ep = ssr && (a->flags & INERF_FLAG_ENDPOINT);
     inerf_composite_out of = a->fine;

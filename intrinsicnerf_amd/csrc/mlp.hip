@@ -406,7 +406,7 @@ int launch_mlp_f32(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream)
 
 static int encode_mlp_impl(const inerf_net_desc* net, const float* packed, const float* rays, const float* z, int64_t n_rays,
                            int n_samples, uint32_t flags, float* raw_out, float* save, float* act_max, int32_t* status, void* stream,
-                           float* sem_scratch = nullptr);
+                           float* sem_scratch = nullptr, int64_t status_rays = 0);
 
 extern "C" int64_t inerf_encode_mlp_workspace_bytes(const inerf_net_desc* net, int64_t n_rays, int n_samples, uint32_t flags) {
     if (!net || !inerf::net_supported(*net) || n_rays < 0 || n_samples < 1) return INERF_E_INVALID;
@@ -421,6 +421,16 @@ extern "C" int inerf_encode_mlp_ws(const inerf_net_desc* net, const float* packe
     if (need > 0 && (!workspace || workspace_bytes < need)) return INERF_E_WORKSPACE;
     return encode_mlp_impl(net, packed, rays, z, n_rays, n_samples, flags, raw_out, nullptr, nullptr, status, stream,
                            need > 0 ? static_cast<float*>(workspace) : nullptr);
+}
+
+extern "C" int inerf_encode_mlp_chunked(const inerf_net_desc* net, const float* packed, const float* rays, const float* z, int64_t n_rays,
+                                        int n_samples, uint32_t flags, float* raw_out, int32_t* status, int64_t status_rays, void* workspace,
+                                        int64_t workspace_bytes, void* stream) {
+    if (!net || !inerf::net_supported(*net) || n_rays < 0 || n_samples < 1) return INERF_E_INVALID;
+    const int64_t need = inerf::sem_scratch_bytes(*net, n_rays * (int64_t)n_samples, (flags & INERF_FLAG_ENDPOINT) != 0);
+    if (need > 0 && (!workspace || workspace_bytes < need)) return INERF_E_WORKSPACE;
+    return encode_mlp_impl(net, packed, rays, z, n_rays, n_samples, flags, raw_out, nullptr, nullptr, status, stream,
+                           need > 0 ? static_cast<float*>(workspace) : nullptr, status_rays);
 }
 
 extern "C" int inerf_encode_mlp(const inerf_net_desc* net, const float* packed, const float* rays, const float* z,
@@ -458,7 +468,7 @@ extern "C" int inerf_encode_mlp_train(const inerf_net_desc* net, const float* pa
 
 static int encode_mlp_impl(const inerf_net_desc* net, const float* packed, const float* rays, const float* z, int64_t n_rays,
                            int n_samples, uint32_t flags, float* raw_out, float* save, float* act_max, int32_t* status, void* stream,
-                           float* sem_scratch) {
+                           float* sem_scratch, int64_t status_rays) {
     using namespace inerf;
     if (net && n_rays == 0) return net_supported(*net) ? INERF_OK : INERF_E_UNSUPPORTED;      // empty batch: pointers may be null
     if (!net || !packed || !rays || !z || !raw_out || n_rays < 0 || n_samples < 1) return INERF_E_INVALID;
@@ -469,6 +479,7 @@ static int encode_mlp_impl(const inerf_net_desc* net, const float* packed, const
     const bool ssr = net->variant == INERF_VARIANT_SSR;
     MlpParams p;
     p.wts = packed; p.rays = rays; p.z = z; p.raw = raw_out; p.status = status;
+    p.status_rays = (status && status_rays > 0 && status_rays < n_rays) ? (int)status_rays : 0;      // (>= n_rays: everything in word 0)
     p.save = save;
     p.act_max = act_max;
     p.sem_scratch = sem_scratch;

@@ -12,7 +12,8 @@ struct MlpParams {
     const float* rays;      // [N,11]
     const float* z;         // [N,S]
     float* raw;             // [N*S, channels]
-    int32_t* status;        // optional device word for INERF_STATUS_* bits
+    int32_t* status;        // optional device word(s) for INERF_STATUS_* bits
+    int status_rays;        // 0: one word; > 0: one word per that many rays (inerf_encode_mlp_chunked)
     float* save;            // training forward: activation buffer (layout.h SaveSlot), else nullptr
     float* act_max;         // training forward, optional: device float that receives max |activation| (caller zeroes it)
     float* sem_scratch;     // SSR inference, optional: per-workgroup scratch for the channel-split semantic head (sem_scratch_bytes)

@@ -65,6 +65,10 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
     wide_prefetch_h<2>(pre2, wb, frag256(L.trunk[0], 4), bias256(L.trunk[0]), scale256(L.trunk[0]), lane);
 
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+        if constexpr (!kSave) {                     // inference: the f16 range guard is per tile (flag_f16_range); training forwards keep the
+            amax = 0.0f;                            // launch's maximum (act_max; their status is one word)
+            amax2 = f16x2{(_Float16)0.0f, (_Float16)0.0f};
+        }
         // ---------------- encode -> hi/lo planes ----------------
         {
             const int pt = tid % kPts, part = tid / kPts;
@@ -267,11 +271,10 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
             __builtin_nontemporal_store(sh, out_row + 7);
             __builtin_nontemporal_store(r0, out_row + 8); __builtin_nontemporal_store(r1, out_row + 9); __builtin_nontemporal_store(r2, out_row + 10);
         }
+        flag_f16_range(p, tile * kPts, kPts, amax, amax2, lane);
     }
-    const float amax_all = fmaxf(amax, fmaxf((float)amax2[0], (float)amax2[1]));
-    if (p.status && __any(!(amax_all <= kF16Safe)) && lane == 0) atomicOr(p.status, INERF_STATUS_F16_RANGE);
     if (kSave && p.act_max) {             // bound of every saved activation (they were split as kActScale * value)
-        float m = amax_all * (1.0f / kActScale);
+        float m = fmaxf(amax, fmaxf((float)amax2[0], (float)amax2[1])) * (1.0f / kActScale);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
         if (lane == 0 && m == m) atomicMax(reinterpret_cast<unsigned int*>(p.act_max), __builtin_bit_cast(unsigned int, m));
@@ -339,6 +342,10 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
         // parts are loop invariants, hoisted out of the tile loop (~15 registers, spilled at this kernel's 256).  Laundered per tile.
         int lane_t = lane;
         asm volatile("" : "+v"(lane_t));
+        if constexpr (!kSave) {                   // inference: the f16 range guard is per tile (flag_f16_range); training forwards keep the
+            amax = 0.0f;                          // launch's maximum (act_max; their status is one word)
+            amax2 = f16x2{(_Float16)0.0f, (_Float16)0.0f};
+        }
         // ---------------- encode -> hi/lo planes (xyz: columns 0..63, dir: columns 256..287) ----------------
         auto encode = [&](bool with_dir) {
             // (the thread index is laundered per call: derived from `tid` itself, this stage's ~20 LDS / slot addresses are
@@ -676,11 +683,10 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
             }
             __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p.raw + (size_t)(tile * kPts + 16 * wave) * INERF_BASE_CHANNELS) + lane_t);
         }
+        flag_f16_range(p, tile * kPts, kPts, amax, amax2, lane_t);
     }
-    const float amax_all = fmaxf(amax, fmaxf((float)amax2[0], (float)amax2[1]));
-    if (p.status && __any(!(amax_all <= kF16Safe)) && lane == 0) atomicOr(p.status, INERF_STATUS_F16_RANGE);
     if (kSave && p.act_max) {
-        float m = amax_all * (1.0f / kActScale);
+        float m = fmaxf(amax, fmaxf((float)amax2[0], (float)amax2[1])) * (1.0f / kActScale);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
         if (lane == 0 && m == m) atomicMax(reinterpret_cast<unsigned int*>(p.act_max), __builtin_bit_cast(unsigned int, m));

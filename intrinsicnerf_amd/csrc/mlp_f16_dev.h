@@ -248,6 +248,26 @@ __device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const Weigh
 // Range check: packed f16 max over the |hi| pairs (inf when |t| > 65504).
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
+// The f16 range guard, once per tile: `amax` / `amax2` are the tile's running maxima (reset at the top of the tile).  A tile that left
+// the range ORs INERF_STATUS_F16_RANGE into the status word of every ray it holds points of: ONE word per launch, or - with
+// MlpParams.status_rays (inerf_encode_mlp_chunked) - one word per that many rays, so that a frame rendered as one launch still tells
+// which of the caller's chunks has to be rendered again in exact fp32.  Returns the tile's maximum (scaled domain).
+__device__ __forceinline__ float flag_f16_range(const MlpParams& p, int first_point, int tile_points, float amax, f16x2 amax2, int lane) {
+    const float m = fmaxf(amax, fmaxf((float)amax2[0], (float)amax2[1]));
+    if (p.status && __any(!(m <= kF16Safe)) && lane == 0) {          // (never taken on a network inside the range)
+        int w0 = 0, w1 = 0;
+        if (p.status_rays > 0) {
+            int last = first_point + tile_points - 1;
+            last = last < p.n_points ? last : p.n_points - 1;
+            w0 = (first_point / p.n_samples) / p.status_rays;
+            w1 = (last / p.n_samples) / p.status_rays;
+        }
+        for (int w = w0; w <= w1; ++w) atomicOr(p.status + w, INERF_STATUS_F16_RANGE);
+    }
+    return m;
+}
+
+
 // hi = (t0, t1) rounded toward zero to f16 (= the 13 low mantissa bits cleared, for |t| in f16's normal range; the
 // conversion saturates at 65504 instead of overflowing), lo = f16(t - hi): the difference is exact in fp32, so lo is the
 // remainder rounded once.  Three instructions per pair: v_cvt_pkrtz_f16_f32 and two v_fma_mix{lo,hi}_f16, which read hi

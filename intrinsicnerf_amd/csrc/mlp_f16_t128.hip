@@ -34,8 +34,6 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..7
     const int cg = wave & 3, ph = wave >> 2;                        // heads' hidden layers: channel group x point half
     const NetLayout& L = p.L;
-    float amax = 0.0f;
-    f16x2 amax2 = {(_Float16)0.0f, (_Float16)0.0f};
 
     _Float16* const xw = ldst + (lane & 31) * kRowD;
     const _Float16* const xr = xw + 8 * (lane >> 5);                       // wide GEMM operand reads (+ column)
@@ -57,6 +55,8 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
         int lane_t = tid;                         // (laundered per tile: keeps the lane_t parts of per-tile offsets out of the loop-invariant set,
         asm volatile("" : "+v"(lane_t));          // and `lane_t` itself out of the registers that live across the tile loop)
         lane_t &= 63;
+        float amax = 0.0f;                        // this tile's running maxima of |scaled value| (encoder inputs / layer outputs): the f16 range guard
+        f16x2 amax2 = {(_Float16)0.0f, (_Float16)0.0f};
         // ---------------- encode -> hi/lo planes (xyz: columns 0..63, dir: columns 256..287) ----------------
         auto encode = [&](bool with_dir) {
             int tid_o = tid;
@@ -249,11 +249,10 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
             }
             __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p.raw + (size_t)(tile * kPtsT + 16 * wave) * INERF_BASE_CHANNELS) + lane_t);
         }
+        flag_f16_range(p, tile * kPtsT, kPtsT, amax, amax2, lane_t);
         // (the next tile's encode writes bytes 0..127 and 512..575 of the rows, both planes: clear of the exchange area (hi plane, bytes
         // 128..255) and of the staging rows (lo plane, bytes 256..299) this tile's last readers may still be in)
     }
-    const float amax_all = fmaxf(amax, fmaxf((float)amax2[0], (float)amax2[1]));
-    if (p.status && __any(!(amax_all <= kF16Safe)) && (tid & 63) == 0) atomicOr(p.status, INERF_STATUS_F16_RANGE);
 }
 
 int launch_mlp_f16x3_t128(MlpParams& p, int64_t n_points, hipStream_t stream) {

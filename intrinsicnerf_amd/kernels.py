@@ -106,6 +106,27 @@ def _new_status(like):
 
 
 _deferred = None          # the innermost open deferred_range_checks() block, else None
+_status_rays = 0          # rays per f16 range word of the launches inside a chunked_status() block (0: one word per launch)
+
+
+class chunked_status:
+    """Launches of ``render_rays_fused`` inside this block keep ONE f16 range word per ``rays_per_word`` rays
+    (inerf_encode_mlp_chunked): the chunk loops of the front-ends render an eval-mode frame as one launch sequence and still learn
+    which of the CALLER's chunks left the range.  In a ``deferred_range_checks`` block such a launch's words are tagged
+    ``(block.tag, word index)``."""
+
+    def __init__(self, rays_per_word):
+        self.rays = int(rays_per_word)
+
+    def __enter__(self):
+        global _status_rays
+        self.outer, _status_rays = _status_rays, self.rays
+        return self
+
+    def __exit__(self, *exc):
+        global _status_rays
+        _status_rays = self.outer
+        return False
 captured_status = None    # list collecting the status words of launches recorded into a HIP graph (graphs.GraphedTrainStep)
 
 
@@ -158,6 +179,7 @@ class deferred_range_checks:
             _defer_to_graph_owner(self.words)
             return False
         flags = (self.words[0] if len(self.words) == 1 else torch.cat(self.words)).cpu().tolist()      # the block's one sync
+        assert len(flags) == len(self.tags)
         for flag, tag in zip(flags, self.tags):
             if int(flag) & _capi.STATUS_F16_RANGE and tag not in self.tripped:
                 self.tripped.append(tag)
@@ -175,14 +197,15 @@ def check_f16_range(status, what, deferrable=False):
     ``deferred_range_checks`` block and with ``deferrable``, leave the word for the block's single check."""
     if status is None:
         return
+    status = status.reshape(-1)                # (one word per launch, or one per chunk of its rays: chunked_status)
     if _capturing():
-        _defer_to_graph_owner([status.reshape(1)])
+        _defer_to_graph_owner([status[i:i + 1] for i in range(status.numel())])
         return
     if deferrable and _deferred is not None:
-        _deferred.words.append(status.reshape(1))
-        _deferred.tags.append(_deferred.tag)
+        _deferred.words.append(status)
+        _deferred.tags.extend([_deferred.tag] if status.numel() == 1 else [(_deferred.tag, i) for i in range(status.numel())])
         return
-    if int(status.item()) & _capi.STATUS_F16_RANGE:
+    if int(status.max().item()) & _capi.STATUS_F16_RANGE:
         raise FloatingPointError(_RANGE_MESSAGE.format(what=what))
 
 
@@ -473,8 +496,11 @@ def render_rays_fused(desc, packed_coarse, packed_fine, rays, n_samples, n_impor
     ws = torch.empty(max(int(ws_bytes), 1), dtype=torch.uint8, device=rays.device)
     args.workspace, args.workspace_bytes = ws.data_ptr(), int(ws_bytes)
     if desc.precision == _capi.PREC_F16X3:
-        out["status"] = _new_status(rays)          # caller checks it (check_f16_range) when it next synchronises
+        # caller checks it (check_f16_range) when it next synchronises; inside a chunked_status() block: one word per chunk of rays
+        words = -(-n // _status_rays) if (_status_rays > 0 and n > _status_rays) else 1
+        out["status"] = torch.zeros(words, dtype=torch.int32, device=rays.device)
         args.status = out["status"].data_ptr()
+        args.status_rays = _status_rays if words > 1 else 0
     with torch.cuda.device(rays.device):
         rc = L.inerf_render_rays(C.byref(args), _stream(rays))
     _capi.check(rc, "inerf_render_rays")

@@ -447,15 +447,25 @@ def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
     big = _coalesced(rays_flat, chunk, kwargs)
     if big > chunk:
         # eval mode, fused networks, no raw: nothing depends on the chunk boundaries (results are bit-identical for any chunking), so
-        # the frame goes through in as few launches as the workspace cap allows (kernels.coalesced_chunk).  A launch that leaves
-        # the f16 range is located by the caller's own chunks below.
+        # the frame goes through in as few launches as the workspace cap allows (kernels.coalesced_chunk) - with one f16 range word
+        # per CALLER's chunk (kernels.chunked_status), so that a chunk that leaves the range is still the only one rendered again
         rets = []
-        with kernels.deferred_range_checks("render", raise_on_trip=False) as block:
+        with kernels.deferred_range_checks("render", raise_on_trip=False) as block, kernels.chunked_status(chunk):
             for j, i in enumerate(range(0, rays_flat.shape[0], big)):
                 block.tag = j
                 rets.append(render_rays(rays_flat[i:i + big], **kwargs))
-        if not block.tripped:
-            return {k: (rets[0][k] if len(rets) == 1 else torch.cat([r[k] for r in rets], 0)) for k in rets[0]}
+        out = {k: (rets[0][k] if len(rets) == 1 else torch.cat([r[k] for r in rets], 0)) for k in rets[0]}
+        if block.tripped:
+            # tags: (piece, word) of a piece with one word per caller's chunk, or the piece itself (it held no more than one chunk)
+            spans = sorted({(t[0] * big + t[1] * chunk, chunk) if isinstance(t, tuple) else (t * big, big) for t in block.tripped})
+            kernels.warn_f32_fallback(f"render: {len(spans)} of {-(-rays_flat.shape[0] // chunk)} chunks left the f16 range of the "
+                                      "split-precision MLP kernel.")
+            with _capi.forced_precision(_capi.PREC_F32):
+                for i, n_i in spans:
+                    again = render_rays(rays_flat[i:i + n_i], **kwargs)
+                    for k in out:
+                        out[k][i:i + n_i] = again[k]
+        return out
     starts = list(range(0, rays_flat.shape[0], chunk))
     rets = []
     with kernels.deferred_range_checks("render", raise_on_trip=False) as block:

@@ -243,15 +243,26 @@ def batchify_rays(render_fn, rays_flat, chunk=1024 * 32, coalesce_to=None):
     """training_utils.py:5-17.  As in object_level.batchify_rays the chunks' f16 range words are read together after the
     last chunk (one host synchronisation per frame) and only the chunks that left the range are rendered again in exact
     fp32.  ``coalesce_to`` (SSRRenderMixin.render_rays, eval-mode frames whose result cannot depend on the chunk boundaries):
-    rays per call to try first instead of ``chunk``; a launch that leaves the f16 range is located by the caller's chunks."""
+    rays per call instead of ``chunk``; the launches keep one f16 range word per ``chunk`` rays, so a chunk that leaves the range is still the
+    only one rendered again."""
     if coalesce_to is not None and coalesce_to > chunk:
         rets = []
-        with kernels.deferred_range_checks("render_rays", raise_on_trip=False) as block:
+        with kernels.deferred_range_checks("render_rays", raise_on_trip=False) as block, kernels.chunked_status(chunk):
             for j, i in enumerate(range(0, rays_flat.shape[0], coalesce_to)):
                 block.tag = j
                 rets.append(render_fn(rays_flat[i:i + coalesce_to]))
-        if not block.tripped:
-            return {k: torch.cat([r[k] for r in rets], 0) for k in rets[0]}
+        out = {k: torch.cat([r[k] for r in rets], 0) for k in rets[0]}
+        if block.tripped:     # one range word per caller's chunk (kernels.chunked_status): only the chunks that left the range, in exact fp32
+            spans = sorted({(t[0] * coalesce_to + t[1] * chunk, chunk) if isinstance(t, tuple) else (t * coalesce_to, coalesce_to)
+                            for t in block.tripped})
+            kernels.warn_f32_fallback(f"render_rays: {len(spans)} of {-(-rays_flat.shape[0] // chunk)} chunks left the f16 range of the "
+                                      "split-precision MLP kernel.")
+            with _capi.forced_precision(_capi.PREC_F32):
+                for i, n_i in spans:
+                    again = render_fn(rays_flat[i:i + n_i])
+                    for k in out:
+                        out[k][i:i + n_i] = again[k]
+        return out
     starts = list(range(0, rays_flat.shape[0], chunk))
     rets = []
     with kernels.deferred_range_checks("render_rays", raise_on_trip=False) as block:

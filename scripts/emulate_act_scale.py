@@ -25,6 +25,9 @@ def gemm3(xh, xl, wh, wl):
     return (xh @ wh.T + xh @ wl.T + xl @ wh.T).astype(np.float32)
 
 def layer(x, w, b, act_scale, relu=True):
+    if act_scale is None:       # PER-LAYER scale (round 6): the largest power of two <= 8 that keeps THIS operand inside f16's range
+        m = float(np.abs(x).max())
+        act_scale = 8.0 * 2.0 ** -max(0, int(np.ceil(np.log2(max(m, 1e-30) * 8.0 / 6.0e4))))
     kw = int(np.floor(np.log2(16384.0 / np.abs(w).max())))           # max |W'| in (2^13, 2^14]
     wh, wl, _ = split(w, 2.0 ** kw)
     xh, xl, amax = split(x, act_scale)
@@ -59,7 +62,7 @@ n = 4096
 pts = (torch.rand(n, 3) * 4 - 2)
 dirs = torch.nn.functional.normalize(torch.randn(n, 3), dim=-1)
 emb = torch.cat([oracle.freq_encode(pts, 10), oracle.freq_encode(dirs, 4)], -1)
-print("activation gain | largest hidden activation | shift | raw error vs fp64: max |err| / (1e-5 + 1e-4 |ref|) over rgb/albedo/shading/residual, sigma relative | fp32 reference's own")
+print("activation gain | largest hidden activation | shift | raw error vs fp64: max |err| / (1e-5 + 1e-4 |ref|) over rgb/albedo/shading/residual, sigma relative | fp32 reference's own | one scale per GEMM operand")
 for gain in (1.0, 2.0 ** 14, 2.0 ** 18, 2.0 ** 24):
     sd = oracle.make_state_dict("object", 0, seed=3)
     # a network whose first trunk layer is `gain` times larger (and whose second undoes most of it): hidden activations of layer 0 ~ gain
@@ -79,4 +82,6 @@ for gain in (1.0, 2.0 ** 14, 2.0 ** 18, 2.0 ** 24):
         raw, worst = forward_emul(sd, emb.numpy(), 8.0 * 2.0 ** -shift)
         ok = worst <= 6.0e4
         line += f" shift {shift:2d}: {'%7.3f' % score(raw) if ok else '  range'}"
+    raw, worst = forward_emul(sd, emb.numpy(), None)
+    line += f" | per-layer scale: {'%7.3f' % score(raw) if worst <= 6.0e4 else '  range'}"
     print(line)

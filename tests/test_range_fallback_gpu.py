@@ -35,8 +35,9 @@ def _scene(dev, H=40, W=40):
 
 @pytest.mark.parametrize("coalesce", [False, True])
 def test_only_the_tripped_chunk_is_rendered_again_in_fp32(coalesce, monkeypatch):
-    """``coalesce``: eval-mode frames go through in one launch sequence where the workspace cap allows (kernels.coalesced_chunk); a
-    launch that trips is then located by the caller's own chunks - one extra f16x3 pass over the frame, same final result."""
+    """``coalesce``: eval-mode frames go through in one launch sequence where the workspace cap allows (kernels.coalesced_chunk), with
+    one f16 range word per CALLER's chunk (inerf_encode_mlp_chunked): the frame is ONE f16x3 call, the chunk that left the range - and
+    only that one - one more call in exact fp32, the final frame the same bits as with the caller's chunks."""
     import bench
     from intrinsicnerf_amd import _capi, object_level as ol
     monkeypatch.setenv("INERF_PRECISION", "f16x3")
@@ -61,14 +62,15 @@ def test_only_the_tripped_chunk_is_rendered_again_in_fp32(coalesce, monkeypatch)
     with torch.no_grad(), warnings.catch_warnings():
         warnings.simplefilter("ignore")
         got = ol.render(H, W, K, chunk=chunk, rays=(flat(ro), flat(rd)), **kw)
-        head = [(H * W, _capi.PREC_F16X3)] if coalesce else []                               # the whole frame first, when coalescing
-        assert calls == head + [(chunk, _capi.PREC_F16X3)] * 10 + [(chunk, _capi.PREC_F32)], calls      # one extra call, in exact fp32
+        whole = [(H * W, _capi.PREC_F16X3)] if coalesce else [(chunk, _capi.PREC_F16X3)] * 10
+        assert calls == whole + [(chunk, _capi.PREC_F32)], calls                               # one extra call, in exact fp32
         calls.clear()
         monkeypatch.setenv("INERF_PRECISION", "f32")
         exact = ol.render(H, W, K, chunk=chunk, rays=(flat(ro), flat(rd)), **kw)
         monkeypatch.setenv("INERF_PRECISION", "f16x3")
         rest = ol.render(H, W, K, chunk=chunk, rays=(flat(ro, rows_per_chunk), flat(rd, rows_per_chunk)), **kw)
-    assert all(p == _capi.PREC_F16X3 for _, p in calls[10:]) and len(calls) == 10 + (1 if coalesce else 9), "the other rows alone must not trip"
+    n_exact = 1 if coalesce else 10                                               # (the pure-fp32 frame's calls come first)
+    assert all(p == _capi.PREC_F16X3 for _, p in calls[n_exact:]) and len(calls) == n_exact + (1 if coalesce else 9), "the other rows alone must not trip"
     for i, name in enumerate(("rgb", "disp", "acc", "albedo", "shading", "residual")):
         g, e, r = got[i], exact[i], rest[i]
         assert torch.isfinite(g[~torch.isnan(e)]).all()
