@@ -25,7 +25,7 @@ bash scripts/pmc_pass.sh ${tag}_dual_cache TCC_HIT_sum TCC_MISS_sum
 python scripts/pmc_report.py $OUT/prof/${tag}_dual_A $OUT/prof/${tag}_dual_fetch $OUT/prof/${tag}_dual_write $OUT/prof/${tag}_dual_cache > $OUT/${tag}_mlp_pmc_summary.txt 2>&1
 for p in A fetch write cache; do find $OUT/prof/${tag}_dual_$p -name "*counter_collection.csv" -exec cp {} $OUT/${tag}_mlp_pmc_dual_$p.csv \; ; done
 # 4. the other kernel forms on the same box (same launch shape)
-for f in dual single; do echo "$f: $(INERF_F16_KERNEL=$f python scripts/bench_mlp.py --rays 640000 --iters 3 2>&1 | tail -1)"; done > $OUT/${tag}_kernel_forms.txt
+for f in t128 dual single; do echo "$f: $(INERF_F16_KERNEL=$f python scripts/bench_mlp.py --rays 640000 --iters 3 2>&1 | tail -1)"; done > $OUT/${tag}_kernel_forms.txt
 # 5. SSR frame and the training step
 python scripts/bench_ssr_frame.py --frames 5 > $OUT/${tag}_ssr_frame.txt 2>&1
 python scripts/bench_train_step.py --iters 8 > $OUT/${tag}_train_step.txt 2>&1

@@ -147,8 +147,19 @@ def test_two_workgroup_chain_equals_the_eight_wave_chain(variant, classes, endpo
         return torch.where(h == 0x8000, torch.zeros_like(h), h)
     a, b = halves(out["single"][0]), halves(out["dual"][0])
     differ = int((a != b).sum())
-    # (the floor cases scale with the batch; a corrupted tile row is 4 096+ words per tile)
-    assert differ <= 64 + a.numel() // 2_000_000, f"{differ} of {a.numel()} gradient words differ between the two chains"
+    if differ > 64:
+        # A floor case flips one mask bit of d h7 at ONE point and the dense layers below carry it into every channel of that point's
+        # dZ_h6 .. dZ_h0: thousands of words, but of ONE tile, and only in the trunk slots.  So on a large batch the bound is on TILES:
+        # (a corrupted LDS row - the round-5 development form - hit every non-first tile of every workgroup.)
+        where = (a != b).nonzero().flatten() // 2                                 # word index within `words`
+        f256, l256 = _slot_range(desc, p, kernels.SAVE_H0, kernels.SAVE_H7)        # the eight trunk slots open `words`
+        n_tiles = (p + 63) // 64
+        words_per_slot = n_tiles * 16384                                           # 64 points x 256 channels x 4 bytes per tile
+        assert l256 - f256 == 8 * words_per_slot
+        outside = int((where >= l256 - f256).sum())
+        tiles = ((where[where < l256 - f256] % words_per_slot) // 16384).unique()
+        assert outside == 0 and tiles.numel() <= max(2, n_tiles // 1000), \
+            f"{differ} gradient words differ between the two chains: {tiles.numel()} of {n_tiles} tiles, {outside} words outside the trunk slots"
     assert out["single"][2] == pytest.approx(out["dual"][2], rel=1e-6)
     hs, hd = out["single"][1], out["dual"][1]
     scale = float(hs.abs().max())
