@@ -70,7 +70,9 @@ struct PerDeviceOnce {
 int record(hipError_t e);
 int launch_mlp_f32(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream);
 int launch_mlp_f16x3(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream);   // p.save != nullptr: saving variant
-int launch_mlp_f16x3_t128(MlpParams& p, int64_t n_points, hipStream_t stream);          // object-level inference, 128-point tile
+int launch_mlp_f16x3_t128(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream);      // inference on the 128-point tile (mlp_f16_t128.hip)
+bool mlp_f16x3_takes_t128(bool ssr, bool save, bool endpoint, int n_classes);                   // which launches take it
+int64_t sem_scratch_bytes_t128(int64_t n_points);                                               // ... and the SSR form's scratch (classes > 0)
 int64_t sem_scratch_bytes(const inerf_net_desc& net, int64_t n_points, bool endpoint);   // 0 when the launch would not use one
 
 }  // namespace inerf

@@ -693,9 +693,21 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
     }
 }
 
+// Which inference launches take the 128-point tile: the object-level network unless a 64-point form is asked for (A/B runs, the forms' own
+// tests); the SSR network (at most 32 classes, no endpoint feature: one 32-class block of partial logits per wave) only on request
+// (INERF_F16_KERNEL=t128) - same box, C = 28: 410.5 / 411.5 / 410.1 TFLOP/s against 414.4 / 414.9 / 414.6 for the two-workgroup kernel with
+// the channel-split head, frames 69.0 vs 68.5 ms (profiles/r06_ssr_t128_ab.txt): there the second workgroup's overlap is worth more than the
+// halved weight stream.
+bool mlp_f16x3_takes_t128(bool ssr, bool save, bool endpoint, int n_classes) {
+    const char* form = getenv("INERF_F16_KERNEL");
+    if (save || endpoint || (form && (form[0] == 'd' || form[0] == 's' || form[0] == 'w' || form[0] == 'c'))) return false;
+    return !ssr || (form && form[0] == 't' && n_classes <= 32);
+}
+
 int64_t sem_scratch_bytes(const inerf_net_desc& net, int64_t n_points, bool endpoint) {
     const char* form = getenv("INERF_F16_KERNEL");
     if (net.precision != INERF_PREC_F16X3 || net.variant != INERF_VARIANT_SSR || net.n_classes <= 0 || endpoint || n_points <= 0) return 0;
+    if (mlp_f16x3_takes_t128(true, false, endpoint, net.n_classes)) return sem_scratch_bytes_t128(n_points);     // the 128-point tile: 8 KiB per wave
     if (form && (form[0] == 's' || form[0] == 'w')) return 0;          // single: one workgroup per CU; wave: the per-wave head (A/B runs)
     // More than 32 classes go block by block through the exchange area (two barriers and an exposed scratch fetch per extra block):
     // measured at C = 101 the channel-split head is 8 % SLOWER than the per-wave one (27.8 vs 25.6 ms per 32768 x 192 launch), at
@@ -731,9 +743,11 @@ int launch_mlp_f16x3(MlpParams& p, int64_t n_points, bool ssr, hipStream_t strea
     // reaches memory in that form).  INERF_F16_KERNEL=single keeps the one-workgroup kernel everywhere (A/B runs).
     // (The SSR training forward takes 10.1-10.3 ms per step in either form.)
     const char* form = getenv("INERF_F16_KERNEL");
-    // object-level inference: the 128-point tile (mlp_f16_t128.hip; bit-identical to the two-workgroup kernel, 0.58 x its L2 -> CU
-    // weight stream, +1.2 % same-box: profiles/r06_weight_stream_ab.txt).  INERF_F16_KERNEL=dual|single select the 64-point forms (A/B runs).
-    if (!ssr && !p.save && !(form && (form[0] == 'd' || form[0] == 's'))) return launch_mlp_f16x3_t128(p, n_points, stream);
+    // inference: the 128-point tile (mlp_f16_t128.hip; object-level: bit-identical to the two-workgroup kernel, 0.58 x its L2 -> CU
+    // weight stream, +1.3-1.7 % same-box: profiles/r06_weight_stream_ab.txt).  INERF_F16_KERNEL=dual|single select the 64-point forms.
+    // (the SSR form parks its partial logits in the caller's scratch: inerf_encode_mlp, which has none, takes the 64-point per-wave head)
+    if (mlp_f16x3_takes_t128(ssr, p.save != nullptr, p.endpoint != 0, p.n_classes) && (!ssr || p.L.sem_rbs == 0 || p.sem_scratch))
+        return launch_mlp_f16x3_t128(p, n_points, ssr, stream);
     if (!(ssr && p.endpoint) && !(form && form[0] == 's')) return launch_dual(p, n_points, ssr, stream);
     p.n_tiles = (int)((n_points + kTilePoints - 1) / kTilePoints);
     const int grid = p.n_tiles < device_cus() ? p.n_tiles : device_cus();

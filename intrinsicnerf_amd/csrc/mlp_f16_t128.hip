@@ -8,6 +8,7 @@
 // L2 -> CU stream - and the operand reads that double instead (8 ds_read_b128 per 12 MFMAs) go to LDS, whose 256 B/clk for
 // that instruction is a quarter used.  151,552 B of LDS, one workgroup per CU, two waves per SIMD (<= 256 registers each).
 //
+// Object-level network and the SSR network with <= 32 classes (no endpoint feature).
 // Same arithmetic, same summation order per output element as the 64-point kernels (the packed blob is the same one: wave
 // w8 reads row block w8 & 1 of packing wave w8 >> 1):  the results are bit-identical to k_encode_mlp_f16x3_dual's.  To keep
 // that true for the two heads whose hidden layers stay in registers (albedo | shading hidden, view-dependent hidden: their
@@ -23,10 +24,23 @@ namespace inerf {
 constexpr int kPtsT = 128;                       // points per tile
 constexpr int kPlaneT = kPtsT * kRowD;           // halfs per plane (rows of 296 halfs = 592 B: conflict-free ds_read_b128)
 constexpr int kLdsBytesT = 2 * kPlaneT * 2;      // 151,552
+constexpr int kSemScratchBytesT = 8 * 2 * 16 * 64 * 4;      // SSR: per workgroup 64 KiB - per wave [2 point blocks][16 registers][64 lanes] floats
 
+int64_t sem_scratch_bytes_t128(int64_t n_points) {
+    const int64_t tiles = (n_points + kPtsT - 1) / kPtsT;
+    return (tiles < device_cus() ? tiles : device_cus()) * (int64_t)kSemScratchBytesT;
+}
+
+// kSsr: the SSR network (Semantic_NeRF, semantic_nerf.py:74-181) with at most 32 classes and no endpoint feature: xyz / 10 in the
+// encoder, and between the albedo|shading head and the feature layer the semantic head - hidden layer (128 channels) split over the
+// waves like the view-dependent one (32-channel group cg x 64-point half ph: semantic_linear.0.0 streamed twice per 128 points; the
+// 64-point kernel streams it twice per 64), the wave's hidden channels stay in registers as B operands of the logits product
+// (layout.h sem2q), and its PARTIAL logits (32 classes x 64 points over 32 hidden channels: 32 accumulator registers) are parked in
+// the wave's own L2-resident scratch slot (MlpParams.sem_scratch: 8 KiB per wave - an explicit spill placed where nothing waits for
+// it; held in registers across the feature and view layers they cost 48 spilled registers inside those loops) until the tile's planes
+// are dead, where the four partials of a point meet in LDS and are added in group order.
 template <bool kSsr>
 __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParams p) {
-    static_assert(!kSsr, "object-level network (the SSR network renders through k_encode_mlp_f16x3_dual)");
     constexpr int kParts = 512 / kPtsT;
     extern __shared__ __attribute__((aligned(16))) _Float16 ldst[];
     const int tid = threadIdx.x;
@@ -155,12 +169,12 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
         store256(L.trunk[7], true, pf256(L.as1, 16));
 
         // ---------------- heads ----------------
+        const bool sem = kSsr && L.sem_rbs > 0;
         const int my_pt = tile * kPtsT + 16 * wave + (lane_t & 15);
         const bool my_valid = my_pt < p.n_points;
         float* const out_row = p.raw + (size_t)(my_valid ? my_pt : 0) * p.channels;
         // (operand addresses of the heads from the per-tile laundered lane_t index: as loop invariants they are two more spilled registers)
         const _Float16* const xs = ldst + (16 * wave + (lane_t & 15)) * kRowD + 8 * (lane_t >> 4);   // skinny operand reads: this wave's 16 points
-        const f32x4 sig4 = skinny_gemm_h<8, kPlaneT>(wb, L.alpha.w * 4, L.alpha.b * 4, (L.alpha.b + 16) * 4, xs, lane_t);
 
         // albedo + shading: hidden layer (this wave: channel group cg of point half ph) -> registers -> partial output sums
         f32x4 part_as[2], part_res[2];
@@ -171,13 +185,43 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
             float inv2;
             wide_gemm_h<2, 16, 0, kRowD, kPlaneT>(pre2, wb, frag256(L.as1, 16), xr_h, 0, 0, lane_t, am2);
             load_bias<2>(bias2, inv2, wb, (L.as1.b + 64 * cg) * 4, (L.as1.b + kWidth) * 4, lane_t);
-            prefetch_w<1, 4096>(pre1, wb, frag32(L.feat, 16));
+            if (sem) prefetch_w<1>(pre1, wb, frag128(L.sem1, 16));
+            else     prefetch_w<1, 4096>(pre1, wb, frag32(L.feat, 16));
             f16x8 hi[4][2], lo[4][2];
             to_operands<2>(am2, inv2, bias2, amax2, hi, lo);
             regop_gemm<4>(wb, (L.as2r.w + cg * 4 * 2 * 256) * 4, hi, lo, part_as);
         }
+        // semantic head (semantic_nerf.py:150-152): hidden = relu(semantic_linear.0.0 h7), this wave's 32 channels x 64 points -> registers
+        // -> partial logits of the (one) 32-class block, kept until the exchange at the end of the tile
+        const __amdgpu_buffer_rsrc_t sem_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            p.sem_scratch, 0, kSsr ? (int)((unsigned)gridDim.x * (unsigned)kSemScratchBytesT) : 0, 0x00020000);
+        const int sem_slot = ((int)blockIdx.x * 8 + wave) * (kSemScratchBytesT / 8) + lane_t * 16;      // + (pb * 4 + g) * 1024
+        if constexpr (kSsr) {
+            if (sem) {
+                f32x16 sem_part[2];
+                f32x16 ams[1][2];
+                f32x4 biass[1][4];
+                float invs;
+                wide_gemm_h<1, 16, 0, kRowD, kPlaneT>(pre1, wb, frag128(L.sem1, 16), xr_h, 0, 0, lane_t, ams);
+                load_bias<1>(biass, invs, wb, (L.sem1.b + 32 * cg) * 4, (L.sem1.b + kHalf) * 4, lane_t);
+                prefetch_w<1, 4096>(pre1, wb, frag32(L.feat, 16));
+                f16x8 hi[2][2], lo[2][2];
+                to_operands<1>(ams, invs, biass, amax2, hi, lo);
+                regop_gemm_full<2, 2>(wb, (L.sem2q.w + cg * 2 * 2 * 256) * 4, hi, lo, sem_part);
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 v = {sem_part[pb][4 * g], sem_part[pb][4 * g + 1], sem_part[pb][4 * g + 2], sem_part[pb][4 * g + 3]};
+                        // (whole offset in the VGPR operand: a 16-byte buffer store with a register SGPR offset gets no hazard wait state, tests/test_isa_audit_cpu.py)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), sem_rsrc, sem_slot + (pb * 4 + g) * 1024, 0, 0);
+                    }
+            }
+        }
         // feature (no activation) in place of h7, then the view-dependent layer over [feature | dir] -> registers
         wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(L.feat, 16), xr, 0, 0, lane_t, am1);
+        // sigma, last of h7's readers (here, not in front of the heads: four registers fewer across their GEMM loops)
+        const f32x4 sig4 = skinny_gemm_h<8, kPlaneT>(wb, L.alpha.w * 4, L.alpha.b * 4, (L.alpha.b + 16) * 4, xs, lane_t);
         {
             WidePreH<1> prev;
             store256(L.feat, false, [&]() { prefetch_w<1>(prev, wb, frag128(L.views, 18)); });
@@ -200,7 +244,46 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
                 *reinterpret_cast<f32x4*>(ex + 4) = part_res[pb];
             }
         }
+        // the four partial logit blocks of a point (one per 32-channel group of the hidden layer), 32 floats each, in dead columns that
+        // neither the heads' exchange area (hi plane, bytes 128..255) nor the next tile's encode (bytes 0..127 and 512..575) touch:
+        // groups 0 / 1 at bytes 256..383 / 384..511 of the row in the hi plane, groups 2 / 3 at bytes 128..255 / 256..383 in the lo plane
+        auto sem_ex = [&](int g, int r) {
+            return reinterpret_cast<float*>(ldst) + (g < 2 ? 64 + 32 * g : kPlaneT / 2 + 32 * (g - 1)) + r * (kRowD / 2);
+        };
+        if constexpr (kSsr) {
+            if (sem) {      // this wave's partial logits back from its slot (sc0: past the vector L1, whose lines of an earlier tile may be stale;
+                            // fetched here, not ahead of the barrier: held across it they were spilled to scratch) and into the exchange area:
+                            // accumulator register 4 g + i = class 8 g + 4 (lane >> 5) + i of point (lane & 31) of point block pb of this wave's half
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb) {
+                    u32x4 sem_v[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) sem_v[g] = __builtin_amdgcn_raw_buffer_load_b128(sem_rsrc, sem_slot + (pb * 4 + g) * 1024, 0, 1);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<u32x4*>(sem_ex(cg, 64 * ph + 32 * pb + (lane_t & 31)) + 8 * g + 4 * (lane_t >> 5)) = sem_v[g];
+                }
+            }
+        }
         __syncthreads();
+        if constexpr (kSsr) {
+            if (sem) {      // this wave's 16 points x 32 classes: lane = (point, 8 classes); the four partials in group order (deterministic)
+                const int r = 16 * wave + (lane_t & 15), c8 = 8 * (lane_t >> 4);
+                f32x4 s0 = *reinterpret_cast<const f32x4*>(sem_ex(0, r) + c8), s1 = *reinterpret_cast<const f32x4*>(sem_ex(0, r) + c8 + 4);
+#pragma unroll
+                for (int g = 1; g < 4; ++g) {
+                    s0 += *reinterpret_cast<const f32x4*>(sem_ex(g, r) + c8);
+                    s1 += *reinterpret_cast<const f32x4*>(sem_ex(g, r) + c8 + 4);
+                }
+                const float sem_inv2 = wb.scalar((L.sem2.b + 16 * L.sem_rbs) * 4);
+                const f32x4 b0 = wb.vec4((L.sem2.b + c8) * 4, 0), b1 = wb.vec4((L.sem2.b + c8 + 4) * 4, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (my_valid && c8 + i < p.n_classes) __builtin_nontemporal_store(__builtin_fmaf(s0[i], sem_inv2, b0[i]), out_row + INERF_BASE_CHANNELS + c8 + i);
+                    if (my_valid && c8 + 4 + i < p.n_classes) __builtin_nontemporal_store(__builtin_fmaf(s1[i], sem_inv2, b1[i]), out_row + INERF_BASE_CHANNELS + c8 + 4 + i);
+                }
+            }
+        }
         // a wave's 16 points x 11 floats are 704 CONTIGUOUS bytes of raw: they leave as 44 sixteen-byte pieces (lanes 0..43, staged in
         // dead columns of the lo plane), every 64-byte sector written once by one instruction
         const bool whole_rows = p.channels == INERF_BASE_CHANNELS && tile * kPtsT + kPtsT <= p.n_points &&
@@ -255,11 +338,12 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
     }
 }
 
-int launch_mlp_f16x3_t128(MlpParams& p, int64_t n_points, hipStream_t stream) {
+int launch_mlp_f16x3_t128(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream) {
     p.n_tiles = (int)((n_points + kPtsT - 1) / kPtsT);
     const int grid = p.n_tiles < device_cus() ? p.n_tiles : device_cus();
-    void (*kern)(const MlpParams) = k_encode_mlp_f16x3_t128<false>;
-    static PerDeviceOnce attr_set;
+    void (*kern)(const MlpParams) = ssr ? k_encode_mlp_f16x3_t128<true> : k_encode_mlp_f16x3_t128<false>;
+    static PerDeviceOnce attr_sets[2];
+    PerDeviceOnce& attr_set = attr_sets[ssr ? 1 : 0];
     if (attr_set.first()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesT);
         if (e != hipSuccess) return record(e);

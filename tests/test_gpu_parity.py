@@ -336,13 +336,14 @@ def test_ssr_semantic_head_forms_agree(c, precision, monkeypatch):
     with torch.no_grad():
         want = oracle.query_network(sd, rays[:, None, 0:3] + rays[:, None, 3:6] * z[:, :, None], rays[:, 8:11], cfg)
     out = {}
-    for form in ("wave", "csplit"):
+    for form in ("wave", "csplit", "t128"):     # t128: the 128-point tile (the default for C <= 32; more classes take the per-wave head)
         monkeypatch.setenv("INERF_F16_KERNEL", form)
         raw = kernels.encode_mlp(_desc(cfg), _packed(cfg, sd), rays.to(dev), z.to(dev))
         assert_maps_close(raw.cpu().numpy(), want.numpy(), RTOL, ATOL, f"raw C={c} {form}")
         out[form] = raw
-    assert torch.equal(out["wave"][..., :11], out["csplit"][..., :11])
+    assert torch.equal(out["wave"][..., :11], out["csplit"][..., :11]) and torch.equal(out["wave"][..., :11], out["t128"][..., :11])
     assert_maps_close(out["csplit"][..., 11:].cpu().numpy(), out["wave"][..., 11:].cpu().numpy(), 1e-5, 1e-6, "logits, split vs per-wave head")
+    assert_maps_close(out["t128"][..., 11:].cpu().numpy(), out["wave"][..., 11:].cpu().numpy(), 1e-5, 1e-6, "logits, 128-point tile vs per-wave head")
 
 
 @pytest.mark.parametrize("n,s", [(1, 64), (3, 1), (1, 191), (33, 64), (1000, 192), (4099, 192), (32768, 64)])

@@ -90,9 +90,9 @@ def test_default_inference_kernels_do_not_live_in_scratch(tmp_path):
         if "ILb0E" in k:
             assert v == 0, f"{k}: {v} bytes of scratch per lane"
     assert scratch["_ZN5inerf23k_encode_mlp_f16x3_dualILb0ELb0ELb0EEEvNS_9MlpParamsE"] == 0          # the 64-point form of the headline kernel: none
-    # the headline kernel (128-point tile, round 6): one lane-derived value written before the tile loop and read back once BEHIND it
+    # the headline kernels (128-point tile, round 6: object-level and SSR): none
     t128 = {k: v for k, v in scratch.items() if "k_encode_mlp_f16x3_t128" in k}
-    assert len(t128) == 1 and max(t128.values()) <= 8, t128
+    assert len(t128) == 2 and max(t128.values()) == 0, t128
     assert scratch.get("_ZN5inerf12k_encode_mlpILb0ELi2EEEvNS_9MlpParamsE", 0) == 0
 
 

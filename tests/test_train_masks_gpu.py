@@ -152,7 +152,7 @@ def test_two_workgroup_chain_equals_the_eight_wave_chain(variant, classes, endpo
         # dZ_h6 .. dZ_h0: thousands of words, but of ONE tile, and only in the trunk slots.  So on a large batch the bound is on TILES:
         # (a corrupted LDS row - the round-5 development form - hit every non-first tile of every workgroup.)
         where = (a != b).nonzero().flatten() // 2                                 # word index within `words`
-        f256, l256 = _slot_range(desc, p, kernels.SAVE_H0, kernels.SAVE_H7)        # the eight trunk slots open `words`
+        f256, l256 = _slot_range(desc, p, kernels.SAVE_H0, kernels.SAVE_H0 + 7)        # the eight trunk slots open `words`
         n_tiles = (p + 63) // 64
         words_per_slot = n_tiles * 16384                                           # 64 points x 256 channels x 4 bytes per tile
         assert l256 - f256 == 8 * words_per_slot
