@@ -665,7 +665,7 @@ def main():
             dts = float(t.item())
         assert sret["rgb_fine"].shape[0] == n_s and torch.isfinite(sret["rgb_fine"]).all() and float(sret["acc_fine"].min()) < 0.999
         out = {"workload": f"Replica room_0-like 320x240 frame ({n_s} rays), Semantic_NeRF C = {SSR_CLASSES}, 64+128 samples, depth "
-                           "[0.1, 10], xyz/10, eval, chunks of <= 32768 rays" +
+                           "[0.1, 10], xyz/10, eval, render_rays called with chunk = 32768 (merged: one launch sequence)" +
                            (f", rays tiled over {world} ranks + one all-gather of {sum(w for _, w in layout)} floats/ray (BASELINE configs[4])"
                             if world > 1 else " (BASELINE configs[3])"),
                "value": n_s / dts, "unit": "rays/s", "ms_per_step": dts * 1e3, "steps": n_steps, "n_gpus": world,
@@ -693,7 +693,7 @@ def main():
         sdesc.xyz_div = 10.0
         spk_c, spk_f = packing.packed_for_module(r.ssr_net_coarse, sdesc, dev), packing.packed_for_module(r.ssr_net_fine, sdesc, dev)
         b0, e0 = idist.shard_bounds(n_s, rank, world)
-        chunk = srays[b0:e0][:32768].contiguous()
+        chunk = srays[b0:e0].contiguous()              # (the frame's chunks are merged: its fine pass IS one launch of the band's rays)
         st = kernels.render_rays_fused(sdesc, spk_c, spk_f, chunk, N_SAMPLES, N_IMPORTANCE, t_vals, u, white_bkgd=False, want_stages=True)
         sz = st["z_fine"]
         del st
@@ -702,7 +702,7 @@ def main():
         flop_s = FLOP_PER_POINT_SSR * chunk.shape[0] * (N_SAMPLES + N_IMPORTANCE)
         out["roofline"] = roofline_entry(f16, mlp_kernel_name(f16, ssr=True),
                                          flop_s / (s_ms * 1e-3) / 1e12, s_ms, len(s_durs), flop_s, chunk.shape[0] * (N_SAMPLES + N_IMPORTANCE))
-        out["roofline"]["launch"] = f"fine pass of this rank's first chunk ({chunk.shape[0]} rays x 192) on the depths the frame itself resampled"
+        out["roofline"]["launch"] = f"fine pass of this rank's rays ({chunk.shape[0]} rays x 192: one launch, the frame's chunks are merged) on the depths the frame itself resampled"
         return out
 
     # ---- BASELINE.json configs[1] and configs[3] through their front-ends (rank 0, N = 1 only; not part of `value`) ----
