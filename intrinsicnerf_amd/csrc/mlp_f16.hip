@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
             prefetch_next();
             const SaveDst sv = save_dst(slot, kWidth, 64 * wave);
             const BitsDst bd = {bits_rsrc, kBits ? (((tile * kReluBitLayers + (slot - SAVE_H0)) * 4 + wave) * 64 + lane) * 8 : 0};
-            wide_store_h<2, kRowH, kPlaneH, kRows, kBits>(am, inv, bias, xd + dcol + 64 * wave, relu, amax2, nullptr, 0, 0, 0, &sv, &bd);
+            wide_store_h<2, kRowH, kPlaneH, kRows, kBits, 2, !kSave>(am, inv, bias, xd + dcol + 64 * wave, relu, amax2, nullptr, 0, 0, 0, &sv, &bd);
             __syncthreads();
             if constexpr (kSave && kFrag) {
                 FragDst d;
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256, 1) void k_encode_mlp_f16x3(const MlpParams p) 
             wide_gemm_h<1, KB0, KB1>(pre1, wb, frag128(s, KB0 + KB1), xr, c0, c1, lane, am);
             prefetch_next();
             const SaveDst sv = save_dst(slot, kHalf, 32 * wave);
-            wide_store_h<1, kRowH, kPlaneH, kSave && !kFrag128>(am, inv, bias, xd + dcol + 32 * wave, relu, amax2, gout, p.channels, pt0 < p.n_points,
+            wide_store_h<1, kRowH, kPlaneH, kSave && !kFrag128, false, 2, !kSave>(am, inv, bias, xd + dcol + 32 * wave, relu, amax2, gout, p.channels, pt0 < p.n_points,
                                                                pt0 + 32 < p.n_points, &sv);
             __syncthreads();
             if constexpr (kFrag128) {
@@ -399,6 +399,9 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
                 }
             }
         };
+#ifdef INERF_ABL_NO_ENCODE      // (timing ablation of a development build: the first tile's encoding stays in LDS; results are wrong)
+        if (tile == (int)blockIdx.x)
+#endif
         encode(true);
         __syncthreads();
         // training forward: the encoding leaves as operand fragments of the products dW = dZ^T enc (pts_linears.0, and .5's
@@ -446,9 +449,13 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
             prefetch_next();
             constexpr bool kBits = kSave && decltype(bits_tag)::value;
             const BitsDst bd = {bits_rsrc, kBits ? (((tile * kReluBitLayers + (frag_slot - SAVE_H0)) * 4 + wave) * 64 + lane_t) * 8 : 0};
+#ifndef INERF_ABL_NO_BARRIER    // (timing ablation of a development build: the layer barriers gone - racy, results are wrong)
             __syncthreads();                       // every wave has read the layer's input
-            wide_store_h<2, kRowD, kPlaneD, false, kBits>(am2, inv2, bias2, xd, relu, amax2, nullptr, 0, 0, 0, nullptr, &bd);
+#endif
+            wide_store_h<2, kRowD, kPlaneD, false, kBits, 2, !kSave>(am2, inv2, bias2, xd, relu, amax2, nullptr, 0, 0, 0, nullptr, &bd);
+#ifndef INERF_ABL_NO_BARRIER
             __syncthreads();
+#endif
             if constexpr (kSave)                   // this wave's 64 channels of all 64 points (the layer is complete behind the barrier)
                 if (frag_slot >= 0) {
                     int lane_o = lane_t;           // (laundered: the selector is rebuilt per layer instead of living in 8 registers)
@@ -503,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
             prefetch_w<2>(pre2, wb, frag256(L.feat, 16));
             if constexpr (kSplit) prefetch_w<2, 2048, 16 * 2048>(pre2s, wb, (L.sem1.w + 2 * (wave & 1) * 16 * 2 * 256) * 4);
             f16x8 hi[4][2], lo[4][2];
-            to_operands<2>(am2, inv2, bias2, amax2, hi, lo);
+            to_operands<2, false, 2, !kSave>(am2, inv2, bias2, amax2, hi, lo);
             if constexpr (kSave) {                // the hidden layer as operand fragments, transposed out of the registers (it never touches LDS)
                 int lane_o = lane_t;
                 asm volatile("" : "+v"(lane_o));
@@ -562,7 +569,7 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
             load_bias<1>(bias1, inv1, wb, (L.views.b + 32 * wave) * 4, (L.views.b + kHalf) * 4, lane);
             prefetch_w<2>(pre2, wb, frag256(L.trunk[0], 4));
             f16x8 hi[2][2], lo[2][2];
-            to_operands<1>(am1, inv1, bias1, amax2, hi, lo);
+            to_operands<1, false, 2, !kSave>(am1, inv1, bias1, amax2, hi, lo);
             if constexpr (kSave) {                // 128 channels: a four-block fragment slot, this wave's block
                 int lane_o = lane_t;
                 asm volatile("" : "+v"(lane_o));

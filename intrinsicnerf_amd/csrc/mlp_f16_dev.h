@@ -30,6 +30,9 @@ struct WeightBuf {
     __amdgpu_buffer_rsrc_t rsrc;
     int voff;                                     // lane * 16 bytes
     __device__ __forceinline__ f16x8 frag(int byte_off) const {          // byte_off: wave-uniform
+#ifdef INERF_ABL_WLOAD_L1       // (timing ablation of a development build, scripts/build_variant.sh: every fragment from one 4 KiB window - the same
+        byte_off &= 0xFFF;      // instructions, no L2 -> CU stream; results are wrong)
+#endif
         return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, byte_off, INERF_WEIGHT_AUX));
     }
     __device__ __forceinline__ f32x4 vec4(int byte_off, int lane_bytes) const {   // small per-lane offset on top
@@ -268,6 +271,18 @@ __device__ __forceinline__ float flag_f16_range(const MlpParams& p, int first_po
 }
 
 
+// running packed maximum of three: amax = maximum(amax, a, b) per f16 half in ONE instruction (v_pk_maximum3_f16, new in gfx950; IEEE
+// maximum: a NaN propagates into the maximum, where the range guard's `!(amax <= safe)` sees it).  Two v_pk_max_f16 before round 6.
+__device__ __forceinline__ void pk_max3_into(f16x2& amax, f16x2 a, f16x2 b) {
+#ifdef INERF_NO_MAX3             // (A/B build: the two-instruction form)
+    amax = __builtin_elementwise_max(amax, __builtin_elementwise_max(a, b));
+    return;
+#endif
+    unsigned m = __builtin_bit_cast(unsigned, amax);
+    asm("v_pk_maximum3_f16 %0, %0, %1, %2" : "+v"(m) : "v"(__builtin_bit_cast(unsigned, a)), "v"(__builtin_bit_cast(unsigned, b)));
+    amax = __builtin_bit_cast(f16x2, m);
+}
+
 // hi = (t0, t1) rounded toward zero to f16 (= the 13 low mantissa bits cleared, for |t| in f16's normal range; the
 // conversion saturates at 65504 instead of overflowing), lo = f16(t - hi): the difference is exact in fp32, so lo is the
 // remainder rounded once.  Three instructions per pair: v_cvt_pkrtz_f16_f32 and two v_fma_mix{lo,hi}_f16, which read hi
@@ -470,12 +485,23 @@ struct BitsDst {
     int off;                          // bytes: (((tile * kReluBitLayers + layer) * 4 + wave) * 64 + lane) * 8
 };
 
-template <int RB, int ROW = kRowH, int PLANE = kPlaneH, bool SAVE = false, bool BITS = false, int PB = 2>
+template <int RB, int ROW = kRowH, int PLANE = kPlaneH, bool SAVE = false, bool BITS = false, int PB = 2, bool MAX3 = true>
 __device__ __forceinline__ void wide_store_h(const f32x16 (&am)[RB][PB], float inv, const f32x4 (&bias)[RB][4],
                                              _Float16* dl,   // plane_hi + (lane&31)*kRowH + 4*(lane>>5) + dcol + chan0
                                              bool relu, f16x2& amax2, float* gout /* or nullptr: + chan0 + 4*(lane>>5) */,
                                              int gstride, int valid0, int valid1, const SaveDst* sv = nullptr,
                                              const BitsDst* bd = nullptr) {
+#ifdef INERF_ABL_NO_EPILOGUE     // (timing ablation of a development build: no bias / ReLU / split / LDS stores - compare CYCLES, the planes keep the encoding)
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+#ifdef __HIP_DEVICE_COMPILE__
+            asm volatile("" :: "v"(am[rb][pb]));      // (the GEMM stays alive)
+#endif
+        }
+    return;
+#endif
     static_assert(!BITS || (RB == 2 && PB == 2), "mask words are defined for the 64-channel x 64-point wave tile");
     static_assert(PB == 2 || !SAVE, "fp32 row copies are defined for the 64-point tile");
     unsigned mask[RB];
@@ -510,7 +536,8 @@ __device__ __forceinline__ void wide_store_h(const f32x16 (&am)[RB][PB], float i
                     a01 = __builtin_bit_cast(f16x2, __builtin_bit_cast(unsigned, h01) & 0x7FFF7FFFu);
                     a23 = __builtin_bit_cast(f16x2, __builtin_bit_cast(unsigned, h23) & 0x7FFF7FFFu);
                 }
-                amax2 = __builtin_elementwise_max(amax2, __builtin_elementwise_max(a01, a23));
+                if constexpr (MAX3) pk_max3_into(amax2, a01, a23);
+                else amax2 = __builtin_elementwise_max(amax2, __builtin_elementwise_max(a01, a23));      // (training forwards: the three-input form costs them 20 bytes of scratch)
                 const f16x4 hi4 = {h01[0], h01[1], h23[0], h23[1]}, lo4 = {l01[0], l01[1], l23[0], l23[1]};
                 _Float16* d = dl + pb * 32 * ROW + 32 * rb + 8 * g;
                 *reinterpret_cast<f16x4*>(d) = hi4;

@@ -13,7 +13,7 @@ constexpr int kColExD = 64;                       // exchange area: floats [wave
 
 // accumulators of this wave's 32*RB channels x 64 points -> (bias, ReLU, hi/lo split) -> B operands, one per
 // 16-channel k-block q (accumulator registers 8*(q&1) .. +7 of row block q>>1) and point block
-template <int RB, bool SAVE = false, int PB = 2>
+template <int RB, bool SAVE = false, int PB = 2, bool MAX3 = true>
 __device__ __forceinline__ void to_operands(const f32x16 (&am)[RB][PB], float inv, const f32x4 (&bias)[RB][4], f16x2& amax2,
                                             f16x8 (&hi)[2 * RB][PB], f16x8 (&lo)[2 * RB][PB], const SaveDst* sv = nullptr) {
 #pragma unroll
@@ -46,9 +46,14 @@ __device__ __forceinline__ void to_operands(const f32x16 (&am)[RB][PB], float in
                     }
                 }
 #endif
-                const f16x2 m = __builtin_elementwise_max(__builtin_elementwise_max(f16x2{fh[0], fh[1]}, f16x2{fh[2], fh[3]}),
-                                                          __builtin_elementwise_max(f16x2{fh[4], fh[5]}, f16x2{fh[6], fh[7]}));
-                amax2 = __builtin_elementwise_max(amax2, m);
+                if constexpr (MAX3) {       // (inference; in the training forward the three-input form costs 20 bytes of scratch)
+                    pk_max3_into(amax2, f16x2{fh[0], fh[1]}, f16x2{fh[2], fh[3]});
+                    pk_max3_into(amax2, f16x2{fh[4], fh[5]}, f16x2{fh[6], fh[7]});
+                } else {
+                    const f16x2 m = __builtin_elementwise_max(__builtin_elementwise_max(f16x2{fh[0], fh[1]}, f16x2{fh[2], fh[3]}),
+                                                              __builtin_elementwise_max(f16x2{fh[4], fh[5]}, f16x2{fh[6], fh[7]}));
+                    amax2 = __builtin_elementwise_max(amax2, m);
+                }
                 {   // pinned: left free, the compiler keeps the eight partial maxima of a call alive (spilled) and folds them in much later
                     unsigned a = __builtin_bit_cast(unsigned, amax2);
                     asm volatile("" : "+v"(a));

@@ -124,6 +124,9 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
                 }
             }
         };
+#ifdef INERF_ABL_NO_ENCODE      // (timing ablation of a development build: the first tile's encoding stays in LDS; results are wrong)
+        if (tile == (int)blockIdx.x)
+#endif
         encode(true);
         __syncthreads();
 
@@ -134,9 +137,13 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
         auto store256 = [&](const GemmSlot& s, bool relu, auto&& prefetch_next) {
             load_bias<1>(bias1, inv1, wb, (s.b + 32 * wave) * 4, (s.b + kWidth) * 4, lane_t);
             prefetch_next();
+#ifndef INERF_ABL_NO_BARRIER    // (timing ablation of a development build: the layer barriers gone - racy, results are wrong)
             __syncthreads();                       // every wave has read the layer's input
+#endif
             wide_store_h<1, kRowD, kPlaneT, false, false, 4>(am1, inv1, bias1, xd, relu, amax2, nullptr, 0, 0, 0);
+#ifndef INERF_ABL_NO_BARRIER
             __syncthreads();
+#endif
         };
         auto pf32 = [&](const GemmSlot& s, int kbt) { return [&, kbt]() { prefetch_w<1, 4096>(pre1, wb, frag32(s, kbt)); }; };
         auto pf32_at = [&](const GemmSlot& s, int kbt, int kb_first) {
