@@ -30,7 +30,7 @@ extern "C" {
 #define INERF_VERSION_MINOR 2
 /* Bumped whenever a struct layout, an argument list or the packed-weight format of this header changes; bindings
  * compare it with inerf_abi_version() of the library they loaded (a stale .so then fails loudly, not silently). */
-#define INERF_ABI_VERSION 40007
+#define INERF_ABI_VERSION 40008
 
 /* error codes */
 #define INERF_OK              0
@@ -429,6 +429,61 @@ int inerf_cluster_lookup(const float* rgb, const int64_t* label, int64_t n_pixel
                          const int32_t* links, const int32_t* anchor_begin, const float* factor, const float* centers,
                          const int32_t* center_begin, int n_classes, uint32_t flags, float* out_color,
                          int64_t* out_class, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Networks outside the fused architecture, and fp32 training batches: one launch per nn.Linear on the fp32 matrix core.
+ *
+ * The reference builds NeRF(D=args.netdepth, W=args.netwidth, skips, use_viewdirs) / Semantic_NeRF(...) from its flags
+ * (object_level/run_nerf.py:286-296, SSR/training/trainer.py:811-846); the fused kernels above implement D=8, W=256,
+ * skips=[4].  These entry points evaluate ANY such network layer by layer (object_level/run_nerf_helpers.py:284-321,
+ * SSR/models/semantic_nerf.py:120-181: every F.linear / F.relu / F.sigmoid / torch.cat of the two forwards) and what
+ * loss.backward() records for those layers (run_nerf.py:1018, trainer.py:990), in exact fp32 (v_mfma_f32_32x32x2_f32,
+ * fp32 accumulate), activations in caller-owned HBM buffers.  The Python mirrors also use them for a training batch whose
+ * activations leave the f16 range of the split-precision kernels, so no ATen GEMM remains on the path.
+ * --------------------------------------------------------------------------------------------------------------- */
+#define INERF_ACT_NONE     0
+#define INERF_ACT_RELU     1   /* F.relu: negative -> 0, NaN stays NaN */
+#define INERF_ACT_SIGMOID  2   /* torch.sigmoid: 1 / (1 + exp(-x)), IEEE division */
+
+/* C[i, j] = epilogue(sum_k A(i, k) B(j, k)),  i < m, j < n, k < k:
+ *   A(i, k) = a[i * a_sm + k * a_sk], B(j, k) = b[j * b_sn + k * b_sk]; each operand needs ONE unit stride (either one);
+ *   epilogue, in this order: + bias[j] (if not NULL), + add[i * add_ld + j] (if not NULL; add == c accumulates), act,
+ *   then zeroed where gate[i * gate_ld + j] <= 0 (if gate is not NULL: the ReLU backward of the layer that produced `gate`);
+ *   c[i * c_ld + j] may be a column range of a wider buffer (that is how torch.cat([input_pts, h]) and
+ *   torch.cat([feature, input_views]) are formed, run_nerf_helpers.py:291,308).
+ * nn.Linear forward: a = X (a_sm = ld, a_sk = 1), b = weight (b_sn = in_features, b_sk = 1), m = points, n = out, k = in.
+ * Its input gradient:  a = dZ (a_sm = ld, a_sk = 1), b = weight (+ first input column), b_sn = 1, b_sk = in_features,
+ *                      n = input columns, k = out_features. */
+typedef struct inerf_linear_args {
+    const float* a; int64_t a_sm, a_sk;
+    const float* b; int64_t b_sn, b_sk;
+    const float* bias;
+    const float* add; int64_t add_ld;
+    const float* gate; int64_t gate_ld;
+    float* c; int64_t c_ld;
+    int64_t m; int32_t n; int32_t act; int64_t k;
+} inerf_linear_args;
+int inerf_linear(const inerf_linear_args* args, void* stream);
+
+/* d_weight[rows, cols] (=|+=) sum_p g[p, r] x[p, c];  d_bias[rows] (=|+=) sum_p g[p, r]  (NULL: not wanted) - what autograd
+ * accumulates into nn.Linear.weight.grad / .bias.grad for g = the gradient of the layer's output (already multiplied by the
+ * activation's derivative), x = its input.  g[p * ldg + r], x[p * ldx + c].  Split over the points into a fixed number of
+ * partial products (workspace: inerf_linear_wgrad_workspace_bytes), added in ascending order: bit-identical run to run. */
+int64_t inerf_linear_wgrad_workspace_bytes(int64_t n_points, int rows, int cols);
+int inerf_linear_wgrad(const float* g, int64_t ldg, int rows, const float* x, int64_t ldx, int cols, int64_t n_points,
+                       float* d_weight, float* d_bias, int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Embedder.embed (run_nerf_helpers.py:195-225; semantic_nerf.py:50-66 with divisor = scalar_factor) into
+ * out[p * ld + 0 .. 3 + 6 n_freqs): [x, sin(x), cos(x), sin(2x), cos(2x), ...] of x = (o + d * z[p]) / divisor
+ * (run_nerf.py:488), or of the ray's view direction when `directions` != 0 (z_vals may then be NULL); p = ray * n_samples + s. */
+int inerf_embed(const float* rays, const float* z_vals, int64_t n_rays, int n_samples, int n_freqs, float divisor, int directions,
+                float* out, int64_t ld, void* stream);
+
+/* raw[p, 0:3] = raw[p, 4:7] * raw[p, 7] + raw[p, 8:11] (rgb = albedo * shading + residual, run_nerf_helpers.py:319) and its
+ * backward together with the three sigmoids': dz[p, 0:3] / [3] / [4:7] = gradients of the PRE-sigmoid albedo / shading /
+ * residual given d_raw (the gradient of all raw channels) and raw (the forward's values); dz is [n_points, 8], dz[p, 7] = 0. */
+int inerf_intrinsic_combine(float* raw, int64_t ld, int64_t n_points, void* stream);
+int inerf_intrinsic_combine_backward(const float* raw, const float* d_raw, int64_t ld, int64_t n_points, float* dz, void* stream);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libinerf.so")
 OBJ_DIR = os.path.join(CSRC, "_obj")          # git-ignored and gpurun-ignored: only the linked library travels
-SOURCES = ["pack.cpp", "api.cpp", "mlp.hip", "mlp_f16.hip", "mlp_f16_t128.hip", "mlp_bwd.hip", "mlp_wgrad.hip", "train_api.hip", "ray_ops.hip", "frame_ops.hip", "cluster.hip"]
+SOURCES = ["pack.cpp", "api.cpp", "mlp.hip", "mlp_f16.hip", "mlp_f16_t128.hip", "mlp_bwd.hip", "mlp_wgrad.hip", "train_api.hip", "ray_ops.hip", "frame_ops.hip", "cluster.hip", "layered.hip"]
 HEADERS = [os.path.join(CSRC, "layout.h"), os.path.join(CSRC, "mlp_common.h"), os.path.join(CSRC, "mlp_f16_dev.h"), os.path.join(CSRC, "mlp_f16_heads.h"), os.path.join(os.path.dirname(PKG_DIR), "include", "inerf.h")]
 # -ffp-contract=off: the reference rounds o + d*z, albedo*shading + residual, near*(1-t) + far*t ... as
 # separate multiplies and adds; fused multiply-adds would move sample positions by an ulp, which the

@@ -10,7 +10,7 @@ import os
 from . import _build
 from ._build import LIB_PATH
 
-ABI_VERSION = 40007          # INERF_ABI_VERSION of include/inerf.h these ctypes declarations mirror
+ABI_VERSION = 40008          # INERF_ABI_VERSION of include/inerf.h these ctypes declarations mirror
 
 OK, E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_HIP = 0, -1, -2, -3, -4
 VARIANT_OBJECT, VARIANT_SSR = 0, 1
@@ -45,6 +45,14 @@ class RenderArgs(C.Structure):
                 ("z_samples", C.c_void_p), ("z_fine", C.c_void_p), ("status", C.c_void_p), ("status_rays", C.c_int64),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
 
+
+class LinearArgs(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("a_sm", C.c_int64), ("a_sk", C.c_int64), ("b", C.c_void_p), ("b_sn", C.c_int64), ("b_sk", C.c_int64),
+                ("bias", C.c_void_p), ("add", C.c_void_p), ("add_ld", C.c_int64), ("gate", C.c_void_p), ("gate_ld", C.c_int64),
+                ("c", C.c_void_p), ("c_ld", C.c_int64), ("m", C.c_int64), ("n", C.c_int32), ("act", C.c_int32), ("k", C.c_int64)]
+
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 
 # every symbol include/inerf.h declares: (restype, argtypes)
 _P, _I, _L, _U = C.c_void_p, C.c_int, C.c_int64, C.c_uint32
@@ -96,6 +104,12 @@ SYMBOLS = {
     "inerf_gen_rays": (_I, [_P, _I, _P, _I, _I, _I, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _U, _P, _P]),
     "inerf_frame_to_u8": (_I, [_P, _L, _P, _P]),
     "inerf_cluster_lookup": (_I, [_P, _P, _L, _P, _P, _P, _P, _P, _P, _I, _U, _P, _P, _P]),
+    "inerf_linear": (_I, [C.POINTER(LinearArgs), _P]),
+    "inerf_linear_wgrad_workspace_bytes": (_L, [_L, _I, _I]),
+    "inerf_linear_wgrad": (_I, [_P, _L, _I, _P, _L, _I, _L, _P, _P, _I, _P, _L, _P]),
+    "inerf_embed": (_I, [_P, _P, _L, _I, _I, C.c_float, _I, _P, _L, _P]),
+    "inerf_intrinsic_combine": (_I, [_P, _L, _L, _P]),
+    "inerf_intrinsic_combine_backward": (_I, [_P, _P, _L, _L, _P, _P]),
 }
 
 _lib = None

@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import _capi, kernels, packing
+from . import _capi, kernels, layered, packing
 
 __all__ = ["Embedder", "get_embedder", "NeRF", "NetworkQuery", "run_network", "raw2outputs", "sample_pdf",
            "render_rays", "batchify_rays", "render", "render_path", "get_rays", "get_rays_np", "ndc_rays", "create_nerf", "to8b"]
@@ -203,14 +203,31 @@ def _train_desc(desc):
     return desc           # precision f32: exact-fp32 forward values, split-precision saved activations + HIP backward (kernels.mlp_train)
 
 
+FP32_LAYERS_NOTE = "Evaluating this batch with the fp32 layer kernels instead."
+
+
 def _train_query(train_desc, fn, ray_batch, z_vals, endpoint=False):
-    """raw for a training step through kernels.mlp_train; None if this batch has to go through torch (f16 range)."""
+    """raw for a training step through kernels.mlp_train; None if this batch left the f16 range (the caller then evaluates it
+    layer by layer in exact fp32: ``_layered_spec``)."""
     try:
         return kernels.mlp_train(train_desc, fn, ray_batch, z_vals, endpoint)
     except FloatingPointError as e:
         import warnings
-        warnings.warn(f"{e}  Evaluating this batch with torch autograd instead.")
+        warnings.warn(f"{e}  {FP32_LAYERS_NOTE}")
         return None
+
+
+def _layered_spec(fn, embed_fn, embeddirs_fn, with_dirs=True):
+    """layered.Spec when ``fn`` can be evaluated layer by layer on the fp32 MFMA kernels (any D / W / skips of this package's
+    networks, fed by this package's encoders), else None.  ``INERF_TRAIN_MLP=torch`` keeps torch's layers for a training step
+    (the comparison baseline of the gradient tests)."""
+    import os
+    if os.environ.get("INERF_TRAIN_MLP", "hip") == "torch" and _wants_grad(fn):
+        return None
+    spec = layered.spec_for(fn, embed_fn, embeddirs_fn if with_dirs else None)
+    if spec is None or spec.use_viewdirs != bool(with_dirs):
+        return None
+    return spec
 
 
 def _run_network_torch(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk):
@@ -233,10 +250,14 @@ def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64
     called like the reference does, on the torch-evaluated embedding.
     """
     desc = _fusable(fn, embed_fn, embeddirs_fn) if viewdirs is not None else None
-    if desc is None:
-        return _run_network_torch(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk)
-    if _wants_grad(fn):
-        _training_path_notice("run_network")
+    if desc is None or _wants_grad(fn):
+        # another depth / width / skip list, no view directions, or gradients wanted for arbitrary points: layer by layer on the
+        # fp32 MFMA kernels (differentiable w.r.t. the parameters); a foreign callable is called as the reference calls it
+        if desc is not None:
+            _training_path_notice("run_network")
+        spec = _layered_spec(fn, embed_fn, embeddirs_fn, viewdirs is not None) if inputs.is_cuda else None
+        if spec is not None:
+            return layered.evaluate_points(spec, fn, inputs, viewdirs)
         return _run_network_torch(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk)
     # arbitrary points: one "ray" per point with origin = point, direction = 0, depth 0 -> o + 0*0 = o
     pts = torch.reshape(inputs, [-1, 3]).float()
@@ -368,8 +389,12 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
             def query(z, fn):
                 raw = _train_query(td, fn, ray_batch, z) if td is not None else None        # nq's encoders
                 if raw is None:
-                    pts = rays_o[..., None, :] + rays_d[..., None, :] * z[..., :, None]
-                    raw = network_query_fn(pts, viewdirs, fn)
+                    spec = _layered_spec(fn, nq.embed_fn, nq.embeddirs_fn) if nq is not None else None
+                    if spec is not None:        # any depth / width / skips, or a batch outside the f16 range: fp32 layer kernels
+                        raw = layered.evaluate(spec, fn, ray_batch, z)
+                    else:                       # a foreign network or query function: called as the reference calls it
+                        pts = rays_o[..., None, :] + rays_d[..., None, :] * z[..., :, None]
+                        raw = network_query_fn(pts, viewdirs, fn)
                 return raw
 
             z_vals = kernels.sample_coarse(ray_batch, t_vals, t_rand, lindisp)
@@ -395,8 +420,8 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
         else:
             # ONE read of the f16 range words per training forward, after every launch of the batch has been enqueued (a read
             # after each network leaves the GPU idle while the host prepares the next launches).  If it trips, the whole batch
-            # is evaluated again with the layers in torch - with the random draws repeated, so it consumes the RNG like the
-            # reference would.
+            # is evaluated again layer by layer in exact fp32 (layered.evaluate: HIP forward and backward, no range limit) - with
+            # the random draws repeated, so it consumes the RNG like the reference would.
             redraw = (raw_noise_std > 0. or (perturb > 0. and N_importance > 0)) and not kernels._capturing()
             rng = (torch.get_rng_state(), torch.cuda.get_rng_state(dev) if dev.type == "cuda" else None) if redraw else None
             np_state = np.random.get_state() if pytest else None
@@ -405,7 +430,7 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
                     ret = staged(train_desc)
             except FloatingPointError as e:
                 import warnings
-                warnings.warn(f"{e}  Evaluating this batch with torch autograd instead.")
+                warnings.warn(f"{e}  {FP32_LAYERS_NOTE}")
                 if rng is not None:
                     torch.set_rng_state(rng[0])
                     if rng[1] is not None:

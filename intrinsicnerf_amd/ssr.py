@@ -15,8 +15,9 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import _capi, kernels, packing
-from .object_level import Embedder, _run_network_torch, _train_desc, _train_query, _training_path_notice, _wants_grad
+from . import _capi, kernels, layered, packing
+from .object_level import (FP32_LAYERS_NOTE, Embedder, _layered_spec, _run_network_torch, _train_desc, _train_query, _training_path_notice,
+                           _wants_grad)
 
 __all__ = ["get_embedder", "Semantic_NeRF", "run_network", "raw2outputs", "sample_pdf", "create_rays",
            "get_rays_camera", "get_rays_world", "batchify_rays", "SSRRenderMixin", "SSRRenderer"]
@@ -111,7 +112,8 @@ def _unfused_notice(what):
     if not _told_unfused:
         import warnings
         warnings.warn(f"{what}: network / encoders outside the fused kernels' architecture (D=8, W=256, skips=[4], multires<=10, "
-                      "multires_views<=4): HIP sampling and compositing, the networks through their torch forward.")
+                      "multires_views<=4): HIP sampling and compositing, the networks layer by layer on the fp32 MFMA kernels "
+                      "(a foreign callable: through its own forward).")
         _told_unfused = True
 
 
@@ -132,11 +134,14 @@ def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64
     any callable on the embedded tensor (called as the reference does).  ``show_endpoint`` is what the
     reference expresses as ``lambda x: net(x, self.endpoint_feat)`` (trainer.py:770)."""
     desc = _fusable(fn, embed_fn, embeddirs_fn) if viewdirs is not None else None
-    if desc is None:         # any other callable / architecture: called as the reference calls it (model_utils.py:19-35)
-        call = (lambda x: fn(x, True)) if show_endpoint else fn          # trainer.py:770
-        return _run_network_torch(inputs, viewdirs, call, embed_fn, embeddirs_fn, netchunk)
-    if _wants_grad(fn):      # training step: the layers go through torch autograd (object_level._training_path_notice)
-        _training_path_notice("run_network")
+    if desc is None or _wants_grad(fn):
+        # another netdepth / netwidth (trainer.py:811-846 builds what the YAML says), or gradients for arbitrary points: layer by
+        # layer on the fp32 MFMA kernels (layered.py).  Any other callable is called as the reference calls it (model_utils.py:19-35)
+        if desc is not None:
+            _training_path_notice("run_network")
+        spec = _layered_spec(fn, embed_fn, embeddirs_fn, viewdirs is not None) if inputs.is_cuda else None
+        if spec is not None:
+            return layered.evaluate_points(spec, fn, inputs, viewdirs, endpoint=show_endpoint)
         call = (lambda x: fn(x, True)) if show_endpoint else fn          # trainer.py:770
         return _run_network_torch(inputs, viewdirs, call, embed_fn, embeddirs_fn, netchunk)
     pts = torch.reshape(inputs, [-1, 3]).float()
@@ -479,7 +484,7 @@ class SSRRenderMixin:
                         o = self._staged(ray_batch, t_vals, t_rand, noise_c, u, noise_f, ep, td)
                 except FloatingPointError as e:
                     import warnings
-                    warnings.warn(f"{e}  Evaluating this batch with torch autograd instead.")
+                    warnings.warn(f"{e}  {FP32_LAYERS_NOTE}")
                     o = self._staged(ray_batch, t_vals, t_rand, noise_c, u, noise_f, ep, None)
         else:
             o = kernels.with_f32_fallback(desc, run)
@@ -516,8 +521,12 @@ class SSRRenderMixin:
         def query(z, fn, endpoint=False):
             raw = _train_query(train_desc, fn, ray_batch, z, endpoint) if train_desc is not None else None
             if raw is None:
-                pts = rays_o[..., None, :] + rays_d[..., None, :] * z[..., :, None]
-                raw = run_network(pts, viewdirs, fn, self.embed_fn, self.embeddirs_fn, self.netchunk, show_endpoint=endpoint)
+                spec = _layered_spec(fn, self.embed_fn, self.embeddirs_fn)
+                if spec is not None:            # another netdepth / netwidth, or a batch outside the f16 range: fp32 layer kernels
+                    raw = layered.evaluate(spec, fn, ray_batch, z, endpoint)
+                else:
+                    pts = rays_o[..., None, :] + rays_d[..., None, :] * z[..., :, None]
+                    raw = run_network(pts, viewdirs, fn, self.embed_fn, self.embeddirs_fn, self.netchunk, show_endpoint=endpoint)
             return raw
 
         z_vals = kernels.sample_coarse(ray_batch, t_vals, t_rand, False)
