@@ -707,7 +707,11 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
 // halved weight stream.
 bool mlp_f16x3_takes_t128(bool ssr, bool save, bool endpoint, int n_classes) {
     const char* form = getenv("INERF_F16_KERNEL");
-    if (save || endpoint || (form && (form[0] == 'd' || form[0] == 's' || form[0] == 'w' || form[0] == 'c'))) return false;
+    if (endpoint || (form && (form[0] == 'd' || form[0] == 's' || form[0] == 'w' || form[0] == 'c'))) return false;
+    if (save) {      // training forward: the object-level network's saving form of the 128-point tile (same save buffer, bit for bit)
+        const char* tf = getenv("INERF_TRAIN_FWD");
+        return !ssr && tf && tf[0] == 't';
+    }
     return !ssr || (form && form[0] == 't' && n_classes <= 32);
 }
 

@@ -502,14 +502,21 @@ __device__ __forceinline__ void wide_store_h(const f32x16 (&am)[RB][PB], float i
         }
     return;
 #endif
-    static_assert(!BITS || (RB == 2 && PB == 2), "mask words are defined for the 64-channel x 64-point wave tile");
+    // mask words (layout.h relu_bits_offset): per 64-point tile, layer, 64-channel group and lane TWO 32-bit words, one per 32-channel
+    // row block, bits in (point block, register) order.  The 64-channel x 64-point wave tile (RB = 2, PB = 2) writes both words of its
+    // tile; the 32-channel x 128-point wave tile (RB = 1, PB = 4: mlp_f16_t128.hip) writes ONE word (bd->off names it) of each of its two
+    // 64-point tiles - the same bits at the same addresses.
+    static_assert(!BITS || (RB == 2 && PB == 2) || (RB == 1 && PB == 4), "mask words are defined for the 64 x 64 and the 32 x 128 wave tile");
     static_assert(PB == 2 || !SAVE, "fp32 row copies are defined for the 64-point tile");
-    unsigned mask[RB];
+    constexpr int kWords = BITS ? RB * PB / 2 : 1;
+    unsigned mask[kWords];
+#pragma unroll
+    for (int w = 0; w < kWords; ++w) mask[w] = 0u;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
-        mask[rb] = 0u;
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) {
+            unsigned& mword = mask[!BITS ? 0 : RB == 2 ? rb : pb >> 1];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float t[4];
@@ -517,7 +524,7 @@ __device__ __forceinline__ void wide_store_h(const f32x16 (&am)[RB][PB], float i
                 for (int i = 0; i < 4; ++i) {
                     t[i] = __builtin_fmaf(am[rb][pb][4 * g + i], inv, bias[rb][g][i]);
                     if (relu) t[i] = fmaxf(t[i], 0.0f);
-                    if constexpr (BITS) mask[rb] = push_positive_bit(mask[rb], t[i]);
+                    if constexpr (BITS) mword = push_positive_bit(mword, t[i]);
                     if (gout && (pb == 0 ? valid0 : valid1))
                         gout[(size_t)pb * 32 * gstride + 32 * rb + 8 * g + i] = t[i] * (1.0f / kActScale);
                 }
@@ -554,8 +561,13 @@ __device__ __forceinline__ void wide_store_h(const f32x16 (&am)[RB][PB], float i
         }
     }
     if constexpr (BITS) {
-        const u32x2 w = {mask[0], mask[RB - 1]};
-        __builtin_amdgcn_raw_buffer_store_b64(w, bd->rsrc, bd->off, 0, 0);
+        if constexpr (RB == 2) {
+            const u32x2 w = {mask[0], mask[1]};
+            __builtin_amdgcn_raw_buffer_store_b64(w, bd->rsrc, bd->off, 0, 0);
+        } else {        // this wave's row-block word of the tile's two 64-point halves
+            __builtin_amdgcn_raw_buffer_store_b32(mask[0], bd->rsrc, bd->off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(mask[1], bd->rsrc, bd->off + kReluBitTileBytes, 0, 0);
+        }
     }
 }
 

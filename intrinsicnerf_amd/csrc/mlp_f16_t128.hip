@@ -16,6 +16,8 @@
 // channel group w8 & 3 x point half w8 >> 2 - and stream their weights twice per tile (15 % of the FLOPs).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "mlp_f16_dev.h"
 #include "mlp_f16_heads.h"
 
@@ -39,8 +41,13 @@ int64_t sem_scratch_bytes_t128(int64_t n_points) {
 // the wave's own L2-resident scratch slot (MlpParams.sem_scratch: 8 KiB per wave - an explicit spill placed where nothing waits for
 // it; held in registers across the feature and view layers they cost 48 spilled registers inside those loops) until the tile's planes
 // are dead, where the four partials of a point meet in LDS and are added in group order.
-template <bool kSsr>
+// kSave (object-level network): the training forward - every layer's output also leaves as operand fragments of the weight-gradient
+// products, the ReLU masks of h0..h7 as bits (mlp_f16.hip, k_encode_mlp_f16x3_dual<true, ..>): the SAME bytes at the same addresses
+// as the 64-point kernel writes (a 128-point tile is two of the slots' 64-point tiles; this wave's 32 channels are one channel block
+// of a fragment, one of the two mask words of a lane), so the chain and the weight-gradient kernels read either forward's buffer.
+template <bool kSsr, bool kSave = false>
 __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParams p) {
+    static_assert(!(kSsr && kSave), "the saving form is the object-level network's");
     constexpr int kParts = 512 / kPtsT;
     extern __shared__ __attribute__((aligned(16))) _Float16 ldst[];
     const int tid = threadIdx.x;
@@ -64,13 +71,18 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
     WidePreH<1> pre1;
     WidePreH<2> pre2;
     prefetch_w<1, 4096>(pre1, wb, frag32(L.trunk[0], 4));
+    float amax = 0.0f;                            // running maxima of |scaled value| (encoder inputs / layer outputs): the f16 range guard
+    f16x2 amax2 = {(_Float16)0.0f, (_Float16)0.0f};
+    const int n_tiles64 = (p.n_points + kTilePoints - 1) / kTilePoints;      // the save slots' tiles
 
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         int lane_t = tid;                         // (laundered per tile: keeps the lane_t parts of per-tile offsets out of the loop-invariant set,
         asm volatile("" : "+v"(lane_t));          // and `lane_t` itself out of the registers that live across the tile loop)
         lane_t &= 63;
-        float amax = 0.0f;                        // this tile's running maxima of |scaled value| (encoder inputs / layer outputs): the f16 range guard
-        f16x2 amax2 = {(_Float16)0.0f, (_Float16)0.0f};
+        if constexpr (!kSave) {                   // inference: the f16 range guard is per tile (flag_f16_range); training forwards keep the
+            amax = 0.0f;                          // launch's maximum (act_max; their status is one word)
+            amax2 = f16x2{(_Float16)0.0f, (_Float16)0.0f};
+        }
         // ---------------- encode -> hi/lo planes (xyz: columns 0..63, dir: columns 256..287) ----------------
         auto encode = [&](bool with_dir) {
             int tid_o = tid;
@@ -129,22 +141,65 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
 #endif
         encode(true);
         __syncthreads();
+        // training forward: the encoding as operand fragments of dW = dZ^T enc (pts_linears.0 and .5's encoding columns), straight from
+        // the planes before the first layer's output lands there: per 64-point half a 64-channel fragment slot, one channel block per
+        // wave (waves 0..3 = half x block); waves 4, 5: the view encoding of half 0 / 1 (32 channels, one block)
+        if constexpr (kSave) {
+            int lane_e = lane_t;
+            asm volatile("" : "+v"(lane_e));
+            if (wave < 4) {
+                const int half = wave >> 1, blk = wave & 1;
+                FragDst d;
+                d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save + p.save_off[SAVE_ENC], 0, (int)((unsigned)n_tiles64 * (unsigned)(kFragTileBytes / 4)), 0x00020000);
+                d.voff = (unsigned)(2 * tile + half) * (unsigned)(kFragTileBytes / 4) + (unsigned)blk * (2u * kFragBytes) + (unsigned)lane_e * 16u;
+                planes_to_frag<1, kRowD, kPlaneT, 2>(xr + half * 64 * kRowD + 32 * blk, plane_selector(lane_e), d);
+            } else if (wave < 6) {
+                const int half = wave - 4;
+                FragDst d;
+                d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save + p.save_off[SAVE_DIR], 0, (int)((unsigned)n_tiles64 * (unsigned)(kFragTileBytes / 8)), 0x00020000);
+                d.voff = (unsigned)(2 * tile + half) * (unsigned)(kFragTileBytes / 8) + (unsigned)lane_e * 16u;
+                planes_to_frag<1, kRowD, kPlaneT, 1>(xr + half * 64 * kRowD + kColDirD, plane_selector(lane_e), d);
+            }
+        }
 
         // a 256-wide layer in place: GEMM over columns [0, 16*KBT) | barrier | store to columns [0, 256) | barrier
         f32x16 am1[1][4];
         f32x4 bias1[1][4];
         float inv1;
-        auto store256 = [&](const GemmSlot& s, bool relu, auto&& prefetch_next) {
+        // ReLU masks of h0..h7 for the input-gradient chain (layout.h relu_bits_offset) and the layers' fragment slots (layout.h SaveSlot)
+        const __amdgpu_buffer_rsrc_t bits_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            p.save + (kSave ? p.bits_off : 0), 0, kSave ? (int)((unsigned)n_tiles64 * (unsigned)kReluBitTileBytes) : 0, 0x00020000);
+        auto frag_dst = [&](int slot, int half, int first_block) {
+            FragDst d;
+            d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save + (kSave ? p.save_off[slot] : 0), 0,
+                                                       kSave ? (int)((unsigned)n_tiles64 * (unsigned)kFragTileBytes) : 0, 0x00020000);
+            d.voff = (unsigned)(2 * tile + half) * (unsigned)kFragTileBytes + (unsigned)first_block * (2u * kFragBytes) + (unsigned)lane_t * 16u;
+            return d;
+        };
+        auto store256 = [&](const GemmSlot& s, bool relu, int frag_slot, auto&& prefetch_next, auto bits_tag) {
             load_bias<1>(bias1, inv1, wb, (s.b + 32 * wave) * 4, (s.b + kWidth) * 4, lane_t);
             prefetch_next();
+            constexpr bool kBits = kSave && decltype(bits_tag)::value;
+            // this wave's 32 channels = row block (wave & 1) of the 64-channel group (wave >> 1): word (wave & 1) of that group's lane pair
+            const BitsDst bd = {bits_rsrc, kBits ? ((((2 * tile) * kReluBitLayers + (frag_slot - SAVE_H0)) * 4 + (wave >> 1)) * 64 + lane_t) * 8 + 4 * (wave & 1) : 0};
 #ifndef INERF_ABL_NO_BARRIER    // (timing ablation of a development build: the layer barriers gone - racy, results are wrong)
             __syncthreads();                       // every wave has read the layer's input
 #endif
-            wide_store_h<1, kRowD, kPlaneT, false, false, 4>(am1, inv1, bias1, xd, relu, amax2, nullptr, 0, 0, 0);
+            wide_store_h<1, kRowD, kPlaneT, false, kBits, 4, !kSave>(am1, inv1, bias1, xd, relu, amax2, nullptr, 0, 0, 0, nullptr, &bd);
 #ifndef INERF_ABL_NO_BARRIER
             __syncthreads();
 #endif
+            if constexpr (kSave)                   // this wave's 32 channels of all 128 points (the layer is complete behind the barrier)
+                if (frag_slot >= 0) {
+                    int lane_o = lane_t;           // (laundered: the selector is rebuilt per layer instead of living in 8 registers)
+                    asm volatile("" : "+v"(lane_o));
+                    const Selector sel = plane_selector(lane_o);
+                    planes_to_frag<1, kRowD, kPlaneT>(xr + 32 * wave, sel, frag_dst(frag_slot, 0, wave));
+                    planes_to_frag<1, kRowD, kPlaneT>(xr + 64 * kRowD + 32 * wave, sel, frag_dst(frag_slot, 1, wave));
+                }
         };
+        constexpr std::true_type kWithBits{};
+        constexpr std::false_type kNoBits{};
         auto pf32 = [&](const GemmSlot& s, int kbt) { return [&, kbt]() { prefetch_w<1, 4096>(pre1, wb, frag32(s, kbt)); }; };
         auto pf32_at = [&](const GemmSlot& s, int kbt, int kb_first) {
             return [&, kbt, kb_first]() { prefetch_w<1, 4096>(pre1, wb, frag32(s, kbt) + kb_first * 4096); };
@@ -153,12 +208,12 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
 
         // ---------------- trunk ----------------
         wide_gemm_h<1, 4, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(L.trunk[0], 4), xr, 0, 0, lane_t, am1);
-        store256(L.trunk[0], true, pf32(L.trunk[1], 16));
+        store256(L.trunk[0], true, SAVE_H0, pf32(L.trunk[1], 16), kWithBits);
 #pragma unroll 1
         for (int layer = 1; layer < kSkipInput; ++layer) {
             wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(L.trunk[layer], 16), xr, 0, 0, lane_t, am1);
-            if (layer + 1 < kSkipInput) store256(L.trunk[layer], true, pf32(L.trunk[layer + 1], 16));
-            else                        store256(L.trunk[layer], true, pf32_at(L.trunk[kSkipInput], 20, 4));
+            if (layer + 1 < kSkipInput) store256(L.trunk[layer], true, SAVE_H0 + layer, pf32(L.trunk[layer + 1], 16), kWithBits);
+            else                        store256(L.trunk[layer], true, SAVE_H0 + layer, pf32_at(L.trunk[kSkipInput], 20, 4), kWithBits);
         }
         {   // pts_linears[5] over cat([pts, h]): h-part (k-blocks 4..19 of the stream), then the encoding again
             const GemmSlot& s = L.trunk[kSkipInput];
@@ -168,12 +223,12 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
             encode(false);
             __syncthreads();
             wide_gemm_h<1, 4, 0, kRowD, kPlaneT, false, 4096, 4>(pre1, wb, frag32(s, 20), xr, 0, 0, lane_t, am1);
-            store256(s, true, pf32(L.trunk[6], 16));
+            store256(s, true, SAVE_H0 + kSkipInput, pf32(L.trunk[6], 16), kWithBits);
         }
         wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(L.trunk[6], 16), xr, 0, 0, lane_t, am1);
-        store256(L.trunk[6], true, pf32(L.trunk[7], 16));
+        store256(L.trunk[6], true, SAVE_H0 + 6, pf32(L.trunk[7], 16), kWithBits);
         wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(L.trunk[7], 16), xr, 0, 0, lane_t, am1);
-        store256(L.trunk[7], true, pf256(L.as1, 16));
+        store256(L.trunk[7], true, SAVE_H7, pf256(L.as1, 16), kWithBits);
 
         // ---------------- heads ----------------
         const bool sem = kSsr && L.sem_rbs > 0;
@@ -195,7 +250,12 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
             if (sem) prefetch_w<1>(pre1, wb, frag128(L.sem1, 16));
             else     prefetch_w<1, 4096>(pre1, wb, frag32(L.feat, 16));
             f16x8 hi[4][2], lo[4][2];
-            to_operands<2>(am2, inv2, bias2, amax2, hi, lo);
+            to_operands<2, false, 2, !kSave>(am2, inv2, bias2, amax2, hi, lo);
+            if constexpr (kSave) {                // the hidden layer as operand fragments, transposed out of the registers (it never touches LDS):
+                int lane_o = lane_t;              // channel group cg of point half ph = the 64-point kernel's wave cg of tile 2 * tile + ph
+                asm volatile("" : "+v"(lane_o));
+                operands_to_frag<2>(hi, lo, accumulator_selector(lane_o), frag_dst(SAVE_AS1H, ph, 2 * cg));
+            }
             regop_gemm<4>(wb, (L.as2r.w + cg * 4 * 2 * 256) * 4, hi, lo, part_as);
         }
         // semantic head (semantic_nerf.py:150-152): hidden = relu(semantic_linear.0.0 h7), this wave's 32 channels x 64 points -> registers
@@ -231,7 +291,7 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
         const f32x4 sig4 = skinny_gemm_h<8, kPlaneT>(wb, L.alpha.w * 4, L.alpha.b * 4, (L.alpha.b + 16) * 4, xs, lane_t);
         {
             WidePreH<1> prev;
-            store256(L.feat, false, [&]() { prefetch_w<1>(prev, wb, frag128(L.views, 18)); });
+            store256(L.feat, false, SAVE_FEAT, [&]() { prefetch_w<1>(prev, wb, frag128(L.views, 18)); }, kNoBits);
             f32x16 amv[1][2];
             f32x4 biasv[1][4];
             float invv;
@@ -239,7 +299,15 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
             load_bias<1>(biasv, invv, wb, (L.views.b + 32 * cg) * 4, (L.views.b + kHalf) * 4, lane_t);
             prefetch_w<1, 4096>(pre1, wb, frag32(L.trunk[0], 4));
             f16x8 hi[2][2], lo[2][2];
-            to_operands<1>(amv, invv, biasv, amax2, hi, lo);
+            to_operands<1, false, 2, !kSave>(amv, invv, biasv, amax2, hi, lo);
+            if constexpr (kSave) {                // 128 channels: a four-block fragment slot, block cg of point half ph
+                int lane_o = lane_t;
+                asm volatile("" : "+v"(lane_o));
+                FragDst d;
+                d.rsrc = __builtin_amdgcn_make_buffer_rsrc(p.save + p.save_off[SAVE_VH], 0, (int)((unsigned)n_tiles64 * (unsigned)(kFragTileBytes / 2)), 0x00020000);
+                d.voff = (unsigned)(2 * tile + ph) * (unsigned)(kFragTileBytes / 2) + (unsigned)cg * (2u * kFragBytes) + (unsigned)lane_o * 16u;
+                operands_to_frag<1, 4>(hi, lo, accumulator_selector(lane_o), d);
+            }
             regop_gemm<2>(wb, (L.resr.w + cg * 2 * 2 * 256) * 4, hi, lo, part_res);
         }
         __syncthreads();                           // feature / dir columns are dead: the exchange area may be written
@@ -343,14 +411,22 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
         // (the next tile's encode writes bytes 0..127 and 512..575 of the rows, both planes: clear of the exchange area (hi plane, bytes
         // 128..255) and of the staging rows (lo plane, bytes 256..299) this tile's last readers may still be in)
     }
+    if (kSave && p.act_max) {
+        float m = fmaxf(amax, fmaxf((float)amax2[0], (float)amax2[1])) * (1.0f / kActScale);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0 && m == m) atomicMax(reinterpret_cast<unsigned int*>(p.act_max), __builtin_bit_cast(unsigned int, m));
+    }
 }
 
 int launch_mlp_f16x3_t128(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream) {
     p.n_tiles = (int)((n_points + kPtsT - 1) / kPtsT);
     const int grid = p.n_tiles < device_cus() ? p.n_tiles : device_cus();
-    void (*kern)(const MlpParams) = ssr ? k_encode_mlp_f16x3_t128<true> : k_encode_mlp_f16x3_t128<false>;
-    static PerDeviceOnce attr_sets[2];
-    PerDeviceOnce& attr_set = attr_sets[ssr ? 1 : 0];
+    const bool save = p.save != nullptr;
+    if (ssr && save) return INERF_E_UNSUPPORTED;
+    void (*kern)(const MlpParams) = ssr ? k_encode_mlp_f16x3_t128<true> : save ? k_encode_mlp_f16x3_t128<false, true> : k_encode_mlp_f16x3_t128<false>;
+    static PerDeviceOnce attr_sets[3];
+    PerDeviceOnce& attr_set = attr_sets[ssr ? 1 : save ? 2 : 0];
     if (attr_set.first()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesT);
         if (e != hipSuccess) return record(e);

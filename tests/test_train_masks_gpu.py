@@ -164,3 +164,38 @@ def test_two_workgroup_chain_equals_the_eight_wave_chain(variant, classes, endpo
     hs, hd = out["single"][1], out["dual"][1]
     scale = float(hs.abs().max())
     assert float((hs - hd).abs().max()) <= 2e-5 * scale, float((hs - hd).abs().max()) / scale
+
+
+@pytest.mark.parametrize("n,s", [(37, 19), (700, 37), (2048, 24), (1, 1), (2, 64), (3, 43)])
+def test_training_forward_on_the_128_point_tile_writes_the_same_buffer(n, s, monkeypatch):
+    """INERF_TRAIN_FWD=t128 (k_encode_mlp_f16x3_t128<false, true>): raw, every fragment slot, the ReLU mask words and act_max are the
+    64-point kernel's bit for bit - on a zeroed buffer, so that what either form leaves unwritten compares too (703 points = eleven
+    64-point tiles: the sixth 128-point tile has no second half)."""
+    import ctypes as C
+    dev = torch.device("cuda:0")
+    desc = _capi.net_desc(_capi.VARIANT_OBJECT, 0, 10, 4, 1.0, _capi.PREC_F16X3)
+    sd = {k: v.to(dev) for k, v in oracle.make_state_dict("object", 0, seed=5).items()}
+    pf = packing.device_packer(desc, False, dev)(sd)
+    rays, z = _rays(n, s, dev, seed=n)
+    lib = _capi.lib()
+    out = {}
+    for form in ("dual", "t128"):
+        if form == "t128":
+            monkeypatch.setenv("INERF_TRAIN_FWD", "t128")
+        else:
+            monkeypatch.delenv("INERF_TRAIN_FWD", raising=False)
+        raw = torch.zeros(n, s, 11, device=dev)
+        save = torch.zeros(lib.inerf_mlp_save_floats(desc, n * s), device=dev)
+        act_max = torch.zeros(1, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        rc = lib.inerf_encode_mlp_train(desc, C.c_void_p(pf.data_ptr()), C.c_void_p(rays.data_ptr()), C.c_void_p(z.data_ptr()), n, s, 0,
+                                        C.c_void_p(raw.data_ptr()), C.c_void_p(save.data_ptr()), C.c_void_p(act_max.data_ptr()),
+                                        C.c_void_p(status.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _capi.check(rc, "inerf_encode_mlp_train")
+        torch.cuda.synchronize()
+        out[form] = (raw, save.view(torch.int32), act_max, status)
+    assert torch.equal(out["dual"][0], out["t128"][0]), "raw differs"
+    diff = (out["dual"][1] != out["t128"][1]).nonzero().flatten()
+    assert diff.numel() == 0, f"{diff.numel()} words of the save buffer differ, first at {int(diff[0])} of {out['dual'][1].numel()}"
+    assert torch.equal(out["dual"][2], out["t128"][2]) and float(out["dual"][2]) > 0
+    assert torch.equal(out["dual"][3], out["t128"][3])
