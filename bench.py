@@ -725,6 +725,31 @@ def main():
             "roofline": roofline_entry(f16, roofline["kernel"], flop_c / (coarse_launch_ms * 1e-3) / 1e12, coarse_launch_ms,
                                        max(1, args.steps), flop_c, n_local * N_SAMPLES)}
         configs["ssr_room0_320x240"] = ssr_frame_leg()
+        # Not a BASELINE config - the reference's `--netwidth 128 --netwidth_fine 128` (run_nerf.py:286-296 builds what the flags say): a network
+        # outside the fused architecture goes layer by layer through the exact-fp32 MFMA kernels (csrc/layered.hip), sampling and compositing as
+        # above.  Default-init networks; roofline against the fp32 matrix peak (the layers are v_mfma_f32_32x32x2_f32).
+        mk128 = lambda: ol.NeRF(D=8, W=128, input_ch=ch, output_ch=5, skips=[4], input_ch_views=ch_d, use_viewdirs=True).to(dev)
+        torch.manual_seed(128)
+        n128 = dict(network_fn=mk128(), network_fine=mk128())
+        import warnings as _w
+        with _w.catch_warnings():
+            _w.simplefilter("ignore")
+            render_band(ro_l, rd_l, **n128); fence()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                wmaps, _ = render_band(ro_l, rd_l, **n128)
+            fence()
+        dtw = (time.perf_counter() - t1) / 2
+        assert torch.isfinite(wmaps["rgb_map"]).all()
+        macs128 = sum(q.numel() for k_, q in n128["network_fn"].named_parameters() if k_.endswith("weight"))
+        flop_w = 2.0 * macs128 * n_local * (2 * N_SAMPLES + N_IMPORTANCE)
+        configs["netwidth128_800x800"] = {
+            "workload": "Blender chair 800x800, 64 + 128 samples, NeRF(D=8, W=128) coarse + fine (the reference's --netwidth 128), white_bkgd, eval: "
+                        "layer-by-layer exact-fp32 MFMA kernels (csrc/layered.hip), HIP sampling and compositing",
+            "value": n_total / dtw, "unit": "rays/s", "ms_per_step": dtw * 1e3, "steps": 2, "dtype": "f32",
+            "roofline": {"bound": "mfma", "achieved": flop_w / dtw / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flop_w / dtw / 1e12 / 157.3,
+                         "flop_per_frame": flop_w, "peak_basis": "fp32 MFMA (v_mfma_f32_32x32x2_f32), whole frame on the wall clock"}}
+        del n128, wmaps
 
     if world > 1 and not args.no_extras:
         # BASELINE.json configs[4]: the Replica frame tiled over the ranks (distributed.render_sharded: contiguous ray bands,
@@ -786,6 +811,25 @@ def main():
         except Exception as e:        # reported, not fatal: the eager figure above stands
             t_graph = None
             n_fallbacks = f"{type(e).__name__}: {e}"
+        # the same step in exact fp32 throughout (INERF_TRAIN_MLP=layered: the fp32 MFMA layer kernels, forward and backward) - what a batch
+        # outside the f16 range costs, and what the reference's own fp32 training arithmetic costs here
+        t_fp32 = None
+        saved_mode = os.environ.get("INERF_TRAIN_MLP")
+        os.environ["INERF_TRAIN_MLP"] = "layered"
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                train_step(); fence()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    train_step()
+                fence()
+            t_fp32 = (time.perf_counter() - t1) / 3
+        finally:
+            if saved_mode is None:
+                os.environ.pop("INERF_TRAIN_MLP", None)
+            else:
+                os.environ["INERF_TRAIN_MLP"] = saved_mode
         # algorithmic work of a step: forward + input gradients + weight gradients = 3 x the forward's GEMM FLOPs of every sample point
         # (coarse network on 64, fine network on 192 depths per ray); peak as for the inference kernel (same three-product arithmetic)
         flop_step = 3.0 * FLOP_PER_POINT * tr.shape[0] * (2 * N_SAMPLES + N_IMPORTANCE)
@@ -793,6 +837,11 @@ def main():
         t_best = t_train if t_graph is None else min(t_train, t_graph)
         train = {"ms_per_step": t_train * 1e3, "rays": int(tr.shape[0]), "rays_per_s": tr.shape[0] / t_train,
                  "graphed_ms_per_step": None if t_graph is None else t_graph * 1e3, "graphed_eager_fallbacks": n_fallbacks,
+                 "exact_fp32_layer_kernels": None if t_fp32 is None else {
+                     "ms_per_step": t_fp32 * 1e3, "achieved": flop_step / t_fp32 / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                     "frac": flop_step / t_fp32 / 1e12 / 157.3,
+                     "note": "INERF_TRAIN_MLP=layered: every layer of both networks on v_mfma_f32_32x32x2_f32 (csrc/layered.hip), forward and "
+                             "backward; also what a batch outside the f16 range of the split-precision kernels is re-evaluated with"},
                  "roofline": {"bound": "mfma", "flop_per_step": flop_step, "peak": peak_t, "unit": "TFLOP/s",
                               "achieved": flop_step / t_best / 1e12, "frac": flop_step / t_best / 1e12 / peak_t,
                               "achieved_eager": flop_step / t_train / 1e12, "frac_eager": flop_step / t_train / 1e12 / peak_t,

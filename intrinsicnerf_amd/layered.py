@@ -197,8 +197,8 @@ def _combine_backward(raw, d_raw):
 # ----------------------------------------------------------------------------------------------
 # the two forwards (run_nerf_helpers.py:284-321, semantic_nerf.py:120-181) and their backward
 # ----------------------------------------------------------------------------------------------
-def _forward(spec, P, src, endpoint, keep):
-    """raw [n, CH] and, with ``keep``, the buffers the backward reads."""
+def _forward(spec, P, src, endpoint, keep, raw_out=None):
+    """raw [n, CH] (written into ``raw_out`` if given) and, with ``keep``, the buffers the backward reads."""
     n, dev = src.n, src.rays.device
     W, kx, kd, R, S = spec.width, spec.in_xyz, spec.in_dir, _capi.ACT_RELU, _capi.ACT_SIGMOID
 
@@ -225,7 +225,8 @@ def _forward(spec, P, src, endpoint, keep):
         cur = nxt
     h = out
     ch = spec.channels(endpoint)
-    raw = new(ch)
+    raw = new(ch) if raw_out is None else raw_out
+    assert raw.shape == (n, ch) and raw.is_contiguous()
     if not spec.use_viewdirs:
         lin("output_linear", h, Cols(raw))
         saved["raw"] = raw
@@ -368,9 +369,9 @@ def evaluate(spec, module, rays, z_vals, endpoint=False):
             return _LayeredFn.apply(rays, z_vals, spec, bool(endpoint), tuple(names), *params)
         P = {k: _dev(p.detach(), k) for k, p in zip(names, params)}
         per = max(1, POINTS_PER_PASS // s)
-        outs = [_forward(spec, P, RaySource(spec, rays[i:i + per], z_vals[i:i + per]), endpoint, keep=False)[0]
-                for i in range(0, n, per)]
-        raw = outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+        raw = torch.empty(n * s, spec.channels(endpoint), dtype=torch.float32, device=rays.device)
+        for i in range(0, n, per):             # activations of one pass at a time; raw rows land in place
+            _forward(spec, P, RaySource(spec, rays[i:i + per], z_vals[i:i + per]), endpoint, keep=False, raw_out=raw[i * s:(i + per) * s])
     return raw.view(n, s, raw.shape[1])
 
 

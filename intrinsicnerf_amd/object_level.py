@@ -185,8 +185,9 @@ def _training_path_notice(what):
     """Training steps (run_nerf.py:942-1018, trainer.py:882-990) take the STAGED path: sampling and compositing run
     on the HIP kernels - compositing with its HIP backward (inerf_composite_backward) - and each network is one
     autograd node (kernels.mlp_train): fused HIP forward that keeps the activations, HIP input-gradient chain, weight
-    gradients by the split-K MFMA kernel.  ``INERF_TRAIN_MLP=torch`` (or a network outside the fused architecture)
-    evaluates the layers with their torch ``forward`` instead.  Said once per process."""
+    gradients by the split-K MFMA kernel.  A network outside the fused architecture, ``INERF_TRAIN_MLP=layered`` and a batch
+    outside the f16 range go layer by layer through the exact-fp32 MFMA kernels (layered.py: HIP forward and backward too);
+    ``INERF_TRAIN_MLP=torch`` evaluates the modules' torch ``forward`` under autograd (debugging).  Said once per process."""
     global _told_training_path
     if not _told_training_path:
         import warnings
@@ -196,9 +197,12 @@ def _training_path_notice(what):
 
 
 def _train_desc(desc):
-    """Descriptor for the fused training evaluation of a fusable network, or None when torch autograd has to do it."""
+    """Descriptor for the fused training evaluation of a fusable network, or None when the layers are evaluated one by one:
+    ``INERF_TRAIN_MLP`` = ``hip`` (default: fused split-precision forward that keeps the activations + HIP backward, kernels.mlp_train) |
+    ``layered`` (exact fp32 throughout, like the reference's run_nerf.py:942-1018: the fp32 MFMA layer kernels, forward and backward) |
+    ``torch`` (the modules' own torch ``forward`` under autograd: the comparison baseline of the gradient tests)."""
     import os
-    if desc is None or os.environ.get("INERF_TRAIN_MLP", "hip") == "torch":
+    if desc is None or os.environ.get("INERF_TRAIN_MLP", "hip") in ("torch", "layered"):
         return None
     return desc           # precision f32: exact-fp32 forward values, split-precision saved activations + HIP backward (kernels.mlp_train)
 
@@ -381,8 +385,9 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
                 ret[rk] = o[ok + "_coarse"]
             ret["z_std"] = o["z_std"]
     else:
-        # user-supplied network, or a training step: the stages run on the HIP kernels (compositing differentiably),
-        # the network is called as given / through its torch forward
+        # a network outside the fused architecture, a user-supplied one, or a training step: the stages run on the HIP kernels
+        # (compositing differentiably); the network through kernels.mlp_train, the fp32 layer kernels (layered.py) or - a foreign
+        # callable - as given
         rays_o, rays_d, viewdirs = ray_batch[:, 0:3], ray_batch[:, 3:6].contiguous(), ray_batch[:, -3:]
 
         def staged(td):

@@ -239,3 +239,37 @@ def test_ssr_front_end_with_another_netwidth_uses_the_layer_kernels():
     close(raw, fx["raw"], "ssr.run_network(show_endpoint=True)")
     close(raw_plain, fx["raw"][..., :16], "ssr.run_network")
     assert layered.spec_for(net, embed, embed_d).channels(True) == 48
+
+
+def test_exact_fp32_training_of_the_default_architecture_on_the_layer_kernels(monkeypatch):
+    """INERF_TRAIN_MLP=layered: the D=8, W=256 networks trained in fp32 throughout, like the reference (run_nerf.py:942-1018) - no ATen
+    GEMM, maps and parameter gradients equal to torch's layers (INERF_TRAIN_MLP=torch) to fp32 summation order."""
+    from _cases import case_weights
+    from conftest import assert_same_within
+    from intrinsicnerf_amd import object_level as ol
+    fx = load_golden("object_chair_det")
+    embed, ch = ol.get_embedder(10, 0)
+    embed_d, ch_d = ol.get_embedder(4, 0)
+    mk = lambda: ol.NeRF(D=8, W=256, input_ch=ch, output_ch=5, skips=[4], input_ch_views=ch_d, use_viewdirs=True).cuda()
+    net_c, net_f = mk(), mk()
+    sd_c, sd_f = case_weights(fx)
+    net_c.load_state_dict(sd_c); net_f.load_state_dict(sd_f)
+    rays = torch.from_numpy(fx["rays"][:16]).cuda()
+    out = {}
+    for mode in ("layered", "torch"):
+        monkeypatch.setenv("INERF_TRAIN_MLP", mode)
+        net_c.zero_grad(); net_f.zero_grad()
+        with warnings.catch_warnings(), aten_gemm_watch() as watch:
+            warnings.simplefilter("ignore")
+            ret = ol.render_rays(rays, net_c, ol.NetworkQuery(embed, embed_d), 64, N_importance=128, network_fine=net_f, white_bkgd=True,
+                                 perturb=0., raw_noise_std=0.)
+            (ret["rgb_map"].square().sum() + ret["rgb0"].square().sum() + ret["acc_map"].sum()).backward()
+        assert (watch.gemms == []) == (mode == "layered"), sorted(set(watch.gemms))
+        out[mode] = ({k: v.detach().clone() for k, v in ret.items()},
+                     {k: p.grad.clone() for k, p in list(net_c.named_parameters()) + [("f." + k, p) for k, p in net_f.named_parameters()]})
+    for k in ("rgb0", "acc0", "albedo0"):                      # the coarse pass (in front of sample_pdf): plain tolerance
+        close(out["layered"][0][k], out["torch"][0][k].cpu(), k)
+    for k in ("rgb_map", "acc_map"):
+        assert_same_within(out["layered"][0][k], out["torch"][0][k], k, rel=2e-3)
+    for k in out["torch"][1]:
+        grad_close(out["layered"][1][k], out["torch"][1][k].cpu(), "d " + k, rel=5e-3)
