@@ -336,6 +336,10 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
     WidePreH<2> pre2;
     WidePreH<1> pre1;
     prefetch_w<2>(pre2, wb, frag256(L.trunk[0], 4));
+#ifdef INERF_DEPHASE            // (experiment of a development build: one of a CU's two workgroups starts INERF_DEPHASE_UNITS x 2048 cycles late)
+    if (INERF_DEPHASE == 1 ? blockIdx.x >= gridDim.x / 2 : (blockIdx.x & 1))
+        for (int d = 0; d < INERF_DEPHASE_UNITS; ++d) __builtin_amdgcn_s_sleep(32);
+#endif
 
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         // The per-tile slot / output offsets below are sums of a tile part and a lane part; derived from `lane` itself the lane
