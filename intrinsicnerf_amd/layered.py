@@ -147,6 +147,8 @@ def linear_wgrad(dz, x):
     """(d_weight [dz.width, x.width], d_bias [dz.width]) of a layer with output gradient ``dz`` and input ``x``."""
     n, rows, cols = dz.buf.shape[0], dz.width, x.width
     dev = dz.buf.device
+    if n == 0:                                   # an empty batch: the sums are empty
+        return torch.zeros(rows, cols, dtype=torch.float32, device=dev), torch.zeros(rows, dtype=torch.float32, device=dev)
     dw = torch.empty(rows, cols, dtype=torch.float32, device=dev)
     db = torch.empty(rows, dtype=torch.float32, device=dev)
     lib = _capi.lib()

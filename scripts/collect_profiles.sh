@@ -40,6 +40,11 @@ bash scripts/pmc_pass.sh ${tag}_tr_m GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ
 python scripts/pmc_report.py $OUT/prof/${tag}_tr_w $OUT/prof/${tag}_tr_f $OUT/prof/${tag}_tr_m > $OUT/${tag}_train_pmc_summary.txt 2>&1
 for p in w f m; do find $OUT/prof/${tag}_tr_$p -name "*counter_collection.csv" -exec cp {} $OUT/${tag}_train_pmc_$p.csv \; ; done
 python scripts/bench_train_kernels.py > $OUT/${tag}_train_kernels.txt 2>&1
+# 6b. the fp32 layer kernels (csrc/layered.hip): single launches and whole networks, and one counter pass on a 256 x 256 layer
+python scripts/bench_layered.py > $OUT/${tag}_layered.txt 2>&1
+export BENCH_SCRIPT=scripts/bench_layered.py BENCH_SIZE="--only 256 256 --iters 3" BENCH_ARGS=""
+timeout 300 bash scripts/pmc_pass.sh ${tag}_lay GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
+python scripts/pmc_report.py $OUT/prof/${tag}_lay k_linear > $OUT/${tag}_layered_pmc.txt 2>&1
 # 7. two ranks sharing this GPU over gloo (sharding + gather logic of bench.py --gpus N, both configs; numbers mean nothing): plain
 #    `python bench.py --gpus 2` - it starts its own ranks through torch.distributed.run on 127.0.0.1
 INERF_BENCH_SHARE_GPU=1 timeout 900 python bench.py --gpus 2 --steps 2 --warmup 1 --cpu-baseline-quick > $OUT/${tag}_bench_n2_shared.json 2> $OUT/${tag}_bench_n2_shared.err

@@ -273,3 +273,20 @@ def test_exact_fp32_training_of_the_default_architecture_on_the_layer_kernels(mo
         assert_same_within(out["layered"][0][k], out["torch"][0][k], k, rel=2e-3)
     for k in out["torch"][1]:
         grad_close(out["layered"][1][k], out["torch"][1][k].cpu(), "d " + k, rel=5e-3)
+
+
+def test_empty_and_single_point_batches():
+    """0 rays (render() of an empty ray set, run_nerf.py:59-71 with nothing to do) and one point: shapes as the reference's, zero gradients for
+    the empty batch."""
+    from intrinsicnerf_amd import layered
+    fx = load_golden("layered_object_d4_w128")
+    net, embed, embed_d = _build(fx)
+    spec = layered.spec_for(net, embed, embed_d)
+    rays, z = torch.from_numpy(fx["rays"]).cuda(), torch.from_numpy(fx["z"]).cuda()
+    raw0 = layered.evaluate(spec, net, rays[:0], z[:0])
+    assert raw0.shape == (0, z.shape[1], 11) and raw0.requires_grad
+    raw0.sum().backward()
+    assert all(p.grad is not None and float(p.grad.abs().max()) == 0.0 for p in net.parameters())
+    with torch.no_grad():
+        raw1 = layered.evaluate(spec, net, rays[:1], z[:1, :1])
+    close(raw1, fx["raw"][:1, :1], "one point")
