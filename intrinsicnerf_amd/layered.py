@@ -353,7 +353,7 @@ class _LayeredFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_raw):
         spec, endpoint, names, (n, s) = ctx.cfg
-        d2 = _dev(d_raw, "d_raw").view(n * s, -1)
+        d2 = _dev(d_raw, "d_raw").view(n * s, d_raw.shape[-1])
         G = _backward(spec, ctx.P, ctx.kept, d2, endpoint)
         ctx.kept = ctx.P = None
         return (None, None, None, None, None) + tuple(G[k] for k in names)

@@ -12,7 +12,7 @@ python -c 'import __graft_entry__ as g; g.build()' || exit 1
 # 0. the GPU suite on this code
 timeout 1200 python -m pytest tests -m gpu -q -x > $OUT/${tag}_pytest_gpu.log 2>&1; tail -3 $OUT/${tag}_pytest_gpu.log
 # 1. the benchmark as the driver runs it (with the CPU oracle: parity + cpu_baseline)
-python bench.py --steps 5 --warmup 1 > $OUT/${tag}_bench.json 2> $OUT/${tag}_bench.err
+python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${tag}_bench.json 2> $OUT/${tag}_bench.err
 # 2. the same under rocprofv3 --kernel-trace --stats (no CPU legs: the profiler only sees the GPU)
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof/${tag}_bench -o bench -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/${tag}_bench_under_rocprof.json 2> $OUT/${tag}_bench_under_rocprof.err )
 find $OUT/prof/${tag}_bench -name "*kernel_stats.csv" -exec cp {} $OUT/${tag}_bench_kernel_stats.csv \;
