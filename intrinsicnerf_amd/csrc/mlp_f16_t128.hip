@@ -20,6 +20,7 @@
 
 #include "mlp_f16_dev.h"
 #include "mlp_f16_heads.h"
+#include "mlp_f16_pp.h"
 
 namespace inerf {
 
@@ -45,9 +46,12 @@ int64_t sem_scratch_bytes_t128(int64_t n_points) {
 // products, the ReLU masks of h0..h7 as bits (mlp_f16.hip, k_encode_mlp_f16x3_dual<true, ..>): the SAME bytes at the same addresses
 // as the 64-point kernel writes (a 128-point tile is two of the slots' 64-point tiles; this wave's 32 channels are one channel block
 // of a fragment, one of the two mask words of a lane), so the chain and the weight-gradient kernels read either forward's buffer.
-template <bool kSsr, bool kSave = false>
+// kPipe (object-level inference, INERF_F16_KERNEL=pp): the trunk as a software pipeline over the tile's two 64-point halves - each half's
+// epilogue is issued between the MFMAs of the other half's GEMM (mlp_f16_pp.h).  Same values, same summation order: bit-identical results.
+template <bool kSsr, bool kSave = false, bool kPipe = false>
 __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParams p) {
     static_assert(!(kSsr && kSave), "the saving form is the object-level network's");
+    static_assert(!kPipe || (!kSsr && !kSave), "the pipelined trunk is the object-level inference form");
     constexpr int kParts = 512 / kPtsT;
     extern __shared__ __attribute__((aligned(16))) _Float16 ldst[];
     const int tid = threadIdx.x;
@@ -207,28 +211,83 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
         auto pf256 = [&](const GemmSlot& s, int kbt) { return [&, kbt]() { prefetch_w<2>(pre2, wb, frag256(s, kbt)); }; };
 
         // ---------------- trunk ----------------
-        wide_gemm_h<1, 4, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(L.trunk[0], 4), xr, 0, 0, lane_t, am1);
-        store256(L.trunk[0], true, SAVE_H0, pf32(L.trunk[1], 16), kWithBits);
+        if constexpr (kPipe) {
+            // halves A (rows 0..63) and B (rows 64..127); accX: the half's accumulators of its latest GEMM, epilogued during the other half's next one
+            f32x16 accA[2], accB[2];
+            f32x4 bias[1][4];                      // of the layer whose epilogue the next step carries (requested a barrier + a k-block ahead)
+            float inv = 0.0f;
+            const _Float16* const xrB = xr + 64 * kRowD;
+            _Float16* const xdB = xd + 64 * kRowD;
+            auto bias_of = [&](const GemmSlot& s, f32x4 (&b)[1][4], float& iv) { load_bias<1>(b, iv, wb, (s.b + 32 * wave) * 4, (s.b + kWidth) * 4, lane_t); };
+            // layer 0 (K = the 64 encoding columns): G(0,A) | G(0,B) || E(0,A)
+            pp_step<4, 0, true, kRowD, kPlaneT>(pre1, wb, frag32(L.trunk[0], 4), xr, 0, accA, accB, inv, bias[0], xdB, amax2);
+            bias_of(L.trunk[0], bias, inv);
+            prefetch_w<1, 4096>(pre1, wb, frag32(L.trunk[0], 4));
+            __syncthreads();                       // every wave has read the encoding of half A
+            pp_step<4, 8, true, kRowD, kPlaneT>(pre1, wb, frag32(L.trunk[0], 4), xrB, 0, accB, accA, inv, bias[0], xd, amax2);
+            prefetch_w<1, 4096>(pre1, wb, frag32(L.trunk[1], 16));
+            __syncthreads();
 #pragma unroll 1
-        for (int layer = 1; layer < kSkipInput; ++layer) {
-            wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(L.trunk[layer], 16), xr, 0, 0, lane_t, am1);
-            if (layer + 1 < kSkipInput) store256(L.trunk[layer], true, SAVE_H0 + layer, pf32(L.trunk[layer + 1], 16), kWithBits);
-            else                        store256(L.trunk[layer], true, SAVE_H0 + layer, pf32_at(L.trunk[kSkipInput], 20, 4), kWithBits);
-        }
-        {   // pts_linears[5] over cat([pts, h]): h-part (k-blocks 4..19 of the stream), then the encoding again
-            const GemmSlot& s = L.trunk[kSkipInput];
-            wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(s, 20) + 4 * 4096, xr, 0, 0, lane_t, am1);
-            prefetch_w<1, 4096>(pre1, wb, frag32(s, 20));
+            for (int layer = 1; layer < kDepth; ++layer) {
+                const GemmSlot& s = L.trunk[layer];
+                if (layer != kSkipInput) {
+                    // A(l): G(l,A) || E(l-1,B);  B(l): G(l,B) || E(l,A)
+                    pp_step<16, 8, true, kRowD, kPlaneT>(pre1, wb, frag32(s, 16), xr, 0, accA, accB, inv, bias[0], xdB, amax2);
+                    bias_of(s, bias, inv);
+                    prefetch_w<1, 4096>(pre1, wb, frag32(s, 16));
+                    __syncthreads();
+                    pp_step<16, 8, true, kRowD, kPlaneT>(pre1, wb, frag32(s, 16), xrB, 0, accB, accA, inv, bias[0], xd, amax2);
+                    if (layer + 1 == kSkipInput) prefetch_w<1, 4096>(pre1, wb, frag32(L.trunk[kSkipInput], 20) + 4 * 4096);
+                    else if (layer + 1 < kDepth) prefetch_w<1, 4096>(pre1, wb, frag32(L.trunk[layer + 1], 16));
+                    __syncthreads();
+                } else {
+                    // pts_linears[5] over cat([pts, h]): the h part (k-blocks 4..19 of the stream) of both halves, then the encoding again in
+                    // columns 0..63 (both halves' h4 are consumed), then the encoding part on top of the same accumulators
+                    pp_step<16, 8, true, kRowD, kPlaneT>(pre1, wb, frag32(s, 20) + 4 * 4096, xr, 0, accA, accB, inv, bias[0], xdB, amax2);      // || E(4,B)
+                    bias_of(s, bias, inv);
+                    prefetch_w<1, 4096>(pre1, wb, frag32(s, 20) + 4 * 4096);
+                    __syncthreads();
+                    pp_step<16, 0, true, kRowD, kPlaneT>(pre1, wb, frag32(s, 20) + 4 * 4096, xrB, 0, accB, accA, inv, bias[0], xd, amax2);
+                    prefetch_w<1, 4096>(pre1, wb, frag32(s, 20));
+                    __syncthreads();
+                    encode(false);
+                    __syncthreads();
+                    pp_step<4, 0, false, kRowD, kPlaneT>(pre1, wb, frag32(s, 20), xr, 0, accA, accB, inv, bias[0], xdB, amax2);
+                    prefetch_w<1, 4096>(pre1, wb, frag32(s, 20));
+                    __syncthreads();               // every wave has read the encoding of half A: E(5,A) may overwrite it
+                    pp_step<4, 8, false, kRowD, kPlaneT>(pre1, wb, frag32(s, 20), xrB, 0, accB, accA, inv, bias[0], xd, amax2);                 // || E(5,A)
+                    prefetch_w<1, 4096>(pre1, wb, frag32(L.trunk[kSkipInput + 1], 16));
+                    __syncthreads();
+                }
+            }
+            prefetch_w<2>(pre2, wb, frag256(L.as1, 16));                      // (outside the layer loop: assigned inside it the 32 registers are loop-carried)
+            pp_epilogue<kRowD, kPlaneT>(accB, inv, bias[0], xdB, amax2);      // E(7,B): nothing left to run it under
             __syncthreads();
-            encode(false);
-            __syncthreads();
-            wide_gemm_h<1, 4, 0, kRowD, kPlaneT, false, 4096, 4>(pre1, wb, frag32(s, 20), xr, 0, 0, lane_t, am1);
-            store256(s, true, SAVE_H0 + kSkipInput, pf32(L.trunk[6], 16), kWithBits);
+        } else {
+            wide_gemm_h<1, 4, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(L.trunk[0], 4), xr, 0, 0, lane_t, am1);
+            store256(L.trunk[0], true, SAVE_H0, pf32(L.trunk[1], 16), kWithBits);
+    #pragma unroll 1
+            for (int layer = 1; layer < kSkipInput; ++layer) {
+                wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(L.trunk[layer], 16), xr, 0, 0, lane_t, am1);
+                if (layer + 1 < kSkipInput) store256(L.trunk[layer], true, SAVE_H0 + layer, pf32(L.trunk[layer + 1], 16), kWithBits);
+                else                        store256(L.trunk[layer], true, SAVE_H0 + layer, pf32_at(L.trunk[kSkipInput], 20, 4), kWithBits);
+            }
+            {   // pts_linears[5] over cat([pts, h]): h-part (k-blocks 4..19 of the stream), then the encoding again
+                const GemmSlot& s = L.trunk[kSkipInput];
+                wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(s, 20) + 4 * 4096, xr, 0, 0, lane_t, am1);
+                prefetch_w<1, 4096>(pre1, wb, frag32(s, 20));
+                __syncthreads();
+                encode(false);
+                __syncthreads();
+                wide_gemm_h<1, 4, 0, kRowD, kPlaneT, false, 4096, 4>(pre1, wb, frag32(s, 20), xr, 0, 0, lane_t, am1);
+                store256(s, true, SAVE_H0 + kSkipInput, pf32(L.trunk[6], 16), kWithBits);
+            }
+            wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(L.trunk[6], 16), xr, 0, 0, lane_t, am1);
+            store256(L.trunk[6], true, SAVE_H0 + 6, pf32(L.trunk[7], 16), kWithBits);
+            wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(L.trunk[7], 16), xr, 0, 0, lane_t, am1);
+            store256(L.trunk[7], true, SAVE_H7, pf256(L.as1, 16), kWithBits);
+
         }
-        wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(L.trunk[6], 16), xr, 0, 0, lane_t, am1);
-        store256(L.trunk[6], true, SAVE_H0 + 6, pf32(L.trunk[7], 16), kWithBits);
-        wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(L.trunk[7], 16), xr, 0, 0, lane_t, am1);
-        store256(L.trunk[7], true, SAVE_H7, pf256(L.as1, 16), kWithBits);
 
         // ---------------- heads ----------------
         const bool sem = kSsr && L.sem_rbs > 0;
@@ -424,9 +483,12 @@ int launch_mlp_f16x3_t128(MlpParams& p, int64_t n_points, bool ssr, hipStream_t 
     const int grid = p.n_tiles < device_cus() ? p.n_tiles : device_cus();
     const bool save = p.save != nullptr;
     if (ssr && save) return INERF_E_UNSUPPORTED;
-    void (*kern)(const MlpParams) = ssr ? k_encode_mlp_f16x3_t128<true> : save ? k_encode_mlp_f16x3_t128<false, true> : k_encode_mlp_f16x3_t128<false>;
-    static PerDeviceOnce attr_sets[3];
-    PerDeviceOnce& attr_set = attr_sets[ssr ? 1 : save ? 2 : 0];
+    const char* form = getenv("INERF_F16_KERNEL");
+    const bool pipe = !ssr && !save && form && form[0] == 'p';        // the pipelined trunk (opt-in)
+    void (*kern)(const MlpParams) = ssr ? k_encode_mlp_f16x3_t128<true> : save ? k_encode_mlp_f16x3_t128<false, true>
+                                  : pipe ? k_encode_mlp_f16x3_t128<false, false, true> : k_encode_mlp_f16x3_t128<false>;
+    static PerDeviceOnce attr_sets[4];
+    PerDeviceOnce& attr_set = attr_sets[ssr ? 1 : save ? 2 : pipe ? 3 : 0];
     if (attr_set.first()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesT);
         if (e != hipSuccess) return record(e);

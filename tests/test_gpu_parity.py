@@ -349,7 +349,8 @@ def test_ssr_semantic_head_forms_agree(c, precision, monkeypatch):
 @pytest.mark.parametrize("n,s", [(1, 64), (3, 1), (1, 191), (33, 64), (1000, 192), (4099, 192), (32768, 64)])
 def test_object_kernel_tile_forms_are_bit_identical(n, s, precision, monkeypatch):
     """The object-level inference kernel's forms - 128-point tile (k_encode_mlp_f16x3_t128, the default since round 6) and
-    64-point tile with two workgroups per CU (k_encode_mlp_f16x3_dual, ``INERF_F16_KERNEL=dual``) - sum every output element in
+    64-point tile with two workgroups per CU (k_encode_mlp_f16x3_dual, ``INERF_F16_KERNEL=dual``), and the 128-point tile's
+    pipelined trunk (``INERF_F16_KERNEL=pp``) - sum every output element in
     the same order: raw must agree bit for bit, whole tiles, ragged tiles and launches smaller than one tile alike - and both meet
     the oracle (reproducible arithmetic: curated weights)."""
     from intrinsicnerf_amd import kernels
@@ -364,10 +365,11 @@ def test_object_kernel_tile_forms_are_bit_identical(n, s, precision, monkeypatch
     z = torch.sort(torch.rand(n, s, generator=g) * 4 + 2, -1)[0]
     sd, _ = oracle.calibrated_lcg_weights("object", 0, 40, rays[:256])
     out = {}
-    for form in ("t128", "dual"):
+    for form in ("t128", "dual", "pp"):      # pp: the 128-point tile with the pipelined trunk (mlp_f16_pp.h; opt-in, measured slower)
         monkeypatch.setenv("INERF_F16_KERNEL", form)
         out[form] = kernels.encode_mlp(_desc(cfg), _packed(cfg, sd), rays.to(dev), z.to(dev))
     assert torch.equal(out["t128"], out["dual"]), f"max |diff| {float((out['t128'] - out['dual']).abs().max()):.3e}"
+    assert torch.equal(out["t128"], out["pp"]), f"pipelined trunk: max |diff| {float((out['t128'] - out['pp']).abs().max()):.3e}"
     k = min(n, 64)
     with torch.no_grad():
         want = oracle.query_network(sd, rays[:k, None, 0:3] + rays[:k, None, 3:6] * z[:k, :, None], rays[:k, 8:11], cfg)
