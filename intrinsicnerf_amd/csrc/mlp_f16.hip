@@ -26,6 +26,10 @@
 #include "mlp_f16_dev.h"
 #include "mlp_f16_heads.h"
 
+#ifndef INERF_DUAL_PEEL
+#define INERF_DUAL_PEEL 1       // (0: development builds for A/B runs)
+#endif
+
 namespace inerf {
 
 // ------------------------------------------------------------------------------------------------
@@ -314,6 +318,9 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
     static_assert(!kSplit || (kSsr && !kSave), "the channel-split semantic head is the SSR inference form");
     constexpr int kPts = kTilePoints;
     constexpr int kParts = 256 / kPts;
+    // the wide GEMMs' first products take a zero C operand (wide_gemm_h PEEL): SSR frame +0.6-0.8 % same-box; the saving forms are
+    // indifferent (1.85-1.87 vs 1.82-1.86 ms) and keep the explicit zeroing (profiles/r06_peel_ab.txt)
+    constexpr bool kPeelD = INERF_DUAL_PEEL && !kSave;
     extern __shared__ __attribute__((aligned(16))) _Float16 ldsd[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -476,17 +483,17 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
         auto pf128 = [&](const GemmSlot& s, int kbt) { return [&, kbt]() { prefetch_w<1>(pre1, wb, frag128(s, kbt)); }; };
 
         // ---------------- trunk ----------------
-        wide_gemm_h<2, 4, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.trunk[0], 4), xr, 0, 0, lane, am2);
+        wide_gemm_h<2, 4, 0, kRowD, kPlaneD, true, 4096, 2, 2048, kPeelD>(pre2, wb, frag256(L.trunk[0], 4), xr, 0, 0, lane, am2);
         store256(L.trunk[0], true, SAVE_H0, pf256(L.trunk[1], 16), kWithBits);
 #pragma unroll 1
         for (int layer = 1; layer < kSkipInput; ++layer) {
-            wide_gemm_h<2, 16, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.trunk[layer], 16), xr, 0, 0, lane, am2);
+            wide_gemm_h<2, 16, 0, kRowD, kPlaneD, true, 4096, 2, 2048, kPeelD>(pre2, wb, frag256(L.trunk[layer], 16), xr, 0, 0, lane, am2);
             if (layer + 1 < kSkipInput) store256(L.trunk[layer], true, SAVE_H0 + layer, pf256(L.trunk[layer + 1], 16), kWithBits);
             else                        store256(L.trunk[layer], true, SAVE_H0 + layer, pf256_at(L.trunk[kSkipInput], 20, 4), kWithBits);
         }
         {   // pts_linears[5] over cat([pts, h]): h-part (k-blocks 4..19 of the stream), then the encoding again
             const GemmSlot& s = L.trunk[kSkipInput];
-            wide_gemm_h<2, 16, 0, kRowD, kPlaneD>(pre2, wb, frag256(s, 20) + 4 * 2 * 2 * 1024, xr, 0, 0, lane, am2);
+            wide_gemm_h<2, 16, 0, kRowD, kPlaneD, true, 4096, 2, 2048, kPeelD>(pre2, wb, frag256(s, 20) + 4 * 2 * 2 * 1024, xr, 0, 0, lane, am2);
             prefetch_w<2>(pre2, wb, frag256(s, 20));
             __syncthreads();
             encode(false);
@@ -494,9 +501,9 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
             wide_gemm_h<2, 4, 0, kRowD, kPlaneD, false>(pre2, wb, frag256(s, 20), xr, 0, 0, lane, am2);
             store256(s, true, SAVE_H0 + kSkipInput, pf256(L.trunk[6], 16), kWithBits);
         }
-        wide_gemm_h<2, 16, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.trunk[6], 16), xr, 0, 0, lane, am2);
+        wide_gemm_h<2, 16, 0, kRowD, kPlaneD, true, 4096, 2, 2048, kPeelD>(pre2, wb, frag256(L.trunk[6], 16), xr, 0, 0, lane, am2);
         store256(L.trunk[6], true, SAVE_H0 + 6, pf256(L.trunk[7], 16), kWithBits);
-        wide_gemm_h<2, 16, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.trunk[7], 16), xr, 0, 0, lane, am2);
+        wide_gemm_h<2, 16, 0, kRowD, kPlaneD, true, 4096, 2, 2048, kPeelD>(pre2, wb, frag256(L.trunk[7], 16), xr, 0, 0, lane, am2);
         store256(L.trunk[7], true, SAVE_H7, pf256(L.as1, 16), kWithBits);
 
         // ---------------- heads ----------------
@@ -509,7 +516,7 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
         f32x4 part_as[2], part_res[2];
         WidePreH<2> pre2s;                           // kSplit: first fragments of the semantic hidden layer, requested under the albedo|shading head
         {
-            wide_gemm_h<2, 16, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.as1, 16), xr, 0, 0, lane, am2);
+            wide_gemm_h<2, 16, 0, kRowD, kPlaneD, true, 4096, 2, 2048, kPeelD>(pre2, wb, frag256(L.as1, 16), xr, 0, 0, lane, am2);
             load_bias<2>(bias2, inv2, wb, (L.as1.b + 64 * wave) * 4, (L.as1.b + kWidth) * 4, lane);
             prefetch_w<2>(pre2, wb, frag256(L.feat, 16));
             if constexpr (kSplit) prefetch_w<2, 2048, 16 * 2048>(pre2s, wb, (L.sem1.w + 2 * (wave & 1) * 16 * 2 * 256) * 4);
@@ -536,7 +543,7 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
             // this wave's two 32-channel streams of the layer's 4-wave packing (16 k-blocks x 2 KiB each)
             // (operand rows from the per-tile laundered lane index: as a loop invariant this address is one more spilled register)
             const _Float16* xr_half = ldsd + ((lane_t & 31) + 32 * ph) * kRowD + 8 * (lane_t >> 5);
-            wide_gemm_h<2, 16, 0, kRowD, kPlaneD, true, 2048, 1, 16 * 2048>(pre2s, wb, (L.sem1.w + 2 * ch * 16 * 2 * 256) * 4, xr_half, 0, 0, lane, am1);
+            wide_gemm_h<2, 16, 0, kRowD, kPlaneD, true, 2048, 1, 16 * 2048, kPeelD>(pre2s, wb, (L.sem1.w + 2 * ch * 16 * 2 * 256) * 4, xr_half, 0, 0, lane, am1);
             load_bias<2>(bias1, inv1, wb, (L.sem1.b + 64 * ch) * 4, (L.sem1.b + kHalf) * 4, lane);
             f16x8 hi[4][1], lo[4][1];
             to_operands<2, false, 1>(am1, inv1, bias1, amax2, hi, lo, nullptr);
@@ -563,13 +570,13 @@ __global__ __launch_bounds__(256, 2) void k_encode_mlp_f16x3_dual(const MlpParam
             sem_head<kSave>(wb, L, xs, lane, amax2, out_row, my_valid, p.n_classes, &sv);
         }
         // feature (no activation) in place of h7, then the view-dependent layer over [feature | dir] -> registers
-        wide_gemm_h<2, 16, 0, kRowD, kPlaneD>(pre2, wb, frag256(L.feat, 16), xr, 0, 0, lane, am2);
+        wide_gemm_h<2, 16, 0, kRowD, kPlaneD, true, 4096, 2, 2048, kPeelD>(pre2, wb, frag256(L.feat, 16), xr, 0, 0, lane, am2);
         store256(L.feat, false, SAVE_FEAT, pf128(L.views, 18), kNoBits);
         {
             f32x16 am1[1][2];
             f32x4 bias1[1][4];
             float inv1;
-            wide_gemm_h<1, 18, 0, kRowD, kPlaneD>(pre1, wb, frag128(L.views, 18), xr, 0, 0, lane, am1);
+            wide_gemm_h<1, 18, 0, kRowD, kPlaneD, true, 2048, 2, 2048, kPeelD>(pre1, wb, frag128(L.views, 18), xr, 0, 0, lane, am1);
             load_bias<1>(bias1, inv1, wb, (L.views.b + 32 * wave) * 4, (L.views.b + kHalf) * 4, lane);
             prefetch_w<2>(pre2, wb, frag256(L.trunk[0], 4));
             f16x8 hi[2][2], lo[2][2];

@@ -129,14 +129,17 @@ __device__ __forceinline__ void wide_prefetch_h(WidePreH<RB>& pre, const WeightB
 // PB: blocks of 32 points (2: the whole tile; 1: the 32 points `xl` points at).  RBSTRIDE: bytes between the wave's row blocks
 // (default: consecutive inside a k-block; a wave that takes two 32-channel STREAMS of a 128-channel layer's 4-wave packing
 // passes the size of one stream).
-template <int RB, int KB0, int KB1, int ROW = kRowH, int PLANE = kPlaneH, bool ZERO = true, int KSTRIDE = RB * 2048, int PB = 2, int RBSTRIDE = 2048>
+// PEEL: the first four k-blocks stand in front of the loop and, with ZERO, the first product of every accumulator takes a zero C operand (an
+// inline constant) instead of 16 * RB * PB v_mov in front of the GEMM - exposed instructions: the matrix pipe is empty until they are through.
+template <int RB, int KB0, int KB1, int ROW = kRowH, int PLANE = kPlaneH, bool ZERO = true, int KSTRIDE = RB * 2048, int PB = 2, int RBSTRIDE = 2048,
+          bool PEEL = false>
 __device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const WeightBuf& wb, int frag_bytes,
                                             const _Float16* xl,      // plane_hi + (lane&31)*kRowH + 8*(lane>>5)
                                             int col0, int col1, int lane, f32x16 (&am)[RB][PB]) {
     constexpr int KBT = KB0 + KB1;
     static_assert(KBT % 2 == 0 && KBT >= 4, "k-block count");
     static_assert(PB == 2 || (PB == 1 && RB == 2) || (PB == 4 && RB == 1), "point blocks");
-    if constexpr (ZERO) {
+    if constexpr (ZERO && !PEEL) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -146,6 +149,7 @@ __device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const Weigh
 #pragma unroll
                     for (int pb = 0; pb < PB; ++pb) am[rb][pb][4 * g + i] = 0.0f;
     }
+    const f32x16 zero_c = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     auto xoff = [&](int kb) { return kb < KB0 ? col0 + 16 * kb : col1 + 16 * (kb - KB0); };
     // 4 rotating weight buffers (two k-blocks ahead; three measured slower), 2 activation buffers (one ahead);
     // all indices static
@@ -164,7 +168,8 @@ __device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const Weigh
 // 2*RB global loads and 2*PB LDS reads interleaved BETWEEN the MFMAs (an f16 MFMA occupies the pipe for only 32
 // cycles, so a burst of 8 memory instructions ahead of them is not hidden; measured +x % vs the burst form).
 // A macro, not a lambda: the buffer indices must stay compile-time constants for the arrays to live in registers.
-#define INERF_F16_STEP(K, I)                                                                                         \
+#define INERF_F16_STEP(K, I) INERF_F16_STEP_(K, I, false)
+#define INERF_F16_STEP_(K, I, FIRST)                                                                                 \
     {                                                                                                                \
         const int k1_ = (K) + 1 < KBT ? (K) + 1 : KBT - 1;                                                           \
         const int k2_ = (K) + 2 < KBT ? (K) + 2 : KBT - 1;                                                           \
@@ -179,7 +184,7 @@ __device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const Weigh
         /* hi*hi, hi*lo, lo*hi into the same accumulator; product-major: an accumulator is touched every 4th MFMA */ \
         _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                                            \
             _Pragma("unroll") for (int pb = 0; pb < PB; ++pb)                                                        \
-                am[rb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[(I) & 3][rb][0], x[(I) & 1][pb][0], am[rb][pb], 0, 0, 0); \
+                am[rb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[(I) & 3][rb][0], x[(I) & 1][pb][0], (FIRST) ? zero_c : am[rb][pb], 0, 0, 0); \
         _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                                            \
             _Pragma("unroll") for (int pb = 0; pb < PB; ++pb)                                                        \
                 am[rb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[(I) & 3][rb][0], x[(I) & 1][pb][1], am[rb][pb], 0, 0, 0); \
@@ -226,8 +231,15 @@ __device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const Weigh
 #if INERF_GEMM_PRIO               // the wave inside a GEMM loop wins the issue arbitration against its SIMD's other wave (the other
     __builtin_amdgcn_s_setprio(INERF_GEMM_PRIO);      // workgroup's, in an epilogue): its MFMAs and weight requests are not queued behind
 #endif                                                // the other's VALU / store bursts; +0.6 % inference, +1.6 % SSR, +1 % training kernels
+    if constexpr (PEEL) {
+        static_assert(KB4 >= 4, "peeled k-blocks");
+        INERF_F16_STEP_(0, 0, ZERO)
+        INERF_F16_STEP(1, 1)
+        INERF_F16_STEP(2, 2)
+        INERF_F16_STEP(3, 3)
+    }
 #pragma unroll 1
-    for (int kb = 0; kb < KB4; kb += 4) {
+    for (int kb = PEEL ? 4 : 0; kb < KB4; kb += 4) {
         INERF_F16_STEP(kb + 0, 0)
         INERF_F16_STEP(kb + 1, 1)
         INERF_F16_STEP(kb + 2, 2)
@@ -241,6 +253,7 @@ __device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const Weigh
     __builtin_amdgcn_s_setprio(0);
 #endif
 #undef INERF_F16_STEP
+#undef INERF_F16_STEP_
 }
 
 // epilogue: t = acc * inv + bias' (= kActScale * layer output; optionally ReLU) -> hi/lo planes;

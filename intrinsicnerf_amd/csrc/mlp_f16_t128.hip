@@ -22,6 +22,10 @@
 #include "mlp_f16_heads.h"
 #include "mlp_f16_pp.h"
 
+#ifndef INERF_T128_PEEL
+#define INERF_T128_PEEL 1       // (0: development builds for A/B runs)
+#endif
+
 namespace inerf {
 
 constexpr int kPtsT = 128;                       // points per tile
@@ -53,6 +57,9 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
     static_assert(!(kSsr && kSave), "the saving form is the object-level network's");
     static_assert(!kPipe || (!kSsr && !kSave), "the pipelined trunk is the object-level inference form");
     constexpr int kParts = 512 / kPtsT;
+    // the wide GEMMs' first products take a zero C operand instead of 64 v_mov in front of every GEMM (wide_gemm_h PEEL): +1.3 % same-box,
+    // same bits (profiles/r06_peel_ab.txt); the saving form keeps the explicit zeroing like the two-workgroup one
+    constexpr bool kPeel = INERF_T128_PEEL && !kSave;
     extern __shared__ __attribute__((aligned(16))) _Float16 ldst[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -264,17 +271,17 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
             pp_epilogue<kRowD, kPlaneT>(accB, inv, bias[0], xdB, amax2);      // E(7,B): nothing left to run it under
             __syncthreads();
         } else {
-            wide_gemm_h<1, 4, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(L.trunk[0], 4), xr, 0, 0, lane_t, am1);
+            wide_gemm_h<1, 4, 0, kRowD, kPlaneT, true, 4096, 4, 2048, kPeel>(pre1, wb, frag32(L.trunk[0], 4), xr, 0, 0, lane_t, am1);
             store256(L.trunk[0], true, SAVE_H0, pf32(L.trunk[1], 16), kWithBits);
     #pragma unroll 1
             for (int layer = 1; layer < kSkipInput; ++layer) {
-                wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(L.trunk[layer], 16), xr, 0, 0, lane_t, am1);
+                wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4, 2048, kPeel>(pre1, wb, frag32(L.trunk[layer], 16), xr, 0, 0, lane_t, am1);
                 if (layer + 1 < kSkipInput) store256(L.trunk[layer], true, SAVE_H0 + layer, pf32(L.trunk[layer + 1], 16), kWithBits);
                 else                        store256(L.trunk[layer], true, SAVE_H0 + layer, pf32_at(L.trunk[kSkipInput], 20, 4), kWithBits);
             }
             {   // pts_linears[5] over cat([pts, h]): h-part (k-blocks 4..19 of the stream), then the encoding again
                 const GemmSlot& s = L.trunk[kSkipInput];
-                wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(s, 20) + 4 * 4096, xr, 0, 0, lane_t, am1);
+                wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4, 2048, kPeel>(pre1, wb, frag32(s, 20) + 4 * 4096, xr, 0, 0, lane_t, am1);
                 prefetch_w<1, 4096>(pre1, wb, frag32(s, 20));
                 __syncthreads();
                 encode(false);
@@ -282,9 +289,9 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
                 wide_gemm_h<1, 4, 0, kRowD, kPlaneT, false, 4096, 4>(pre1, wb, frag32(s, 20), xr, 0, 0, lane_t, am1);
                 store256(s, true, SAVE_H0 + kSkipInput, pf32(L.trunk[6], 16), kWithBits);
             }
-            wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(L.trunk[6], 16), xr, 0, 0, lane_t, am1);
+            wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4, 2048, kPeel>(pre1, wb, frag32(L.trunk[6], 16), xr, 0, 0, lane_t, am1);
             store256(L.trunk[6], true, SAVE_H0 + 6, pf32(L.trunk[7], 16), kWithBits);
-            wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(L.trunk[7], 16), xr, 0, 0, lane_t, am1);
+            wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4, 2048, kPeel>(pre1, wb, frag32(L.trunk[7], 16), xr, 0, 0, lane_t, am1);
             store256(L.trunk[7], true, SAVE_H7, pf256(L.as1, 16), kWithBits);
 
         }
@@ -304,7 +311,7 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
             f32x16 am2[2][2];
             f32x4 bias2[2][4];
             float inv2;
-            wide_gemm_h<2, 16, 0, kRowD, kPlaneT>(pre2, wb, frag256(L.as1, 16), xr_h, 0, 0, lane_t, am2);
+            wide_gemm_h<2, 16, 0, kRowD, kPlaneT, true, 4096, 2, 2048, kPeel>(pre2, wb, frag256(L.as1, 16), xr_h, 0, 0, lane_t, am2);
             load_bias<2>(bias2, inv2, wb, (L.as1.b + 64 * cg) * 4, (L.as1.b + kWidth) * 4, lane_t);
             if (sem) prefetch_w<1>(pre1, wb, frag128(L.sem1, 16));
             else     prefetch_w<1, 4096>(pre1, wb, frag32(L.feat, 16));
@@ -328,7 +335,7 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
                 f32x16 ams[1][2];
                 f32x4 biass[1][4];
                 float invs;
-                wide_gemm_h<1, 16, 0, kRowD, kPlaneT>(pre1, wb, frag128(L.sem1, 16), xr_h, 0, 0, lane_t, ams);
+                wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 2048, 2, 2048, kPeel>(pre1, wb, frag128(L.sem1, 16), xr_h, 0, 0, lane_t, ams);
                 load_bias<1>(biass, invs, wb, (L.sem1.b + 32 * cg) * 4, (L.sem1.b + kHalf) * 4, lane_t);
                 prefetch_w<1, 4096>(pre1, wb, frag32(L.feat, 16));
                 f16x8 hi[2][2], lo[2][2];
@@ -345,7 +352,7 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
             }
         }
         // feature (no activation) in place of h7, then the view-dependent layer over [feature | dir] -> registers
-        wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4>(pre1, wb, frag32(L.feat, 16), xr, 0, 0, lane_t, am1);
+        wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4, 2048, kPeel>(pre1, wb, frag32(L.feat, 16), xr, 0, 0, lane_t, am1);
         // sigma, last of h7's readers (here, not in front of the heads: four registers fewer across their GEMM loops)
         const f32x4 sig4 = skinny_gemm_h<8, kPlaneT>(wb, L.alpha.w * 4, L.alpha.b * 4, (L.alpha.b + 16) * 4, xs, lane_t);
         {
@@ -354,7 +361,7 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
             f32x16 amv[1][2];
             f32x4 biasv[1][4];
             float invv;
-            wide_gemm_h<1, 18, 0, kRowD, kPlaneT>(prev, wb, frag128(L.views, 18), xr_h, 0, 0, lane_t, amv);
+            wide_gemm_h<1, 18, 0, kRowD, kPlaneT, true, 2048, 2, 2048, kPeel>(prev, wb, frag128(L.views, 18), xr_h, 0, 0, lane_t, amv);
             load_bias<1>(biasv, invv, wb, (L.views.b + 32 * cg) * 4, (L.views.b + kHalf) * 4, lane_t);
             prefetch_w<1, 4096>(pre1, wb, frag32(L.trunk[0], 4));
             f16x8 hi[2][2], lo[2][2];
