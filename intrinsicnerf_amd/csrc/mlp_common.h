@@ -16,7 +16,7 @@ struct MlpParams {
     int status_rays;        // 0: one word; > 0: one word per that many rays (inerf_encode_mlp_chunked)
     float* save;            // training forward: activation buffer (layout.h SaveSlot), else nullptr
     float* act_max;         // training forward, optional: device float that receives max |activation| (caller zeroes it)
-    float* sem_scratch;     // SSR inference, optional: per-workgroup scratch for the channel-split semantic head (sem_scratch_bytes)
+    float* sem_scratch;     // inference, optional scratch (sem_scratch_bytes): SSR - per-workgroup slots of the channel-split semantic head; object-level 128-point tile - the parked position encoding (sem_scratch_bytes)
     int64_t save_off[SAVE_SLOTS];   // float offsets of the slots for this launch's n_points
     int64_t bits_off;       // float offset of the ReLU-mask area (layout.h relu_bits_offset)
     NetLayout L;
@@ -72,6 +72,7 @@ int launch_mlp_f32(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream)
 int launch_mlp_f16x3(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream);   // p.save != nullptr: saving variant
 int launch_mlp_f16x3_t128(MlpParams& p, int64_t n_points, bool ssr, hipStream_t stream);      // inference on the 128-point tile (mlp_f16_t128.hip)
 bool mlp_f16x3_takes_t128(bool ssr, bool save, bool endpoint, int n_classes);                   // which launches take it
+int64_t enc_cache_bytes_t128(int64_t n_points);                                                 // object-level inference on the 128-point tile: the parked encoding
 int64_t sem_scratch_bytes_t128(int64_t n_points);                                               // ... and the SSR form's scratch (classes > 0)
 int64_t sem_scratch_bytes(const inerf_net_desc& net, int64_t n_points, bool endpoint);   // 0 when the launch would not use one
 

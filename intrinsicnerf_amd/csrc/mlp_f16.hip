@@ -728,6 +728,10 @@ bool mlp_f16x3_takes_t128(bool ssr, bool save, bool endpoint, int n_classes) {
 
 int64_t sem_scratch_bytes(const inerf_net_desc& net, int64_t n_points, bool endpoint) {
     const char* form = getenv("INERF_F16_KERNEL");
+    if (net.precision == INERF_PREC_F16X3 && net.variant == INERF_VARIANT_OBJECT && n_points > 0 && mlp_f16x3_takes_t128(false, false, false, 0)) {
+        const char* ec = getenv("INERF_ENC_CACHE");         // 0: evaluate the encoder twice per tile (A/B runs)
+        return ec && ec[0] == '0' ? 0 : enc_cache_bytes_t128(n_points);
+    }          // the 128-point tile parks its position encoding for the skip layer (mlp_f16_t128.hip)
     if (net.precision != INERF_PREC_F16X3 || net.variant != INERF_VARIANT_SSR || net.n_classes <= 0 || endpoint || n_points <= 0) return 0;
     if (mlp_f16x3_takes_t128(true, false, endpoint, net.n_classes)) return sem_scratch_bytes_t128(n_points);     // the 128-point tile: 8 KiB per wave
     if (form && (form[0] == 's' || form[0] == 'w')) return 0;          // single: one workgroup per CU; wave: the per-wave head (A/B runs)

@@ -163,6 +163,12 @@ __device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const Weigh
 #pragma unroll
         for (int part = 0; part < 2; ++part)
             x[0][pb][part] = *reinterpret_cast<const f16x8*>(xl + part * PLANE + xoff(0) + pb * 32 * ROW);
+    // PEEL forms: the lo plane through a base register of its own (laundered: derived from `xl` by a constant the compiler re-adds it per read -
+    // PLANE is beyond the 64 KB an LDS instruction's immediate offset reaches - 17 v_add per 48 MFMAs of the 128-point tile's loop, now 2)
+    // (the OFFSET is laundered, not the pointer: a laundered pointer loses its LDS address space and the reads become flat loads)
+    int lo_off = PLANE;
+    if constexpr (PEEL) asm volatile("" : "+v"(lo_off));
+    const _Float16* xl_lo = xl + lo_off;
 
 // one k-block: request operands for k+2 (weights) / k+1 (activations) and run 3*RB*PB MFMAs on block k, with the
 // 2*RB global loads and 2*PB LDS reads interleaved BETWEEN the MFMAs (an f16 MFMA occupies the pipe for only 32
@@ -173,14 +179,17 @@ __device__ __forceinline__ void wide_gemm_h(const WidePreH<RB>& pre, const Weigh
     {                                                                                                                \
         const int k1_ = (K) + 1 < KBT ? (K) + 1 : KBT - 1;                                                           \
         const int k2_ = (K) + 2 < KBT ? (K) + 2 : KBT - 1;                                                           \
-        const int xo_ = xoff(k1_);                                                                                   \
+        /* one column range (KB1 = 0): the NEXT k-block's columns without the clamp - affine in the loop counter, so the four steps of an   \
+           iteration share one address per plane (+ immediates) instead of one v_add per read; the last step then reads 16 columns past    \
+           the layer's input (inside the row: unused values) */                                                                            \
+        const int xo_ = (KB1 == 0 && PEEL) ? col0 + 16 * ((K) + 1) : xoff(k1_);                                      \
         _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                                            \
             _Pragma("unroll") for (int part = 0; part < 2; ++part)                                                   \
                 w[((I) + 2) & 3][rb][part] = wb.frag(frag_bytes + k2_ * KSTRIDE + rb * RBSTRIDE + part * 1024);      \
         _Pragma("unroll") for (int pb = 0; pb < PB; ++pb)                                                            \
             _Pragma("unroll") for (int part = 0; part < 2; ++part)                                                   \
                 x[((I) + 1) & 1][pb][part] =                                                                         \
-                    *reinterpret_cast<const f16x8*>(xl + part * PLANE + xo_ + pb * 32 * ROW);                        \
+                    *reinterpret_cast<const f16x8*>((PEEL && part ? xl_lo : xl + part * PLANE) + xo_ + pb * 32 * ROW); \
         /* hi*hi, hi*lo, lo*hi into the same accumulator; product-major: an accumulator is touched every 4th MFMA */ \
         _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                                            \
             _Pragma("unroll") for (int pb = 0; pb < PB; ++pb)                                                        \

@@ -33,6 +33,16 @@ constexpr int kPlaneT = kPtsT * kRowD;           // halfs per plane (rows of 296
 constexpr int kLdsBytesT = 2 * kPlaneT * 2;      // 151,552
 constexpr int kSemScratchBytesT = 8 * 2 * 16 * 64 * 4;      // SSR: per workgroup 64 KiB - per wave [2 point blocks][16 registers][64 lanes] floats
 
+// Object-level inference: the tile's position encoding (columns 0..63 of both planes: 32 KiB) parked in an L2-resident slot per workgroup
+// between the first layer and the skip layer, which needs it again after the layers in between overwrote it in place - 4 LDS reads + 4
+// stores + 4 loads + 4 LDS writes of 16 bytes per thread instead of a second evaluation of the encoder (~540 VALU instructions and 42
+// two-byte LDS writes per thread; the kernel is bound by instruction issue: profiles/r06_pp_pipeline.txt).  The same bits.
+constexpr int kEncCacheBytesT = 2 * kPtsT * kEncCols * 2;      // 32,768 per workgroup
+int64_t enc_cache_bytes_t128(int64_t n_points) {
+    const int64_t tiles = (n_points + kPtsT - 1) / kPtsT;
+    return (tiles < device_cus() ? tiles : device_cus()) * (int64_t)kEncCacheBytesT;
+}
+
 int64_t sem_scratch_bytes_t128(int64_t n_points) {
     const int64_t tiles = (n_points + kPtsT - 1) / kPtsT;
     return (tiles < device_cus() ? tiles : device_cus()) * (int64_t)kSemScratchBytesT;
@@ -152,6 +162,36 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
 #endif
         encode(true);
         __syncthreads();
+        // park the encoding for the skip layer (piece q = tid + 512 i of the tile's 2 048 sixteen-byte pieces: plane q / 1024, row (q % 1024) / 8)
+        const bool enc_cached = !kSsr && !kSave && p.sem_scratch != nullptr;
+        const __amdgpu_buffer_rsrc_t enc_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            p.sem_scratch, 0, enc_cached ? (int)((unsigned)gridDim.x * (unsigned)kEncCacheBytesT) : 0, 0x00020000);
+        auto enc_piece = [&](int i) {
+            const int q = (tid & 511) + 512 * i;
+            return ldst + (q >> 10) * kPlaneT + ((q & 1023) >> 3) * kRowD + (q & 7) * 8;
+        };
+        if constexpr (!kSsr && !kSave) {
+            if (enc_cached) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(enc_piece(i)), enc_rsrc,
+                                                           (int)blockIdx.x * kEncCacheBytesT + (tid + 512 * i) * 16, 0, 0);
+            }
+        }
+        auto encode_again = [&]() {         // the encoding back into columns 0..63 (sc0: past the vector L1, whose lines of an earlier tile may be stale)
+            if constexpr (!kSsr && !kSave) {
+                if (enc_cached) {
+                    u32x4 v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        v[i] = __builtin_amdgcn_raw_buffer_load_b128(enc_rsrc, (int)blockIdx.x * kEncCacheBytesT + (tid + 512 * i) * 16, 0, 1);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(enc_piece(i)) = v[i];
+                    return;
+                }
+            }
+            encode(false);
+        };
         // training forward: the encoding as operand fragments of dW = dZ^T enc (pts_linears.0 and .5's encoding columns), straight from
         // the planes before the first layer's output lands there: per 64-point half a 64-channel fragment slot, one channel block per
         // wave (waves 0..3 = half x block); waves 4, 5: the view encoding of half 0 / 1 (32 channels, one block)
@@ -257,7 +297,7 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
                     pp_step<16, 0, true, kRowD, kPlaneT>(pre1, wb, frag32(s, 20) + 4 * 4096, xrB, 0, accB, accA, inv, bias[0], xd, amax2);
                     prefetch_w<1, 4096>(pre1, wb, frag32(s, 20));
                     __syncthreads();
-                    encode(false);
+                    encode_again();
                     __syncthreads();
                     pp_step<4, 0, false, kRowD, kPlaneT>(pre1, wb, frag32(s, 20), xr, 0, accA, accB, inv, bias[0], xdB, amax2);
                     prefetch_w<1, 4096>(pre1, wb, frag32(s, 20));
@@ -284,7 +324,7 @@ __global__ __launch_bounds__(512, 2) void k_encode_mlp_f16x3_t128(const MlpParam
                 wide_gemm_h<1, 16, 0, kRowD, kPlaneT, true, 4096, 4, 2048, kPeel>(pre1, wb, frag32(s, 20) + 4 * 4096, xr, 0, 0, lane_t, am1);
                 prefetch_w<1, 4096>(pre1, wb, frag32(s, 20));
                 __syncthreads();
-                encode(false);
+                encode_again();
                 __syncthreads();
                 wide_gemm_h<1, 4, 0, kRowD, kPlaneT, false, 4096, 4>(pre1, wb, frag32(s, 20), xr, 0, 0, lane_t, am1);
                 store256(s, true, SAVE_H0 + kSkipInput, pf32(L.trunk[6], 16), kWithBits);
