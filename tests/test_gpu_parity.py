@@ -556,3 +556,38 @@ def test_empty_batches():
     with torch.no_grad():
         ret = ol.render_rays(rays, net, ol.NetworkQuery(embed, embed_d), 64, N_importance=128, white_bkgd=True, retraw=True)
     assert tuple(ret["rgb_map"].shape) == (0, 3) and tuple(ret["raw"].shape) == (0, 192, 11)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,s", [(3, 1), (33, 64), (700, 192)])
+def test_parked_encoding_equals_the_second_encoder_pass(n, s, precision, monkeypatch):
+    """The 128-point tile parks the tile's position encoding in the caller's workspace for the skip layer (inerf_encode_mlp_ws /
+    _chunked / inerf_render_rays); without a workspace (inerf_encode_mlp) and with INERF_ENC_CACHE=0 it evaluates the encoder a second time
+    (run_nerf_helpers.py:290-291: cat([input_pts, h])).  Same bits."""
+    import ctypes as C
+    from intrinsicnerf_amd import _capi, kernels
+    if precision != "f16x3":
+        pytest.skip("a form of the default f16x3 kernel")
+    dev = _dev()
+    cfg = oracle.RenderConfig(variant="object", n_samples=s, n_importance=0)
+    g = torch.Generator().manual_seed(7 * n + s)
+    o = torch.tensor([[2.5, 1.5, 2.0]]).expand(n, 3)
+    d = -o / o.norm(dim=-1, keepdim=True) + 0.2 * torch.randn(n, 3, generator=g)
+    rays = torch.cat([o, d, 2 * torch.ones(n, 1), 6 * torch.ones(n, 1), d / d.norm(dim=-1, keepdim=True)], -1).contiguous().to(dev)
+    z = torch.sort(torch.rand(n, s, generator=g) * 4 + 2, -1)[0].to(dev)
+    sd, _ = oracle.calibrated_lcg_weights("object", 0, 40, rays[:256].cpu())
+    desc = _capi.net_desc(_capi.VARIANT_OBJECT, 0, 10, 4, 1.0, _capi.PREC_F16X3)
+    packed = _packed(cfg, sd)
+    lib = _capi.lib()
+    monkeypatch.delenv("INERF_F16_KERNEL", raising=False)
+    monkeypatch.delenv("INERF_ENC_CACHE", raising=False)
+    assert lib.inerf_encode_mlp_workspace_bytes(desc, n, s, 0) > 0, "the default object-level launch is expected to ask for the parking slot"
+    with_ws = kernels.encode_mlp(desc, packed, rays, z)
+    plain = torch.empty_like(with_ws)
+    rc = lib.inerf_encode_mlp(desc, C.c_void_p(packed.data_ptr()), C.c_void_p(rays.data_ptr()), C.c_void_p(z.data_ptr()), n, s, 0,
+                              C.c_void_p(plain.data_ptr()), None, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _capi.check(rc, "inerf_encode_mlp")
+    monkeypatch.setenv("INERF_ENC_CACHE", "0")
+    assert lib.inerf_encode_mlp_workspace_bytes(desc, n, s, 0) == 0
+    twice = kernels.encode_mlp(desc, packed, rays, z)
+    assert torch.equal(with_ws, plain) and torch.equal(with_ws, twice)
