@@ -92,7 +92,11 @@ def test_default_inference_kernels_do_not_live_in_scratch(tmp_path):
     assert scratch["_ZN5inerf23k_encode_mlp_f16x3_dualILb0ELb0ELb0EEEvNS_9MlpParamsE"] == 0          # the 64-point form of the headline kernel: none
     # the headline kernels (128-point tile, round 6: object-level and SSR): none
     t128 = {k: v for k, v in scratch.items() if "k_encode_mlp_f16x3_t128" in k}
-    assert len(t128) == 2 and max(t128.values()) == 0, t128
+    # <kSsr, kSave, kPipe>: the two default inference forms hold no scratch; the opt-in saving form (INERF_TRAIN_FWD=t128) and the opt-in
+    # pipelined trunk (INERF_F16_KERNEL=pp) may keep a few dwords (at most 128 bytes per lane)
+    assert len(t128) == 4, t128
+    for k, v in t128.items():
+        assert v == 0 if k.endswith(("ILb0ELb0ELb0EEEvNS_9MlpParamsE", "ILb1ELb0ELb0EEEvNS_9MlpParamsE")) else v <= 128, (k, v)
     assert scratch.get("_ZN5inerf12k_encode_mlpILb0ELi2EEEvNS_9MlpParamsE", 0) == 0
 
 
