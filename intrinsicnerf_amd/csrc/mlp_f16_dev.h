@@ -96,6 +96,9 @@ __device__ __forceinline__ void fast_sincosf(float a, float* sn, float* cs) {
 // ------------------------------------------------------------------------------------------------
 // wide GEMM: RB blocks of 32 channels per wave x 2 blocks of 32 points, K = 16 * (KB0 + KB1)
 // ------------------------------------------------------------------------------------------------
+#ifndef INERF_EPI_PKFMA
+#define INERF_EPI_PKFMA 0
+#endif
 #ifndef INERF_GEMM_PRIO
 #define INERF_GEMM_PRIO 1      // s_setprio level inside the wide GEMM loops (0: none)
 #endif
@@ -542,9 +545,25 @@ __device__ __forceinline__ void wide_store_h(const f32x16 (&am)[RB][PB], float i
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float t[4];
+#if INERF_EPI_PKFMA     // two values per v_pk_fma_f32 (the same IEEE fma per element): the epilogue is instruction issue, not arithmetic
+                {
+                    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+                    const f32x2_ i2 = {inv, inv};
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x2_ a2 = {am[rb][pb][4 * g + 2 * h], am[rb][pb][4 * g + 2 * h + 1]};
+                        const f32x2_ b2 = {bias[rb][g][2 * h], bias[rb][g][2 * h + 1]};
+                        const f32x2_ r2 = __builtin_elementwise_fma(a2, i2, b2);
+                        t[2 * h] = r2[0];
+                        t[2 * h + 1] = r2[1];
+                    }
+                }
+#endif
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
+#if !INERF_EPI_PKFMA
                     t[i] = __builtin_fmaf(am[rb][pb][4 * g + i], inv, bias[rb][g][i]);
+#endif
                     if (relu) t[i] = fmaxf(t[i], 0.0f);
                     if constexpr (BITS) mword = push_positive_bit(mword, t[i]);
                     if (gout && (pb == 0 ? valid0 : valid1))
