@@ -112,7 +112,7 @@ def mlp_kernel_name(f16, ssr=False):
     form = os.environ.get("INERF_F16_KERNEL", "")[:1]
     if ssr:
         return "k_encode_mlp_f16x3<true, false>" if form == "s" else "k_encode_mlp_f16x3_dual<false, true, true>"
-    return {"s": "k_encode_mlp_f16x3<false, false>", "d": "k_encode_mlp_f16x3_dual<false, false, false>"}.get(form, "k_encode_mlp_f16x3_t128<false, false>")
+    return {"s": "k_encode_mlp_f16x3<false, false>", "d": "k_encode_mlp_f16x3_dual<false, false, false>"}.get(form, "k_encode_mlp_f16x3_t128<false, false, false>")
 
 
 def host_description():

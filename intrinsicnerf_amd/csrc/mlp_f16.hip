@@ -729,8 +729,11 @@ bool mlp_f16x3_takes_t128(bool ssr, bool save, bool endpoint, int n_classes) {
 int64_t sem_scratch_bytes(const inerf_net_desc& net, int64_t n_points, bool endpoint) {
     const char* form = getenv("INERF_F16_KERNEL");
     if (net.precision == INERF_PREC_F16X3 && net.variant == INERF_VARIANT_OBJECT && n_points > 0 && mlp_f16x3_takes_t128(false, false, false, 0)) {
-        const char* ec = getenv("INERF_ENC_CACHE");         // 0: evaluate the encoder twice per tile (A/B runs)
-        return ec && ec[0] == '0' ? 0 : enc_cache_bytes_t128(n_points);
+        // INERF_ENC_CACHE=1 parks the position encoding in the workspace instead of evaluating the encoder a second time per tile: +0.7 % -
+        // and 6.6 x the kernel's HBM traffic (32 KB written and read back per 128 points: the slots do not survive in an L2 that also holds
+        // the 2.7 MB of weights; profiles/r06_enc_cache_traffic.txt).  Off by default: the kernel's traffic stays 1.00 x its algorithmic bytes.
+        const char* ec = getenv("INERF_ENC_CACHE");
+        return ec && ec[0] == '1' ? enc_cache_bytes_t128(n_points) : 0;
     }          // the 128-point tile parks its position encoding for the skip layer (mlp_f16_t128.hip)
     if (net.precision != INERF_PREC_F16X3 || net.variant != INERF_VARIANT_SSR || net.n_classes <= 0 || endpoint || n_points <= 0) return 0;
     if (mlp_f16x3_takes_t128(true, false, endpoint, net.n_classes)) return sem_scratch_bytes_t128(n_points);     // the 128-point tile: 8 KiB per wave

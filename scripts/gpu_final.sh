@@ -23,7 +23,7 @@ for c, d in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
     v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "k_encode_mlp_f16x3_t128" in r["Kernel_Name"] and r["Counter_Name"] == c]
     tot[c] = sum(v) / len(v) * 1024 / 1e6
 alg = pts * 48.0 + 640000 * 44 + 2.7e6
-print(f"k_encode_mlp_f16x3_t128<false, false>, bench frame's fine launch ({pts} points), PMC in separate passes: FETCH_SIZE {tot['FETCH_SIZE']:.1f} MB + "
+print(f"k_encode_mlp_f16x3_t128<false, false, false>, bench frame's fine launch ({pts} points), PMC in separate passes: FETCH_SIZE {tot['FETCH_SIZE']:.1f} MB + "
       f"WRITE_SIZE {tot['WRITE_SIZE']:.1f} MB = {sum(tot.values()):.1f} MB = {sum(tot.values()) * 1e6 / pts:.1f} B per point = {sum(tot.values()) * 1e6 / alg:.3f} x algorithmic ({alg / 1e6:.1f} MB)")
 PY
 cat $OUT/${tag}_final_traffic.txt

@@ -11,7 +11,7 @@ import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src, dst = "gpurun_out/", "profiles/"
-KERNEL = "k_encode_mlp_f16x3_t128<false, false>"          # the headline kernel since round 6 (rounds 2-5: k_encode_mlp_f16x3_dual<false, false, false>)
+KERNEL = "k_encode_mlp_f16x3_t128<false, false, false>"          # the headline kernel since round 6 (rounds 2-5: k_encode_mlp_f16x3_dual<false, false, false>)
 
 rows = [r for r in csv.DictReader(open(f"{src}prof/{tag}_bench/bench_kernel_trace.csv")) if KERNEL in r["Kernel_Name"]]
 durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]

@@ -541,11 +541,17 @@ def test_workspace_skips_caller_provided_stage_tensors(capi):
     b.net, b.n_rays, b.n_samples, b.n_importance = desc, n, sc, 0
     assert lib.inerf_render_workspace_bytes(C.byref(b)) == up(n * sc) + up(n * sc * (11 + c)) + mlp_ws
     obj = capi.net_desc(capi.VARIANT_OBJECT, 0, 10, 4, 1.0)
-    # the object-level network on the 128-point tile parks its position encoding: 32 KiB per workgroup (f16x3 only; INERF_ENC_CACHE=0: none)
-    ws_obj = lib.inerf_encode_mlp_workspace_bytes(obj, n, sc + ni, 0)
-    assert (ws_obj > 0 and ws_obj % 32768 == 0) if obj.precision == capi.PREC_F16X3 else ws_obj == 0
-    obj32 = capi.net_desc(capi.VARIANT_OBJECT, 0, 10, 4, 1.0, capi.PREC_F32)
-    assert lib.inerf_encode_mlp_workspace_bytes(obj32, n, sc + ni, 0) == 0
+    # the object-level network needs no scratch by default; INERF_ENC_CACHE=1 asks for the slot of the parked position encoding (32 KiB per
+    # workgroup of the 128-point tile, f16x3 only)
+    assert lib.inerf_encode_mlp_workspace_bytes(obj, n, sc + ni, 0) == 0
+    os.environ["INERF_ENC_CACHE"] = "1"
+    try:
+        ws_obj = lib.inerf_encode_mlp_workspace_bytes(obj, n, sc + ni, 0)
+        assert (ws_obj > 0 and ws_obj % 32768 == 0) if obj.precision == capi.PREC_F16X3 else ws_obj == 0
+        obj32 = capi.net_desc(capi.VARIANT_OBJECT, 0, 10, 4, 1.0, capi.PREC_F32)
+        assert lib.inerf_encode_mlp_workspace_bytes(obj32, n, sc + ni, 0) == 0
+    finally:
+        del os.environ["INERF_ENC_CACHE"]
     assert lib.inerf_render_workspace_bytes(None) == capi.E_INVALID
 
 

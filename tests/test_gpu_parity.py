@@ -561,9 +561,9 @@ def test_empty_batches():
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,s", [(3, 1), (33, 64), (700, 192)])
 def test_parked_encoding_equals_the_second_encoder_pass(n, s, precision, monkeypatch):
-    """The 128-point tile parks the tile's position encoding in the caller's workspace for the skip layer (inerf_encode_mlp_ws /
-    _chunked / inerf_render_rays); without a workspace (inerf_encode_mlp) and with INERF_ENC_CACHE=0 it evaluates the encoder a second time
-    (run_nerf_helpers.py:290-291: cat([input_pts, h])).  Same bits."""
+    """INERF_ENC_CACHE=1: the 128-point tile parks the tile's position encoding in the caller's workspace for the skip layer
+    (inerf_encode_mlp_ws / _chunked / inerf_render_rays); by default, and without a workspace (inerf_encode_mlp), it evaluates the encoder a
+    second time (run_nerf_helpers.py:290-291: cat([input_pts, h])).  Same bits."""
     import ctypes as C
     from intrinsicnerf_amd import _capi, kernels
     if precision != "f16x3":
@@ -580,14 +580,14 @@ def test_parked_encoding_equals_the_second_encoder_pass(n, s, precision, monkeyp
     packed = _packed(cfg, sd)
     lib = _capi.lib()
     monkeypatch.delenv("INERF_F16_KERNEL", raising=False)
-    monkeypatch.delenv("INERF_ENC_CACHE", raising=False)
-    assert lib.inerf_encode_mlp_workspace_bytes(desc, n, s, 0) > 0, "the default object-level launch is expected to ask for the parking slot"
+    monkeypatch.setenv("INERF_ENC_CACHE", "1")
+    assert lib.inerf_encode_mlp_workspace_bytes(desc, n, s, 0) > 0, "INERF_ENC_CACHE=1: the object-level launch asks for the parking slot"
     with_ws = kernels.encode_mlp(desc, packed, rays, z)
     plain = torch.empty_like(with_ws)
     rc = lib.inerf_encode_mlp(desc, C.c_void_p(packed.data_ptr()), C.c_void_p(rays.data_ptr()), C.c_void_p(z.data_ptr()), n, s, 0,
                               C.c_void_p(plain.data_ptr()), None, C.c_void_p(torch.cuda.current_stream().cuda_stream))
     _capi.check(rc, "inerf_encode_mlp")
-    monkeypatch.setenv("INERF_ENC_CACHE", "0")
-    assert lib.inerf_encode_mlp_workspace_bytes(desc, n, s, 0) == 0
+    monkeypatch.delenv("INERF_ENC_CACHE")
+    assert lib.inerf_encode_mlp_workspace_bytes(desc, n, s, 0) == 0          # the default: the encoder runs a second time
     twice = kernels.encode_mlp(desc, packed, rays, z)
     assert torch.equal(with_ws, plain) and torch.equal(with_ws, twice)
