@@ -64,12 +64,12 @@ PEAK_F32_MFMA_TFLOPS = 157.3                 # MI355X_MICROARCH.md: dense fp32 m
 PEAK_F16_MFMA_TFLOPS = 2500.0                # MI355X_MICROARCH.md: dense f16/bf16 matrix peak
 MEASURED_F16_MFMA_ONLY_TFLOPS = 1590.0       # dense f16, random operands, 170-340 ms runs (zero operands: 2470)
 # HBM bytes per sample point of the encode+MLP kernels from the PMC passes (FETCH_SIZE + WRITE_SIZE, separate passes).
-# f16x3: profiles/r05_pmc_raw_rows.txt, measured on the bench frame's own fine launch (640,000 rays x 192 samples): FETCH 445.3 MB +
-# WRITE 5495.7 MB = 5941.0 MB per 122,880,000-point launch (algorithmic 5929.1 MB).  (Until late in round 5 the 44-byte raw rows left as
+# f16x3: profiles/r06_final_pmc_digest.txt, measured on the bench frame's own fine launch (640,000 rays x 192 samples): FETCH 410.9 MB +
+# WRITE 5442.4 MB = 5853.3 MB per 122,880,000-point launch (algorithmic 5929.1 MB; round 5: 5941.0 MB, profiles/r05_pmc_raw_rows.txt).  (Until late in round 5 the 44-byte raw rows left as
 # 4-byte non-temporal pieces: 6230 - 7126 MB, 1.05 - 1.20 x, depending on how far the waves that share a line had drifted apart; now as
 # 16-byte pieces of whole 704-byte wave blocks.)  f32: profiles/r01_mlp_pmc_traffic.txt.
-PMC_HBM_BYTES_PER_POINT = {"f16x3": 48.3, "f32": 49.5}
-PMC_SOURCE = {"f16x3": ("profiles/r05_pmc_raw_rows.txt", "1.00"), "f32": ("profiles/r01_mlp_pmc_traffic.txt", "1.02")}
+PMC_HBM_BYTES_PER_POINT = {"f16x3": 47.6, "f32": 49.5}
+PMC_SOURCE = {"f16x3": ("profiles/r06_final_pmc_digest.txt", "0.99"), "f32": ("profiles/r01_mlp_pmc_traffic.txt", "1.02")}
 PARITY_RAYS = 4096
 RTOL, ATOL, RTOL_DISP = 1e-4, 1e-5, 5e-4
 PSNR_BUDGET_DB = 1e-4                        # north_star: <= 1e-4 dB PSNR delta against the reference
